@@ -1,0 +1,360 @@
+// bk_api.cpp -- context, memory and the non-script entry points of include/blinky_hip.h.
+#include "bk_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+static thread_local std::string g_create_error;
+
+static int ensure_device(bk_ctx *ctx) { BK_HIP(ctx, hipSetDevice(ctx->device)); return BK_OK; }
+
+extern "C" const char *bk_version(void) { return "blinky-hip 0.1 (gfx950)"; }
+
+extern "C" bk_ctx *bk_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("bk_create: no usable HIP device (") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                         "); libblinkyhip has no CPU fallback";
+        return nullptr;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) {
+        g_create_error = "bk_create: device index out of range";
+        return nullptr;
+    }
+    bk_ctx *ctx = new bk_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_pal, BK_MAX_PLATES * 256) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_display, BK_MAX_PLATES * sizeof(int)) != hipSuccess) {
+        g_create_error = "bk_create: hipSetDevice/hipMalloc failed";
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+static void free_maps(bk_ctx *ctx)
+{
+    hipFree(ctx->d_offsets); ctx->d_offsets = nullptr;
+    hipFree(ctx->d_tints); ctx->d_tints = nullptr;
+    hipFree(ctx->d_frame); ctx->d_frame = nullptr;
+    hipFree(ctx->d_mask); ctx->d_mask = nullptr;
+    if (ctx->h_frame) hipHostFree(ctx->h_frame);
+    if (ctx->h_mask) hipHostFree(ctx->h_mask);
+    ctx->h_frame = nullptr; ctx->h_mask = nullptr;
+    ctx->map_px = 0;
+    ctx->lensmap_valid = false;
+    ctx->spans_valid = false;
+    bk::tilemap_invalidate(ctx);
+}
+
+extern "C" void bk_destroy(bk_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_maps(ctx);
+    hipFree(ctx->d_globe);
+    hipFree(ctx->d_pal);
+    hipFree(ctx->d_display);
+    bk::tilemap_free(ctx->tilemap);
+    bk::lensprogram_free(ctx->prog);
+    delete ctx;
+}
+
+extern "C" const char *bk_last_error(const bk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int bk_set_stream(bk_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BK_E_INVALID;
+    ctx->stream = (hipStream_t)hip_stream;
+    return BK_OK;
+}
+
+extern "C" int bk_synchronize(bk_ctx *ctx)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (int r = ensure_device(ctx)) return r;
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
+// (re)allocate the row-dependent buffers: lens.pixels / lens.pixel_tints of fisheye.c:719-720
+static int alloc_maps(bk_ctx *ctx)
+{
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    if (px == ctx->map_px && ctx->d_offsets) return BK_OK;
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_maps(ctx);
+    if (!px) return BK_OK;
+    const size_t words = (px + 63) / 64;
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_offsets, px * sizeof(uint32_t)));
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_tints, px));
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_frame, px));
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_mask, words * sizeof(uint64_t)));
+    BK_HIP(ctx, hipHostMalloc((void **)&ctx->h_frame, px, hipHostMallocDefault));
+    BK_HIP(ctx, hipHostMalloc((void **)&ctx->h_mask, words * sizeof(uint64_t), hipHostMallocDefault));
+    ctx->map_px = px;
+    return BK_OK;
+}
+
+static int alloc_globe(bk_ctx *ctx)
+{
+    const size_t need = (size_t)ctx->nframes * BK_MAX_PLATES * ctx->ps * ctx->ps;   // fisheye.c:718, per frame
+    if (need == ctx->globe_bytes && ctx->d_globe) return BK_OK;
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->d_globe);
+    ctx->d_globe = nullptr;
+    ctx->globe_bytes = 0;
+    if (!need) return BK_OK;
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_globe, need));
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_globe, 0, need, ctx->stream));
+    ctx->globe_bytes = need;
+    return BK_OK;
+}
+
+extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (width <= 0 || height <= 0) return ctx->fail(BK_E_INVALID, "bk_resize: bad size %dx%d", width, height);
+    if (int r = ensure_device(ctx)) return r;
+    if (width == ctx->W && height == ctx->H) return BK_OK;
+    // (6*ps*ps and W*H must fit the uint32 lensmap entries)
+    const int ps = std::min(width, height);                                  // fisheye.c:707
+    if ((uint64_t)BK_MAX_PLATES * ps * ps >= 0xFFFFFFFFull)
+        return ctx->fail(BK_E_INVALID, "bk_resize: platesize %d overflows 32-bit offsets", ps);
+    ctx->W = width; ctx->H = height; ctx->ps = ps;
+    ctx->row0 = 0; ctx->row1 = height;
+    ctx->lensmap_valid = false;
+    if (int r = alloc_maps(ctx)) return r;
+    return alloc_globe(ctx);
+}
+
+extern "C" int bk_set_rows(bk_ctx *ctx, int row0, int row1)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (row0 < 0 || row1 > ctx->H || row0 > row1)
+        return ctx->fail(BK_E_INVALID, "bk_set_rows: [%d,%d) outside 0..%d", row0, row1, ctx->H);
+    if (int r = ensure_device(ctx)) return r;
+    if (row0 == ctx->row0 && row1 == ctx->row1) return BK_OK;
+    ctx->row0 = row0; ctx->row1 = row1;
+    ctx->lensmap_valid = false;
+    ctx->spans_valid = false;
+    return alloc_maps(ctx);
+}
+
+extern "C" int bk_set_frames(bk_ctx *ctx, int nframes)
+{
+    if (!ctx || nframes < 1) return BK_E_INVALID;
+    if (int r = ensure_device(ctx)) return r;
+    ctx->nframes = nframes;
+    if (!ctx->ps) return BK_OK;
+    return alloc_globe(ctx);
+}
+
+extern "C" int bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesize, int *row0, int *row1)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (width) *width = ctx->W;
+    if (height) *height = ctx->H;
+    if (platesize) *platesize = ctx->ps;
+    if (row0) *row0 = ctx->row0;
+    if (row1) *row1 = ctx->row1;
+    return BK_OK;
+}
+
+extern "C" int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_size)
+{
+    if (!ctx) return BK_E_INVALID;
+    ctx->rubix.numcells = numcells; ctx->rubix.cell = cell_size; ctx->rubix.pad = pad_size;
+    return BK_OK;
+}
+
+extern "C" int bk_set_zoom(bk_ctx *ctx, int zoom_type, int fov_degrees)
+{
+    if (!ctx || zoom_type < BK_ZOOM_NONE || zoom_type > BK_ZOOM_CONTAIN) return BK_E_INVALID;
+    ctx->zoom_type = zoom_type;
+    ctx->zoom_fov = (zoom_type == BK_ZOOM_FOV || zoom_type == BK_ZOOM_VFOV) ? fov_degrees : 0;   // clear_zoom :1273
+    return BK_OK;
+}
+
+extern "C" int bk_set_apply_variant(bk_ctx *ctx, int variant)
+{
+    if (!ctx) return BK_E_INVALID;
+    ctx->apply_variant = variant;
+    return BK_OK;
+}
+
+extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }
+
+// ---- lensmap table -------------------------------------------------------------------
+
+extern "C" int bk_set_lensmap(bk_ctx *ctx, const uint32_t *offsets, const uint8_t *tints)
+{
+    if (!ctx || !offsets) return BK_E_INVALID;
+    if (!ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_set_lensmap: call bk_resize first");
+    if (int r = ensure_device(ctx)) return r;
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (tints) BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tints, px, hipMemcpyHostToDevice, ctx->stream));
+    else BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->lensmap_valid = true;
+    ctx->spans_valid = false;
+    bk::tilemap_invalidate(ctx);
+    return BK_OK;
+}
+
+extern "C" int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_read_lensmap: no lensmap has been built");
+    if (int r = ensure_device(ctx)) return r;
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    if (offsets) BK_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (tints) BK_HIP(ctx, hipMemcpyAsync(tints, ctx->d_tints, px, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
+// ---- globe plates ---------------------------------------------------------------------
+
+extern "C" void *bk_globe_device_ptr(bk_ctx *ctx, int frame)
+{
+    if (!ctx || !ctx->d_globe || frame < 0 || frame >= ctx->nframes) return nullptr;
+    return ctx->d_globe + (size_t)frame * BK_MAX_PLATES * ctx->ps * ctx->ps;
+}
+
+extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch)
+{
+    if (!ctx || !src) return BK_E_INVALID;
+    if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate: call bk_resize first");
+    if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
+        return ctx->fail(BK_E_INVALID, "bk_upload_plate: bad frame/plate/pitch");
+    if (int r = ensure_device(ctx)) return r;
+    const size_t ps = ctx->ps;
+    uint8_t *dst = ctx->d_globe + ((size_t)frame * BK_MAX_PLATES + plate) * ps * ps;
+    // the row memcpy loop of render_plate, fisheye.c:2441-2449
+    BK_HIP(ctx, hipMemcpy2DAsync(dst, ps, src, (size_t)src_pitch, ps, ps, hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
+extern "C" int bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t seed_frame)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_fill_plate_lcg: call bk_resize first");
+    if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes)
+        return ctx->fail(BK_E_INVALID, "bk_fill_plate_lcg: bad frame/plate");
+    if (int r = ensure_device(ctx)) return r;
+    const size_t ps2 = (size_t)ctx->ps * ctx->ps;
+    const uint32_t seed = 0x9E3779B9u * (uint32_t)(plate + 1 + 6 * (int)seed_frame);
+    return bk::launch_fill_lcg(ctx, ctx->d_globe + ((size_t)frame * BK_MAX_PLATES + plate) * ps2, ps2, seed);
+}
+
+// ---- apply ------------------------------------------------------------------------------
+
+static int upload_pal(bk_ctx *ctx, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256])
+{
+    if (!rubix_on) return BK_OK;
+    if (!pal) return ctx->fail(BK_E_INVALID, "rubix_on needs the palette LUTs");
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_pal, pal, BK_MAX_PLATES * 256, hipMemcpyHostToDevice, ctx->stream));
+    return BK_OK;
+}
+
+extern "C" int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst_pitch,
+                               size_t frame_stride, int x0, int y0, int rubix_on,
+                               const uint8_t pal[BK_MAX_PLATES][256])
+{
+    if (!ctx || !dst_dev) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_apply: no lensmap (bk_build / bk_set_lensmap first)");
+    if (dst_pitch < ctx->W + x0 || x0 < 0 || y0 < 0 || frame0 < 0 || nframes < 1)
+        return ctx->fail(BK_E_INVALID, "bk_apply_device: bad pitch/origin/frames");
+    if (int r = ensure_device(ctx)) return r;
+    if (int r = upload_pal(ctx, rubix_on, pal)) return r;
+    uint8_t *first = (uint8_t *)dst_dev + (size_t)(y0 + ctx->row0) * dst_pitch + x0;
+    return bk::launch_apply(ctx, frame0, nframes, first, dst_pitch, frame_stride, rubix_on);
+}
+
+// mapped spans of the owned rows from the device bitmap (once per lensmap)
+static int ensure_spans(bk_ctx *ctx)
+{
+    if (ctx->spans_valid) return BK_OK;
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    const size_t words = (px + 63) / 64;
+    if (int r = bk::launch_mask(ctx)) return r;
+    BK_HIP(ctx, hipMemcpyAsync(ctx->h_mask, ctx->d_mask, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->spans.clear();
+    for (int r = 0; r < ctx->rows(); ++r) {
+        int start = -1;
+        for (int x = 0; x <= ctx->W; ++x) {
+            bool m = false;
+            if (x < ctx->W) {
+                const size_t i = (size_t)r * ctx->W + x;
+                m = (ctx->h_mask[i >> 6] >> (i & 63)) & 1u;
+            }
+            if (m && start < 0) start = x;
+            if (!m && start >= 0) { ctx->spans.push_back({r, start, x}); start = -1; }
+        }
+    }
+    ctx->spans_valid = true;
+    return BK_OK;
+}
+
+extern "C" int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int x0, int y0,
+                        int rubix_on, const uint8_t pal[BK_MAX_PLATES][256])
+{
+    if (!ctx || !dst) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_apply: no lensmap (bk_build / bk_set_lensmap first)");
+    if (frame < 0 || frame >= ctx->nframes) return ctx->fail(BK_E_INVALID, "bk_apply: bad frame %d", frame);
+    if (int r = ensure_device(ctx)) return r;
+    if (int r = ensure_spans(ctx)) return r;
+    if (int r = upload_pal(ctx, rubix_on, pal)) return r;
+    // warp the owned rows into a tight staging frame, then merge only the mapped spans
+    // into the caller's buffer (VBUFFER(x+scr_vrect.x, y+scr_vrect.y), fisheye.c:2414-2421)
+    const int rows = ctx->rows();
+    if (int r = bk::launch_apply(ctx, frame, 1, ctx->d_frame, ctx->W, 0, rubix_on)) return r;
+    BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (const bk::Span &s : ctx->spans)
+        memcpy(dst + (size_t)(y0 + ctx->row0 + s.row) * dst_pitch + x0 + s.x0,
+               ctx->h_frame + (size_t)s.row * ctx->W + s.x0, (size_t)(s.x1 - s.x0));
+    return BK_OK;
+}
+
+// ---- rubix palettes (fisheye.c:835-908), integer host precompute -----------------------------
+
+static int closest_pal_index(const uint8_t *basepal, int r, int g, int b)
+{
+    int best = 256 * 256 * 256, besti = 0;
+    for (int i = 0; i < 256; ++i) {
+        const int dr = basepal[3 * i] - r, dg = basepal[3 * i + 1] - g, db = basepal[3 * i + 2] - b;
+        const int d = dr * dr + dg * dg + db * db;
+        if (d < best) { best = d; besti = i; }   // first minimum wins, fisheye.c:847
+    }
+    return besti;
+}
+
+extern "C" void bk_create_palmap(const uint8_t *basepal, uint8_t pal_out[BK_MAX_PLATES][256])
+{
+    static const int tint[BK_MAX_PLATES][3] = {{255, 255, 255}, {0, 0, 255}, {255, 0, 0},
+                                               {255, 255, 0}, {255, 0, 255}, {0, 255, 255}};   // fisheye.c:866-886
+    const int percent = 256 / 6;
+    for (int j = 0; j < BK_MAX_PLATES; ++j)
+        for (int i = 0; i < 256; ++i) {
+            int c[3];
+            for (int k = 0; k < 3; ++k) {
+                int v = basepal[3 * i + k];
+                v += percent * (tint[j][k] - v) >> 8;                                         // fisheye.c:895
+                c[k] = v < 0 ? 0 : v > 255 ? 255 : v;
+            }
+            pal_out[j][i] = (uint8_t)closest_pal_index(basepal, c[0], c[1], c[2]);
+        }
+}

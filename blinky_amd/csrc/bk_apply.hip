@@ -1,0 +1,202 @@
+// bk_apply.hip -- lensmap APPLY for gfx950: the per-frame 8-bit palettised gather.
+//
+// replaces render_lensmap (engine/NQ/fisheye.c:2406-2424):
+//     if (*lmap) dst = rubix && tint != 255 ? palette[tint][**lmap] : **lmap
+// Unmapped pixels (BK_NULL_OFFSET) leave dst untouched.
+//
+// Data in HBM:
+//     lensmap  u32 [rows][W]     offset = plate*ps*ps + py*ps + px   (4 B/px, streamed once)
+//     tints    u8  [rows][W]     only read when rubix is on
+//     globe    u8  [F][6][ps][ps]
+//     dst      u8  [F][..pitch..]
+// Pure integer/byte work bound by HBM bandwidth: 6 algorithmic B/px (4 index + 1 texel + 1 store).
+#include "bk_internal.h"
+
+namespace bk {
+
+// ---------------------------------------------------------------------------------------
+// Variant 0: direct gather.  One thread = 4 consecutive pixels of one row: one 16-byte
+// coalesced index load, 4 byte gathers per frame, one packed dword store per frame.
+// A launch covers `nframes` frames; each thread re-uses its 4 indices for `fchunk` frames
+// (the lensmap is frame-invariant), so index traffic is amortised across a batch.
+// ---------------------------------------------------------------------------------------
+template <bool RUBIX>
+__global__ __launch_bounds__(256) void apply_direct4(
+    const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
+    const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
+    uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
+    int W, int groups_per_row, int ngroups, int nframes, int fchunk,
+    const uint8_t *__restrict__ pal)
+{
+    __shared__ uint8_t s_pal[RUBIX ? BK_MAX_PLATES * 256 : 4];
+    if (RUBIX) {
+        for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += blockDim.x) s_pal[i] = pal[i];
+        __syncthreads();
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const int row = g / groups_per_row;
+    const int x = (g - row * groups_per_row) * 4;
+    const size_t px = (size_t)row * W + x;
+    const uint4 idx = *reinterpret_cast<const uint4 *>(lmap + px);
+    const uint32_t o[4] = {idx.x, idx.y, idx.z, idx.w};
+    if ((o[0] & o[1] & o[2] & o[3]) == BK_NULL_OFFSET) return;   // all four unmapped
+    const bool all = o[0] != BK_NULL_OFFSET && o[1] != BK_NULL_OFFSET &&
+                     o[2] != BK_NULL_OFFSET && o[3] != BK_NULL_OFFSET;
+    uint32_t t4 = 0xFFFFFFFFu;
+    if (RUBIX) t4 = *reinterpret_cast<const uint32_t *>(tints + px);
+
+    const int f_begin = blockIdx.y * fchunk;
+    const int f_end = min(nframes, f_begin + fchunk);
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row * dst_pitch + x;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = o[k] != BK_NULL_OFFSET ? gl[o[k]] : 0u;
+        if (RUBIX) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t t = (t4 >> (8 * k)) & 0xFFu;
+                if (t != 255u) v[k] = s_pal[t * 256 + v[k]];
+            }
+        }
+        if (all && ((reinterpret_cast<uintptr_t>(out) & 3u) == 0)) {
+            *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (o[k] != BK_NULL_OFFSET) out[k] = (uint8_t)v[k];
+        }
+    }
+}
+
+// scalar form for widths that are not a multiple of 4
+template <bool RUBIX>
+__global__ __launch_bounds__(256) void apply_direct1(
+    const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
+    const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
+    uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
+    int W, int npix, int nframes, int fchunk, const uint8_t *__restrict__ pal)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t o = lmap[i];
+    if (o == BK_NULL_OFFSET) return;
+    const int row = i / W, x = i - row * W;
+    const uint32_t t = RUBIX ? tints[i] : 255u;
+    const int f_begin = blockIdx.y * fchunk;
+    const int f_end = min(nframes, f_begin + fchunk);
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        uint32_t v = gl[o];
+        if (RUBIX && t != 255u) v = pal[t * 256 + v];
+        dst[(size_t)f * frame_stride + (size_t)row * dst_pitch + x] = (uint8_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mapped-pixel bitmap: one wave ballot per 64 pixels (bit i = pixel i mapped).
+// Used by the host to merge a warped frame into vid.buffer span by span.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_kernel(const uint32_t *__restrict__ lmap, size_t npix,
+                                                   uint64_t *__restrict__ mask)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mapped = i < npix && lmap[i] != BK_NULL_OFFSET;
+    const uint64_t b = __ballot(mapped);
+    if ((threadIdx.x & 63) == 0 && i < npix) mask[i >> 6] = b;
+}
+
+// ---------------------------------------------------------------------------------------
+// synthetic plates: SURVEY.md 8(d)  s0 = seed, s <- s*1664525 + 1013904223, texel = s>>24.
+// Each thread jumps ahead to its first element by composing the affine map in O(log i).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, size_t n, uint32_t seed)
+{
+    constexpr int K = 16;
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K;
+    if (i0 >= n) return;
+    uint32_t A = 1u, C = 0u, a = 1664525u, c = 1013904223u;
+    for (size_t e = i0; e; e >>= 1) {
+        if (e & 1) { A = a * A; C = a * C + c; }
+        c = a * c + c;
+        a = a * a;
+    }
+    uint32_t s = A * seed + C;
+    uint32_t w[4] = {0, 0, 0, 0};
+    const int cnt = (int)min((size_t)K, n - i0);
+    for (int k = 0; k < cnt; ++k) {
+        s = s * 1664525u + 1013904223u;
+        w[k >> 2] |= (s >> 24) << (8 * (k & 3));
+    }
+    if (cnt == K && ((reinterpret_cast<uintptr_t>(dst + i0) & 15u) == 0)) {
+        *reinterpret_cast<uint4 *>(dst + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int k = 0; k < cnt; ++k) dst[i0 + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+// dst = address of pixel (0, row0) of frame 0, i.e. the first owned row
+int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pitch,
+                 size_t frame_stride, int rubix_on)
+{
+    const int rows = ctx->rows();
+    if (rows <= 0 || nframes <= 0) return BK_OK;
+    const size_t gstride = (size_t)BK_MAX_PLATES * ctx->ps * ctx->ps;
+    const int fchunk = nframes < 8 ? nframes : 8;
+    const int fblocks = (nframes + fchunk - 1) / fchunk;
+    if (ctx->W % 4 == 0) {
+        const int gpr = ctx->W / 4;
+        const int ngroups = gpr * rows;
+        dim3 grid((ngroups + 255) / 256, fblocks);
+        if (rubix_on)
+            hipLaunchKernelGGL(apply_direct4<true>, grid, dim3(256), 0, ctx->stream, ctx->d_offsets,
+                               ctx->d_tints, ctx->d_globe, gstride, ctx->nframes, frame0, dst,
+                               dst_pitch, frame_stride, ctx->W, gpr, ngroups, nframes, fchunk, ctx->d_pal);
+        else
+            hipLaunchKernelGGL(apply_direct4<false>, grid, dim3(256), 0, ctx->stream, ctx->d_offsets,
+                               ctx->d_tints, ctx->d_globe, gstride, ctx->nframes, frame0, dst,
+                               dst_pitch, frame_stride, ctx->W, gpr, ngroups, nframes, fchunk, ctx->d_pal);
+    } else {
+        const int npix = ctx->W * rows;
+        dim3 grid((npix + 255) / 256, fblocks);
+        if (rubix_on)
+            hipLaunchKernelGGL(apply_direct1<true>, grid, dim3(256), 0, ctx->stream, ctx->d_offsets,
+                               ctx->d_tints, ctx->d_globe, gstride, ctx->nframes, frame0, dst,
+                               dst_pitch, frame_stride, ctx->W, npix, nframes, fchunk, ctx->d_pal);
+        else
+            hipLaunchKernelGGL(apply_direct1<false>, grid, dim3(256), 0, ctx->stream, ctx->d_offsets,
+                               ctx->d_tints, ctx->d_globe, gstride, ctx->nframes, frame0, dst,
+                               dst_pitch, frame_stride, ctx->W, npix, nframes, fchunk, ctx->d_pal);
+    }
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+int launch_mask(bk_ctx *ctx)
+{
+    const size_t npix = (size_t)ctx->W * ctx->rows();
+    if (!npix) return BK_OK;
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->d_offsets, npix, ctx->d_mask);
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+int launch_fill_lcg(bk_ctx *ctx, uint8_t *dst, size_t n, uint32_t seed)
+{
+    const size_t threads = (n + 15) / 16;
+    hipLaunchKernelGGL(lcg_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                       dst, n, seed);
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+void tilemap_invalidate(bk_ctx *) {}
+void tilemap_free(TileMap *) {}
+
+}  // namespace bk

@@ -1,0 +1,103 @@
+// bk_internal.h -- private state of libblinkyhip.so (see include/blinky_hip.h for the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/blinky_hip.h"
+
+namespace bk {
+
+// A run of mapped pixels in one output row (host-side, for merging a warped
+// frame into the caller's vid.buffer without touching unmapped pixels).
+struct Span { int row, x0, x1; };
+
+struct Rubix { int numcells = 10; double cell = 4, pad = 1; };   // defaults: fisheye.c:672
+
+struct LensProgram;   // bk_lens.cpp: parsed scripts + hiprtc modules
+struct TileMap;       // bk_apply.hip: compact tiled lensmap for the staged apply kernel
+
+}  // namespace bk
+
+struct bk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // geometry (fisheye.c:704-708)
+    int W = 0, H = 0, ps = 0;
+    int row0 = 0, row1 = 0;          // owned output rows
+    int nframes = 1;
+
+    // globe (fisheye.c:334-377)
+    bk_plate plates[BK_MAX_PLATES] = {};
+    int numplates = 0;
+    bool globe_valid = false;
+    int display[BK_MAX_PLATES] = {};
+
+    // zoom / rubix (fisheye.c:453-474)
+    int zoom_type = BK_ZOOM_NONE, zoom_fov = 0;
+    double scale = -1;
+    bk::Rubix rubix;
+
+    // device memory
+    uint8_t *d_globe = nullptr;      // [nframes][6][ps][ps]
+    uint32_t *d_offsets = nullptr;   // [row1-row0][W]
+    uint8_t *d_tints = nullptr;      // [row1-row0][W]
+    uint8_t *d_frame = nullptr;      // [row1-row0][W] staging for bk_apply (host dst)
+    uint8_t *d_pal = nullptr;        // [6][256]
+    uint64_t *d_mask = nullptr;      // mapped bits, 1 per pixel of the owned rows
+    int *d_display = nullptr;        // [6] display flags written by the build kernels
+    uint8_t *h_frame = nullptr;      // pinned, [row1-row0][W]
+    uint64_t *h_mask = nullptr;      // pinned
+    size_t globe_bytes = 0;          // allocated size of d_globe
+    size_t map_px = 0;               // allocated pixels for the map buffers
+
+    bool lensmap_valid = false;
+    std::vector<bk::Span> spans;     // mapped spans of the owned rows
+    bool spans_valid = false;
+
+    int apply_variant = -1;          // -1 auto
+    bk::TileMap *tilemap = nullptr;       // owned; freed with bk::tilemap_free
+    bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
+    double last_build_ms = 0;
+
+    int fail(int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)))
+    {
+        char buf[2048];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    int rows() const { return row1 - row0; }
+};
+
+#define BK_HIP(ctx, expr)                                                               \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return (ctx)->fail(BK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace bk {
+
+// bk_apply.hip
+int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,
+                 size_t frame_stride, int rubix_on);
+int launch_mask(bk_ctx *ctx);                 // d_offsets -> d_mask
+int launch_fill_lcg(bk_ctx *ctx, uint8_t *dst, size_t n, uint32_t seed);
+void tilemap_invalidate(bk_ctx *ctx);
+void tilemap_free(TileMap *);
+
+// bk_lens.cpp
+void lensprogram_free(LensProgram *);
+
+}  // namespace bk

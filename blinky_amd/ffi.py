@@ -1,0 +1,221 @@
+"""ctypes binding of include/blinky_hip.h (1:1, no logic of its own)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblinkyhip.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C blinky_amd/csrc`).  There is no CPU fallback."
+    )
+lib = C.CDLL(LIB_PATH)
+
+MAX_PLATES = 6
+NULL_OFFSET = 0xFFFFFFFF
+OK = 0
+MAP_NONE, MAP_INVERSE, MAP_FORWARD = 0, 1, 2
+ZOOM_NONE, ZOOM_FOV, ZOOM_VFOV, ZOOM_COVER, ZOOM_CONTAIN = range(5)
+
+
+class Plate(C.Structure):
+    _fields_ = [("forward", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov", C.c_float), ("dist", C.c_float)]
+
+
+class LensInfo(C.Structure):
+    _fields_ = [("map_type", C.c_int), ("has_inverse", C.c_int), ("has_forward", C.c_int),
+                ("max_fov", C.c_int), ("max_vfov", C.c_int),
+                ("lens_width", C.c_double), ("lens_height", C.c_double), ("onload", C.c_char * 128)]
+
+
+_vp, _i, _sz, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+_SIGS = {
+    "bk_create": (_vp, [_i]),
+    "bk_destroy": (None, [_vp]),
+    "bk_last_error": (C.c_char_p, [_vp]),
+    "bk_set_stream": (_i, [_vp, _vp]),
+    "bk_synchronize": (_i, [_vp]),
+    "bk_load_globe": (_i, [_vp, C.c_char_p, _sz, C.c_char_p]),
+    "bk_load_lens": (_i, [_vp, C.c_char_p, _sz, C.c_char_p]),
+    "bk_get_lens_info": (_i, [_vp, C.POINTER(LensInfo)]),
+    "bk_get_globe": (_i, [_vp, C.POINTER(Plate), C.POINTER(_i)]),
+    "bk_set_globe_plates": (_i, [_vp, C.POINTER(Plate), _i]),
+    "bk_resize": (_i, [_vp, _i, _i]),
+    "bk_set_rows": (_i, [_vp, _i, _i]),
+    "bk_set_frames": (_i, [_vp, _i]),
+    "bk_set_zoom": (_i, [_vp, _i, _i]),
+    "bk_set_rubixgrid": (_i, [_vp, _i, _d, _d]),
+    "bk_build": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
+    "bk_calc_zoom": (_i, [_vp, C.POINTER(_d)]),
+    "bk_set_lensmap": (_i, [_vp, _vp, _vp]),
+    "bk_read_lensmap": (_i, [_vp, _vp, _vp]),
+    "bk_upload_plate": (_i, [_vp, _i, _i, _vp, _i]),
+    "bk_globe_device_ptr": (_vp, [_vp, _i]),
+    "bk_fill_plate_lcg": (_i, [_vp, _i, _i, C.c_uint32]),
+    "bk_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "bk_apply_device": (_i, [_vp, _i, _i, _vp, _i, _sz, _i, _i, _i, _vp]),
+    "bk_create_palmap": (None, [_vp, _vp]),
+    "bk_get_size": (_i, [_vp] + [C.POINTER(_i)] * 5),
+    "bk_version": (C.c_char_p, []),
+    "bk_set_apply_variant": (_i, [_vp, _i]),
+    "bk_last_build_ms": (_d, [_vp]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch
+    _fn.restype, _fn.argtypes = _res, _args
+
+EXPORTS = tuple(_SIGS)
+
+
+class BlinkyError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Thin object wrapper over a ``bk_ctx*``."""
+
+    def __init__(self, device=-1):
+        self._h = lib.bk_create(device)
+        if not self._h:
+            raise BlinkyError(lib.bk_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            lib.bk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise BlinkyError(f"[{rc}] {lib.bk_last_error(self._h).decode()}")
+
+    # lifecycle
+    def set_stream(self, stream_handle):
+        self._chk(lib.bk_set_stream(self._h, stream_handle))
+
+    def synchronize(self):
+        self._chk(lib.bk_synchronize(self._h))
+
+    # scripts
+    def load_globe(self, src, name="globe"):
+        b = src.encode() if isinstance(src, str) else src
+        self._chk(lib.bk_load_globe(self._h, b, len(b), name.encode()))
+
+    def load_lens(self, src, name="lens"):
+        b = src.encode() if isinstance(src, str) else src
+        self._chk(lib.bk_load_lens(self._h, b, len(b), name.encode()))
+
+    def lens_info(self):
+        info = LensInfo()
+        self._chk(lib.bk_get_lens_info(self._h, C.byref(info)))
+        return info
+
+    def globe(self):
+        plates = (Plate * MAX_PLATES)()
+        n = _i()
+        self._chk(lib.bk_get_globe(self._h, plates, C.byref(n)))
+        return list(plates)[: n.value]
+
+    def set_globe_plates(self, plates):
+        arr = (Plate * len(plates))(*plates)
+        self._chk(lib.bk_set_globe_plates(self._h, arr, len(plates)))
+
+    # geometry
+    def resize(self, w, h):
+        self._chk(lib.bk_resize(self._h, w, h))
+
+    def set_rows(self, r0, r1):
+        self._chk(lib.bk_set_rows(self._h, r0, r1))
+
+    def set_frames(self, n):
+        self._chk(lib.bk_set_frames(self._h, n))
+
+    def set_zoom(self, ztype, fov=0):
+        self._chk(lib.bk_set_zoom(self._h, ztype, fov))
+
+    def set_rubixgrid(self, numcells, cell, pad):
+        self._chk(lib.bk_set_rubixgrid(self._h, numcells, cell, pad))
+
+    def size(self):
+        v = [_i() for _ in range(5)]
+        self._chk(lib.bk_get_size(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    # build
+    def build(self):
+        disp = (_i * MAX_PLATES)()
+        scale = _d()
+        self._chk(lib.bk_build(self._h, disp, C.byref(scale)))
+        return list(disp), scale.value
+
+    def calc_zoom(self):
+        scale = _d()
+        self._chk(lib.bk_calc_zoom(self._h, C.byref(scale)))
+        return scale.value
+
+    def last_build_ms(self):
+        return lib.bk_last_build_ms(self._h)
+
+    def set_lensmap(self, offsets, tints=None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        if tints is not None:
+            tints = np.ascontiguousarray(tints, dtype=np.uint8)
+        self._chk(lib.bk_set_lensmap(self._h, _ptr(offsets), _ptr(tints)))
+
+    def read_lensmap(self):
+        w, h, ps, r0, r1 = self.size()
+        off = np.empty((r1 - r0) * w, np.uint32)
+        tin = np.empty((r1 - r0) * w, np.uint8)
+        self._chk(lib.bk_read_lensmap(self._h, _ptr(off), _ptr(tin)))
+        return off, tin
+
+    # globe
+    def upload_plate(self, frame, plate, src, pitch=None):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if pitch is None:
+            pitch = src.shape[-1]
+        self._chk(lib.bk_upload_plate(self._h, frame, plate, _ptr(src), pitch))
+
+    def globe_device_ptr(self, frame=0):
+        return lib.bk_globe_device_ptr(self._h, frame)
+
+    def fill_plate_lcg(self, frame, plate, seed_frame=None):
+        self._chk(lib.bk_fill_plate_lcg(self._h, frame, plate, frame if seed_frame is None else seed_frame))
+
+    # apply
+    def apply(self, dst, frame=0, pitch=None, x0=0, y0=0, rubix_on=False, pal=None):
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        if pitch is None:
+            pitch = dst.shape[-1]
+        if pal is not None:
+            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        self._chk(lib.bk_apply(self._h, frame, _ptr(dst), pitch, x0, y0, int(rubix_on), _ptr(pal)))
+        return dst
+
+    def apply_device(self, dst_ptr, pitch, frame_stride, frame0=0, nframes=1, x0=0, y0=0,
+                     rubix_on=False, pal=None):
+        if pal is not None:
+            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
+                                      int(rubix_on), _ptr(pal)))
+
+    def set_apply_variant(self, v):
+        self._chk(lib.bk_set_apply_variant(self._h, v))
+
+
+def create_palmap(basepal):
+    basepal = np.ascontiguousarray(basepal, dtype=np.uint8)
+    out = np.empty((MAX_PLATES, 256), np.uint8)
+    lib.bk_create_palmap(_ptr(basepal), _ptr(out))
+    return out

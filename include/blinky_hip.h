@@ -1,0 +1,146 @@
+/*
+ * blinky_hip.h -- C ABI of libblinkyhip.so: the MI355X (gfx950) implementation of
+ * Blinky's globe->screen warp (lensmap build + per-frame lensmap apply).
+ *
+ * The reference has no FFI for this path: engine/NQ/fisheye.c is one C
+ * translation unit of static functions (engine/include/fisheye.h:4-9 is its
+ * whole public face).  This header is the seam a maintainer binds instead of
+ * those statics; every entry point names the reference code it replaces
+ * (paths relative to /root/reference/engine).  Plain C types only; the host
+ * side (blinky_amd/host/fisheye_hip.c) stays C, exactly like the reference.
+ *
+ * Conventions
+ *   - every int-returning function returns BK_OK (0) or a negative BK_E_* code;
+ *     bk_last_error() gives the message (the reference's Con_Printf text where
+ *     one exists).  Nothing ever exit()s (the reference does on OOM, fisheye.c:723-726).
+ *   - a lensmap entry is offset = ptr - globe.pixels = plate*ps*ps + py*ps + px
+ *     (GLOBEPIXEL, fisheye.c:349) as uint32, BK_NULL_OFFSET for a NULL pointer;
+ *     tints are the bytes of lens.pixel_tints (255 = none, fisheye.c:432-449).
+ *   - all device work is enqueued on the context's HIP stream (bk_set_stream);
+ *     host-pointer entry points are synchronous with respect to their buffers.
+ *   - there is no CPU fallback: without a usable GPU bk_create fails.
+ */
+#ifndef BLINKY_HIP_H
+#define BLINKY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_MAX_PLATES   6             /* MAX_PLATES, fisheye.c:352 */
+#define BK_NULL_OFFSET  0xFFFFFFFFu
+
+enum {
+    BK_OK = 0,
+    BK_E_INVALID = -1,     /* bad argument / call order */
+    BK_E_HIP = -2,         /* HIP runtime or hiprtc failure (message has the detail) */
+    BK_E_SCRIPT = -3,      /* lens / globe script failed to load, run or compile */
+    BK_E_ZOOM = -4,        /* calc_zoom() failure (fisheye.c:1293-1386) */
+    BK_E_NOMEM = -5,
+    BK_E_STATE = -6        /* no valid lens/globe/lensmap for the requested operation */
+};
+
+enum { BK_MAP_NONE = 0, BK_MAP_INVERSE = 1, BK_MAP_FORWARD = 2 };                 /* fisheye.c:391 */
+enum { BK_ZOOM_NONE = 0, BK_ZOOM_FOV, BK_ZOOM_VFOV, BK_ZOOM_COVER, BK_ZOOM_CONTAIN }; /* fisheye.c:457 */
+
+typedef struct bk_ctx bk_ctx;
+
+/* One globe plate as LUA_load_globe leaves it (fisheye.c:353-361, 1796-1869). */
+typedef struct {
+    float forward[3], right[3], up[3];
+    float fov;      /* radians */
+    float dist;     /* 0.5 / tan(fov/2) */
+} bk_plate;
+
+/* What LUA_load_lens reads back from the script's globals (fisheye.c:1684-1747). */
+typedef struct {
+    int    map_type;             /* BK_MAP_* after the `map` override */
+    int    has_inverse, has_forward;
+    int    max_fov, max_vfov;    /* 0 when absent */
+    double lens_width, lens_height;   /* 0 when absent */
+    char   onload[128];          /* "" when absent or not a string (fisheye.c:1087-1102) */
+} bk_lens_info;
+
+/* ---- lifecycle -------------------------------------------------------------------
+ * replaces: the three malloc blocks and static state of fisheye.c (306-528, 712-727),
+ * init_lua / lua_close (fisheye.c:1222-1265, 678-681). */
+bk_ctx     *bk_create(int device);            /* device < 0: current HIP device */
+void        bk_destroy(bk_ctx *ctx);
+const char *bk_last_error(const bk_ctx *ctx); /* ctx may be NULL: error of the last failed bk_create */
+int         bk_set_stream(bk_ctx *ctx, void *hip_stream);   /* hipStream_t; NULL = default stream */
+int         bk_synchronize(bk_ctx *ctx);
+
+/* ---- scripts (the Lua callback surface) -----------------------------------------
+ * replaces: LUA_load_globe (fisheye.c:1752-1875) and LUA_load_lens (1659-1750);
+ * `src` is the text of <basedir>/lua-scripts/{globes,lenses}/<name>.lua.
+ * One interpreter state lives in the context, so script globals leak between
+ * loads exactly as in the reference (only the names of fisheye.c:1880-1903 are cleared). */
+int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
+int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
+int bk_get_lens_info(const bk_ctx *ctx, bk_lens_info *out);
+int bk_get_globe(const bk_ctx *ctx, bk_plate plates[BK_MAX_PLATES], int *numplates);
+/* bypass the script for the globe (plates already in LUA_load_globe's float form) */
+int bk_set_globe_plates(bk_ctx *ctx, const bk_plate *plates, int numplates);
+
+/* ---- geometry / parameters ------------------------------------------------------
+ * bk_resize  replaces F_RenderView's size-change block (fisheye.c:704-727): ps = min(W,H),
+ *            (re)allocates globe[6*ps*ps], lensmap[W*H], tints[W*H] in HBM.
+ * bk_set_rows restricts this context to output rows [row0,row1) (multi-GPU stripes);
+ *            the lensmap, tints and frames it holds cover only those rows.
+ * bk_set_frames sizes the resident globe ring: nframes globes of 6*ps*ps bytes. */
+int bk_resize(bk_ctx *ctx, int width, int height);
+int bk_set_rows(bk_ctx *ctx, int row0, int row1);
+int bk_set_frames(bk_ctx *ctx, int nframes);
+int bk_set_zoom(bk_ctx *ctx, int zoom_type, int fov_degrees);                       /* cmd_fov/vfov/cover/contain, fisheye.c:955-965,1032-1058 */
+int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_size); /* cmd_rubixgrid, fisheye.c:939-953 */
+
+/* ---- lensmap build ----------------------------------------------------------------
+ * replaces: create_lensmap (fisheye.c:2367-2397) = calc_zoom + resume_lensmap_inverse
+ * (2084-2124) or resume_lensmap_forward (2126-2217), run to completion on the GPU,
+ * including the NULL/255 clears of F_RenderView (731-732).
+ * display_out (nullable) receives globe.plates[i].display; scale_out lens.scale. */
+int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
+int bk_calc_zoom(bk_ctx *ctx, double *scale_out);                                   /* calc_zoom only */
+/* direct access to the table (lens.pixels / lens.pixel_tints of the owned rows) */
+int bk_set_lensmap(bk_ctx *ctx, const uint32_t *offsets, const uint8_t *tints);
+int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints);
+
+/* ---- globe plates -------------------------------------------------------------------
+ * bk_upload_plate replaces render_plate's row memcpy loop (fisheye.c:2441-2449):
+ * ps rows of ps bytes from src (pitch src_pitch) into plate `plate` of globe `frame`. */
+int   bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch);
+void *bk_globe_device_ptr(bk_ctx *ctx, int frame);   /* device address of globe `frame` (6*ps*ps bytes) */
+/* synthetic plates: the SURVEY.md 8(d) LCG stream generated on the device */
+int   bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t seed_frame);
+
+/* ---- lensmap apply ------------------------------------------------------------------
+ * replaces: render_lensmap (fisheye.c:2406-2424).  Unmapped pixels leave dst untouched.
+ * pal (nullable unless rubix_on): the 6 tint LUTs of create_palmap (fisheye.c:857-908).
+ * bk_apply        dst is host memory (vid.buffer), pitch vid.rowbytes, origin scr_vrect.{x,y};
+ *                 it is synchronous.  Only the owned rows are touched.
+ * bk_apply_device dst is device memory holding nframes frames of frame_stride bytes each;
+ *                 frame f is warped from globe (frame0+f) % nframes_resident.  Asynchronous on the stream. */
+int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int x0, int y0,
+             int rubix_on, const uint8_t pal[BK_MAX_PLATES][256]);
+int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst_pitch,
+                    size_t frame_stride, int x0, int y0, int rubix_on,
+                    const uint8_t pal[BK_MAX_PLATES][256]);
+
+/* rubix palettes: create_palmap / find_closest_pal_index (fisheye.c:835-908); basepal = 768 bytes */
+void bk_create_palmap(const uint8_t *basepal, uint8_t pal_out[BK_MAX_PLATES][256]);
+
+/* ---- introspection (tests, bench) ------------------------------------------------------ */
+int         bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesize, int *row0, int *row1);
+const char *bk_version(void);
+/* selects the apply kernel: 0 = direct gather, 1 = tiled/LDS-staged (default: best available) */
+int         bk_set_apply_variant(bk_ctx *ctx, int variant);
+/* milliseconds of the last bk_build's device work (HIP events on the context stream) */
+double      bk_last_build_ms(const bk_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

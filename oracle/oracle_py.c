@@ -1,0 +1,65 @@
+/*
+ * oracle_py.c -- CPU ORACLE (test infrastructure): flat entry points for ctypes.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* build a lensmap for (globe, lens, zoom) at W x H with the given rubix grid.
+ * returns 1 if built; fills offsets/tints (W*H), display[6], scale, numplates, map_type */
+int okpy_lensmap(const char *globe, const char *lens, const char *zoomcmd, int W, int H,
+                 int numcells, double cell, double pad,
+                 uint32_t *offsets, uint8_t *tints, int *display, double *scale,
+                 int *numplates, int *map_type)
+{
+    ok_state s;
+    int i, ok;
+    if (!ok_configure(&s, globe, lens, zoomcmd, W, H)) return -1;
+    s.rubix_numcells = numcells; s.rubix_cell = cell; s.rubix_pad = pad;
+    s.offsets = offsets; s.tints = tints;
+    ok = ok_create_lensmap(&s);
+    for (i = 0; i < OK_MAX_PLATES; ++i) display[i] = i < s.numplates ? s.plates[i].display : 0;
+    *scale = s.scale; *numplates = s.numplates; *map_type = s.map_type;
+    return ok;
+}
+
+/* plates of a transliterated globe, in LUA_load_globe's float form (13 floats per plate:
+ * forward[3] right[3] up[3] fov dist) */
+int okpy_globe(const char *globe, float *out13, int *numplates)
+{
+    ok_state s;
+    int i;
+    memset(&s, 0, sizeof s);
+    if (!ok_use_globe(&s, globe)) return 0;
+    for (i = 0; i < s.numplates; ++i) {
+        float *o = out13 + 13 * i;
+        memcpy(o, s.plates[i].forward, 12); memcpy(o + 3, s.plates[i].right, 12);
+        memcpy(o + 6, s.plates[i].up, 12); o[9] = s.plates[i].fov; o[10] = s.plates[i].dist;
+        o[11] = o[12] = 0;
+    }
+    *numplates = s.numplates;
+    return 1;
+}
+
+/* render_lensmap over a table of `rows` rows */
+void okpy_apply(const uint32_t *offsets, const uint8_t *tints, int W, int rows,
+                const uint8_t *globe, uint8_t *dst, int dst_pitch, int x0, int y0,
+                int rubix_on, const uint8_t *pal /* [6][256] or NULL */)
+{
+    ok_state s;
+    int i;
+    memset(&s, 0, sizeof s);
+    s.width_px = W; s.height_px = rows;
+    s.offsets = (uint32_t *)offsets; s.tints = (uint8_t *)tints;
+    if (pal) for (i = 0; i < OK_MAX_PLATES; ++i) memcpy(s.plates[i].palette, pal + 256 * i, 256);
+    ok_apply(&s, globe, dst, dst_pitch, x0, y0, rubix_on);
+}
+
+void okpy_palmap(const uint8_t *basepal, uint8_t *out /* [6][256] */)
+{
+    ok_state s;
+    int i;
+    memset(&s, 0, sizeof s);
+    ok_create_palmap(&s, basepal);
+    for (i = 0; i < OK_MAX_PLATES; ++i) memcpy(out + 256 * i, s.plates[i].palette, 256);
+}

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/lensmaps.json from the UNMODIFIED reference (oracle/_ref).
+
+Run in the build container (needs /root/reference):
+    make -C oracle _ref && python tests/golden/make_golden.py
+Each record pins, for one (globe, lens, zoom, W, H): lens.scale, display flags, the
+number of non-NULL entries, and FNV-1a-64 of the uint32 offset table, of the tint table
+and of one warped frame over the SURVEY.md 8(d) LCG globe (frame 0, rubix off).
+The GPU box has no /root/reference; tests there compare against this file."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_ffi as O  # noqa: E402
+
+CONFIGS = [
+    # BASELINE.json configs[0] (C1) and scaled-down / full versions of C2..C5
+    ("cube", "panini", None, 640, 480),
+    ("cube", "stereographic", None, 1920, 1080),
+    ("cube", "quincuncial", None, 640, 480),
+    ("cube", "quincuncial", None, 3840, 2160),
+    ("trism", "panini", None, 960, 540),
+    ("trism", "panini", None, 3840, 2160),
+    ("cube", "hammer", None, 960, 540),
+    ("cube", "hammer", None, 3840, 2160),
+    ("cube", "panini", None, 3840, 2160),
+    ("cube", "eckert5", None, 640, 480),          # forward map
+    ("cube", "panini", "f_fov 120", 322, 203),    # odd sizes, W%4 != 0
+    ("cube", "hammer", "f_cover", 500, 300),
+    ("cube", "stereographic", "f_vfov 90", 300, 500),   # portrait: ps = W
+]
+
+
+def main():
+    out = []
+    for globe, lens, zoom, W, H in CONFIGS:
+        lm, frame = O.ref_run(globe, lens, zoom, W, H)
+        rec = dict(globe=globe, lens=lens, zoom=zoom, W=W, H=H, built=bool(lm.built), scale=repr(lm.scale),
+                   display=lm.display, nonnull=lm.nonnull, fnv_offsets=O.fnv(lm.offsets),
+                   fnv_tints=O.fnv(lm.tints), fnv_frame=O.fnv(frame))
+        print(rec)
+        out.append(rec)
+    pal = O.ref_palettes()
+    doc = dict(source="oracle/_ref = unmodified /root/reference/engine/NQ/fisheye.c, gcc 11.4 -O2, glibc 2.35",
+               lensmaps=out, fnv_palettes=O.fnv(pal))
+    with open(os.path.join(HERE, "lensmaps.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

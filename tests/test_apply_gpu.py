@@ -1,0 +1,190 @@
+"""Parity of the HIP lensmap APPLY (bk_apply / bk_apply_device, replacing render_lensmap,
+fisheye.c:2406-2424) against the CPU oracle, through the C ABI.  Byte-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = {(r["globe"], r["lens"], r["zoom"], r["W"], r["H"]): r
+        for r in json.load(open(os.path.join(HERE, "golden", "lensmaps.json")))["lensmaps"]}
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import blinky_amd
+    return blinky_amd
+
+
+def make_ctx(bk, lm, nframes=1, rows=None):
+    ctx = bk.Context()
+    ctx.set_frames(nframes)
+    ctx.resize(lm.W, lm.H)
+    if rows:
+        ctx.set_rows(*rows)
+    return ctx
+
+
+def upload_globe(ctx, globe, frame=0):
+    for p in range(6):
+        ctx.upload_plate(frame, p, globe[p])
+
+
+VARIANTS = [0]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("cfg", [
+    ("cube", "panini", None, 640, 480),
+    ("cube", "hammer", None, 960, 540),            # 30 % unmapped
+    ("cube", "quincuncial", None, 640, 480),
+    ("trism", "panini", None, 960, 540),
+    ("cube", "panini", "f_fov 120", 322, 203),     # W % 4 != 0
+    ("cube", "stereographic", "f_vfov 90", 300, 500),   # portrait, one NULL pixel in the middle
+    ("cube", "eckert5", None, 640, 480),           # forward-built map (ragged mapped region)
+])
+@pytest.mark.parametrize("rubix", [False, True])
+def test_apply_host_matches_oracle(bk, cfg, rubix, variant):
+    lm = O.lensmap(*cfg)
+    W, H = lm.W, lm.H
+    globe = O.lcg_globe(lm.ps, 6, 3)
+    pal = O.palmap(O.synthetic_basepal())
+    ctx = make_ctx(bk, lm)
+    ctx.set_apply_variant(variant)
+    upload_globe(ctx, globe)
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    # vid.buffer larger than the view: pitch > W, origin (x0,y0), background must survive
+    pitch, x0, y0 = W + 24, 5, 3
+    bg = (np.arange((H + 7) * pitch, dtype=np.uint32) * 7 % 251).astype(np.uint8).reshape(H + 7, pitch)
+    want = O.apply(lm.offsets, lm.tints, W, H, globe, bg.copy(), pitch, x0, y0, rubix, pal)
+    got = ctx.apply(bg.copy(), 0, pitch, x0, y0, rubix, pal)
+    np.testing.assert_array_equal(got, want)
+    ctx.close()
+
+
+def test_palmap_matches_oracle(bk):
+    base = O.synthetic_basepal()
+    np.testing.assert_array_equal(bk.ffi.create_palmap(base), O.palmap(base))
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, 768, dtype=np.uint8)
+    np.testing.assert_array_equal(bk.ffi.create_palmap(base), O.palmap(base))
+
+
+def test_device_lcg_equals_oracle_stream(bk):
+    import torch
+    lm = O.lensmap("cube", "panini", None, 322, 203)    # ps = 203: odd sizes, unaligned plate starts
+    ctx = make_ctx(bk, lm, nframes=2)
+    for f in range(2):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, seed_frame=f + 4)
+    ctx.synchronize()
+    n = 6 * lm.ps * lm.ps
+    for f in range(2):
+        dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(dev.data_ptr(), ctx.globe_device_ptr(f), n, 3) == 0
+        np.testing.assert_array_equal(dev.cpu().numpy().reshape(6, lm.ps, lm.ps), O.lcg_globe(lm.ps, 6, f + 4))
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_apply_device_batch_distinct_globes(bk, variant):
+    """One launch warps a batch of frames, frame f from resident globe (frame0+f) % nframes."""
+    import torch
+    lm = O.lensmap("cube", "hammer", None, 960, 540)
+    W, H, F = lm.W, lm.H, 11          # > the kernel's per-thread frame chunk
+    ctx = make_ctx(bk, lm, nframes=F)
+    ctx.set_apply_variant(variant)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for f in range(F):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, seed_frame=f)
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    pitch = W + 8
+    out = torch.full((F, H + 2, pitch), 9, dtype=torch.uint8, device="cuda")
+    ctx.apply_device(out.data_ptr(), pitch, (H + 2) * pitch, frame0=3, nframes=F, x0=4, y0=1)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for f in range(F):
+        want = np.full((H + 2, pitch), 9, np.uint8)
+        O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, (3 + f) % F), want, pitch, 4, 1)
+        np.testing.assert_array_equal(got[f], want, err_msg=f"frame {f}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_row_stripes_reassemble_to_full_frame(bk, variant):
+    """Multi-GPU sharding unit: a context owning rows [r0,r1) touches only those rows and the
+    stripes of all 'ranks' reassemble to the oracle's full frame (uneven split included)."""
+    lm = O.lensmap("trism", "panini", None, 960, 540)
+    W, H = lm.W, lm.H
+    globe = O.lcg_globe(lm.ps, 6, 1)
+    want = O.apply(lm.offsets, lm.tints, W, H, globe, np.zeros((H, W), np.uint8))
+    frame = np.zeros((H, W), np.uint8)
+    bounds = [0, 100, 101, 333, 540]
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        ctx = make_ctx(bk, lm, rows=(r0, r1))
+        ctx.set_apply_variant(variant)
+        upload_globe(ctx, globe)
+        ctx.set_lensmap(lm.offsets.reshape(H, W)[r0:r1], lm.tints.reshape(H, W)[r0:r1])
+        before = frame.copy()
+        ctx.apply(frame)
+        assert np.array_equal(frame[:r0], before[:r0]) and np.array_equal(frame[r1:], before[r1:])
+        ctx.close()
+    np.testing.assert_array_equal(frame, want)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_empty_and_single_pixel_maps(bk, variant):
+    lm = O.lensmap("cube", "panini", None, 64, 48)
+    ctx = make_ctx(bk, lm)
+    ctx.set_apply_variant(variant)
+    upload_globe(ctx, O.lcg_globe(48, 6, 0))
+    off = np.full(64 * 48, O.NULL, np.uint32)
+    ctx.set_lensmap(off, None)
+    dst = np.full((48, 64), 77, np.uint8)
+    ctx.apply(dst)
+    assert (dst == 77).all()                      # nothing mapped -> nothing written
+    off[5 * 64 + 9] = 6 * 48 * 48 - 1             # last texel of the last plate
+    ctx.set_lensmap(off, None)
+    ctx.apply(dst)
+    want = np.full((48, 64), 77, np.uint8)
+    want[5, 9] = O.lcg_globe(48, 6, 0).ravel()[-1]
+    np.testing.assert_array_equal(dst, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("key", [("cube", "panini", None, 3840, 2160), ("cube", "hammer", None, 3840, 2160)])
+def test_apply_4k_frame_hash_equals_reference_golden(bk, key, variant):
+    """BASELINE.json full size: the frame hash recorded from the unmodified reference."""
+    rec = GOLD[key]
+    lm = O.lensmap(*key)
+    assert O.fnv(lm.offsets) == rec["fnv_offsets"]
+    ctx = make_ctx(bk, lm)
+    ctx.set_apply_variant(variant)
+    for p in range(lm.numplates):
+        ctx.fill_plate_lcg(0, p, seed_frame=0)
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    frame = ctx.apply(np.zeros((lm.H, lm.W), np.uint8))
+    assert O.fnv(frame) == rec["fnv_frame"]
+    ctx.close()
+
+
+def test_errors_are_reported_not_fatal(bk):
+    ctx = bk.Context()
+    with pytest.raises(bk.BlinkyError):
+        ctx.resize(0, 10)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match="no lensmap"):
+        ctx.apply(np.zeros((48, 64), np.uint8))
+    with pytest.raises(bk.BlinkyError):
+        ctx.set_rows(10, 100)
+    ctx.close()

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Developer probe (not the bench): time the apply kernel variants on oracle-built lensmaps.
+usage: python tools/apply_probe.py [lens] [W] [H] [frames] [variant...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import blinky_amd
+import oracle_ffi as O
+
+lens = sys.argv[1] if len(sys.argv) > 1 else "panini"
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 2160
+F = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+variants = [int(v) for v in sys.argv[5:]] or [0]
+
+t = time.time()
+lm = O.lensmap("cube", lens, None, W, H)
+print(f"oracle lensmap {lens} {W}x{H}: {time.time()-t:.2f}s nonnull={lm.nonnull}", flush=True)
+ctx = blinky_amd.Context()
+ctx.set_frames(F)
+ctx.resize(W, H)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+for f in range(F):
+    for p in range(6):
+        ctx.fill_plate_lcg(f, p, f)
+ctx.set_lensmap(lm.offsets, lm.tints)
+out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
+for v in variants:
+    ctx.set_apply_variant(v)
+    for nf in sorted(set([1, F])):
+        for _ in range(3):
+            ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)
+        torch.cuda.synchronize()
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(reps):
+            ctx.apply_device(out.data_ptr(), W, H * W, (r * nf) % F, nf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        px = W * H * nf
+        print(f"variant {v} frames/launch {nf}: {ms*1e3/nf:.2f} us/frame  {px/ms/1e3:.0f} Mpx/s  "
+              f"algorithmic {6*px/ms/1e9:.2f} TB/s = {6*px/ms/1e9/8*100:.1f}% of 8 TB/s", flush=True)
