@@ -4,6 +4,14 @@ import os
 
 import numpy as np
 
+try:
+    # torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first in a process
+    # is the only one that sees the GPU, so when torch is installed it must be loaded before
+    # libblinkyhip.so pulls in the system runtime (bench.py / tests share device memory with torch).
+    import torch  # noqa: F401
+except ImportError:  # the C host layer (blinky_amd/host) does not need torch at all
+    torch = None
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblinkyhip.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError(
