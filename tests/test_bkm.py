@@ -1,0 +1,139 @@
+"""Accuracy of the portable libm blinky_amd/csrc/bkm.h (host build) against mpmath, and the
+special values C99 Annex F prescribes.  The same header is compiled by hiprtc into the lensmap
+build kernels; tests/test_build_gpu.py checks the device build is bit-identical to this one."""
+import ctypes as C
+import math
+import os
+
+import mpmath as mp
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = C.CDLL(os.path.join(ROOT, "blinky_amd", "libbkm_host.so"))
+lib.bkmh_map1.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_long]
+lib.bkmh_map2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+mp.mp.prec = 220
+rng = np.random.default_rng(20240924)
+N = 700
+
+
+def f1(name, xs):
+    xs = np.ascontiguousarray(xs, np.float64)
+    out = np.empty_like(xs)
+    lib.bkmh_map1(name.encode(), xs.ctypes.data, out.ctypes.data, len(xs))
+    return out
+
+
+def f2(name, xs, ys):
+    xs = np.ascontiguousarray(xs, np.float64)
+    ys = np.ascontiguousarray(ys, np.float64)
+    out = np.empty_like(xs)
+    lib.bkmh_map2(name.encode(), xs.ctypes.data, ys.ctypes.data, out.ctypes.data, len(xs))
+    return out
+
+
+def err_ulps(got, exact):
+    if abs(exact) > mp.mpf(1.7976931348623157e308):
+        return 0.0 if math.isinf(got) else float("inf")
+    ref = float(exact)
+    u = math.ulp(ref) if ref != 0 else 5e-324
+    return float(abs(mp.mpf(got) - exact) / mp.mpf(u))
+
+
+def u(a, b, n=N):
+    return rng.uniform(a, b, n)
+
+
+def logu(a, b, n=N):
+    return np.exp(rng.uniform(math.log(a), math.log(b), n)) * rng.choice([-1.0, 1.0], n)
+
+
+TRIG = lambda: np.concatenate([u(-10, 10), logu(1e-8, 1e6), logu(1e6, 1e300, N // 4),
+                               np.arange(1, 120) * math.pi / 2, np.arange(1, 120) * math.pi / 32])
+CASES1 = {
+    "sin": (TRIG, mp.sin), "cos": (TRIG, mp.cos), "tan": (TRIG, mp.tan),
+    "atan": (lambda: np.concatenate([u(-3, 3), logu(1e-9, 1e9)]), mp.atan),
+    "asin": (lambda: np.concatenate([u(-1, 1), logu(1e-9, 1), 1 - logu(1e-16, 1e-3, N // 4) ** 2]), mp.asin),
+    "acos": (lambda: np.concatenate([u(-1, 1), logu(1e-9, 1), 1 - logu(1e-16, 1e-3, N // 4) ** 2]), mp.acos),
+    "exp": (lambda: np.concatenate([u(-5, 5), u(-745, 709), logu(1e-10, 1)]), mp.exp),
+    "log": (lambda: np.concatenate([u(0.5, 2), np.abs(logu(1e-300, 1e300)), 1 + logu(1e-12, 1e-2, N // 4),
+                                    np.abs(logu(1e-320, 1e-308, 40))]), mp.log),
+    "log10": (lambda: np.concatenate([u(0.5, 2), np.abs(logu(1e-300, 1e300))]), mp.log10),
+    "sinh": (lambda: np.concatenate([u(-3, 3), logu(1e-9, 700)]), mp.sinh),
+    "cosh": (lambda: np.concatenate([u(-3, 3), logu(1e-9, 700)]), mp.cosh),
+    "tanh": (lambda: np.concatenate([u(-3, 3), logu(1e-9, 30)]), mp.tanh),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES1))
+def test_unary_within_0p52_ulp(name):
+    gen, exact = CASES1[name]
+    xs = gen()
+    got = f1(name, xs)
+    worst = max(err_ulps(float(g), exact(mp.mpf(float(x)))) for x, g in zip(xs, got))
+    assert worst < 0.52, f"{name}: worst error {worst} ulp"
+
+
+def test_atan2_pow_within_0p52_ulp():
+    xs = np.concatenate([u(-3, 3), logu(1e-9, 1e9), logu(1e-300, 1e300)])
+    ys = np.concatenate([u(-3, 3), logu(1e-9, 1e9), logu(1e-300, 1e300)])
+    got = f2("atan2", ys, xs)
+    worst = max(err_ulps(float(g), mp.atan2(mp.mpf(float(y)), mp.mpf(float(x)))) for x, y, g in zip(xs, ys, got))
+    assert worst < 0.52
+    xs = np.concatenate([u(0.1, 3), np.abs(logu(1e-5, 1e5)), u(0.01, 4)])
+    ys = np.concatenate([u(-5, 5), u(-60, 60), rng.integers(-6, 7, N).astype(float)])
+    got = f2("pow", xs, ys)
+    worst = max(err_ulps(float(g), mp.power(mp.mpf(float(x)), mp.mpf(float(y)))) for x, y, g in zip(xs, ys, got))
+    assert worst < 0.52
+
+
+def test_fmod_is_exact_and_equals_c_fmod():
+    xs = np.concatenate([u(-100, 100), logu(1e-300, 1e300), [5.0, -5.0, 0.0, 7.5, 1e308, 5e-324]])
+    ys = np.concatenate([u(-7, 7), logu(1e-300, 1e300), [5.0, 5.0, 3.0, 2.5, 3e-310, 3.0]])
+    got = f2("fmod", xs, ys)
+    want = np.array([math.fmod(x, y) for x, y in zip(xs, ys)])
+    assert (got.view(np.uint64) == want.view(np.uint64)).all()
+
+
+def test_special_values():
+    inf, nan = math.inf, math.nan
+    assert math.isnan(f1("sin", [inf])[0]) and math.isnan(f1("cos", [-inf])[0]) and math.isnan(f1("tan", [nan])[0])
+    assert f1("sin", [0.0, -0.0]).view(np.uint64).tolist() == np.array([0.0, -0.0]).view(np.uint64).tolist()
+    assert f1("cos", [0.0])[0] == 1.0
+    assert f1("atan", [inf, -inf]).tolist() == [math.pi / 2, -math.pi / 2]
+    assert math.isnan(f1("asin", [1.0000001])[0]) and math.isnan(f1("acos", [-1.5])[0])
+    assert f1("asin", [1.0, -1.0]).tolist() == [math.pi / 2, -math.pi / 2]
+    assert f1("acos", [1.0, -1.0, 0.0]).tolist() == [0.0, math.pi, math.pi / 2]
+    assert f1("exp", [-inf, inf, 0.0, 710.0, -746.0]).tolist() == [0.0, inf, 1.0, inf, 0.0]
+    assert f1("log", [0.0, inf, 1.0]).tolist() == [-inf, inf, 0.0] and math.isnan(f1("log", [-1.0])[0])
+    assert f1("tanh", [inf, -inf, 30.0]).tolist() == [1.0, -1.0, 1.0]
+    assert f1("sinh", [inf, -inf]).tolist() == [inf, -inf] and f1("cosh", [-inf])[0] == inf
+    # atan2 quadrants / zeros / infinities (C99 F.9.1.4)
+    cases = [(0.0, 1.0, 0.0), (-0.0, 1.0, -0.0), (0.0, -1.0, math.pi), (-0.0, -1.0, -math.pi),
+             (1.0, 0.0, math.pi / 2), (-1.0, 0.0, -math.pi / 2), (0.0, -0.0, math.pi), (-0.0, -0.0, -math.pi),
+             (0.0, 0.0, 0.0), (1.0, inf, 0.0), (1.0, -inf, math.pi), (inf, 1.0, math.pi / 2),
+             (inf, inf, math.pi / 4), (inf, -inf, 3 * math.pi / 4), (-inf, -inf, -3 * math.pi / 4)]
+    got = f2("atan2", [c[0] for c in cases], [c[1] for c in cases])
+    want = np.array([c[2] for c in cases])
+    assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist()
+    # pow (C99 F.9.4.4)
+    pc = [(2.0, 0.0, 1.0), (nan, 0.0, 1.0), (1.0, nan, 1.0), (-8.0, 3.0, -512.0), (-8.0, 2.0, 64.0),
+          (0.0, -1.0, inf), (-0.0, -1.0, -inf), (-0.0, 3.0, -0.0), (0.0, 2.5, 0.0), (inf, -2.0, 0.0),
+          (-inf, 3.0, -inf), (0.5, inf, 0.0), (2.0, inf, inf), (2.0, -inf, 0.0), (-1.0, inf, 1.0),
+          (3.0, 2.0, 9.0), (2.0, 0.5, math.sqrt(2.0)), (2.0, -1.0, 0.5), (10.0, 308.0, 1e308), (2.0, -1074.0, 5e-324)]
+    got = f2("pow", [c[0] for c in pc], [c[1] for c in pc])
+    want = np.array([c[2] for c in pc])
+    assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist()
+    assert math.isnan(f2("pow", [-8.0], [0.5])[0])
+
+
+def test_agreement_with_platform_libm_is_high():
+    """Informational bound: on this platform (glibc) sin/cos/atan2/atan/asin agree on >= 99.5 % of
+    random inputs - the differences are last-bit near-ties (SURVEY.md A.7 measured that +-1 ulp
+    noise moves no lensmap entry)."""
+    xs = u(-8, 8, 4000)
+    for name, fn in [("sin", math.sin), ("cos", math.cos), ("atan", math.atan)]:
+        got = f1(name, xs)
+        same = sum(1 for x, g in zip(xs, got) if fn(float(x)) == g)
+        assert same >= 0.995 * len(xs), (name, same)
