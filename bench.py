@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- Blinky warp hot path on MI355X: lensmap APPLY throughput (+ lensmap BUILD ms).
+
+Workload (BASELINE.json metric): 3840x2160 output, cube globe (6 faces of 2160x2160), panini
+lens, f_fov 180.  Synthetic data: LCG globe faces generated on the device;
+the lensmap is built on the device from the bundled Lua scripts before the timed region.
+
+A *step* = one pass of the hot path over one batch: `frames` frames (distinct resident globes,
+one shared lensmap) warped by one bk_apply_device launch; with N > 1 ranks each rank owns a
+stripe of output rows (it builds and keeps only that stripe of the lensmap, holds a full globe
+replica) and the step ends with the RCCL gather of the stripes onto rank 0.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job Mpixels/s = W*H*frames*steps / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+W, H = 3840, 2160
+GLOBE, LENS, ZOOM = "cube", "panini", "f_fov 180"
+ALGO_BYTES_PER_PX = 6          # 4 B lensmap index + 1 B texel + 1 B store
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(frames_budget_s=6.0):
+    """The reference CPU path timed on this host's cores (1 thread: the reference is single-threaded).
+    Uses oracle/_ref (unmodified fisheye.c) when the prebuilt library travelled with the repo,
+    otherwise the oracle's C restatement.  Bounded sample: the 4K lensmap build once plus
+    ~frames_budget_s of render_lensmap() calls."""
+    import ctypes as C
+    import oracle_ffi as O
+    if O.have_ref():
+        t0 = time.time()
+        O.ref_run(GLOBE, LENS, None, W, H, want_frame=False)        # build (create_lensmap) + one apply
+        build_s = time.time() - t0
+        ref = C.CDLL(O.REF_SO)
+        ref.ref_time_apply.restype = C.c_double
+        best = C.c_double()
+        ref.ref_time_apply(2, C.byref(best))
+        reps = max(3, int(frames_budget_s / (best.value * 1e-3)))
+        total = ref.ref_time_apply(reps, C.byref(best))
+        kind = "reference"
+    else:
+        t0 = time.time()
+        lm = O.lensmap(GLOBE, LENS, None, W, H)
+        build_s = time.time() - t0
+        globe = O.lcg_globe(lm.ps, 6, 0)
+        dst = np.zeros((H, W), np.uint8)
+        t0 = time.time(); O.apply(lm.offsets, lm.tints, W, H, globe, dst); one = time.time() - t0
+        reps = max(3, int(frames_budget_s / one))
+        t0 = time.time()
+        for _ in range(reps):
+            O.apply(lm.offsets, lm.tints, W, H, globe, dst)
+        total = time.time() - t0
+        best = C.c_double(total / reps * 1e3)
+        kind = "port"
+    return {"value": round(W * H * reps / total / 1e6, 1), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": f"{reps} x render_lensmap at {W}x{H} {GLOBE}/{LENS} on LCG plates (best {best.value:.2f} ms/frame); "
+                      f"lensmap build {build_s * 1e3:.0f} ms wall incl. setup",
+            "build_ms": round(build_s * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=16, help="frames per step (batch warped by one launch)")
+    ap.add_argument("--variant", type=int, default=-1, help="apply kernel variant (-1 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import blinky_amd
+    import scripts as S
+
+    F = args.frames
+    ctx = blinky_amd.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_frames(F)
+    S.configure(ctx, GLOBE, LENS, ZOOM, (W, H))
+    bounds = [H * r // world for r in range(world + 1)]
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    ctx.set_rows(r0, r1)
+    if args.variant >= 0:
+        ctx.set_apply_variant(args.variant)
+
+    # ---- lensmap build (each rank: its own stripe; no exchange) ----------------------------------
+    t0 = time.time()
+    ctx.build()                                   # includes hiprtc compilation of the lens
+    build_first_wall_ms = (time.time() - t0) * 1e3
+    t0 = time.time()
+    display, scale = ctx.build()                  # module cached: emit + launch only
+    build_wall_ms = (time.time() - t0) * 1e3
+    build_kernel_ms = ctx.last_build_ms()
+    for f in range(F):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, f)
+    torch.cuda.synchronize()
+
+    rows = r1 - r0
+    stripe = torch.zeros((F, rows, W), dtype=torch.uint8, device=dev)       # Draw_TileClear stand-in: 0
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty((F, bounds[r + 1] - bounds[r], W), dtype=torch.uint8, device=dev) for r in range(world)]
+
+    def step(i):
+        ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=(i * F) % F, nframes=F)
+        if world > 1:
+            dist.gather(stripe, gather_list, dst=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- the dominant kernel alone, HIP events on the launch stream (roofline) ------------------------
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    e0.record(stream)
+    for i in range(args.steps):
+        ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=0, nframes=F)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+    stripe_mpx = W * rows * F / (kernel_ms * 1e-3) / 1e6
+    if world > 1:
+        t = torch.tensor([stripe_mpx], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        stripe_complete_mpx = float(t.item())
+    else:
+        stripe_complete_mpx = stripe_mpx
+    # single-frame launches (launch-latency sensitive)
+    barrier()
+    e0.record(stream)
+    for i in range(args.steps):
+        ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=i % F, nframes=1)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    single_ms = e0.elapsed_time(e1) / args.steps
+
+    if rank == 0:
+        px_per_step = W * H * F
+        value = px_per_step * args.steps / elapsed / 1e6
+        algo_bytes = ALGO_BYTES_PER_PX * W * rows * F                      # per launch on this rank
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "apply_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath))
+                if rec.get("workload") == f"{W}x{H} {GLOBE}/{LENS} x{F}" and world == 1:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "warped Mpixels/s (lensmap apply)", "value": round(value, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step (distinct resident globes, one lensmap)",
+                       "frames_per_step": F, "parallelism": f"row-stripes x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                       "apply_variant": args.variant},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms_per_launch": round(kernel_ms, 5), "algorithmic_bytes_per_launch": algo_bytes},
+            "lensmap_build_ms": round(build_kernel_ms, 3),
+            "lensmap_build_wall_ms": round(build_wall_ms, 2),
+            "lensmap_build_first_wall_ms_incl_hiprtc": round(build_first_wall_ms, 1),
+            "stripe_complete_mpx_s": round(stripe_complete_mpx, 1),
+            "single_frame_launch_us": round(single_ms * 1e3, 2),
+            "single_frame_mpx_s": round(W * rows / (single_ms * 1e-3) / 1e6, 1),
+            "lens_scale": scale,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

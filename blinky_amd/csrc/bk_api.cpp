@@ -6,19 +6,29 @@
 
 static thread_local std::string g_create_error;
 
-static int ensure_device(bk_ctx *ctx) { BK_HIP(ctx, hipSetDevice(ctx->device)); return BK_OK; }
+static int ensure_device(bk_ctx *ctx)
+{
+    if (ctx->device < 0) return ctx->fail(BK_E_STATE, "this context was created without a device (BK_DEVICE_NONE)");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    return BK_OK;
+}
 
 extern "C" const char *bk_version(void) { return "blinky-hip 0.1 (gfx950)"; }
 
 extern "C" bk_ctx *bk_create(int device)
 {
     int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
+    hipError_t e = device == BK_DEVICE_NONE ? hipSuccess : hipGetDeviceCount(&n);
+    if (device != BK_DEVICE_NONE && (e != hipSuccess || n <= 0)) {
         g_create_error = std::string("bk_create: no usable HIP device (") +
                          (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                          "); libblinkyhip has no CPU fallback";
         return nullptr;
+    }
+    if (device == BK_DEVICE_NONE) {          // host-only context: scripts, zoom, code generation
+        bk_ctx *ctx = new bk_ctx();
+        ctx->device = BK_DEVICE_NONE;
+        return ctx;
     }
     if (device < 0) {
         if (hipGetDevice(&device) != hipSuccess) device = 0;
@@ -31,7 +41,7 @@ extern "C" bk_ctx *bk_create(int device)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc((void **)&ctx->d_pal, BK_MAX_PLATES * 256) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_display, BK_MAX_PLATES * sizeof(int)) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_display, (BK_MAX_PLATES + 2) * sizeof(int)) != hipSuccess) {
         g_create_error = "bk_create: hipSetDevice/hipMalloc failed";
         delete ctx;
         return nullptr;
@@ -43,6 +53,7 @@ static void free_maps(bk_ctx *ctx)
 {
     hipFree(ctx->d_offsets); ctx->d_offsets = nullptr;
     hipFree(ctx->d_tints); ctx->d_tints = nullptr;
+    hipFree(ctx->d_convert); ctx->d_convert = nullptr;
     hipFree(ctx->d_frame); ctx->d_frame = nullptr;
     hipFree(ctx->d_mask); ctx->d_mask = nullptr;
     if (ctx->h_frame) hipHostFree(ctx->h_frame);
@@ -57,6 +68,7 @@ static void free_maps(bk_ctx *ctx)
 extern "C" void bk_destroy(bk_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->device < 0) { bk::lensprogram_free(ctx->prog); delete ctx; return; }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     free_maps(ctx);
@@ -96,6 +108,7 @@ static int alloc_maps(bk_ctx *ctx)
     const size_t words = (px + 63) / 64;
     BK_HIP(ctx, hipMalloc((void **)&ctx->d_offsets, px * sizeof(uint32_t)));
     BK_HIP(ctx, hipMalloc((void **)&ctx->d_tints, px));
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_convert, px * sizeof(uint32_t)));
     BK_HIP(ctx, hipMalloc((void **)&ctx->d_frame, px));
     BK_HIP(ctx, hipMalloc((void **)&ctx->d_mask, words * sizeof(uint64_t)));
     BK_HIP(ctx, hipHostMalloc((void **)&ctx->h_frame, px, hipHostMallocDefault));
@@ -106,7 +119,7 @@ static int alloc_maps(bk_ctx *ctx)
 
 static int alloc_globe(bk_ctx *ctx)
 {
-    const size_t need = (size_t)ctx->nframes * BK_MAX_PLATES * ctx->ps * ctx->ps;   // fisheye.c:718, per frame
+    const size_t need = (size_t)ctx->nframes * ctx->globe_stride();   // fisheye.c:718 per frame, rows padded to gp
     if (need == ctx->globe_bytes && ctx->d_globe) return BK_OK;
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(ctx->d_globe);
@@ -123,13 +136,19 @@ extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
 {
     if (!ctx) return BK_E_INVALID;
     if (width <= 0 || height <= 0) return ctx->fail(BK_E_INVALID, "bk_resize: bad size %dx%d", width, height);
+    if (ctx->device < 0) {                      // host-only: geometry for calc_zoom / code generation
+        ctx->W = width; ctx->H = height; ctx->ps = std::min(width, height); ctx->gp = (ctx->ps + 63) & ~63;
+        ctx->row0 = 0; ctx->row1 = height;
+        return BK_OK;
+    }
     if (int r = ensure_device(ctx)) return r;
     if (width == ctx->W && height == ctx->H) return BK_OK;
     // (6*ps*ps and W*H must fit the uint32 lensmap entries)
     const int ps = std::min(width, height);                                  // fisheye.c:707
-    if ((uint64_t)BK_MAX_PLATES * ps * ps >= 0xFFFFFFFFull)
+    const int gp = (ps + 63) & ~63;
+    if ((uint64_t)BK_MAX_PLATES * gp * ps >= 0xFFFFFFFFull)
         return ctx->fail(BK_E_INVALID, "bk_resize: platesize %d overflows 32-bit offsets", ps);
-    ctx->W = width; ctx->H = height; ctx->ps = ps;
+    ctx->W = width; ctx->H = height; ctx->ps = ps; ctx->gp = gp;
     ctx->row0 = 0; ctx->row1 = height;
     ctx->lensmap_valid = false;
     if (int r = alloc_maps(ctx)) return r;
@@ -202,6 +221,7 @@ extern "C" int bk_set_lensmap(bk_ctx *ctx, const uint32_t *offsets, const uint8_
     if (int r = ensure_device(ctx)) return r;
     const size_t px = (size_t)ctx->W * ctx->rows();
     BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (int r = bk::launch_convert_offsets(ctx, ctx->d_offsets, px, 1)) return r;      // reference -> padded layout
     if (tints) BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tints, px, hipMemcpyHostToDevice, ctx->stream));
     else BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -217,7 +237,11 @@ extern "C" int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints)
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_read_lensmap: no lensmap has been built");
     if (int r = ensure_device(ctx)) return r;
     const size_t px = (size_t)ctx->W * ctx->rows();
-    if (offsets) BK_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (offsets) {
+        BK_HIP(ctx, hipMemcpyAsync(ctx->d_convert, ctx->d_offsets, px * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (int r = bk::launch_convert_offsets(ctx, ctx->d_convert, px, 0)) return r;  // padded -> reference layout
+        BK_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_convert, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (tints) BK_HIP(ctx, hipMemcpyAsync(tints, ctx->d_tints, px, hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BK_OK;
@@ -228,8 +252,10 @@ extern "C" int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints)
 extern "C" void *bk_globe_device_ptr(bk_ctx *ctx, int frame)
 {
     if (!ctx || !ctx->d_globe || frame < 0 || frame >= ctx->nframes) return nullptr;
-    return ctx->d_globe + (size_t)frame * BK_MAX_PLATES * ctx->ps * ctx->ps;
+    return ctx->d_globe + (size_t)frame * ctx->globe_stride();
 }
+
+extern "C" int bk_globe_pitch(const bk_ctx *ctx) { return ctx ? ctx->gp : 0; }
 
 extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch)
 {
@@ -239,9 +265,9 @@ extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t 
         return ctx->fail(BK_E_INVALID, "bk_upload_plate: bad frame/plate/pitch");
     if (int r = ensure_device(ctx)) return r;
     const size_t ps = ctx->ps;
-    uint8_t *dst = ctx->d_globe + ((size_t)frame * BK_MAX_PLATES + plate) * ps * ps;
-    // the row memcpy loop of render_plate, fisheye.c:2441-2449
-    BK_HIP(ctx, hipMemcpy2DAsync(dst, ps, src, (size_t)src_pitch, ps, ps, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *dst = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
+    // the row memcpy loop of render_plate, fisheye.c:2441-2449 (device rows are gp bytes apart)
+    BK_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)ctx->gp, src, (size_t)src_pitch, ps, ps, hipMemcpyHostToDevice, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BK_OK;
 }
@@ -253,9 +279,8 @@ extern "C" int bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t see
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes)
         return ctx->fail(BK_E_INVALID, "bk_fill_plate_lcg: bad frame/plate");
     if (int r = ensure_device(ctx)) return r;
-    const size_t ps2 = (size_t)ctx->ps * ctx->ps;
     const uint32_t seed = 0x9E3779B9u * (uint32_t)(plate + 1 + 6 * (int)seed_frame);
-    return bk::launch_fill_lcg(ctx, ctx->d_globe + ((size_t)frame * BK_MAX_PLATES + plate) * ps2, ps2, seed);
+    return bk::launch_fill_lcg(ctx, ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes(), seed);
 }
 
 // ---- apply ------------------------------------------------------------------------------

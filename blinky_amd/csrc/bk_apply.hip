@@ -112,11 +112,15 @@ __global__ __launch_bounds__(256) void mask_kernel(const uint32_t *__restrict__ 
 // synthetic plates: SURVEY.md 8(d)  s0 = seed, s <- s*1664525 + 1013904223, texel = s>>24.
 // Each thread jumps ahead to its first element by composing the affine map in O(log i).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, size_t n, uint32_t seed)
+__global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, int ps, int gp, uint32_t seed)
 {
-    constexpr int K = 16;
-    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K;
-    if (i0 >= n) return;
+    // texel i = py*ps + px of the stream lands at dst[py*gp + px]; each thread produces up to 16
+    // consecutive texels of one row
+    const int chunks_per_row = (ps + 15) / 16;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= chunks_per_row * ps) return;
+    const int py = id / chunks_per_row, px0 = (id - py * chunks_per_row) * 16;
+    const size_t i0 = (size_t)py * ps + px0;
     uint32_t A = 1u, C = 0u, a = 1664525u, c = 1013904223u;
     for (size_t e = i0; e; e >>= 1) {
         if (e & 1) { A = a * A; C = a * C + c; }
@@ -125,16 +129,32 @@ __global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, siz
     }
     uint32_t s = A * seed + C;
     uint32_t w[4] = {0, 0, 0, 0};
-    const int cnt = (int)min((size_t)K, n - i0);
+    const int cnt = min(16, ps - px0);
     for (int k = 0; k < cnt; ++k) {
         s = s * 1664525u + 1013904223u;
         w[k >> 2] |= (s >> 24) << (8 * (k & 3));
     }
-    if (cnt == K && ((reinterpret_cast<uintptr_t>(dst + i0) & 15u) == 0)) {
-        *reinterpret_cast<uint4 *>(dst + i0) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        for (int k = 0; k < cnt; ++k) dst[i0 + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-    }
+    uint8_t *out = dst + (size_t)py * gp + px0;       // gp % 64 == 0 and px0 % 16 == 0: 16-byte aligned
+    if (cnt == 16) *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (int k = 0; k < cnt; ++k) out[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+}
+
+// ---------------------------------------------------------------------------------------
+// lensmap entries cross the ABI in the reference layout (plate*ps*ps + py*ps + px, GLOBEPIXEL
+// fisheye.c:349); on the device they address the padded globe (plate*gp*ps + py*gp + px)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convert_offsets_kernel(uint32_t *__restrict__ buf, size_t n, uint32_t ps,
+                                                              uint32_t gp, int to_padded)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = buf[i];
+    if (o == BK_NULL_OFFSET) return;
+    const uint32_t pitch_in = to_padded ? ps : gp, pitch_out = to_padded ? gp : ps;
+    const uint32_t plate = o / (pitch_in * ps), rem = o - plate * (pitch_in * ps);
+    if (plate >= BK_MAX_PLATES) { buf[i] = BK_NULL_OFFSET; return; }    // never address outside the globe
+    const uint32_t py = rem / pitch_in, px = rem - py * pitch_in;
+    buf[i] = plate * (pitch_out * ps) + py * pitch_out + px;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -146,7 +166,7 @@ int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pit
 {
     const int rows = ctx->rows();
     if (rows <= 0 || nframes <= 0) return BK_OK;
-    const size_t gstride = (size_t)BK_MAX_PLATES * ctx->ps * ctx->ps;
+    const size_t gstride = ctx->globe_stride();
     const int fchunk = nframes < 8 ? nframes : 8;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     if (ctx->W % 4 == 0) {
@@ -187,11 +207,20 @@ int launch_mask(bk_ctx *ctx)
     return BK_OK;
 }
 
-int launch_fill_lcg(bk_ctx *ctx, uint8_t *dst, size_t n, uint32_t seed)
+int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed)
 {
-    const size_t threads = (n + 15) / 16;
+    const int threads = ((ctx->ps + 15) / 16) * ctx->ps;
     hipLaunchKernelGGL(lcg_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                       dst, n, seed);
+                       plate_dst, ctx->ps, ctx->gp, seed);
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_padded)
+{
+    if (!n) return BK_OK;
+    hipLaunchKernelGGL(convert_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       buf, n, (uint32_t)ctx->ps, (uint32_t)ctx->gp, to_padded);
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;
 }

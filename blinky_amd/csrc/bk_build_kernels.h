@@ -1,0 +1,293 @@
+/* bk_build_kernels.h -- the generic lensmap BUILD kernels (embedded last into the hiprtc unit).
+ * The emitter provides LF_lens_inverse / LF_lens_forward / LF_globe_plate (when the scripts
+ * define them), BK_HAS_* and BK_INIT_GLOBALS.  One thread = one output pixel (inverse map) or
+ * one plate texel / texel corner (forward map).  Arithmetic follows fisheye.c line by line:
+ * float where the reference uses vec_t, double elsewhere, no contraction. */
+
+BK_DEV void bk_state_init(BkState &S, const BkBuildParams *P)
+{
+    S.P = P;
+    S.err = 0;
+    S.steps = 0;
+    BK_INIT_GLOBALS(S)
+}
+
+/* fisheye.c:2023-2050 */
+BK_DEV int bk_ray_to_plate_index(BkState &S, const float *ray)
+{
+    const BkBuildParams &P = *S.P;
+#ifdef BK_HAS_GLOBE_PLATE
+    bkv a[3] = {bk_num((double)ray[0]), bk_num((double)ray[1]), bk_num((double)ray[2])};
+    bkv r[BK_MAXRET];
+    int n = LF_globe_plate(S, a, 3, r);
+    if (n < 1 || !bk_isnum(r[n - 1])) return -1;            /* !lua_isnumber(lua,-1)  :1642 */
+    double d = r[n - 1].n;                                  /* lua_tointeger: round to nearest (LUA_IEEE754TRICK) */
+    if (!(d > -2147483648.0 && d < 2147483647.0)) return -1;
+    int plate = (int)bkm_rint(d);
+    if (plate < 0 || plate >= P.numplates) return -1;       /* the reference would index out of bounds */
+    return plate;
+#else
+    int plate_index = 0;
+    double max_dp = -2;
+    for (int i = 0; i < P.numplates; ++i) {
+        double dp = (double)bk_dot3(ray, P.plates[i].forward);   /* float dot, widened   :2042 */
+        if (dp > max_dp) { max_dp = dp; plate_index = i; }   /* strict >: first maximum wins */
+    }
+    return plate_index;
+#endif
+}
+
+/* set_lensmap_grid, fisheye.c:1922-1960: true when the texel is NOT on a grid line */
+BK_DEV bool bk_offgrid(const BkBuildParams &P, int px, int py)
+{
+    double ux = (double)px / P.rubix_unit_px;
+    double uy = (double)py / P.rubix_unit_px;
+    bool ongrid = bkm_fmod(ux, P.rubix_block) < P.rubix_pad || bkm_fmod(uy, P.rubix_block) < P.rubix_pad;
+    return !ongrid;
+}
+
+BK_DEV unsigned int bk_padded_offset(const BkBuildParams &P, int plate, int px, int py)
+{
+    return (unsigned int)plate * ((unsigned int)P.gp * (unsigned int)P.ps) + (unsigned int)py * (unsigned int)P.gp + (unsigned int)px;
+}
+
+__device__ __forceinline__ void bk_publish_flags(const int *s_disp, int *display, int serr, int *err)
+{
+    /* per-block reduction of the display[] flags: at most 6 atomics per block, none once set */
+    if (threadIdx.x < 6 && s_disp[threadIdx.x]) {
+        if (__hip_atomic_load(&display[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            atomicOr(&display[threadIdx.x], 1);
+    }
+    if (serr) atomicOr(err, serr);
+}
+
+#ifdef BK_HAS_INVERSE
+/* resume_lensmap_inverse + LUAtoC_lens_inverse + set_lensmap_from_ray (fisheye.c:2084-2124, 1545-1588, 1995-2013) */
+extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams P)
+{
+    __shared__ int s_disp[6];
+    if (threadIdx.x < 6) s_disp[threadIdx.x] = 0;
+    __syncthreads();
+    const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lyl = blockIdx.y;                      /* row inside the owned stripe */
+    const int ly = P.row0 + lyl;
+    int err = 0;
+    if (lx < P.W) {
+        unsigned int off = 0xFFFFFFFFu;
+        unsigned char tint = 255;
+        BkState S;
+        bk_state_init(S, &P);
+        const double y = (double)(-(ly - P.H / 2)) * P.scale;     /* :2100, integer H/2 */
+        const double x = (double)(lx - P.W / 2) * P.scale;        /* :2105 */
+        bkv a[2] = {bk_num(x), bk_num(y)};
+        bkv r[BK_MAXRET];
+        const int n = LF_lens_inverse(S, a, 2, r);
+        if (n == 3 && bk_isnum(r[0]) && bk_isnum(r[1]) && bk_isnum(r[2])) {
+            float ray[3] = {(float)r[0].n, (float)r[1].n, (float)r[2].n};   /* :1559-1561 */
+            bk_vector_normalize(ray);                                        /* :1562 */
+            const int plate = bk_ray_to_plate_index(S, ray);
+            if (plate >= 0) {
+                const BkPlateDev &p = P.plates[plate];
+                const double px_ = (double)bk_dot3(p.right, ray);            /* :2055-2057 */
+                const double py_ = (double)bk_dot3(p.up, ray);
+                const double pz_ = (double)bk_dot3(p.forward, ray);
+                const double u = px_ / pz_ * p.dist64 + 0.5;                 /* :2061 */
+                const double v = -py_ / pz_ * p.dist64 + 0.5;                /* :2062 */
+                if (u >= 0 && u <= 1 && v >= 0 && v <= 1) {                  /* :2065 */
+                    const int px = bk_trunc_to_int(u * P.ps);                /* :1988 */
+                    const int py = bk_trunc_to_int(v * P.ps);
+                    if (px >= 0 && px < P.ps && py >= 0 && py < P.ps) {      /* :1971 */
+                        s_disp[plate] = 1;                                   /* :1976 */
+                        off = bk_padded_offset(P, plate, px, py);            /* :1979 */
+                        if (bk_offgrid(P, px, py)) tint = (unsigned char)plate;   /* :1959 */
+                    }
+                }
+            }
+        } else if (!(n == 1 && r[0].t == BK_TNIL)) {
+            S.err |= BK_ERR_RESULT;                                          /* status -1  :1565-1584 */
+        }
+        err = S.err;
+        const size_t o = (size_t)lyl * P.W + lx;
+        P.offsets[o] = off;
+        P.tints[o] = tint;
+    }
+    __syncthreads();
+    bk_publish_flags(s_disp, P.display, err, P.err);
+}
+#endif
+
+#ifdef BK_HAS_FORWARD
+/* uv_to_screen (fisheye.c:2227-2243) for every texel-corner of every plate:
+ * corner (i,j), i,j in 0..ps, is (u,v) = ((i-0.5)/ps, (j-0.5)/ps) */
+extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildParams P)
+{
+    const int n1 = P.ps + 1;
+    const long long total = (long long)P.numplates * n1 * n1;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int plate = (int)(id / ((long long)n1 * n1));
+    const int rem = (int)(id - (long long)plate * n1 * n1);
+    const int j = rem / n1, i = rem - j * n1;
+    const double u = ((double)i - 0.5) / P.ps;
+    const double v = ((double)j - 0.5) / P.ps;
+    BkState S;
+    bk_state_init(S, &P);
+    float ray[3];
+    bk_plate_uv_to_ray(P, plate, u, v, ray);
+    bkv a[3] = {bk_num((double)ray[0]), bk_num((double)ray[1]), bk_num((double)ray[2])};
+    bkv r[BK_MAXRET];
+    const int n = LF_lens_forward(S, a, 3, r);
+    unsigned char ok = 0;
+    int sx = 0, sy = 0;
+    if (n == 2 && bk_isnum(r[0]) && bk_isnum(r[1])) {
+        sx = bk_trunc_to_int(r[0].n / P.scale + (double)(P.W / 2));          /* :2239 */
+        sy = bk_trunc_to_int(-r[1].n / P.scale + (double)(P.H / 2));         /* :2240 */
+        ok = 1;
+    } else if (!(n == 1 && r[0].t == BK_TNIL)) {
+        S.err |= BK_ERR_RESULT;
+    }
+    P.corner_xy[2 * id] = sx;
+    P.corner_xy[2 * id + 1] = sy;
+    P.corner_ok[id] = ok;
+    if (S.err) atomicOr(P.err, S.err);
+}
+
+/* set_lensmap_from_plate (fisheye.c:1963-1982) as an ordered-overwrite commit */
+BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key, bool offgrid, int *wrote)
+{
+    if (lx < 0 || lx >= P.W || ly < 0 || ly >= P.H) return;                  /* :1966 */
+    *wrote = 1;                                                               /* display (:1976) is global, not per stripe */
+    if (ly < P.row0 || ly >= P.row0 + P.rows) return;                        /* stripe-filtered commit */
+    const size_t o = (size_t)(ly - P.row0) * P.W + lx;
+    atomicMax(&P.fwd_key_px[o], key);
+    if (offgrid) atomicMax(&P.fwd_key_tint[o], key);
+}
+
+/* draw_quad (fisheye.c:2246-2338); int overflow on INT_MIN coordinates wraps as on x86-64 */
+BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, const int *bl, const int *br,
+                         unsigned int key, bool offgrid, int *wrote)
+{
+    const int *p[4] = {tl, tr, br, bl};
+    int x = tl[0], y = tl[1];
+    int miny = y, maxy = y, minx = x, maxx = x;
+    for (int i = 1; i < 4; i++) {
+        int tx = p[i][0], ty = p[i][1];
+        if (tx < minx) minx = tx; else if (tx > maxx) maxx = tx;
+        if (ty < miny) miny = ty; else if (ty > maxy) maxy = ty;
+    }
+    const int maxdiff = 20;
+    {
+        int dx = (int)((unsigned)minx - (unsigned)maxx), dy = (int)((unsigned)miny - (unsigned)maxy);
+        int adx = dx < 0 ? (int)(0u - (unsigned)dx) : dx, ady = dy < 0 ? (int)(0u - (unsigned)dy) : dy;
+        if (adx > maxdiff || ady > maxdiff) return;                          /* :2272 */
+    }
+    const int nx = (int)((unsigned)maxx - (unsigned)minx), ny = (int)((unsigned)maxy - (unsigned)miny);   /* 0..20 */
+    if (miny == maxy && minx == maxx) { bk_fwd_set(P, x, y, key, offgrid, wrote); return; }
+    if (miny == maxy) { for (int k = 0; k <= nx; ++k) bk_fwd_set(P, minx + k, miny, key, offgrid, wrote); return; }
+    if (minx == maxx) { for (int k = 0; k <= ny; ++k) bk_fwd_set(P, x, miny + k, key, offgrid, wrote); return; }
+    for (int ky = 0; ky <= ny; ++ky) {
+        y = miny + ky;
+        int tx[2] = {minx, maxx};
+        int txi = 0, j = 3;
+        for (int i = 0; i < 4; ++i) {
+            int ix = p[i][0], iy = p[i][1];
+            int jx = p[j][0], jy = p[j][1];
+            if ((iy < y && y <= jy) || (jy < y && y <= iy)) {                /* :2310 */
+                double dy = (double)(jy - iy);
+                double dx = (double)(jx - ix);
+                tx[txi] = bk_trunc_to_int((double)ix + (double)(y - iy) / dy * dx);   /* :2313 */
+                if (++txi == 2) break;
+            }
+            j = i;
+        }
+        if (tx[0] > tx[1]) { int t = tx[0]; tx[0] = tx[1]; tx[1] = t; }
+        if ((int)((unsigned)tx[1] - (unsigned)tx[0]) > maxdiff) return;      /* :2327 aborts the quad */
+        const int n = tx[1] - tx[0];
+        for (int k = 0; k <= n; ++k) bk_fwd_set(P, tx[0] + k, y, key, offgrid, wrote);
+    }
+}
+
+/* the quad loop of resume_lensmap_forward (fisheye.c:2189-2202): one thread per plate texel.
+ * The reference writes plate-major, py descending, px ascending, later writers overwriting;
+ * key = 1 + that sequence number, committed with atomicMax, reproduces the final state. */
+extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams P)
+{
+    __shared__ int s_disp[6];
+    if (threadIdx.x < 6) s_disp[threadIdx.x] = 0;
+    __syncthreads();
+    const long long total = (long long)P.numplates * P.ps * P.ps;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int err = 0;
+    if (id < total) {
+        const int plate = (int)(id / ((long long)P.ps * P.ps));
+        const int rem = (int)(id - (long long)plate * P.ps * P.ps);
+        const int py = rem / P.ps, px = rem - py * P.ps;
+        BkState S;
+        bk_state_init(S, &P);
+        float ray[3];
+        bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
+        if (plate == bk_ray_to_plate_index(S, ray)) {                               /* :2196 */
+            const int n1 = P.ps + 1;
+            const long long base = (long long)plate * n1 * n1;
+            const long long c_tl = base + (long long)py * n1 + px, c_bl = c_tl + n1;
+            if (P.corner_ok[c_tl] && P.corner_ok[c_tl + 1] && P.corner_ok[c_bl] && P.corner_ok[c_bl + 1]) {
+                const unsigned int order = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)(P.ps - 1 - py)) * (unsigned int)P.ps + (unsigned int)px;
+                int wrote = 0;
+                bk_draw_quad(P, &P.corner_xy[2 * c_tl], &P.corner_xy[2 * (c_tl + 1)], &P.corner_xy[2 * c_bl],
+                             &P.corner_xy[2 * (c_bl + 1)], order + 1u, bk_offgrid(P, px, py), &wrote);
+                if (wrote) s_disp[plate] = 1;
+            }
+        }
+        err = S.err;
+    }
+    __syncthreads();
+    bk_publish_flags(s_disp, P.display, err, P.err);
+}
+
+/* decode the winning keys into lens.pixels / lens.pixel_tints */
+extern "C" __global__ __launch_bounds__(256) void bk_forward_resolve(BkBuildParams P)
+{
+    const size_t n = (size_t)P.rows * P.W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned int off = 0xFFFFFFFFu;
+    unsigned char tint = 255;
+    const unsigned int k = P.fwd_key_px[i];
+    if (k) {
+        const unsigned int o = k - 1u, ps = (unsigned int)P.ps;
+        const unsigned int px = o % ps, q = o / ps, plate = q / ps, py = ps - 1u - (q % ps);
+        off = bk_padded_offset(P, (int)plate, (int)px, (int)py);
+        const unsigned int kt = P.fwd_key_tint[i];
+        if (kt) tint = (unsigned char)(((kt - 1u) / ps) / ps);
+    }
+    P.offsets[i] = off;
+    P.tints[i] = tint;
+}
+#endif
+
+/* test / diagnosis hook: run one callback over an array of argument tuples and return the raw
+ * double results (bk_debug_eval_device).  which: 0 lens_inverse, 1 lens_forward, 2 globe_plate.
+ * nout[i] = number of results, -1 for a single nil, -100-err on a runtime error. */
+extern "C" __global__ __launch_bounds__(256) void bk_eval_callback(BkBuildParams P, int which, const double *args,
+                                                                   int nargs, int n, double *out, int *nout)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BkState S;
+    bk_state_init(S, &P);
+    bkv a[4], r[BK_MAXRET];
+    for (int k = 0; k < 4; ++k) a[k] = k < nargs ? bk_num(args[(size_t)i * nargs + k]) : bk_nil();
+    for (int k = 0; k < BK_MAXRET; ++k) r[k] = bk_nil();
+    int m = 0;
+#ifdef BK_HAS_INVERSE
+    if (which == 0) m = LF_lens_inverse(S, a, nargs, r);
+#endif
+#ifdef BK_HAS_FORWARD
+    if (which == 1) m = LF_lens_forward(S, a, nargs, r);
+#endif
+#ifdef BK_HAS_GLOBE_PLATE
+    if (which == 2) m = LF_globe_plate(S, a, nargs, r);
+#endif
+    for (int k = 0; k < BK_MAXRET; ++k) out[(size_t)i * BK_MAXRET + k] = (k < m && r[k].t == BK_TNUM) ? r[k].n : __builtin_nan("");
+    nout[i] = S.err ? -100 - S.err : (m == 1 && r[0].t == BK_TNIL) ? -1 : m;
+}

@@ -1,0 +1,38 @@
+/* bk_build_params.h -- kernel-argument block of the lensmap build kernels.  Included by the
+ * host (bk_lens.cpp) and embedded verbatim into the hiprtc translation unit, so both sides
+ * see one definition.  Plain C types only. */
+#ifndef BK_BUILD_PARAMS_H
+#define BK_BUILD_PARAMS_H
+
+typedef struct {
+    float forward[3], right[3], up[3];   /* vec3_t, as LUA_load_globe leaves them (fisheye.c:1818-1850) */
+    float fov, dist;                     /* fisheye.c:1858, 1868 */
+    double dist64;                       /* 0.5 / tan(fov/2) recomputed in double (fisheye.c:2060) */
+} BkPlateDev;
+
+typedef struct {
+    int W, H;                /* lens.width_px / height_px */
+    int row0, rows;          /* owned output rows [row0, row0+rows) */
+    int ps, gp;              /* platesize; padded row pitch of the device globe */
+    int numplates, has_globe_plate;
+    double scale;            /* lens.scale */
+    double rubix_block, rubix_pad, rubix_unit_px;   /* set_lensmap_grid constants (fisheye.c:1938-1948) */
+    BkPlateDev plates[6];
+    unsigned int *offsets;   /* [rows][W] padded-layout offsets, 0xFFFFFFFF = NULL */
+    unsigned char *tints;    /* [rows][W] */
+    int *display;            /* [6] */
+    int *err;                /* [1] OR of BK_ERR_* bits */
+    /* forward build (fisheye.c:2126-2338) */
+    unsigned int *fwd_key_px;    /* [rows][W] 1 + order index of the last writer (0 = none), max-reduced */
+    unsigned int *fwd_key_tint;  /* [rows][W] same, over writers that were off the rubix grid */
+    int *corner_xy;          /* [numplates][ps+1][ps+1][2] screen coords of the texel corners */
+    unsigned char *corner_ok;/* [numplates][ps+1][ps+1] */
+} BkBuildParams;
+
+#define BK_ERR_ARITH 1       /* arithmetic on a non-number */
+#define BK_ERR_COMPARE 2     /* ordering comparison on non-numbers */
+#define BK_ERR_INDEX 4       /* table store out of range / unsupported index */
+#define BK_ERR_RESULT 8      /* callback returned a malformed result (status -1, fisheye.c:1565-1584) */
+#define BK_ERR_LOOP 16       /* per-pixel iteration budget exceeded */
+
+#endif

@@ -1,0 +1,663 @@
+// bk_emit.cpp -- Lua AST -> HIP C++.
+//
+// The per-pixel callbacks of a lens / globe script (lens_inverse, lens_forward, globe_plate:
+// fisheye.c:1545-1651) and every script function they reach are translated into device
+// functions over tagged doubles (bk_device_rt.h).  The translation is a direct, statement by
+// statement restatement of the interpreter in bk_lua.cpp - same operation order, every
+// arithmetic operation a single IEEE double operation or a bkm.h call - so the device result
+// is bit-identical to what the host interpreter computes for the same arguments.
+//
+// Script globals: a global that device code never assigns is a constant (its value after the
+// chunk ran and calc_zoom called lens_forward); one that device code assigns becomes a
+// per-thread variable initialised from that value (the shipped scripts only use such globals
+// as scratch within one call or as pure caches).
+#include "bk_emit.h"
+
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <sstream>
+
+namespace bk {
+using namespace bklua;
+
+namespace {
+
+[[noreturn]] void unsupported(const std::string &chunk, int line, const std::string &what)
+{
+    throw LuaError(chunk + ":" + std::to_string(line) + ": not supported in a GPU callback: " + what);
+}
+
+std::string sanitize(const std::string &s)
+{
+    std::string o;
+    for (char c : s) o += (isalnum((unsigned char)c) ? c : '_');
+    return o;
+}
+
+std::string num_literal(double d)
+{
+    if (d != d) return "bk_num(__builtin_nan(\"\"))";
+    if (std::isinf(d)) return d > 0 ? "bk_num(__builtin_inf())" : "bk_num(-__builtin_inf())";
+    char buf[64];
+    snprintf(buf, sizeof buf, "bk_num(%a)", d);
+    return buf;
+}
+
+struct FnInfo {
+    const FuncProto *proto = nullptr;
+    const Closure *cl = nullptr;
+    std::string cname;
+    bool emitting = false, done = false;
+};
+
+struct Emitter {
+    Interp &I;
+    std::map<const FuncProto *, FnInfo> fns;
+    std::vector<std::string> fn_code;                 // in dependency order
+    std::set<std::string> mutable_globals;
+    std::map<const Table *, std::pair<std::string, int>> const_tables;   // table -> (array name, n)
+    std::ostringstream table_code;
+    int uid = 0;
+
+    explicit Emitter(Interp &i) : I(i) {}
+
+    // ---- per-function state --------------------------------------------------------------
+    struct Fn {
+        const FuncProto *proto;
+        const Closure *cl;
+        std::ostringstream out;
+        int indent = 1;
+        std::map<int, int> array_slots;               // local slot -> capacity (array tables)
+        std::string chunk;
+    };
+    std::string tmp(const char *p = "t") { return std::string(p) + std::to_string(++uid); }
+    static void line(Fn &f, const std::string &s) { f.out << std::string((size_t)f.indent * 4, ' ') << s << "\n"; }
+
+    // ---- static resolution of a callee / constant ------------------------------------------
+    // value a Name evaluates to at build time; `known` false for locals
+    bool static_value(Fn &f, const Expr &e, Value *v)
+    {
+        if (e.kind == Expr::Name) {
+            if (e.var == VarKind::Global) {
+                if (mutable_globals.count(e.str)) return false;
+                *v = I.get_global(e.str);
+                return true;
+            }
+            if (e.var == VarKind::Upvalue) { *v = *f.cl->upvals[e.slot]; return true; }
+            return false;
+        }
+        if (e.kind == Expr::Index && e.b->kind == Expr::String) {
+            Value o;
+            if (static_value(f, *e.a, &o) && o.t == Value::TABLE) { *v = o.tab->get(Value::string(e.b->str)); return true; }
+        }
+        return false;
+    }
+
+    // ---- pre-pass: which globals does device code assign? ------------------------------------
+    void scan_block(const Block &b, const Closure *cl, std::set<const FuncProto *> &seen)
+    {
+        for (const StmtP &s : b) scan_stmt(*s, cl, seen);
+    }
+    void scan_expr(const Expr *e, const Closure *cl, std::set<const FuncProto *> &seen)
+    {
+        if (!e) return;
+        if (e->kind == Expr::Call) {
+            Value callee;
+            bool known = false;
+            if (e->a->kind == Expr::Name && e->a->var == VarKind::Global) { callee = I.get_global(e->a->str); known = true; }
+            else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) { callee = *cl->upvals[e->a->slot]; known = true; }
+            if (known && callee.t == Value::FUNC && !seen.count(callee.fn->proto)) {
+                seen.insert(callee.fn->proto);
+                scan_block(callee.fn->proto->body, callee.fn.get(), seen);
+            }
+        }
+        scan_expr(e->a.get(), cl, seen);
+        scan_expr(e->b.get(), cl, seen);
+        for (auto &x : e->args) scan_expr(x.get(), cl, seen);
+        for (auto &x : e->fields) { scan_expr(x.first.get(), cl, seen); scan_expr(x.second.get(), cl, seen); }
+    }
+    void scan_stmt(const Stmt &s, const Closure *cl, std::set<const FuncProto *> &seen)
+    {
+        for (auto &t : s.targets) {
+            if (t->kind == Expr::Name && t->var == VarKind::Global) mutable_globals.insert(t->str);
+            scan_expr(t.get(), cl, seen);
+        }
+        for (auto &x : s.exprs) scan_expr(x.get(), cl, seen);
+        scan_expr(s.call.get(), cl, seen);
+        scan_expr(s.cond.get(), cl, seen);
+        scan_block(s.body, cl, seen);
+        for (auto &c : s.clauses) { scan_expr(c.first.get(), cl, seen); scan_block(c.second, cl, seen); }
+    }
+
+    // ---- constant (never assigned) global / upvalue tables -----------------------------------
+    std::pair<std::string, int> const_table(Fn &f, const Expr &at, const std::shared_ptr<Table> &t, const std::string &hint)
+    {
+        auto it = const_tables.find(t.get());
+        if (it != const_tables.end()) return it->second;
+        if (!t->nhash.empty() || !t->shash.empty())
+            unsupported(f.chunk, at.line, "table '" + hint + "' with non-array keys");
+        std::string name = "GT" + std::to_string(++uid) + "_" + sanitize(hint);
+        int n = (int)t->arr.size();
+        table_code << "static __device__ const bkv " << name << "[" << n + 1 << "] = {{0.0, BK_TNIL}";
+        for (const Value &v : t->arr) {
+            char buf[80];
+            switch (v.t) {
+            case Value::NUM:
+                if (v.n != v.n || std::isinf(v.n)) unsupported(f.chunk, at.line, "non-finite number in table '" + hint + "'");
+                snprintf(buf, sizeof buf, ", {%a, BK_TNUM}", v.n);
+                break;
+            case Value::BOOL: snprintf(buf, sizeof buf, ", {0.0, %s}", v.b ? "BK_TTRUE" : "BK_TFALSE"); break;
+            case Value::NIL: snprintf(buf, sizeof buf, ", {0.0, BK_TNIL}"); break;
+            default: unsupported(f.chunk, at.line, std::string("table '") + hint + "' holding a " + v.type_name());
+            }
+            table_code << buf;
+        }
+        table_code << "};\n";
+        return const_tables[t.get()] = {name, n};
+    }
+
+    // ---- expressions ----------------------------------------------------------------------------
+    std::string const_value(Fn &f, const Expr &e, const Value &v, const std::string &what)
+    {
+        switch (v.t) {
+        case Value::NIL: return "bk_nil()";
+        case Value::BOOL: return v.b ? "bk_bool(true)" : "bk_bool(false)";
+        case Value::NUM: return num_literal(v.n);
+        default: unsupported(f.chunk, e.line, what + " (a " + v.type_name() + ") used as a value");
+        }
+    }
+
+    std::string emit_expr(Fn &f, const Expr &e)
+    {
+        switch (e.kind) {
+        case Expr::Nil: return "bk_nil()";
+        case Expr::True: return "bk_bool(true)";
+        case Expr::False: return "bk_bool(false)";
+        case Expr::Number: return num_literal(e.num);
+        case Expr::String: unsupported(f.chunk, e.line, "string values");
+        case Expr::Vararg: unsupported(f.chunk, e.line, "'...'");
+        case Expr::Function: unsupported(f.chunk, e.line, "function values / closures");
+        case Expr::Table: unsupported(f.chunk, e.line, "table constructors other than 'local t = {a, b, ...}'");
+        case Expr::Name:
+            if (e.var == VarKind::Local) {
+                if (f.array_slots.count(e.slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
+                return "l" + std::to_string(e.slot);
+            }
+            if (e.var == VarKind::Global && mutable_globals.count(e.str)) return "S.g_" + sanitize(e.str);
+            {
+                Value v;
+                static_value(f, e, &v);
+                return const_value(f, e, v, "'" + e.str + "'");
+            }
+        case Expr::Index: {
+            if (e.a->kind == Expr::Name && e.a->var == VarKind::Local && f.array_slots.count(e.a->slot)) {
+                std::string k = emit_expr(f, *e.b), t = tmp();
+                line(f, "bkv " + t + " = bk_aget(A" + std::to_string(e.a->slot) + ", " + std::to_string(f.array_slots[e.a->slot]) + ", " + k + ");");
+                return t;
+            }
+            Value sv;
+            if (static_value(f, e, &sv)) return const_value(f, e, sv, "field '" + e.b->str + "'");
+            Value o;
+            if (static_value(f, *e.a, &o) && o.t == Value::TABLE) {
+                auto ct = const_table(f, e, o.tab, e.a->kind == Expr::Name ? e.a->str : "table");
+                std::string k = emit_expr(f, *e.b), t = tmp();
+                line(f, "bkv " + t + " = bk_aget(" + ct.first + ", " + std::to_string(ct.second) + ", " + k + ");");
+                return t;
+            }
+            unsupported(f.chunk, e.line, "indexing this expression");
+        }
+        case Expr::Call: {
+            std::string arr, cnt;
+            emit_call(f, e, &arr, &cnt);
+            std::string t = tmp();
+            line(f, "bkv " + t + " = " + cnt + " > 0 ? " + arr + "[0] : bk_nil();");
+            return t;
+        }
+        case Expr::Unop: {
+            if (e.str == "()") return emit_expr(f, *e.a);
+            if (e.str == "#") {
+                if (e.a->kind == Expr::Name && e.a->var == VarKind::Local && f.array_slots.count(e.a->slot))
+                    return num_literal((double)f.array_slots[e.a->slot]);
+                unsupported(f.chunk, e.line, "the length operator on this expression");
+            }
+            std::string a = emit_expr(f, *e.a), t = tmp();
+            if (e.str == "not") line(f, "bkv " + t + " = bk_not(" + a + ");");
+            else line(f, "bkv " + t + " = bk_unm(S, " + a + ");");
+            return t;
+        }
+        case Expr::Binop: {
+            const std::string &op = e.str;
+            if (op == "and" || op == "or") {
+                std::string a = emit_expr(f, *e.a), t = tmp();
+                line(f, "bkv " + t + " = " + a + ";");
+                line(f, std::string("if (") + (op == "and" ? "" : "!") + "bk_truthy(" + t + ")) {");
+                f.indent++;
+                std::string b = emit_expr(f, *e.b);
+                line(f, t + " = " + b + ";");
+                f.indent--;
+                line(f, "}");
+                return t;
+            }
+            if (op == "..") unsupported(f.chunk, e.line, "string concatenation");
+            std::string a = emit_expr(f, *e.a);
+            std::string b = emit_expr(f, *e.b);
+            std::string t = tmp(), call;
+            if (op == "+") call = "bk_add(S, " + a + ", " + b + ")";
+            else if (op == "-") call = "bk_sub(S, " + a + ", " + b + ")";
+            else if (op == "*") call = "bk_mul(S, " + a + ", " + b + ")";
+            else if (op == "/") call = "bk_div(S, " + a + ", " + b + ")";
+            else if (op == "%") call = "bk_mod(S, " + a + ", " + b + ")";
+            else if (op == "^") call = "bk_pow(S, " + a + ", " + b + ")";
+            else if (op == "==") call = "bk_eq(" + a + ", " + b + ")";
+            else if (op == "~=") call = "bk_ne(" + a + ", " + b + ")";
+            else if (op == "<") call = "bk_lt(S, " + a + ", " + b + ")";
+            else if (op == "<=") call = "bk_le(S, " + a + ", " + b + ")";
+            else if (op == ">") call = "bk_lt(S, " + b + ", " + a + ")";
+            else if (op == ">=") call = "bk_le(S, " + b + ", " + a + ")";
+            else unsupported(f.chunk, e.line, "operator '" + op + "'");
+            line(f, "bkv " + t + " = " + call + ";");
+            return t;
+        }
+        }
+        return "bk_nil()";
+    }
+
+    // evaluated argument list: fixed single values, then optionally an expanded multi-value tail
+    struct Args {
+        std::vector<std::string> fixed;
+        bool multi = false;
+        std::string marr, mcnt;
+    };
+    Args emit_args(Fn &f, const std::vector<ExprP> &list)
+    {
+        Args a;
+        for (size_t i = 0; i < list.size(); ++i) {
+            const Expr &x = *list[i];
+            if (i + 1 == list.size() && x.kind == Expr::Call) {
+                a.multi = true;
+                emit_call(f, x, &a.marr, &a.mcnt);
+            } else a.fixed.push_back(emit_expr(f, x));
+        }
+        return a;
+    }
+    static std::string arg_at(const Args &a, size_t i)
+    {
+        if (i < a.fixed.size()) return a.fixed[i];
+        if (a.multi) {
+            size_t k = i - a.fixed.size();
+            return "(" + a.mcnt + " > " + std::to_string(k) + " ? " + a.marr + "[" + std::to_string(k) + "] : bk_nil())";
+        }
+        return "bk_nil()";
+    }
+    // materialise an evaluated value list into a fresh array; returns (array, count expression)
+    std::pair<std::string, std::string> pack(Fn &f, const Args &a, int min_size)
+    {
+        std::string arr = tmp("v"), cnt = tmp("n");
+        int cap = (int)a.fixed.size() + (a.multi ? 8 : 0);
+        if (cap < min_size) cap = min_size;
+        if (cap < 1) cap = 1;
+        line(f, "bkv " + arr + "[" + std::to_string(cap) + "];");
+        for (size_t i = 0; i < a.fixed.size(); ++i) line(f, arr + "[" + std::to_string(i) + "] = " + a.fixed[i] + ";");
+        if (a.multi) {
+            line(f, "int " + cnt + " = " + std::to_string(a.fixed.size()) + " + " + a.mcnt + ";");
+            line(f, "for (int q = 0; q < " + a.mcnt + "; ++q) " + arr + "[" + std::to_string(a.fixed.size()) + " + q] = " + a.marr + "[q];");
+        } else {
+            line(f, "const int " + cnt + " = " + std::to_string(a.fixed.size()) + ";");
+        }
+        return {arr, cnt};
+    }
+
+    // a call in multi-value context: results land in *arr (bkv[BK_MAXRET]) with count *cnt
+    void emit_call(Fn &f, const Expr &e, std::string *arr, std::string *cnt)
+    {
+        Value callee;
+        if (!static_value(f, *e.a, &callee)) {
+            std::string n = e.a->kind == Expr::Name ? "'" + e.a->str + "'" : "this expression";
+            unsupported(f.chunk, e.line, "calling " + n + " (callee must be a script function or builtin known at build time)");
+        }
+        *arr = tmp("r");
+        *cnt = tmp("n");
+        if (callee.t == Value::FUNC) {
+            const FnInfo &fi = ensure_function(callee.fn.get(), e.line, f.chunk);
+            Args a = emit_args(f, e.args);
+            auto packed = pack(f, a, 1);
+            line(f, "bkv " + *arr + "[BK_MAXRET];");
+            line(f, "const int " + *cnt + " = " + fi.cname + "(S, " + packed.first + ", " + packed.second + ", " + *arr + ");");
+            return;
+        }
+        if (callee.t != Value::BUILTIN) {
+            std::string n = e.a->kind == Expr::Name ? e.a->str : "?";
+            unsupported(f.chunk, e.line, "attempt to call '" + n + "' (a " + callee.type_name() + " value)");
+        }
+        const std::string &bn = callee.bi->name;
+        if (bn == "print") {                              // no console on the device: drop the call
+            line(f, "bkv " + *arr + "[1]; const int " + *cnt + " = 0; (void)" + *arr + ";");
+            return;
+        }
+        Args a = emit_args(f, e.args);
+        auto A = [&](size_t i) { return arg_at(a, i); };
+        auto num = [&](size_t i) { return "bk_tonum(S, " + A(i) + ")"; };
+        auto single = [&](const std::string &expr) {
+            line(f, "bkv " + *arr + "[1] = {" + expr + "}; const int " + *cnt + " = 1;");
+        };
+        static const std::map<std::string, std::string> unary = {
+            {"math.sin", "bkm_sin"}, {"math.cos", "bkm_cos"}, {"math.tan", "bkm_tan"}, {"math.asin", "bkm_asin"},
+            {"math.acos", "bkm_acos"}, {"math.atan", "bkm_atan"}, {"math.sinh", "bkm_sinh"}, {"math.cosh", "bkm_cosh"},
+            {"math.tanh", "bkm_tanh"}, {"math.exp", "bkm_exp"}, {"math.log10", "bkm_log10"}, {"math.sqrt", "bkm_sqrt"},
+            {"math.abs", "bkm_fabs"}, {"math.floor", "bkm_floor"}, {"math.ceil", "bkm_ceil"}};
+        auto u = unary.find(bn);
+        if (u != unary.end()) { single("bk_num(" + u->second + "(" + num(0) + "))"); return; }
+        if (bn == "math.atan2") { single("bk_num(bkm_atan2(" + num(0) + ", " + num(1) + "))"); return; }
+        if (bn == "math.pow") { single("bk_num(bkm_pow(" + num(0) + ", " + num(1) + "))"); return; }
+        if (bn == "math.fmod") { single("bk_num(bkm_fmod(" + num(0) + ", " + num(1) + "))"); return; }
+        if (bn == "math.deg") { single("bk_num(" + num(0) + " / (0x1.921fb54442d18p+1 / 180.0))"); return; }
+        if (bn == "math.rad") { single("bk_num(" + num(0) + " * (0x1.921fb54442d18p+1 / 180.0))"); return; }
+        if (bn == "math.log") {
+            if (a.fixed.size() < 2 && !a.multi) { single("bk_num(bkm_log(" + num(0) + "))"); return; }
+            std::string x = tmp(), b = tmp();
+            line(f, "const double " + x + " = " + num(0) + "; const bkv " + b + " = " + A(1) + ";");
+            single(b + ".t == BK_TNIL ? bk_num(bkm_log(" + x + ")) : (bk_tonum(S, " + b + ") == 10.0 ? bk_num(bkm_log10(" + x + ")) : bk_num(bkm_log(" + x + ") / bkm_log(" + b + ".n)))");
+            return;
+        }
+        if (bn == "math.max" || bn == "math.min") {
+            if (a.multi) unsupported(f.chunk, e.line, bn + " over an expanded call");
+            if (a.fixed.empty()) unsupported(f.chunk, e.line, bn + " without arguments");
+            std::string m = tmp("m");
+            line(f, "double " + m + " = " + num(0) + ";");
+            for (size_t i = 1; i < a.fixed.size(); ++i) {
+                std::string d = tmp("d");
+                line(f, "{ const double " + d + " = " + num(i) + "; if (" + d + (bn == "math.max" ? " > " : " < ") + m + ") " + m + " = " + d + "; }");
+            }
+            single("bk_num(" + m + ")");
+            return;
+        }
+        if (bn == "math.modf") {
+            std::string x = tmp("x"), ip = tmp("ip");
+            line(f, "const double " + x + " = " + num(0) + ", " + ip + " = bkm_trunc(" + x + ");");
+            line(f, "bkv " + *arr + "[2] = {bk_num(" + ip + "), bk_num(bkm_isinf(" + x + ") ? bkm_copysign(0.0, " + x + ") : " + x + " - " + ip + ")}; const int " + *cnt + " = 2;");
+            return;
+        }
+        if (bn == "latlon_to_ray") {
+            line(f, "bkv " + *arr + "[3]; const int " + *cnt + " = bk_host_latlon_to_ray(S, " + A(0) + ", " + A(1) + ", " + *arr + ");");
+            return;
+        }
+        if (bn == "ray_to_latlon") {
+            line(f, "bkv " + *arr + "[2]; const int " + *cnt + " = bk_host_ray_to_latlon(S, " + A(0) + ", " + A(1) + ", " + A(2) + ", " + *arr + ");");
+            return;
+        }
+        if (bn == "plate_to_ray") {
+            line(f, "bkv " + *arr + "[3]; const int " + *cnt + " = bk_host_plate_to_ray(S, " + A(0) + ", " + A(1) + ", " + A(2) + ", " + *arr + ");");
+            return;
+        }
+        unsupported(f.chunk, e.line, "builtin '" + bn + "'");
+    }
+
+    // ---- statements ---------------------------------------------------------------------------------
+    void emit_block(Fn &f, const Block &b)
+    {
+        for (const StmtP &s : b) emit_stmt(f, *s);
+    }
+
+    // evaluate an expression list adjusted to exactly `want` values (temps)
+    std::vector<std::string> emit_values(Fn &f, const std::vector<ExprP> &exprs, size_t want)
+    {
+        Args a = emit_args(f, exprs);
+        std::vector<std::string> v;
+        for (size_t i = 0; i < want; ++i) {
+            std::string t = tmp();
+            line(f, "const bkv " + t + " = " + arg_at(a, i) + ";");
+            v.push_back(t);
+        }
+        return v;
+    }
+
+    void store(Fn &f, const Expr &target, const std::string &val)
+    {
+        if (target.kind == Expr::Name) {
+            if (target.var == VarKind::Local) {
+                if (f.array_slots.count(target.slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
+                line(f, "l" + std::to_string(target.slot) + " = " + val + ";");
+            } else if (target.var == VarKind::Global) {
+                line(f, "S.g_" + sanitize(target.str) + " = " + val + ";");
+            } else unsupported(f.chunk, target.line, "assigning to the enclosing function's local '" + target.str + "'");
+            return;
+        }
+        if (target.a->kind == Expr::Name && target.a->var == VarKind::Local && f.array_slots.count(target.a->slot)) {
+            std::string k = emit_expr(f, *target.b);
+            line(f, "bk_aset(S, A" + std::to_string(target.a->slot) + ", " + std::to_string(f.array_slots[target.a->slot]) + ", " + k + ", " + val + ");");
+            return;
+        }
+        unsupported(f.chunk, target.line, "storing into this table (only tables created by 'local t = {..}' in the same function are writable)");
+    }
+
+    void emit_stmt(Fn &f, const Stmt &s)
+    {
+        switch (s.kind) {
+        case Stmt::Local: {
+            if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table) {
+                const Expr &t = *s.exprs[0];
+                if (!t.fields.empty()) unsupported(f.chunk, s.line, "table constructors with named fields");
+                for (auto &x : t.args) if (x->kind == Expr::Call && &x == &t.args.back()) unsupported(f.chunk, s.line, "call expansion inside a table constructor");
+                std::vector<std::string> vals;
+                for (auto &x : t.args) vals.push_back(emit_expr(f, *x));
+                int n = (int)vals.size();
+                if (f.array_slots.count(s.slots[0]) && f.array_slots[s.slots[0]] != n) unsupported(f.chunk, s.line, "re-declaring a table with a different size");
+                f.array_slots[s.slots[0]] = n;
+                for (int i = 0; i < n; ++i) line(f, "A" + std::to_string(s.slots[0]) + "[" + std::to_string(i + 1) + "] = " + vals[i] + ";");
+                return;
+            }
+            auto v = emit_values(f, s.exprs, s.slots.size());
+            for (size_t i = 0; i < s.slots.size(); ++i) line(f, "l" + std::to_string(s.slots[i]) + " = " + v[i] + ";");
+            return;
+        }
+        case Stmt::LocalFunction: unsupported(f.chunk, s.line, "nested function definitions");
+        case Stmt::Assign: {
+            auto v = emit_values(f, s.exprs, s.targets.size());
+            for (size_t i = 0; i < s.targets.size(); ++i) store(f, *s.targets[i], v[i]);
+            return;
+        }
+        case Stmt::CallStmt: {
+            std::string arr, cnt;
+            line(f, "{");
+            f.indent++;
+            emit_call(f, *s.call, &arr, &cnt);
+            line(f, "(void)" + cnt + ";");
+            f.indent--;
+            line(f, "}");
+            return;
+        }
+        case Stmt::Do:
+            line(f, "{");
+            f.indent++;
+            emit_block(f, s.body);
+            f.indent--;
+            line(f, "}");
+            return;
+        case Stmt::While: {
+            line(f, "for (;;) {");
+            f.indent++;
+            line(f, "if (!bk_tick(S)) break;");
+            std::string c = emit_expr(f, *s.cond);
+            line(f, "if (!bk_truthy(" + c + ")) break;");
+            emit_block(f, s.body);
+            f.indent--;
+            line(f, "}");
+            return;
+        }
+        case Stmt::Repeat: {
+            line(f, "for (;;) {");
+            f.indent++;
+            line(f, "if (!bk_tick(S)) break;");
+            emit_block(f, s.body);
+            std::string c = emit_expr(f, *s.cond);
+            line(f, "if (bk_truthy(" + c + ")) break;");
+            f.indent--;
+            line(f, "}");
+            return;
+        }
+        case Stmt::If: {
+            int opened = 0;
+            for (size_t i = 0; i < s.clauses.size(); ++i) {
+                const auto &c = s.clauses[i];
+                if (!c.first) {
+                    emit_block(f, c.second);
+                    break;
+                }
+                std::string cv = emit_expr(f, *c.first);
+                line(f, "if (bk_truthy(" + cv + ")) {");
+                f.indent++;
+                emit_block(f, c.second);
+                f.indent--;
+                if (i + 1 < s.clauses.size()) {
+                    line(f, "} else {");
+                    f.indent++;
+                    opened++;
+                } else line(f, "}");
+            }
+            for (int k = 0; k < opened; ++k) { f.indent--; line(f, "}"); }
+            return;
+        }
+        case Stmt::NumFor: {
+            std::string start = emit_expr(f, *s.exprs[0]), stop = emit_expr(f, *s.exprs[1]);
+            std::string step = s.exprs.size() > 2 ? emit_expr(f, *s.exprs[2]) : "bk_num(1.0)";
+            std::string st = tmp("step"), lim = tmp("lim"), idx = tmp("idx");
+            line(f, "const double " + st + " = bk_tonum(S, " + step + "), " + lim + " = bk_tonum(S, " + stop + ");");
+            line(f, "double " + idx + " = bk_tonum(S, " + start + ") - " + st + ";");       // OP_FORPREP
+            line(f, "for (;;) {");
+            f.indent++;
+            line(f, idx + " = " + idx + " + " + st + ";");                                     // OP_FORLOOP
+            line(f, "if (!(0 < " + st + " ? " + idx + " <= " + lim + " : " + lim + " <= " + idx + ")) break;");
+            line(f, "if (!bk_tick(S)) break;");
+            line(f, "l" + std::to_string(s.slots[0]) + " = bk_num(" + idx + ");");
+            emit_block(f, s.body);
+            f.indent--;
+            line(f, "}");
+            return;
+        }
+        case Stmt::GenFor: unsupported(f.chunk, s.line, "generic 'for ... in' loops");
+        case Stmt::Return: {
+            if (s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Call) {
+                std::string arr, cnt;
+                line(f, "{");
+                f.indent++;
+                emit_call(f, *s.exprs[0], &arr, &cnt);
+                line(f, "for (int q = 0; q < " + cnt + "; ++q) r[q] = " + arr + "[q];");
+                line(f, "return " + cnt + ";");
+                f.indent--;
+                line(f, "}");
+                return;
+            }
+            line(f, "{");
+            f.indent++;
+            Args a = emit_args(f, s.exprs);
+            if (a.fixed.size() > 8 || (a.multi && a.fixed.size() > 4)) unsupported(f.chunk, s.line, "more than 8 return values");
+            for (size_t i = 0; i < a.fixed.size(); ++i) line(f, "r[" + std::to_string(i) + "] = " + a.fixed[i] + ";");
+            if (a.multi) {
+                line(f, "for (int q = 0; q < " + a.mcnt + " && " + std::to_string(a.fixed.size()) + " + q < BK_MAXRET; ++q) r[" + std::to_string(a.fixed.size()) + " + q] = " + a.marr + "[q];");
+                line(f, "return " + std::to_string(a.fixed.size()) + " + " + a.mcnt + ";");
+            } else line(f, "return " + std::to_string(a.fixed.size()) + ";");
+            f.indent--;
+            line(f, "}");
+            return;
+        }
+        case Stmt::Break: line(f, "break;"); return;
+        }
+    }
+
+    // ---- functions -------------------------------------------------------------------------------------
+    const FnInfo &ensure_function(const Closure *cl, int line_no, const std::string &from_chunk)
+    {
+        FnInfo &fi = fns[cl->proto];
+        if (fi.done) {
+            if (fi.cl != cl) unsupported(from_chunk, line_no, "two closures of the same function body");
+            return fi;
+        }
+        if (fi.emitting) unsupported(from_chunk, line_no, "recursion ('" + cl->proto->name + "')");
+        fi.proto = cl->proto;
+        fi.cl = cl;
+        fi.cname = "LF" + std::to_string(++uid) + "_" + sanitize(cl->proto->name);
+        fi.emitting = true;
+        if (cl->proto->is_vararg) unsupported(cl->chunk->name, cl->proto->line, "vararg functions");
+
+        Fn f;
+        f.proto = cl->proto;
+        f.cl = cl;
+        f.chunk = cl->chunk->name;
+        emit_block(f, cl->proto->body);
+
+        std::ostringstream o;
+        o << "/* " << f.chunk << ":" << cl->proto->line << "  function " << cl->proto->name << " */\n";
+        o << "BK_DEV int " << fi.cname << "(BkState &S, const bkv *a, int na, bkv *r)\n{\n";
+        for (int i = 0; i < cl->proto->nslots; ++i) {
+            if (f.array_slots.count(i)) {
+                o << "    bkv A" << i << "[" << f.array_slots[i] + 1 << "];   /* " << cl->proto->slot_names[i] << " */\n";
+                o << "    for (int q = 0; q <= " << f.array_slots[i] << "; ++q) A" << i << "[q] = bk_nil();\n";
+            } else if (i < cl->proto->nparams) {
+                o << "    bkv l" << i << " = na > " << i << " ? a[" << i << "] : bk_nil();   /* " << cl->proto->slot_names[i] << " */\n";
+            } else {
+                o << "    bkv l" << i << " = bk_nil();   /* " << cl->proto->slot_names[i] << " */\n";
+            }
+        }
+        o << "    (void)a; (void)na; (void)r;\n";
+        o << f.out.str();
+        o << "    return 0;\n}\n\n";
+        fn_code.push_back(o.str());
+        fi.emitting = false;
+        fi.done = true;
+        return fi;
+    }
+};
+
+}  // namespace
+
+std::string emit_build_source(const EmitRequest &req)
+{
+    Emitter em(*req.interp);
+    std::set<const FuncProto *> seen;
+    const Value *roots[3] = {&req.lens_inverse, &req.lens_forward, &req.globe_plate};
+    for (const Value *v : roots)
+        if (v->t == Value::FUNC && !seen.count(v->fn->proto)) {
+            seen.insert(v->fn->proto);
+            em.scan_block(v->fn->proto->body, v->fn.get(), seen);
+        }
+    for (const Value *v : roots)
+        if (v->t != Value::NIL && v->t != Value::FUNC)
+            throw LuaError(std::string("a lens / globe callback must be a Lua function, got a ") + v->type_name());
+
+    std::string names[3];
+    for (int i = 0; i < 3; ++i)
+        if (roots[i]->t == Value::FUNC) names[i] = em.ensure_function(roots[i]->fn.get(), 0, "callback").cname;
+
+    std::ostringstream src;
+    src << "/* generated by libblinkyhip (bk_emit.cpp) */\n";
+    src << "#define BK_MUTABLE_GLOBALS";
+    for (const std::string &g : em.mutable_globals) src << " bkv g_" << sanitize(g) << ";";
+    src << "\n";
+    src << "#include \"bkm.h\"\n#include \"bk_build_params.h\"\n#include \"bk_device_rt.h\"\n\n";
+    src << em.table_code.str() << "\n";
+    for (const std::string &c : em.fn_code) src << c;
+    src << "#define BK_INIT_GLOBALS(S)";
+    for (const std::string &g : em.mutable_globals) {
+        Value v = req.interp->get_global(g);
+        std::string init;
+        switch (v.t) {
+        case Value::NIL: init = "bk_nil()"; break;
+        case Value::BOOL: init = v.b ? "bk_bool(true)" : "bk_bool(false)"; break;
+        case Value::NUM: init = num_literal(v.n); break;
+        default:
+            throw LuaError("global '" + g + "' is assigned inside a GPU callback but holds a " + v.type_name() +
+                           " when the lensmap build starts; only nil / boolean / number globals can be per-pixel state");
+        }
+        src << " (S).g_" << sanitize(g) << " = " << init << ";";
+    }
+    src << "\n";
+    if (!names[0].empty()) src << "#define BK_HAS_INVERSE 1\n#define LF_lens_inverse " << names[0] << "\n";
+    if (!names[1].empty()) src << "#define BK_HAS_FORWARD 1\n#define LF_lens_forward " << names[1] << "\n";
+    if (!names[2].empty()) src << "#define BK_HAS_GLOBE_PLATE 1\n#define LF_globe_plate " << names[2] << "\n";
+    src << "#include \"bk_build_kernels.h\"\n";
+    return src.str();
+}
+
+}  // namespace bk

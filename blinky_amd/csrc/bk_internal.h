@@ -31,6 +31,7 @@ struct bk_ctx {
 
     // geometry (fisheye.c:704-708)
     int W = 0, H = 0, ps = 0;
+    int gp = 0;                      // padded row pitch of the device globe: round_up(ps, 64)
     int row0 = 0, row1 = 0;          // owned output rows
     int nframes = 1;
 
@@ -46,13 +47,14 @@ struct bk_ctx {
     bk::Rubix rubix;
 
     // device memory
-    uint8_t *d_globe = nullptr;      // [nframes][6][ps][ps]
-    uint32_t *d_offsets = nullptr;   // [row1-row0][W]
+    uint8_t *d_globe = nullptr;      // [nframes][6][ps][gp]  (rows padded to gp bytes)
+    uint32_t *d_offsets = nullptr;   // [row1-row0][W]  offsets into the PADDED globe layout
+    uint32_t *d_convert = nullptr;   // [row1-row0][W]  scratch for layout conversion at the ABI boundary
     uint8_t *d_tints = nullptr;      // [row1-row0][W]
     uint8_t *d_frame = nullptr;      // [row1-row0][W] staging for bk_apply (host dst)
     uint8_t *d_pal = nullptr;        // [6][256]
     uint64_t *d_mask = nullptr;      // mapped bits, 1 per pixel of the owned rows
-    int *d_display = nullptr;        // [6] display flags written by the build kernels
+    int *d_display = nullptr;        // [6] display flags + [1] error bits written by the build kernels
     uint8_t *h_frame = nullptr;      // pinned, [row1-row0][W]
     uint64_t *h_mask = nullptr;      // pinned
     size_t globe_bytes = 0;          // allocated size of d_globe
@@ -78,6 +80,8 @@ struct bk_ctx {
         return code;
     }
     int rows() const { return row1 - row0; }
+    size_t plate_bytes() const { return (size_t)gp * ps; }
+    size_t globe_stride() const { return (size_t)BK_MAX_PLATES * gp * ps; }
 };
 
 #define BK_HIP(ctx, expr)                                                               \
@@ -93,7 +97,8 @@ namespace bk {
 int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,
                  size_t frame_stride, int rubix_on);
 int launch_mask(bk_ctx *ctx);                 // d_offsets -> d_mask
-int launch_fill_lcg(bk_ctx *ctx, uint8_t *dst, size_t n, uint32_t seed);
+int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed);   // one plate, padded rows
+int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_padded);   // reference <-> padded layout
 void tilemap_invalidate(bk_ctx *ctx);
 void tilemap_free(TileMap *);
 

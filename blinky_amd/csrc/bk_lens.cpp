@@ -1,10 +1,215 @@
-// bk_lens.cpp -- script front-end glue (placeholder until the Lua front-end lands)
+// bk_lens.cpp -- the script side of the C ABI: globe / lens loading, zoom, and the GPU lensmap
+// build (emit -> hiprtc -> launch).  Host logic mirrors fisheye.c's LUA_load_globe (1752-1875),
+// LUA_load_lens (1659-1750), calc_zoom (1293-1386) and create_lensmap (2367-2397).
+#include <hip/hiprtc.h>
+
+#include <cstring>
+
+#include "bk_build_params.h"
+#include "bk_emit.h"
 #include "bk_internal.h"
-namespace bk { struct LensProgram {}; void lensprogram_free(LensProgram *p) { delete p; } }
-#define NOTYET(ctx) ((ctx) ? (ctx)->fail(BK_E_STATE, "%s: script front-end not built yet", __func__) : BK_E_INVALID)
-extern "C" int bk_load_globe(bk_ctx *ctx, const char *, size_t, const char *) { return NOTYET(ctx); }
-extern "C" int bk_load_lens(bk_ctx *ctx, const char *, size_t, const char *) { return NOTYET(ctx); }
-extern "C" int bk_get_lens_info(const bk_ctx *, bk_lens_info *) { return BK_E_STATE; }
+#include "bk_lua.h"
+#include "bkm.h"
+
+using namespace bklua;
+
+namespace bk {
+
+struct LensProgram {
+    Interp interp;
+    // lens (fisheye.c:379-451 + lua_refs 328-332)
+    bool lens_valid = false;
+    bk_lens_info info{};
+    Value lens_inverse, lens_forward, globe_plate;
+    // compiled build kernels, keyed by the generated source text
+    std::string module_source;
+    hipModule_t module = nullptr;
+    hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr;
+    std::string last_source;      // for bk_debug_kernel_source
+    std::string console;          // print() output of the scripts
+
+    explicit LensProgram(bk_ctx *ctx);
+};
+
+// ---- host versions of the converters (fisheye.c:1184-1214), on the portable libm ----------------
+static void h_vector_ma(const float *a, float scale, const float *b, float *c)
+{
+    c[0] = a[0] + scale * b[0];
+    c[1] = a[1] + scale * b[1];
+    c[2] = a[2] + scale * b[2];
+}
+static void h_vector_normalize(float *v)
+{
+    float length = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    length = (float)__builtin_sqrt((double)length);
+    if (length) {
+        float ilength = 1 / length;
+        v[0] *= ilength;
+        v[1] *= ilength;
+        v[2] *= ilength;
+    }
+}
+static void h_latlon_to_ray(const MathLib &M, double lat, double lon, float *ray)
+{
+    double clat = M.cos(lat);
+    ray[0] = (float)(M.sin(lon) * clat);
+    ray[1] = (float)M.sin(lat);
+    ray[2] = (float)(M.cos(lon) * clat);
+}
+static void h_ray_to_latlon(const MathLib &M, const float *ray, double *lat, double *lon)
+{
+    *lon = M.atan2((double)ray[0], (double)ray[2]);
+    *lat = M.atan2((double)ray[1], M.sqrt((double)(ray[0] * ray[0] + ray[2] * ray[2])));
+}
+static void h_plate_uv_to_ray(const bk_plate &p, double u, double v, float *ray)
+{
+    u -= 0.5;
+    v -= 0.5;
+    v = -v;
+    ray[0] = ray[1] = ray[2] = 0;
+    h_vector_ma(ray, p.dist, p.forward, ray);
+    h_vector_ma(ray, (float)u, p.right, ray);
+    h_vector_ma(ray, (float)v, p.up, ray);
+    h_vector_normalize(ray);
+}
+static void h_cross(const float *v1, const float *v2, float *cross)            /* mathlib.c:389 */
+{
+    cross[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    cross[1] = v1[2] * v2[0] - v1[0] * v2[2];
+    cross[2] = v1[0] * v2[1] - v1[1] * v2[0];
+}
+
+static double need_num(const Values &a, size_t i, const char *fn)
+{
+    if (i >= a.size() || a[i].t != Value::NUM)
+        throw LuaError(std::string("bad argument #") + std::to_string(i + 1) + " to '" + fn + "' (number expected)");
+    return a[i].n;
+}
+
+// Host-side script execution (chunks, calc_zoom, globe loading) runs on the PLATFORM libm by
+// default: that is what the reference's Lua VM calls on this machine, so lens.scale, lens_width,
+// plate vectors etc. come out bit-identical to the reference's.  bk_set_host_math() switches
+// to the portable bkm.h functions (= what the GPU kernels use) for platform-independent results.
+LensProgram::LensProgram(bk_ctx *ctx) : interp(math_platform())
+{
+    interp.print_sink = [this](const std::string &s) { console += s + "\n"; };
+    // the aliases init_lua installs (fisheye.c:1230-1248): cos = math.cos ... tau = math.pi*2
+    static const char *alias[] = {"cos", "sin", "tan", "asin", "acos", "atan", "atan2", "sinh", "cosh", "tanh",
+                                  "log", "log10", "abs", "sqrt", "exp", "pow"};
+    Value math = interp.get_global("math");
+    for (const char *a : alias) interp.set_global(a, math.tab->get(Value::string(a)));
+    interp.set_global("pi", math.tab->get(Value::string("pi")));
+    interp.set_global("tau", Value::number(math.tab->get(Value::string("pi")).n * 2));
+    // the three C functions scripts may call (fisheye.c:1257-1264, 1494-1537)
+    interp.register_builtin("latlon_to_ray", [](Interp &I, const Values &a, Values &r) {
+        float ray[3];
+        h_latlon_to_ray(*I.math, need_num(a, 0, "latlon_to_ray"), need_num(a, 1, "latlon_to_ray"), ray);
+        for (int i = 0; i < 3; ++i) r.push_back(Value::number((double)ray[i]));
+    });
+    interp.register_builtin("ray_to_latlon", [](Interp &I, const Values &a, Values &r) {
+        float ray[3] = {(float)need_num(a, 0, "ray_to_latlon"), (float)need_num(a, 1, "ray_to_latlon"),
+                        (float)need_num(a, 2, "ray_to_latlon")};
+        double lat, lon;
+        h_ray_to_latlon(*I.math, ray, &lat, &lon);
+        r.push_back(Value::number(lat));
+        r.push_back(Value::number(lon));
+    });
+    interp.register_builtin("plate_to_ray", [ctx](Interp &, const Values &a, Values &r) {
+        int pi = (int)need_num(a, 0, "plate_to_ray");
+        double u = need_num(a, 1, "plate_to_ray"), v = need_num(a, 2, "plate_to_ray");
+        if (pi < 0 || pi >= ctx->numplates) { r.push_back(Value()); return; }       /* fisheye.c:1527-1530 */
+        float ray[3];
+        h_plate_uv_to_ray(ctx->plates[pi], u, v, ray);
+        for (int i = 0; i < 3; ++i) r.push_back(Value::number((double)ray[i]));
+    });
+}
+
+void lensprogram_free(LensProgram *p)
+{
+    if (!p) return;
+    if (p->module) (void)hipModuleUnload(p->module);
+    delete p;
+}
+
+static LensProgram *prog_of(bk_ctx *ctx)
+{
+    if (!ctx->prog) ctx->prog = new LensProgram(ctx);
+    return ctx->prog;
+}
+
+static void fill_plate(const MathLib &M, bk_plate &p, const double fwd[3], const double up[3], double fov_deg, bool *fov_ok)
+{
+    for (int j = 0; j < 3; ++j) p.forward[j] = (float)fwd[j];                  /* fisheye.c:1818 */
+    for (int j = 0; j < 3; ++j) p.up[j] = (float)up[j];                        /* :1843 */
+    h_cross(p.up, p.forward, p.right);                                          /* :1849 */
+    h_cross(p.forward, p.right, p.up);                                          /* :1850 */
+    p.fov = (float)(fov_deg * 3.14159265358979323846 / 180);                    /* :1858 */
+    *fov_ok = p.fov > 0;                                                        /* :1861 */
+    p.dist = (float)(0.5 / M.tan((double)(p.fov / 2)));                         /* :1868 */
+}
+
+}  // namespace bk
+
+using bk::LensProgram;
+
+// ---- globe ---------------------------------------------------------------------------------------------
+
+extern "C" int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const char *chunkname)
+{
+    if (!ctx || !src) return BK_E_INVALID;
+    LensProgram *P = bk::prog_of(ctx);
+    Interp &I = P->interp;
+    const std::string name = chunkname ? chunkname : "globe";
+    // LUA_clear_globe, fisheye.c:1897-1903
+    I.set_global("plates", Value());
+    I.set_global("globe_plate", Value());
+    ctx->numplates = 0;
+    ctx->globe_valid = false;
+    P->globe_plate = Value();
+    try {
+        I.run(std::string(src, len), name);
+        Value gp = I.get_global("globe_plate");
+        if (gp.is_function()) P->globe_plate = gp;                              /* :1778-1782 */
+        Value plates = I.get_global("plates");
+        if (plates.t != Value::TABLE || plates.tab->length() < 1)
+            return ctx->fail(BK_E_SCRIPT, "plates must be an array of one or more elements");   /* :1788 */
+        // lua_next order: array part, then the rest (:1796)
+        Values items = plates.tab->arr;
+        for (auto &kv : plates.tab->nhash) items.push_back(kv.second);
+        for (auto &kv : plates.tab->shash) items.push_back(kv.second);
+        if (items.size() > BK_MAX_PLATES)
+            return ctx->fail(BK_E_SCRIPT, "globe defines %zu plates; at most %d are supported (MAX_PLATES, fisheye.c:352)",
+                             items.size(), BK_MAX_PLATES);
+        int i = 0;
+        for (const Value &plate : items) {
+            double vec[2][3];
+            static const char *vname[2] = {"forward", "up"};
+            if (plate.t != Value::TABLE) return ctx->fail(BK_E_SCRIPT, "plate %d: not a table", i + 1);
+            for (int k = 0; k < 2; ++k) {
+                Value v = plate.tab->get(Value::number(k + 1));
+                if (v.t != Value::TABLE || v.tab->length() != 3)
+                    return ctx->fail(BK_E_SCRIPT, "plate %d: %s vector is not a 3d vector", i + 1, vname[k]);   /* :1804,1829 */
+                for (int j = 0; j < 3; ++j) {
+                    Value e = v.tab->get(Value::number(j + 1));
+                    if (e.t != Value::NUM)
+                        return ctx->fail(BK_E_SCRIPT, "plate %d: %s vector: element %d not a number", i + 1, vname[k], j + 1);
+                    vec[k][j] = e.n;
+                }
+            }
+            Value fov = plate.tab->get(Value::number(3));
+            bool fov_ok = false;
+            bk::fill_plate(*I.math, ctx->plates[i], vec[0], vec[1], fov.t == Value::NUM ? fov.n : 0.0, &fov_ok);
+            if (!fov_ok) return ctx->fail(BK_E_SCRIPT, "plate %d: fov must > 0", i + 1);                       /* :1863 */
+            ++i;
+        }
+        ctx->numplates = i;                                                     /* :1872 */
+        ctx->globe_valid = true;
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "could not load globe: %s", e.what());
+    }
+    return BK_OK;
+}
+
 extern "C" int bk_get_globe(const bk_ctx *ctx, bk_plate plates[BK_MAX_PLATES], int *n)
 {
     if (!ctx) return BK_E_INVALID;
@@ -12,13 +217,406 @@ extern "C" int bk_get_globe(const bk_ctx *ctx, bk_plate plates[BK_MAX_PLATES], i
     if (n) *n = ctx->numplates;
     return BK_OK;
 }
+
 extern "C" int bk_set_globe_plates(bk_ctx *ctx, const bk_plate *plates, int numplates)
 {
     if (!ctx || !plates || numplates < 1 || numplates > BK_MAX_PLATES) return BK_E_INVALID;
     for (int i = 0; i < numplates; ++i) ctx->plates[i] = plates[i];
     ctx->numplates = numplates;
     ctx->globe_valid = true;
+    if (ctx->prog) ctx->prog->globe_plate = Value();
     return BK_OK;
 }
-extern "C" int bk_build(bk_ctx *ctx, int *, double *) { return NOTYET(ctx); }
-extern "C" int bk_calc_zoom(bk_ctx *ctx, double *) { return NOTYET(ctx); }
+
+// ---- lens ------------------------------------------------------------------------------------------------
+
+extern "C" int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char *chunkname)
+{
+    if (!ctx || !src) return BK_E_INVALID;
+    LensProgram *P = bk::prog_of(ctx);
+    Interp &I = P->interp;
+    const std::string name = chunkname ? chunkname : "lens";
+    // LUA_clear_lens, fisheye.c:1880-1894
+    for (const char *g : {"map", "max_fov", "max_vfov", "lens_width", "lens_height", "lens_inverse", "lens_forward", "onload"})
+        I.set_global(g, Value());
+    I.set_global("numplates", Value::number((double)ctx->numplates));
+    P->lens_valid = false;
+    P->lens_inverse = P->lens_forward = Value();
+    memset(&P->info, 0, sizeof P->info);
+    try {
+        I.run(std::string(src, len), name);
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "could not load lens: %s", e.what());
+    }
+    bk_lens_info &info = P->info;
+    info.map_type = BK_MAP_NONE;
+    Value inv = I.get_global("lens_inverse"), fwd = I.get_global("lens_forward");
+    if (inv.is_function()) { P->lens_inverse = inv; info.has_inverse = 1; info.map_type = BK_MAP_INVERSE; }      /* :1688-1696 */
+    if (fwd.is_function()) {                                                                                  /* :1699-1709 */
+        P->lens_forward = fwd;
+        info.has_forward = 1;
+        if (info.map_type == BK_MAP_NONE) info.map_type = BK_MAP_FORWARD;
+    }
+    Value map = I.get_global("map");                                                                          /* :1712-1731 */
+    if (map.t == Value::STR || map.t == Value::NUM) {
+        std::string fn = I.tostring(map);
+        if (fn == "lens_inverse") info.map_type = BK_MAP_INVERSE;
+        else if (fn == "lens_forward") info.map_type = BK_MAP_FORWARD;
+        else return ctx->fail(BK_E_SCRIPT, "Unsupported map function: %s", fn.c_str());
+    }
+    auto num_or_zero = [&](const char *g) { Value v = I.get_global(g); return v.t == Value::NUM ? v.n : 0.0; };
+    info.max_fov = (int)num_or_zero("max_fov");                                                               /* :1733-1739 */
+    info.max_vfov = (int)num_or_zero("max_vfov");
+    info.lens_width = num_or_zero("lens_width");                                                              /* :1741-1747 */
+    info.lens_height = num_or_zero("lens_height");
+    Value onload = I.get_global("onload");                                                                    /* cmd_lens :1087-1095 */
+    if (onload.t == Value::STR || onload.t == Value::NUM) snprintf(info.onload, sizeof info.onload, "%s", I.tostring(onload).c_str());
+    P->lens_valid = true;
+    return BK_OK;
+}
+
+extern "C" int bk_get_lens_info(const bk_ctx *ctx, bk_lens_info *out)
+{
+    if (!ctx || !out) return BK_E_INVALID;
+    if (!ctx->prog || !ctx->prog->lens_valid) { memset(out, 0, sizeof *out); return BK_E_STATE; }
+    *out = ctx->prog->info;
+    return BK_OK;
+}
+
+// ---- callbacks on the host (calc_zoom only; per-pixel evaluation happens on the GPU) ---------------------
+
+// LUAtoC_lens_forward, fisheye.c:1590-1632: 1 ok, 0 nil, -1 malformed
+static int host_lens_forward(bk_ctx *ctx, const float ray[3], double *x, double *y)
+{
+    LensProgram *P = ctx->prog;
+    Values r = P->interp.call(P->lens_forward, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
+                                                      Value::number((double)ray[2])});
+    if (r.size() == 2) {
+        if (r[0].t == Value::NUM && r[1].t == Value::NUM) { *x = r[0].n; *y = r[1].n; return 1; }
+        ctx->fail(BK_E_SCRIPT, "lens_forward returned a non-number value for x,y");
+        return -1;
+    }
+    if (r.size() == 1) {
+        if (r[0].t == Value::NIL) return 0;
+        ctx->fail(BK_E_SCRIPT, "lens_forward returned a single non-nil value");
+        return -1;
+    }
+    ctx->fail(BK_E_SCRIPT, "lens_forward returned %zu values instead of 2", r.size());
+    return -1;
+}
+
+extern "C" int bk_calc_zoom(bk_ctx *ctx, double *scale_out)
+{
+    if (!ctx) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "no valid lens");
+    if (ctx->W <= 0 || ctx->H <= 0) return ctx->fail(BK_E_STATE, "bk_calc_zoom: call bk_resize first");
+    const bk_lens_info &L = P->info;
+    double scale = -1;                                                                   /* :1296 */
+    try {
+        if (ctx->zoom_type == BK_ZOOM_FOV || ctx->zoom_type == BK_ZOOM_VFOV) {
+            if (L.max_fov <= 0 || L.max_vfov <= 0)
+                return ctx->fail(BK_E_ZOOM, "max_fov & max_vfov not specified, try \"f_cover\"");            /* :1303 */
+            if (ctx->zoom_type == BK_ZOOM_FOV && ctx->zoom_fov > L.max_fov)
+                return ctx->fail(BK_E_ZOOM, "fov must be less than %d", L.max_fov);                           /* :1307 */
+            if (ctx->zoom_type == BK_ZOOM_VFOV && ctx->zoom_fov > L.max_vfov)
+                return ctx->fail(BK_E_ZOOM, "vfov must be less than %d", L.max_vfov);                         /* :1311 */
+            if (!L.has_forward)
+                return ctx->fail(BK_E_ZOOM, "Please specify a forward mapping function in your script for FOV scaling");   /* :1343 */
+            float ray[3];
+            double x = 0, y = 0;
+            const double fovr = ctx->zoom_fov * 3.14159265358979323846 / 180;                                 /* :1319 */
+            if (ctx->zoom_type == BK_ZOOM_FOV) bk::h_latlon_to_ray(*P->interp.math, 0, fovr * 0.5, ray);       /* :1321 */
+            else bk::h_latlon_to_ray(*P->interp.math, fovr * 0.5, 0, ray);                                     /* :1331 */
+            const int st = host_lens_forward(ctx, ray, &x, &y);
+            if (st == -1) return BK_E_SCRIPT;
+            if (st == 0) return ctx->fail(BK_E_ZOOM, "ray_to_xy did not return a valid r value for determining FOV scale");
+            scale = ctx->zoom_type == BK_ZOOM_FOV ? x / (ctx->W * 0.5) : y / (ctx->H * 0.5);                   /* :1323, 1333 */
+        } else if (ctx->zoom_type == BK_ZOOM_CONTAIN || ctx->zoom_type == BK_ZOOM_COVER) {
+            const double fit_w = L.lens_width / ctx->W, fit_h = L.lens_height / ctx->H;                        /* :1349-1350 */
+            const bool wp = L.lens_width > 0, hp = L.lens_height > 0;
+            if (!wp && hp) scale = fit_h;
+            else if (wp && !hp) scale = fit_w;
+            else if (!wp && !hp)
+                return ctx->fail(BK_E_ZOOM, "neither lens_height nor lens_width are valid/specified.  Try f_fov instead.");
+            else {
+                const double lens_aspect = L.lens_width / L.lens_height;
+                const double screen_aspect = (double)ctx->W / ctx->H;
+                const bool lens_wider = lens_aspect > screen_aspect;
+                if (ctx->zoom_type == BK_ZOOM_CONTAIN) scale = lens_wider ? fit_w : fit_h;
+                else scale = lens_wider ? fit_h : fit_w;
+            }
+        }
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "lens_forward failed: %s", e.what());
+    }
+    if (!(scale > 0)) return ctx->fail(BK_E_ZOOM, "init returned a scale of %f, which is  <= 0", scale);       /* :1380 */
+    ctx->scale = scale;
+    if (scale_out) *scale_out = scale;
+    return BK_OK;
+}
+
+// ---- hiprtc ---------------------------------------------------------------------------------------------
+
+static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source)
+{
+    if (P->module && source == P->module_source) return BK_OK;
+    if (P->module) { (void)hipModuleUnload(P->module); P->module = nullptr; }
+    P->k_inverse = P->k_corners = P->k_quads = P->k_resolve = nullptr;
+    std::vector<const char *> hnames, htexts;
+    for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) {
+        hnames.push_back(bk::kEmbeddedHeaders[i].name);
+        htexts.push_back(bk::kEmbeddedHeaders[i].text);
+    }
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "bk_lens_build.hip", (int)hnames.size(), htexts.data(), hnames.data()) != HIPRTC_SUCCESS)
+        return ctx->fail(BK_E_HIP, "hiprtcCreateProgram failed");
+    hipDeviceProp_t prop;
+    std::string arch = "--offload-arch=gfx950";
+    if (ctx->device >= 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.gcnArchName[0])
+        arch = std::string("--offload-arch=") + prop.gcnArchName;
+    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+    hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, 0);
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return ctx->fail(BK_E_HIP, "hiprtc failed to compile the lens kernels: %s", log.c_str());
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    if (ctx->device < 0) {              // host-only context: compiling is all we can do
+        P->module_source = source;
+        return BK_OK;
+    }
+    BK_HIP(ctx, hipModuleLoadData(&P->module, code.data()));
+    (void)hipModuleGetFunction(&P->k_inverse, P->module, "bk_build_inverse");
+    (void)hipModuleGetFunction(&P->k_corners, P->module, "bk_forward_corners");
+    (void)hipModuleGetFunction(&P->k_quads, P->module, "bk_forward_quads");
+    (void)hipModuleGetFunction(&P->k_resolve, P->module, "bk_forward_resolve");
+    (void)hipGetLastError();
+    P->module_source = source;
+    return BK_OK;
+}
+
+static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out)
+{
+    bk::EmitRequest rq;
+    rq.interp = &P->interp;
+    rq.lens_inverse = P->lens_inverse;
+    rq.lens_forward = P->lens_forward;
+    rq.globe_plate = P->globe_plate;
+    try {
+        *out = bk::emit_build_source(rq);
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "%s", e.what());
+    }
+    P->last_source = *out;
+    return BK_OK;
+}
+
+// debug / test hook: the generated HIP translation unit for the current lens + globe
+extern "C" int bk_debug_kernel_source(bk_ctx *ctx, char *buf, size_t cap, size_t *needed, int compile)
+{
+    if (!ctx) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "no valid lens");
+    std::string src;
+    if (int r = generate_source(ctx, P, &src)) return r;
+    if (needed) *needed = src.size() + 1;
+    if (buf && cap) snprintf(buf, cap, "%s", src.c_str());
+    if (compile) return compile_module(ctx, P, src);
+    return BK_OK;
+}
+
+// debug / test hook: evaluate a callback with the HOST interpreter (the same AST the GPU code was
+// generated from).  which: 0 = lens_inverse(x,y), 1 = lens_forward(x,y,z), 2 = globe_plate(x,y,z)
+extern "C" int bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs, double *out, int *nout)
+{
+    if (!ctx || !ctx->prog) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    const Value &f = which == 0 ? P->lens_inverse : which == 1 ? P->lens_forward : P->globe_plate;
+    if (!f.is_function()) return ctx->fail(BK_E_STATE, "callback not defined");
+    try {
+        Values a;
+        for (int i = 0; i < nargs; ++i) a.push_back(Value::number(args[i]));
+        Values r = P->interp.call(f, a);
+        *nout = (int)r.size();
+        for (size_t i = 0; i < r.size() && i < 8; ++i) out[i] = r[i].t == Value::NUM ? r[i].n : __builtin_nan("");
+        if (r.size() == 1 && r[0].t == Value::NIL) *nout = -1;       // a single nil
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "%s", e.what());
+    }
+    return BK_OK;
+}
+
+extern "C" int bk_set_host_math(bk_ctx *ctx, int portable)
+{
+    if (!ctx) return BK_E_INVALID;
+    bk::prog_of(ctx)->interp.math = portable ? &math_portable() : &math_platform();
+    return BK_OK;
+}
+
+extern "C" const char *bk_script_console(bk_ctx *ctx) { return ctx && ctx->prog ? ctx->prog->console.c_str() : ""; }
+
+// ---- build -----------------------------------------------------------------------------------------------
+
+static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
+{
+    memset(bp, 0, sizeof *bp);
+    bp->W = ctx->W; bp->H = ctx->H;
+    bp->row0 = ctx->row0; bp->rows = ctx->rows();
+    bp->ps = ctx->ps; bp->gp = ctx->gp;
+    bp->numplates = ctx->numplates;
+    bp->has_globe_plate = ctx->prog->globe_plate.is_function();
+    bp->scale = ctx->scale;
+    // set_lensmap_grid constants, fisheye.c:1938-1948 (same double operations)
+    const double block_size = ctx->rubix.pad + ctx->rubix.cell;
+    const double num_units = ctx->rubix.numcells * block_size + ctx->rubix.pad;
+    bp->rubix_block = block_size;
+    bp->rubix_pad = ctx->rubix.pad;
+    bp->rubix_unit_px = (double)ctx->ps / num_units;
+    for (int i = 0; i < ctx->numplates; ++i) {
+        const bk_plate &p = ctx->plates[i];
+        BkPlateDev &d = bp->plates[i];
+        memcpy(d.forward, p.forward, 12); memcpy(d.right, p.right, 12); memcpy(d.up, p.up, 12);
+        d.fov = p.fov; d.dist = p.dist;
+        d.dist64 = 0.5 / ctx->prog->interp.math->tan((double)(p.fov / 2));      /* fisheye.c:2060 */
+    }
+    bp->offsets = ctx->d_offsets;
+    bp->tints = ctx->d_tints;
+    bp->display = ctx->d_display;
+    bp->err = ctx->d_display + BK_MAX_PLATES;
+}
+
+static const char *err_text(int bits)
+{
+    if (bits & BK_ERR_RESULT) return "a lens callback returned a malformed result (not 3 numbers / 2 numbers / a single nil)";
+    if (bits & BK_ERR_ARITH) return "a lens callback performed arithmetic on a non-number (nil?)";
+    if (bits & BK_ERR_COMPARE) return "a lens callback compared non-numbers with < or <=";
+    if (bits & BK_ERR_INDEX) return "a lens callback stored outside a table's bounds";
+    if (bits & BK_ERR_LOOP) return "a lens callback exceeded the per-pixel iteration budget (infinite loop?)";
+    return "unknown device error";
+}
+
+extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_build: this context has no device");
+    if (!ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_build: call bk_resize first");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    // F_RenderView clears the maps before (re)building, fisheye.c:731-732; whatever fails below,
+    // the lensmap stays valid-and-empty so that bk_apply draws nothing, as the reference does.
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 2) * sizeof(int), ctx->stream));
+    ctx->lensmap_valid = true;
+    ctx->spans_valid = false;
+    bk::tilemap_invalidate(ctx);
+    for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
+    ctx->last_build_ms = 0;
+
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
+    if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
+    if (int r = bk_calc_zoom(ctx, scale_out)) return r;                                        /* :2376 */
+    if (P->info.map_type == BK_MAP_NONE) return ctx->fail(BK_E_STATE, "no inverse or forward map being used");   /* :2395 */
+
+    std::string src;
+    if (int r = generate_source(ctx, P, &src)) return r;
+    if (int r = compile_module(ctx, P, src)) return r;
+
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    void *args[] = {&bp};
+    hipEvent_t e0, e1;
+    BK_HIP(ctx, hipEventCreate(&e0));
+    BK_HIP(ctx, hipEventCreate(&e1));
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = BK_OK;
+    auto cleanup = [&]() {
+        for (void *p : scratch) if (p) (void)hipFree(p);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    };
+#define BK_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = ctx->fail(BK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+
+    if (P->info.map_type == BK_MAP_INVERSE) {
+        if (!P->k_inverse) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_inverse (map = \"lens_inverse\" without the function)"); }
+        BK_HIP_C(hipEventRecord(e0, ctx->stream));
+        BK_HIP_C(hipModuleLaunchKernel(P->k_inverse, (unsigned)((ctx->W + 255) / 256), (unsigned)ctx->rows(), 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+        BK_HIP_C(hipEventRecord(e1, ctx->stream));
+    } else {
+        if (!P->k_corners || !P->k_quads || !P->k_resolve) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_forward"); }
+        const size_t n1 = (size_t)ctx->ps + 1;
+        const size_t ncorner = (size_t)ctx->numplates * n1 * n1;
+        BK_HIP_C(hipMalloc(&scratch[0], ncorner * 2 * sizeof(int)));
+        BK_HIP_C(hipMalloc(&scratch[1], ncorner));
+        BK_HIP_C(hipMalloc(&scratch[2], px * 4));
+        BK_HIP_C(hipMalloc(&scratch[3], px * 4));
+        bp.corner_xy = (int *)scratch[0];
+        bp.corner_ok = (unsigned char *)scratch[1];
+        bp.fwd_key_px = (unsigned int *)scratch[2];
+        bp.fwd_key_tint = (unsigned int *)scratch[3];
+        BK_HIP_C(hipMemsetAsync(scratch[2], 0, px * 4, ctx->stream));
+        BK_HIP_C(hipMemsetAsync(scratch[3], 0, px * 4, ctx->stream));
+        const size_t ntexel = (size_t)ctx->numplates * ctx->ps * ctx->ps;
+        BK_HIP_C(hipEventRecord(e0, ctx->stream));
+        BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((ncorner + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+        BK_HIP_C(hipModuleLaunchKernel(P->k_quads, (unsigned)((ntexel + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+        BK_HIP_C(hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+        BK_HIP_C(hipEventRecord(e1, ctx->stream));
+    }
+    int flags[BK_MAX_PLATES + 2];
+    BK_HIP_C(hipMemcpyAsync(flags, ctx->d_display, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP_C(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ctx->last_build_ms = ms;
+    cleanup();
+#undef BK_HIP_C
+    for (int i = 0; i < BK_MAX_PLATES; ++i) {
+        ctx->display[i] = i < ctx->numplates ? flags[i] : 0;
+        if (display_out) display_out[i] = ctx->display[i];
+    }
+    if (flags[BK_MAX_PLATES]) return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(flags[BK_MAX_PLATES]));
+    return BK_OK;
+}
+
+// debug / test hook: run a callback on the DEVICE over n argument tuples (nargs doubles each);
+// out receives 8 doubles per tuple, nout the result count (-1 single nil, <= -100 runtime error)
+extern "C" int bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout)
+{
+    if (!ctx || !args || !out || !nout || nargs < 1 || nargs > 4 || n < 1) return BK_E_INVALID;
+    if (ctx->device < 0) return ctx->fail(BK_E_STATE, "this context has no device");
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "no valid lens");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    std::string src;
+    if (int r = generate_source(ctx, P, &src)) return r;
+    if (int r = compile_module(ctx, P, src)) return r;
+    hipFunction_t fn = nullptr;
+    BK_HIP(ctx, hipModuleGetFunction(&fn, P->module, "bk_eval_callback"));
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    double *d_args = nullptr, *d_out = nullptr;
+    int *d_nout = nullptr;
+    BK_HIP(ctx, hipMalloc((void **)&d_args, sizeof(double) * nargs * n));
+    BK_HIP(ctx, hipMalloc((void **)&d_out, sizeof(double) * 8 * n));
+    BK_HIP(ctx, hipMalloc((void **)&d_nout, sizeof(int) * n));
+    BK_HIP(ctx, hipMemcpyAsync(d_args, args, sizeof(double) * nargs * n, hipMemcpyHostToDevice, ctx->stream));
+    void *kargs[] = {&bp, &which, &d_args, &nargs, &n, &d_out, &d_nout};
+    hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, kargs, nullptr);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(nout, d_nout, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_args); (void)hipFree(d_out); (void)hipFree(d_nout);
+    if (e != hipSuccess) return ctx->fail(BK_E_HIP, "bk_debug_eval_device: %s", hipGetErrorString(e));
+    return BK_OK;
+}

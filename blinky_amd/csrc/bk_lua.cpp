@@ -1,0 +1,1351 @@
+// bk_lua.cpp -- lexer, parser and host interpreter for the Lua 5.2 subset (see bk_lua.h).
+#include "bk_lua.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "bkm.h"
+
+namespace bklua {
+
+// ---- math backends ---------------------------------------------------------------------------
+static double p_sin(double x) { return bkm_sin(x); }
+static double p_cos(double x) { return bkm_cos(x); }
+static double p_tan(double x) { return bkm_tan(x); }
+static double p_asin(double x) { return bkm_asin(x); }
+static double p_acos(double x) { return bkm_acos(x); }
+static double p_atan(double x) { return bkm_atan(x); }
+static double p_atan2(double y, double x) { return bkm_atan2(y, x); }
+static double p_sinh(double x) { return bkm_sinh(x); }
+static double p_cosh(double x) { return bkm_cosh(x); }
+static double p_tanh(double x) { return bkm_tanh(x); }
+static double p_exp(double x) { return bkm_exp(x); }
+static double p_log(double x) { return bkm_log(x); }
+static double p_log10(double x) { return bkm_log10(x); }
+static double p_pow(double x, double y) { return bkm_pow(x, y); }
+static double p_sqrt(double x) { return bkm_sqrt(x); }
+static double p_fmod(double x, double y) { return bkm_fmod(x, y); }
+
+const MathLib &math_portable()
+{
+    static const MathLib m = {p_sin, p_cos, p_tan, p_asin, p_acos, p_atan, p_atan2, p_sinh, p_cosh, p_tanh,
+                              p_exp, p_log, p_log10, p_pow, p_sqrt, p_fmod};
+    return m;
+}
+const MathLib &math_platform()
+{
+    static const MathLib m = {::sin, ::cos, ::tan, ::asin, ::acos, ::atan, ::atan2, ::sinh, ::cosh, ::tanh,
+                              ::exp, ::log, ::log10, ::pow, ::sqrt, ::fmod};
+    return m;
+}
+
+// ---- lexer -------------------------------------------------------------------------------------
+enum Tok {
+    T_EOF, T_NAME, T_NUMBER, T_STRING,
+    // keywords
+    T_AND, T_BREAK, T_DO, T_ELSE, T_ELSEIF, T_END, T_FALSE, T_FOR, T_FUNCTION, T_GOTO, T_IF, T_IN, T_LOCAL,
+    T_NIL, T_NOT, T_OR, T_REPEAT, T_RETURN, T_THEN, T_TRUE, T_UNTIL, T_WHILE,
+    // multi-char operators
+    T_EQ, T_NE, T_LE, T_GE, T_CONCAT, T_DOTS, T_DBCOLON,
+    T_CHAR   // single character, in Token::ch
+};
+
+struct Token {
+    Tok t = T_EOF;
+    char ch = 0;
+    double num = 0;
+    std::string str;
+    int line = 1;
+};
+
+static const struct { const char *w; Tok t; } KEYWORDS[] = {
+    {"and", T_AND}, {"break", T_BREAK}, {"do", T_DO}, {"else", T_ELSE}, {"elseif", T_ELSEIF}, {"end", T_END},
+    {"false", T_FALSE}, {"for", T_FOR}, {"function", T_FUNCTION}, {"goto", T_GOTO}, {"if", T_IF}, {"in", T_IN},
+    {"local", T_LOCAL}, {"nil", T_NIL}, {"not", T_NOT}, {"or", T_OR}, {"repeat", T_REPEAT}, {"return", T_RETURN},
+    {"then", T_THEN}, {"true", T_TRUE}, {"until", T_UNTIL}, {"while", T_WHILE}};
+
+struct Lexer {
+    const std::string &src;
+    std::string chunk;
+    size_t p = 0;
+    int line = 1;
+    Lexer(const std::string &s, const std::string &c) : src(s), chunk(c) {}
+
+    [[noreturn]] void error(const std::string &msg, int ln) const
+    {
+        throw LuaError(chunk + ":" + std::to_string(ln) + ": " + msg);
+    }
+    int peekc(size_t o = 0) const { return p + o < src.size() ? (unsigned char)src[p + o] : -1; }
+
+    // [[ ... ]] or [==[ ... ]==]; p at the first '['.  Returns false if this is not a long bracket.
+    bool long_bracket(std::string *out)
+    {
+        size_t q = p + 1;
+        int level = 0;
+        while (q < src.size() && src[q] == '=') { ++level; ++q; }
+        if (q >= src.size() || src[q] != '[') return false;
+        ++q;
+        if (q < src.size() && src[q] == '\n') { ++line; ++q; }        // first newline is skipped
+        const int start_line = line;
+        std::string close = "]" + std::string((size_t)level, '=') + "]";
+        size_t e = src.find(close, q);
+        if (e == std::string::npos) error("unfinished long string/comment", start_line);
+        for (size_t i = q; i < e; ++i) if (src[i] == '\n') ++line;
+        if (out) *out = src.substr(q, e - q);
+        p = e + close.size();
+        return true;
+    }
+
+    Token next()
+    {
+        for (;;) {
+            int c = peekc();
+            if (c == -1) { Token t; t.t = T_EOF; t.line = line; return t; }
+            if (c == '\n') { ++line; ++p; continue; }
+            if (c == ' ' || c == '\t' || c == '\r' || c == '\f' || c == '\v') { ++p; continue; }
+            if (c == '-' && peekc(1) == '-') {
+                p += 2;
+                if (peekc() == '[' && long_bracket(nullptr)) continue;
+                while (peekc() != -1 && peekc() != '\n') ++p;
+                continue;
+            }
+            break;
+        }
+        Token t;
+        t.line = line;
+        int c = peekc();
+        if (isalpha(c) || c == '_') {
+            size_t s = p;
+            while (isalnum(peekc()) || peekc() == '_') ++p;
+            t.str = src.substr(s, p - s);
+            t.t = T_NAME;
+            for (auto &k : KEYWORDS) if (t.str == k.w) { t.t = k.t; break; }
+            return t;
+        }
+        if (isdigit(c) || (c == '.' && isdigit(peekc(1)))) {
+            // the stock lexer collects [0-9a-zA-Z.+-after-exponent] and hands it to strtod; so do we
+            size_t s = p;
+            bool hex = c == '0' && (peekc(1) == 'x' || peekc(1) == 'X');
+            if (hex) p += 2;
+            for (;;) {
+                int d = peekc();
+                if (d == -1) break;
+                if ((hex ? (d == 'p' || d == 'P') : (d == 'e' || d == 'E')) && (peekc(1) == '+' || peekc(1) == '-')) { p += 2; continue; }
+                if (isalnum(d) || d == '.') { ++p; continue; }
+                break;
+            }
+            std::string lit = src.substr(s, p - s);
+            char *end = nullptr;
+            t.num = strtod(lit.c_str(), &end);
+            if (!end || *end) error("malformed number near '" + lit + "'", line);
+            t.t = T_NUMBER;
+            return t;
+        }
+        if (c == '"' || c == '\'') {
+            ++p;
+            std::string s;
+            for (;;) {
+                int d = peekc();
+                if (d == -1 || d == '\n') error("unfinished string", line);
+                ++p;
+                if (d == c) break;
+                if (d == '\\') {
+                    int e = peekc();
+                    ++p;
+                    switch (e) {
+                    case 'n': s += '\n'; break;
+                    case 't': s += '\t'; break;
+                    case 'r': s += '\r'; break;
+                    case 'a': s += '\a'; break;
+                    case 'b': s += '\b'; break;
+                    case 'f': s += '\f'; break;
+                    case 'v': s += '\v'; break;
+                    case '\\': s += '\\'; break;
+                    case '"': s += '"'; break;
+                    case '\'': s += '\''; break;
+                    case '\n': s += '\n'; ++line; break;
+                    default:
+                        if (isdigit(e)) {
+                            int v = e - '0';
+                            for (int k = 0; k < 2 && isdigit(peekc()); ++k) v = v * 10 + (src[p++] - '0');
+                            s += (char)v;
+                        } else error("invalid escape sequence", line);
+                    }
+                } else s += (char)d;
+            }
+            t.t = T_STRING;
+            t.str = s;
+            return t;
+        }
+        if (c == '[' && (peekc(1) == '[' || peekc(1) == '=')) {
+            std::string s;
+            if (long_bracket(&s)) { t.t = T_STRING; t.str = s; return t; }
+        }
+        ++p;
+        auto two = [&](char second, Tok tk) { if (peekc() == second) { ++p; t.t = tk; return true; } return false; };
+        switch (c) {
+        case '=': if (two('=', T_EQ)) return t; break;
+        case '~': if (two('=', T_NE)) return t; error("unexpected symbol near '~'", line);
+        case '<': if (two('=', T_LE)) return t; break;
+        case '>': if (two('=', T_GE)) return t; break;
+        case ':': if (two(':', T_DBCOLON)) return t; break;
+        case '.':
+            if (peekc() == '.') { ++p; if (peekc() == '.') { ++p; t.t = T_DOTS; } else t.t = T_CONCAT; return t; }
+            break;
+        default: break;
+        }
+        t.t = T_CHAR;
+        t.ch = (char)c;
+        return t;
+    }
+};
+
+// ---- parser ------------------------------------------------------------------------------------------
+struct FuncState {
+    FuncProto *f;
+    FuncState *parent;
+    std::vector<std::vector<std::pair<std::string, int>>> scopes;
+};
+
+struct Parser {
+    Lexer lx;
+    Token tok, ahead;
+    bool has_ahead = false;
+    std::shared_ptr<Chunk> chunk;
+    FuncState *fs = nullptr;
+
+    Parser(const std::string &src, const std::string &name) : lx(src, name)
+    {
+        chunk = std::make_shared<Chunk>();
+        chunk->name = name;
+        tok = lx.next();
+    }
+    [[noreturn]] void error(const std::string &msg) { lx.error(msg, tok.line); }
+    void advance()
+    {
+        if (has_ahead) { tok = ahead; has_ahead = false; } else tok = lx.next();
+    }
+    const Token &lookahead()
+    {
+        if (!has_ahead) { ahead = lx.next(); has_ahead = true; }
+        return ahead;
+    }
+    bool is_char(char c) const { return tok.t == T_CHAR && tok.ch == c; }
+    bool accept_char(char c) { if (is_char(c)) { advance(); return true; } return false; }
+    bool accept(Tok t) { if (tok.t == t) { advance(); return true; } return false; }
+    void expect_char(char c, const char *what)
+    {
+        if (!accept_char(c)) error(std::string("'") + what + "' expected");
+    }
+    void expect(Tok t, const char *what) { if (!accept(t)) error(std::string("'") + what + "' expected"); }
+    std::string expect_name()
+    {
+        if (tok.t != T_NAME) error("<name> expected");
+        std::string s = tok.str;
+        advance();
+        return s;
+    }
+
+    // -- scopes
+    void open_scope() { fs->scopes.emplace_back(); }
+    void close_scope() { fs->scopes.pop_back(); }
+    int declare_local(const std::string &name)
+    {
+        int slot = fs->f->nslots++;
+        fs->f->slot_names.push_back(name);
+        fs->scopes.back().emplace_back(name, slot);
+        return slot;
+    }
+    static int find_local(FuncState *s, const std::string &name)
+    {
+        for (auto sc = s->scopes.rbegin(); sc != s->scopes.rend(); ++sc)
+            for (auto v = sc->rbegin(); v != sc->rend(); ++v)
+                if (v->first == name) return v->second;
+        return -1;
+    }
+    static int find_upval(FuncState *s, const std::string &name)
+    {
+        for (size_t i = 0; i < s->f->upvals.size(); ++i)
+            if (s->f->upvals[i].name == name) return (int)i;
+        if (!s->parent) return -1;
+        int l = find_local(s->parent, name);
+        if (l >= 0) { s->f->upvals.push_back({true, l, name}); return (int)s->f->upvals.size() - 1; }
+        int u = find_upval(s->parent, name);
+        if (u < 0) return -1;
+        s->f->upvals.push_back({false, u, name});
+        return (int)s->f->upvals.size() - 1;
+    }
+    ExprP name_expr(const std::string &name, int line)
+    {
+        ExprP e(new Expr());
+        e->kind = Expr::Name;
+        e->line = line;
+        e->str = name;
+        int l = find_local(fs, name);
+        if (l >= 0) { e->var = VarKind::Local; e->slot = l; return e; }
+        int u = find_upval(fs, name);
+        if (u >= 0) { e->var = VarKind::Upvalue; e->slot = u; return e; }
+        e->var = VarKind::Global;
+        return e;
+    }
+
+    // -- functions
+    FuncProto *new_proto(const std::string &name, int line)
+    {
+        chunk->protos.emplace_back(new FuncProto());
+        FuncProto *f = chunk->protos.back().get();
+        f->name = name;
+        f->line = line;
+        f->id = (int)chunk->protos.size() - 1;
+        return f;
+    }
+    ExprP function_body(const std::string &name, int line)
+    {
+        FuncProto *f = new_proto(name, line);
+        f->parent = fs ? fs->f : nullptr;
+        FuncState nfs{f, fs, {}};
+        fs = &nfs;
+        open_scope();
+        expect_char('(', "(");
+        if (!is_char(')')) {
+            do {
+                if (tok.t == T_DOTS) { advance(); f->is_vararg = true; break; }
+                declare_local(expect_name());
+                f->nparams++;
+            } while (accept_char(','));
+        }
+        expect_char(')', ")");
+        f->body = block();
+        expect(T_END, "end");
+        close_scope();
+        fs = nfs.parent;
+        ExprP e(new Expr());
+        e->kind = Expr::Function;
+        e->line = line;
+        e->proto = f;
+        return e;
+    }
+
+    // -- expressions
+    ExprP mk(Expr::Kind k)
+    {
+        ExprP e(new Expr());
+        e->kind = k;
+        e->line = tok.line;
+        return e;
+    }
+    ExprP table_constructor()
+    {
+        ExprP t = mk(Expr::Table);
+        expect_char('{', "{");
+        while (!is_char('}')) {
+            if (tok.t == T_NAME && lookahead().t == T_CHAR && lookahead().ch == '=') {
+                ExprP k = mk(Expr::String);
+                k->str = tok.str;
+                advance(); advance();
+                t->fields.emplace_back(std::move(k), expr());
+                t->item_order.push_back(-(int)t->fields.size());
+            } else if (is_char('[')) {
+                advance();
+                ExprP k = expr();
+                expect_char(']', "]");
+                expect_char('=', "=");
+                t->fields.emplace_back(std::move(k), expr());
+                t->item_order.push_back(-(int)t->fields.size());
+            } else {
+                t->args.push_back(expr());
+                t->item_order.push_back((int)t->args.size() - 1);
+            }
+            if (!accept_char(',') && !accept_char(';')) break;
+        }
+        expect_char('}', "}");
+        return t;
+    }
+    std::vector<ExprP> call_args()
+    {
+        std::vector<ExprP> args;
+        if (tok.t == T_STRING) {
+            ExprP s = mk(Expr::String);
+            s->str = tok.str;
+            advance();
+            args.push_back(std::move(s));
+            return args;
+        }
+        if (is_char('{')) { args.push_back(table_constructor()); return args; }
+        expect_char('(', "(");
+        if (!is_char(')')) {
+            do args.push_back(expr()); while (accept_char(','));
+        }
+        expect_char(')', ")");
+        return args;
+    }
+    ExprP primary_expr()
+    {
+        if (tok.t == T_NAME) {
+            std::string n = tok.str;
+            int line = tok.line;
+            advance();
+            return name_expr(n, line);
+        }
+        if (accept_char('(')) {
+            ExprP e = expr();
+            expect_char(')', ")");
+            // parenthesised call/vararg is truncated to one value: wrap in a no-op unary
+            if (e->kind == Expr::Call || e->kind == Expr::Vararg) {
+                ExprP w = mk(Expr::Unop);
+                w->str = "()";
+                w->a = std::move(e);
+                return w;
+            }
+            return e;
+        }
+        error("unexpected symbol");
+    }
+    ExprP suffixed_expr()
+    {
+        ExprP e = primary_expr();
+        for (;;) {
+            if (accept_char('.')) {
+                ExprP k = mk(Expr::String);
+                k->str = expect_name();
+                ExprP i = mk(Expr::Index);
+                i->a = std::move(e);
+                i->b = std::move(k);
+                e = std::move(i);
+            } else if (is_char('[')) {
+                advance();
+                ExprP i = mk(Expr::Index);
+                i->a = std::move(e);
+                i->b = expr();
+                expect_char(']', "]");
+                e = std::move(i);
+            } else if (is_char(':')) {
+                error("method call syntax (a:b()) is not supported");
+            } else if (is_char('(') || is_char('{') || tok.t == T_STRING) {
+                ExprP c = mk(Expr::Call);
+                c->a = std::move(e);
+                c->args = call_args();
+                e = std::move(c);
+            } else {
+                return e;
+            }
+        }
+    }
+    ExprP simple_expr()
+    {
+        ExprP e;
+        switch (tok.t) {
+        case T_NUMBER: e = mk(Expr::Number); e->num = tok.num; advance(); return e;
+        case T_STRING: e = mk(Expr::String); e->str = tok.str; advance(); return e;
+        case T_NIL: e = mk(Expr::Nil); advance(); return e;
+        case T_TRUE: e = mk(Expr::True); advance(); return e;
+        case T_FALSE: e = mk(Expr::False); advance(); return e;
+        case T_DOTS:
+            if (!fs->f->is_vararg) error("cannot use '...' outside a vararg function");
+            e = mk(Expr::Vararg); advance(); return e;
+        case T_FUNCTION: { int line = tok.line; advance(); return function_body("anonymous", line); }
+        default:
+            if (is_char('{')) return table_constructor();
+            return suffixed_expr();
+        }
+    }
+    struct OpInfo { const char *name; int left, right; };
+    bool binop_info(OpInfo *o) const
+    {
+        switch (tok.t) {
+        case T_OR: *o = {"or", 1, 1}; return true;
+        case T_AND: *o = {"and", 2, 2}; return true;
+        case T_EQ: *o = {"==", 3, 3}; return true;
+        case T_NE: *o = {"~=", 3, 3}; return true;
+        case T_LE: *o = {"<=", 3, 3}; return true;
+        case T_GE: *o = {">=", 3, 3}; return true;
+        case T_CONCAT: *o = {"..", 5, 4}; return true;
+        case T_CHAR:
+            switch (tok.ch) {
+            case '<': *o = {"<", 3, 3}; return true;
+            case '>': *o = {">", 3, 3}; return true;
+            case '+': *o = {"+", 6, 6}; return true;
+            case '-': *o = {"-", 6, 6}; return true;
+            case '*': *o = {"*", 7, 7}; return true;
+            case '/': *o = {"/", 7, 7}; return true;
+            case '%': *o = {"%", 7, 7}; return true;
+            case '^': *o = {"^", 10, 9}; return true;
+            default: return false;
+            }
+        default: return false;
+        }
+    }
+    ExprP subexpr(int limit)
+    {
+        ExprP e;
+        const char *un = nullptr;
+        if (tok.t == T_NOT) un = "not";
+        else if (is_char('-')) un = "-";
+        else if (is_char('#')) un = "#";
+        if (un) {
+            ExprP u = mk(Expr::Unop);
+            u->str = un;
+            advance();
+            u->a = subexpr(8);                                   // UNARY_PRIORITY
+            // fold -<number literal> like the stock compiler (exact)
+            if (u->str == "-" && u->a->kind == Expr::Number) { u->a->num = -u->a->num; e = std::move(u->a); }
+            else e = std::move(u);
+        } else {
+            e = simple_expr();
+        }
+        OpInfo op;
+        while (binop_info(&op) && op.left > limit) {
+            ExprP b = mk(Expr::Binop);
+            b->str = op.name;
+            advance();
+            b->a = std::move(e);
+            b->b = subexpr(op.right);
+            e = std::move(b);
+        }
+        return e;
+    }
+    ExprP expr() { return subexpr(0); }
+    std::vector<ExprP> exprlist()
+    {
+        std::vector<ExprP> v;
+        do v.push_back(expr()); while (accept_char(','));
+        return v;
+    }
+
+    // -- statements
+    bool block_follow() const
+    {
+        return tok.t == T_EOF || tok.t == T_END || tok.t == T_ELSE || tok.t == T_ELSEIF || tok.t == T_UNTIL;
+    }
+    StmtP mks(Stmt::Kind k)
+    {
+        StmtP s(new Stmt());
+        s->kind = k;
+        s->line = tok.line;
+        return s;
+    }
+    Block block()
+    {
+        Block b;
+        open_scope();
+        while (!block_follow()) {
+            if (tok.t == T_RETURN) {
+                StmtP s = mks(Stmt::Return);
+                advance();
+                if (!block_follow() && !is_char(';')) s->exprs = exprlist();
+                accept_char(';');
+                b.push_back(std::move(s));
+                break;
+            }
+            StmtP s = statement();
+            if (s) b.push_back(std::move(s));
+        }
+        close_scope();
+        return b;
+    }
+    StmtP statement()
+    {
+        switch (tok.t) {
+        case T_CHAR:
+            if (tok.ch == ';') { advance(); return nullptr; }
+            break;
+        case T_IF: {
+            StmtP s = mks(Stmt::If);
+            advance();
+            ExprP c = expr();
+            expect(T_THEN, "then");
+            s->clauses.emplace_back(std::move(c), block());
+            for (;;) {
+                if (accept(T_ELSEIF)) {
+                    ExprP c2 = expr();
+                    expect(T_THEN, "then");
+                    s->clauses.emplace_back(std::move(c2), block());
+                } else if (accept(T_ELSE)) {
+                    s->clauses.emplace_back(nullptr, block());
+                    expect(T_END, "end");
+                    break;
+                } else { expect(T_END, "end"); break; }
+            }
+            return s;
+        }
+        case T_WHILE: {
+            StmtP s = mks(Stmt::While);
+            advance();
+            s->cond = expr();
+            expect(T_DO, "do");
+            s->body = block();
+            expect(T_END, "end");
+            return s;
+        }
+        case T_DO: {
+            StmtP s = mks(Stmt::Do);
+            advance();
+            s->body = block();
+            expect(T_END, "end");
+            return s;
+        }
+        case T_FOR: {
+            int line = tok.line;
+            advance();
+            std::string n1 = expect_name();
+            if (is_char('=')) {
+                StmtP s = mks(Stmt::NumFor);
+                s->line = line;
+                advance();
+                s->exprs.push_back(expr());
+                expect_char(',', ",");
+                s->exprs.push_back(expr());
+                if (accept_char(',')) s->exprs.push_back(expr());
+                expect(T_DO, "do");
+                open_scope();
+                s->slots.push_back(declare_local(n1));
+                s->names.push_back(n1);
+                s->body = block();
+                close_scope();
+                expect(T_END, "end");
+                return s;
+            }
+            StmtP s = mks(Stmt::GenFor);
+            s->line = line;
+            s->names.push_back(n1);
+            while (accept_char(',')) s->names.push_back(expect_name());
+            expect(T_IN, "in");
+            s->exprs = exprlist();
+            expect(T_DO, "do");
+            open_scope();
+            for (auto &n : s->names) s->slots.push_back(declare_local(n));
+            s->body = block();
+            close_scope();
+            expect(T_END, "end");
+            return s;
+        }
+        case T_REPEAT: {
+            StmtP s = mks(Stmt::Repeat);
+            advance();
+            // the until-condition sees the body's locals: parse the body without closing its scope
+            open_scope();
+            Block b;
+            while (!block_follow()) {
+                if (tok.t == T_RETURN) {
+                    StmtP r = mks(Stmt::Return);
+                    advance();
+                    if (!block_follow() && !is_char(';')) r->exprs = exprlist();
+                    accept_char(';');
+                    b.push_back(std::move(r));
+                    break;
+                }
+                StmtP st = statement();
+                if (st) b.push_back(std::move(st));
+            }
+            expect(T_UNTIL, "until");
+            s->cond = expr();
+            close_scope();
+            s->body = std::move(b);
+            return s;
+        }
+        case T_FUNCTION: {
+            int line = tok.line;
+            advance();
+            std::string n = expect_name();
+            ExprP target = name_expr(n, line);
+            std::string full = n;
+            while (accept_char('.')) {
+                ExprP k = mk(Expr::String);
+                k->str = expect_name();
+                full += "." + k->str;
+                ExprP i = mk(Expr::Index);
+                i->a = std::move(target);
+                i->b = std::move(k);
+                target = std::move(i);
+            }
+            if (is_char(':')) error("method definitions (function a:b()) are not supported");
+            StmtP s = mks(Stmt::Assign);
+            s->line = line;
+            s->targets.push_back(std::move(target));
+            s->exprs.push_back(function_body(full, line));
+            return s;
+        }
+        case T_LOCAL: {
+            int line = tok.line;
+            advance();
+            if (accept(T_FUNCTION)) {
+                StmtP s = mks(Stmt::LocalFunction);
+                s->line = line;
+                std::string n = expect_name();
+                s->names.push_back(n);
+                s->slots.push_back(declare_local(n));        // visible inside its own body (recursion)
+                s->exprs.push_back(function_body(n, line));
+                return s;
+            }
+            StmtP s = mks(Stmt::Local);
+            s->line = line;
+            do s->names.push_back(expect_name()); while (accept_char(','));
+            if (accept_char('=')) s->exprs = exprlist();
+            for (auto &n : s->names) s->slots.push_back(declare_local(n));   // after the initialisers
+            return s;
+        }
+        case T_RETURN: error("'return' must be the last statement of a block");
+        case T_BREAK: { StmtP s = mks(Stmt::Break); advance(); return s; }
+        case T_GOTO: error("goto is not supported");
+        case T_DBCOLON: error("labels are not supported");
+        default: break;
+        }
+        // expression statement: call or assignment
+        int line = tok.line;
+        ExprP e = suffixed_expr();
+        if (is_char('=') || is_char(',')) {
+            StmtP s = mks(Stmt::Assign);
+            s->line = line;
+            s->targets.push_back(std::move(e));
+            while (accept_char(',')) s->targets.push_back(suffixed_expr());
+            expect_char('=', "=");
+            s->exprs = exprlist();
+            for (auto &t : s->targets)
+                if (t->kind != Expr::Name && t->kind != Expr::Index) error("syntax error: cannot assign to this expression");
+            return s;
+        }
+        if (e->kind != Expr::Call) error("syntax error near unexpected expression");
+        StmtP s = mks(Stmt::CallStmt);
+        s->line = line;
+        s->call = std::move(e);
+        return s;
+    }
+
+    std::shared_ptr<Chunk> parse_chunk()
+    {
+        FuncProto *m = new_proto("main chunk", 0);
+        m->is_vararg = true;
+        FuncState mfs{m, nullptr, {}};
+        fs = &mfs;
+        m->body = block();
+        if (tok.t != T_EOF) error("'<eof>' expected");
+        fs = nullptr;
+        return chunk;
+    }
+};
+
+std::shared_ptr<Chunk> parse(const std::string &src, const std::string &chunkname)
+{
+    Parser p(src, chunkname);
+    return p.parse_chunk();
+}
+
+// ---- values ---------------------------------------------------------------------------------------------
+const char *Value::type_name() const
+{
+    switch (t) {
+    case NIL: return "nil";
+    case BOOL: return "boolean";
+    case NUM: return "number";
+    case STR: return "string";
+    case TABLE: return "table";
+    default: return "function";
+    }
+}
+
+Value Table::get(const Value &k) const
+{
+    if (k.t == Value::NUM) {
+        double d = k.n;
+        if (d >= 1 && d <= (double)arr.size() && d == std::floor(d)) return arr[(size_t)d - 1];
+        auto it = nhash.find(d);
+        return it == nhash.end() ? Value() : it->second;
+    }
+    if (k.t == Value::STR) {
+        auto it = shash.find(*k.s);
+        return it == shash.end() ? Value() : it->second;
+    }
+    return Value();
+}
+
+void Table::set(const Value &k, const Value &v)
+{
+    if (k.t == Value::NUM) {
+        double d = k.n;
+        if (d != d) throw LuaError("table index is NaN");
+        if (d >= 1 && d == std::floor(d) && d <= (double)arr.size() + 1) {
+            size_t i = (size_t)d;
+            if (i <= arr.size()) {
+                arr[i - 1] = v;
+                if (v.t == Value::NIL && i == arr.size()) {               // shrink a trailing nil
+                    while (!arr.empty() && arr.back().t == Value::NIL) arr.pop_back();
+                }
+                return;
+            }
+            if (v.t == Value::NIL) return;
+            arr.push_back(v);
+            for (;;) {                                                    // migrate following keys
+                auto it = nhash.find((double)arr.size() + 1);
+                if (it == nhash.end()) break;
+                arr.push_back(it->second);
+                nhash.erase(it);
+            }
+            return;
+        }
+        if (v.t == Value::NIL) nhash.erase(d); else nhash[d] = v;
+        return;
+    }
+    if (k.t == Value::STR) {
+        if (v.t == Value::NIL) shash.erase(*k.s); else shash[*k.s] = v;
+        return;
+    }
+    if (k.t == Value::NIL) throw LuaError("table index is nil");
+    throw LuaError(std::string("unsupported table key type: ") + k.type_name());
+}
+
+// ---- interpreter --------------------------------------------------------------------------------------------
+namespace {
+
+struct Frame {
+    Closure *cl;
+    std::vector<std::shared_ptr<Value>> cells;
+    Values varargs;
+};
+
+enum Flow { F_NORMAL, F_BREAK, F_RETURN };
+
+struct Exec {
+    Interp &I;
+    explicit Exec(Interp &i) : I(i) {}
+
+    [[noreturn]] void error(int line, const std::string &chunk, const std::string &msg)
+    {
+        throw LuaError(chunk + ":" + std::to_string(line) + ": " + msg);
+    }
+    const std::string &chunk_of(Frame &f) { return f.cl->chunk->name; }
+
+    static bool tonumber(const Value &v, double *out)
+    {
+        if (v.t == Value::NUM) { *out = v.n; return true; }
+        if (v.t == Value::STR) {
+            const char *s = v.s->c_str();
+            char *end = nullptr;
+            while (isspace((unsigned char)*s)) ++s;
+            if (!*s) return false;
+            double d = strtod(s, &end);
+            while (end && isspace((unsigned char)*end)) ++end;
+            if (!end || *end) return false;
+            *out = d;
+            return true;
+        }
+        return false;
+    }
+
+    Value arith(Frame &f, const Expr &e, const std::string &op, const Value &a, const Value &b)
+    {
+        double x, y;
+        if (!tonumber(a, &x)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + a.type_name() + " value");
+        if (!tonumber(b, &y)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + b.type_name() + " value");
+        switch (op[0]) {
+        case '+': return Value::number(x + y);
+        case '-': return Value::number(x - y);
+        case '*': return Value::number(x * y);
+        case '/': return Value::number(x / y);
+        case '%': return Value::number(x - std::floor(x / y) * y);      // luai_nummod
+        case '^': return Value::number(I.math->pow(x, y));               // luai_numpow = pow()
+        }
+        error(e.line, chunk_of(f), "bad arithmetic operator");
+    }
+    static bool raw_equal(const Value &a, const Value &b)
+    {
+        if (a.t != b.t) return false;
+        switch (a.t) {
+        case Value::NIL: return true;
+        case Value::BOOL: return a.b == b.b;
+        case Value::NUM: return a.n == b.n;
+        case Value::STR: return *a.s == *b.s;
+        case Value::TABLE: return a.tab == b.tab;
+        case Value::FUNC: return a.fn == b.fn;
+        default: return a.bi == b.bi;
+        }
+    }
+    bool less(Frame &f, const Expr &e, const Value &a, const Value &b, bool or_equal)
+    {
+        if (a.t == Value::NUM && b.t == Value::NUM) return or_equal ? a.n <= b.n : a.n < b.n;
+        if (a.t == Value::STR && b.t == Value::STR) return or_equal ? *a.s <= *b.s : *a.s < *b.s;
+        error(e.line, chunk_of(f), std::string("attempt to compare ") + a.type_name() + " with " + b.type_name());
+    }
+
+    Value index(Frame &f, const Expr &e, const Value &obj, const Value &key)
+    {
+        if (obj.t == Value::TABLE) return obj.tab->get(key);
+        std::string what = e.a && e.a->kind == Expr::Name ? " (" + std::string(e.a->var == VarKind::Global ? "global" : "local") + " '" + e.a->str + "')" : "";
+        error(e.line, chunk_of(f), std::string("attempt to index a ") + obj.type_name() + " value" + what);
+    }
+
+    Value &local_cell(Frame &f, int slot)
+    {
+        if (!f.cells[slot]) f.cells[slot] = std::make_shared<Value>();
+        return *f.cells[slot];
+    }
+
+    Value eval(Frame &f, const Expr &e)
+    {
+        switch (e.kind) {
+        case Expr::Nil: return Value();
+        case Expr::True: return Value::boolean(true);
+        case Expr::False: return Value::boolean(false);
+        case Expr::Number: return Value::number(e.num);
+        case Expr::String: return Value::string(e.str);
+        case Expr::Vararg: return f.varargs.empty() ? Value() : f.varargs[0];
+        case Expr::Name:
+            if (e.var == VarKind::Local) return local_cell(f, e.slot);
+            if (e.var == VarKind::Upvalue) return *f.cl->upvals[e.slot];
+            return I.get_global(e.str);
+        case Expr::Index: {
+            Value o = eval(f, *e.a);
+            Value k = eval(f, *e.b);
+            return index(f, e, o, k);
+        }
+        case Expr::Call: {
+            Values r = eval_multi(f, e);
+            return r.empty() ? Value() : r[0];
+        }
+        case Expr::Function: {
+            Value v;
+            v.t = Value::FUNC;
+            v.fn = std::make_shared<Closure>();
+            v.fn->proto = e.proto;
+            v.fn->chunk = f.cl->chunk;
+            for (const UpvalDesc &u : e.proto->upvals) {
+                if (u.from_parent_local) {
+                    if (!f.cells[u.index]) f.cells[u.index] = std::make_shared<Value>();
+                    v.fn->upvals.push_back(f.cells[u.index]);
+                } else v.fn->upvals.push_back(f.cl->upvals[u.index]);
+            }
+            return v;
+        }
+        case Expr::Table: {
+            Value v;
+            v.t = Value::TABLE;
+            v.tab = std::make_shared<Table>();
+            double next = 1;
+            for (size_t oi = 0; oi < e.item_order.size(); ++oi) {
+                int o = e.item_order[oi];
+                if (o >= 0) {
+                    bool last = oi + 1 == e.item_order.size();
+                    const Expr &item = *e.args[o];
+                    if (last && (item.kind == Expr::Call || item.kind == Expr::Vararg)) {
+                        for (const Value &x : eval_multi(f, item)) { v.tab->set(Value::number(next), x); next += 1; }
+                    } else {
+                        v.tab->set(Value::number(next), eval(f, item));
+                        next += 1;
+                    }
+                } else {
+                    const auto &fld = e.fields[-1 - o];
+                    Value k = eval(f, *fld.first);
+                    v.tab->set(k, eval(f, *fld.second));
+                }
+            }
+            return v;
+        }
+        case Expr::Unop: {
+            if (e.str == "()") return eval(f, *e.a);
+            Value a = eval(f, *e.a);
+            if (e.str == "not") return Value::boolean(!a.truthy());
+            if (e.str == "-") {
+                double x;
+                if (!tonumber(a, &x)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + a.type_name() + " value");
+                return Value::number(-x);
+            }
+            if (e.str == "#") {
+                if (a.t == Value::STR) return Value::number((double)a.s->size());
+                if (a.t == Value::TABLE) return Value::number((double)a.tab->length());
+                error(e.line, chunk_of(f), std::string("attempt to get length of a ") + a.type_name() + " value");
+            }
+            error(e.line, chunk_of(f), "bad unary operator");
+        }
+        case Expr::Binop: {
+            const std::string &op = e.str;
+            if (op == "and") { Value a = eval(f, *e.a); return a.truthy() ? eval(f, *e.b) : a; }
+            if (op == "or") { Value a = eval(f, *e.a); return a.truthy() ? a : eval(f, *e.b); }
+            Value a = eval(f, *e.a);
+            Value b = eval(f, *e.b);
+            if (op == "==") return Value::boolean(raw_equal(a, b));
+            if (op == "~=") return Value::boolean(!raw_equal(a, b));
+            if (op == "<") return Value::boolean(less(f, e, a, b, false));
+            if (op == "<=") return Value::boolean(less(f, e, a, b, true));
+            if (op == ">") return Value::boolean(less(f, e, b, a, false));
+            if (op == ">=") return Value::boolean(less(f, e, b, a, true));
+            if (op == "..") {
+                if ((a.t != Value::STR && a.t != Value::NUM) || (b.t != Value::STR && b.t != Value::NUM))
+                    error(e.line, chunk_of(f), std::string("attempt to concatenate a ") + (a.t != Value::STR && a.t != Value::NUM ? a : b).type_name() + " value");
+                return Value::string(I.tostring(a) + I.tostring(b));
+            }
+            return arith(f, e, op, a, b);
+        }
+        }
+        return Value();
+    }
+
+    Values eval_list(Frame &f, const std::vector<ExprP> &list)
+    {
+        Values out;
+        for (size_t i = 0; i < list.size(); ++i) {
+            const Expr &e = *list[i];
+            if (i + 1 == list.size() && (e.kind == Expr::Call || e.kind == Expr::Vararg)) {
+                Values m = eval_multi(f, e);
+                out.insert(out.end(), m.begin(), m.end());
+            } else out.push_back(eval(f, e));
+        }
+        return out;
+    }
+
+    Values eval_multi(Frame &f, const Expr &e)
+    {
+        if (e.kind == Expr::Vararg) return f.varargs;
+        if (e.kind != Expr::Call) return Values{eval(f, e)};
+        Value fn = eval(f, *e.a);
+        Values args = eval_list(f, e.args);
+        if (!fn.is_function()) {
+            std::string what;
+            if (e.a->kind == Expr::Name) what = std::string(" (") + (e.a->var == VarKind::Global ? "global" : "local") + " '" + e.a->str + "')";
+            else if (e.a->kind == Expr::Index && e.a->b->kind == Expr::String) what = " (field '" + e.a->b->str + "')";
+            error(e.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value" + what);
+        }
+        return I.call(fn, args);
+    }
+
+    void assign(Frame &f, const Expr &target, const Value &v)
+    {
+        if (target.kind == Expr::Name) {
+            if (target.var == VarKind::Local) local_cell(f, target.slot) = v;
+            else if (target.var == VarKind::Upvalue) *f.cl->upvals[target.slot] = v;
+            else I.set_global(target.str, v);
+            return;
+        }
+        Value o = eval(f, *target.a);
+        Value k = eval(f, *target.b);
+        if (o.t != Value::TABLE) error(target.line, chunk_of(f), std::string("attempt to index a ") + o.type_name() + " value");
+        try { o.tab->set(k, v); } catch (LuaError &err) { error(target.line, chunk_of(f), err.what()); }
+    }
+
+    void tick(Frame &f, int line)
+    {
+        if (++I.steps > I.max_steps) error(line, chunk_of(f), "script exceeded the execution budget (infinite loop?)");
+    }
+
+    Flow exec_block(Frame &f, const Block &b, Values &ret)
+    {
+        for (const StmtP &sp : b) {
+            Flow fl = exec(f, *sp, ret);
+            if (fl != F_NORMAL) return fl;
+        }
+        return F_NORMAL;
+    }
+
+    Flow exec(Frame &f, const Stmt &s, Values &ret)
+    {
+        tick(f, s.line);
+        switch (s.kind) {
+        case Stmt::Local: {
+            Values v = eval_list(f, s.exprs);
+            for (size_t i = 0; i < s.slots.size(); ++i)
+                f.cells[s.slots[i]] = std::make_shared<Value>(i < v.size() ? v[i] : Value());   // fresh cell
+            return F_NORMAL;
+        }
+        case Stmt::LocalFunction: {
+            f.cells[s.slots[0]] = std::make_shared<Value>();
+            *f.cells[s.slots[0]] = eval(f, *s.exprs[0]);
+            return F_NORMAL;
+        }
+        case Stmt::Assign: {
+            Values v = eval_list(f, s.exprs);
+            for (size_t i = 0; i < s.targets.size(); ++i) assign(f, *s.targets[i], i < v.size() ? v[i] : Value());
+            return F_NORMAL;
+        }
+        case Stmt::CallStmt: eval_multi(f, *s.call); return F_NORMAL;
+        case Stmt::Do: return exec_block(f, s.body, ret);
+        case Stmt::While:
+            while (eval(f, *s.cond).truthy()) {
+                tick(f, s.line);
+                Flow fl = exec_block(f, s.body, ret);
+                if (fl == F_BREAK) break;
+                if (fl == F_RETURN) return fl;
+            }
+            return F_NORMAL;
+        case Stmt::Repeat:
+            for (;;) {
+                tick(f, s.line);
+                Flow fl = exec_block(f, s.body, ret);
+                if (fl == F_BREAK) break;
+                if (fl == F_RETURN) return fl;
+                if (eval(f, *s.cond).truthy()) break;
+            }
+            return F_NORMAL;
+        case Stmt::If:
+            for (const auto &c : s.clauses)
+                if (!c.first || eval(f, *c.first).truthy()) return exec_block(f, c.second, ret);
+            return F_NORMAL;
+        case Stmt::NumFor: {
+            double start, stop, step = 1;
+            if (!tonumber(eval(f, *s.exprs[0]), &start)) error(s.line, chunk_of(f), "'for' initial value must be a number");
+            if (!tonumber(eval(f, *s.exprs[1]), &stop)) error(s.line, chunk_of(f), "'for' limit must be a number");
+            if (s.exprs.size() > 2 && !tonumber(eval(f, *s.exprs[2]), &step)) error(s.line, chunk_of(f), "'for' step must be a number");
+            // OP_FORPREP / OP_FORLOOP: idx = start - step; loop { idx += step; test; body }
+            double idx = start - step;
+            for (;;) {
+                idx = idx + step;
+                if (!(0 < step ? idx <= stop : stop <= idx)) break;
+                tick(f, s.line);
+                f.cells[s.slots[0]] = std::make_shared<Value>(Value::number(idx));
+                Flow fl = exec_block(f, s.body, ret);
+                if (fl == F_BREAK) break;
+                if (fl == F_RETURN) return fl;
+            }
+            return F_NORMAL;
+        }
+        case Stmt::GenFor: {
+            Values init = eval_list(f, s.exprs);
+            init.resize(3);
+            Value fn = init[0], st = init[1], ctl = init[2];
+            for (;;) {
+                tick(f, s.line);
+                if (!fn.is_function()) error(s.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value");
+                Values r = I.call(fn, Values{st, ctl});
+                if (r.empty() || r[0].t == Value::NIL) break;
+                ctl = r[0];
+                for (size_t i = 0; i < s.slots.size(); ++i)
+                    f.cells[s.slots[i]] = std::make_shared<Value>(i < r.size() ? r[i] : Value());
+                Flow fl = exec_block(f, s.body, ret);
+                if (fl == F_BREAK) break;
+                if (fl == F_RETURN) return fl;
+            }
+            return F_NORMAL;
+        }
+        case Stmt::Return: ret = eval_list(f, s.exprs); return F_RETURN;
+        case Stmt::Break: return F_BREAK;
+        }
+        return F_NORMAL;
+    }
+};
+
+}  // namespace
+
+Value Interp::get_global(const std::string &name) const
+{
+    auto it = globals.find(name);
+    return it == globals.end() ? Value() : it->second;
+}
+void Interp::set_global(const std::string &name, const Value &v)
+{
+    if (v.t == Value::NIL) globals.erase(name); else globals[name] = v;
+}
+void Interp::register_builtin(const std::string &name, BuiltinFn fn)
+{
+    Value v;
+    v.t = Value::BUILTIN;
+    v.bi = std::make_shared<Builtin>();
+    v.bi->name = name;
+    v.bi->fn = std::move(fn);
+    size_t dot = name.find('.');
+    if (dot == std::string::npos) { globals[name] = v; return; }
+    std::string tname = name.substr(0, dot), field = name.substr(dot + 1);
+    Value t = get_global(tname);
+    if (t.t != Value::TABLE) { t = Value(); t.t = Value::TABLE; t.tab = std::make_shared<Table>(); globals[tname] = t; }
+    t.tab->shash[field] = v;
+}
+
+std::string Interp::tostring(const Value &v) const
+{
+    char buf[64];
+    switch (v.t) {
+    case Value::NIL: return "nil";
+    case Value::BOOL: return v.b ? "true" : "false";
+    case Value::NUM: snprintf(buf, sizeof buf, "%.14g", v.n); return buf;     // LUA_NUMBER_FMT
+    case Value::STR: return *v.s;
+    case Value::TABLE: snprintf(buf, sizeof buf, "table: %p", (void *)v.tab.get()); return buf;
+    case Value::FUNC: snprintf(buf, sizeof buf, "function: %p", (void *)v.fn.get()); return buf;
+    default: return "function: builtin: " + v.bi->name;
+    }
+}
+
+Values Interp::call(const Value &fv, const Values &args)
+{
+    if (fv.t == Value::BUILTIN) {
+        Values rets;
+        fv.bi->fn(*this, args, rets);
+        return rets;
+    }
+    if (fv.t != Value::FUNC) throw LuaError(std::string("attempt to call a ") + fv.type_name() + " value");
+    if (depth > 180) throw LuaError("stack overflow (recursion too deep)");
+    const FuncProto *p = fv.fn->proto;
+    Frame fr;
+    fr.cl = fv.fn.get();
+    fr.cells.resize((size_t)p->nslots);
+    for (int i = 0; i < p->nparams; ++i)
+        fr.cells[i] = std::make_shared<Value>((size_t)i < args.size() ? args[i] : Value());
+    if (p->is_vararg && args.size() > (size_t)p->nparams) fr.varargs.assign(args.begin() + p->nparams, args.end());
+    Values ret;
+    Exec ex(*this);
+    ++depth;
+    try {
+        ex.exec_block(fr, p->body, ret);
+    } catch (...) { --depth; throw; }
+    --depth;
+    return ret;
+}
+
+void Interp::run(const std::string &src, const std::string &chunkname)
+{
+    std::shared_ptr<Chunk> ch = parse(src, chunkname);
+    Value f;
+    f.t = Value::FUNC;
+    f.fn = std::make_shared<Closure>();
+    f.fn->proto = ch->main();
+    f.fn->chunk = ch;
+    call(f, Values());
+}
+
+// ---- standard library subset ----------------------------------------------------------------------------
+static double argnum(const Values &a, size_t i, const char *fn)
+{
+    double d;
+    if (i >= a.size() || !Exec::tonumber(a[i], &d))
+        throw LuaError(std::string("bad argument #") + std::to_string(i + 1) + " to '" + fn + "' (number expected, got " +
+                       (i < a.size() ? a[i].type_name() : "no value") + ")");
+    return d;
+}
+
+Interp::Interp(const MathLib &m) : math(&m)
+{
+    auto m1 = [this](const char *name, double (*MathLib::*fp)(double)) {
+        std::string n = std::string("math.") + name;
+        register_builtin(n, [this, fp, n](Interp &, const Values &a, Values &r) {
+            r.push_back(Value::number((math->*fp)(argnum(a, 0, n.c_str() + 5))));
+        });
+    };
+    m1("sin", &MathLib::sin); m1("cos", &MathLib::cos); m1("tan", &MathLib::tan);
+    m1("asin", &MathLib::asin); m1("acos", &MathLib::acos); m1("atan", &MathLib::atan);
+    m1("sinh", &MathLib::sinh); m1("cosh", &MathLib::cosh); m1("tanh", &MathLib::tanh);
+    m1("exp", &MathLib::exp); m1("log10", &MathLib::log10); m1("sqrt", &MathLib::sqrt);
+    register_builtin("math.atan2", [this](Interp &, const Values &a, Values &r) { r.push_back(Value::number(math->atan2(argnum(a, 0, "atan2"), argnum(a, 1, "atan2")))); });
+    register_builtin("math.pow", [this](Interp &, const Values &a, Values &r) { r.push_back(Value::number(math->pow(argnum(a, 0, "pow"), argnum(a, 1, "pow")))); });
+    register_builtin("math.fmod", [this](Interp &, const Values &a, Values &r) { r.push_back(Value::number(math->fmod(argnum(a, 0, "fmod"), argnum(a, 1, "fmod")))); });
+    register_builtin("math.log", [this](Interp &, const Values &a, Values &r) {      // math_log, Lua 5.2
+        double x = argnum(a, 0, "log");
+        if (a.size() < 2 || a[1].t == Value::NIL) { r.push_back(Value::number(math->log(x))); return; }
+        double b = argnum(a, 1, "log");
+        r.push_back(Value::number(b == 10.0 ? math->log10(x) : math->log(x) / math->log(b)));
+    });
+    register_builtin("math.abs", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(std::fabs(argnum(a, 0, "abs")))); });
+    register_builtin("math.floor", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(std::floor(argnum(a, 0, "floor")))); });
+    register_builtin("math.ceil", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(std::ceil(argnum(a, 0, "ceil")))); });
+    register_builtin("math.deg", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(argnum(a, 0, "deg") / (3.14159265358979323846 / 180.0))); });
+    register_builtin("math.rad", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(argnum(a, 0, "rad") * (3.14159265358979323846 / 180.0))); });
+    register_builtin("math.modf", [](Interp &, const Values &a, Values &r) {
+        double x = argnum(a, 0, "modf"), ip = std::trunc(x);
+        r.push_back(Value::number(ip));
+        r.push_back(Value::number(std::isinf(x) ? std::copysign(0.0, x) : x - ip));
+    });
+    register_builtin("math.max", [](Interp &, const Values &a, Values &r) {
+        double m = argnum(a, 0, "max");
+        for (size_t i = 1; i < a.size(); ++i) { double d = argnum(a, i, "max"); if (d > m) m = d; }
+        r.push_back(Value::number(m));
+    });
+    register_builtin("math.min", [](Interp &, const Values &a, Values &r) {
+        double m = argnum(a, 0, "min");
+        for (size_t i = 1; i < a.size(); ++i) { double d = argnum(a, i, "min"); if (d < m) m = d; }
+        r.push_back(Value::number(m));
+    });
+    get_global("math").tab->shash["pi"] = Value::number(3.14159265358979323846);
+    get_global("math").tab->shash["huge"] = Value::number(HUGE_VAL);
+
+    register_builtin("table.unpack", [](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'unpack' (table expected)");
+        double i = a.size() > 1 && a[1].t != Value::NIL ? argnum(a, 1, "unpack") : 1;
+        double e = a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "unpack") : (double)a[0].tab->length();
+        for (double k = i; k <= e; k += 1) r.push_back(a[0].tab->get(Value::number(k)));
+    });
+    register_builtin("table.insert", [](Interp &, const Values &a, Values &) {
+        if (a.size() < 2 || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'insert' (table expected)");
+        Table &t = *a[0].tab;
+        if (a.size() == 2) { t.set(Value::number((double)t.length() + 1), a[1]); return; }
+        size_t pos = (size_t)argnum(a, 1, "insert");
+        if (pos < 1 || pos > t.length() + 1) throw LuaError("bad argument #2 to 'insert' (position out of bounds)");
+        t.arr.insert(t.arr.begin() + (pos - 1), a[2]);
+    });
+    register_builtin("print", [](Interp &I, const Values &a, Values &) {
+        std::string line;
+        for (size_t i = 0; i < a.size(); ++i) { if (i) line += "\t"; line += I.tostring(a[i]); }
+        if (I.print_sink) I.print_sink(line);
+    });
+    register_builtin("tostring", [](Interp &I, const Values &a, Values &r) { r.push_back(Value::string(I.tostring(a.empty() ? Value() : a[0]))); });
+    register_builtin("tonumber", [](Interp &, const Values &a, Values &r) {
+        double d;
+        if (!a.empty() && Exec::tonumber(a[0], &d)) r.push_back(Value::number(d)); else r.push_back(Value());
+    });
+    register_builtin("type", [](Interp &, const Values &a, Values &r) {
+        if (a.empty()) throw LuaError("bad argument #1 to 'type' (value expected)");
+        r.push_back(Value::string(a[0].type_name()));
+    });
+    register_builtin("assert", [](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || !a[0].truthy()) throw LuaError(a.size() > 1 ? I.tostring(a[1]) : "assertion failed!");
+        r = a;
+    });
+    register_builtin("error", [](Interp &I, const Values &a, Values &) { throw LuaError(a.empty() ? "nil" : I.tostring(a[0])); });
+    register_builtin("select", [](Interp &, const Values &a, Values &r) {
+        if (!a.empty() && a[0].t == Value::STR && *a[0].s == "#") { r.push_back(Value::number((double)a.size() - 1)); return; }
+        double n = argnum(a, 0, "select");
+        if (n < 1) throw LuaError("bad argument #1 to 'select' (index out of range)");
+        for (size_t i = (size_t)n; i < a.size(); ++i) r.push_back(a[i]);
+    });
+    register_builtin("next", [](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'next' (table expected)");
+        const Table &t = *a[0].tab;
+        const Value k = a.size() > 1 ? a[1] : Value();
+        // order: array part, numeric hash, string hash
+        size_t ai = 0;
+        bool after_arr = false;
+        if (k.t == Value::NIL) ai = 0;
+        else if (k.t == Value::NUM && k.n >= 1 && k.n <= (double)t.arr.size() && k.n == std::floor(k.n)) ai = (size_t)k.n;
+        else after_arr = true;
+        if (!after_arr) {
+            if (ai < t.arr.size()) { r.push_back(Value::number((double)ai + 1)); r.push_back(t.arr[ai]); return; }
+            if (!t.nhash.empty()) { r.push_back(Value::number(t.nhash.begin()->first)); r.push_back(t.nhash.begin()->second); return; }
+            if (!t.shash.empty()) { r.push_back(Value::string(t.shash.begin()->first)); r.push_back(t.shash.begin()->second); return; }
+            r.push_back(Value());
+            return;
+        }
+        if (k.t == Value::NUM) {
+            auto it = t.nhash.find(k.n);
+            if (it != t.nhash.end() && ++it != t.nhash.end()) { r.push_back(Value::number(it->first)); r.push_back(it->second); return; }
+            if (!t.shash.empty()) { r.push_back(Value::string(t.shash.begin()->first)); r.push_back(t.shash.begin()->second); return; }
+            r.push_back(Value());
+            return;
+        }
+        if (k.t == Value::STR) {
+            auto it = t.shash.find(*k.s);
+            if (it != t.shash.end() && ++it != t.shash.end()) { r.push_back(Value::string(it->first)); r.push_back(it->second); return; }
+        }
+        r.push_back(Value());
+    });
+    register_builtin("pairs", [](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'pairs' (table expected)");
+        r.push_back(I.get_global("next"));
+        r.push_back(a[0]);
+        r.push_back(Value());
+    });
+    register_builtin("ipairs", [](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'ipairs' (table expected)");
+        Value it;
+        it.t = Value::BUILTIN;
+        it.bi = std::make_shared<Builtin>();
+        it.bi->name = "ipairs_iter";
+        it.bi->fn = [](Interp &, const Values &x, Values &out) {
+            double i = x[1].n + 1;
+            Value v = x[0].tab->get(Value::number(i));
+            if (v.t == Value::NIL) { out.push_back(Value()); return; }
+            out.push_back(Value::number(i));
+            out.push_back(v);
+        };
+        (void)I;
+        r.push_back(it);
+        r.push_back(a[0]);
+        r.push_back(Value::number(0));
+    });
+}
+
+}  // namespace bklua

@@ -1,0 +1,160 @@
+// bk_lua.h -- from-scratch front-end for the Lua 5.2 subset that Blinky lens / globe scripts
+// use: lexer, parser -> AST with resolved locals/upvalues, and a host
+// tree-walking interpreter.  The reference links the stock Lua 5.2 VM (engine/Makefile:818);
+// that dependency is absent here, and the GPU needs the callbacks as compiled code anyway,
+// so one AST feeds two back-ends: this interpreter (chunk execution, calc_zoom, globe
+// loading: fisheye.c:1659-1875, 1293-1386) and the HIP emitter in bk_emit.cpp (per-pixel
+// callbacks: fisheye.c:1545-1651).
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace bklua {
+
+struct LuaError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---- math backend -----------------------------------------------------------------------
+// Scripts see math.sin etc.  The product uses the portable bkm.h functions (bit-identical to
+// the device build); a platform-libm table exists so that test infrastructure can run the
+// interpreter the way the stock Lua VM would (math.sin == libm sin).
+struct MathLib {
+    double (*sin)(double), (*cos)(double), (*tan)(double);
+    double (*asin)(double), (*acos)(double), (*atan)(double), (*atan2)(double, double);
+    double (*sinh)(double), (*cosh)(double), (*tanh)(double);
+    double (*exp)(double), (*log)(double), (*log10)(double), (*pow)(double, double);
+    double (*sqrt)(double), (*fmod)(double, double);
+};
+const MathLib &math_portable();   // bkm.h
+const MathLib &math_platform();   // <cmath>
+
+// ---- AST -----------------------------------------------------------------------------------
+struct Expr;
+struct Stmt;
+struct FuncProto;
+using ExprP = std::unique_ptr<Expr>;
+using StmtP = std::unique_ptr<Stmt>;
+using Block = std::vector<StmtP>;
+
+enum class VarKind { Local, Upvalue, Global };
+
+struct Expr {
+    enum Kind { Nil, True, False, Number, String, Vararg, Name, Index, Call, Binop, Unop, Function, Table } kind;
+    int line = 0;
+    double num = 0;
+    std::string str;              // String value / Name / operator
+    // Name
+    VarKind var = VarKind::Global;
+    int slot = -1;                // local slot or upvalue index
+    // Index: a[b]; Call: a(args); Binop: a op b; Unop: op a
+    ExprP a, b;
+    std::vector<ExprP> args;      // Call arguments / Table array items
+    std::vector<std::pair<ExprP, ExprP>> fields;   // Table [k]=v / name=v entries, in source order
+    std::vector<int> item_order;  // Table: >=0 -> args[i] (positional), <0 -> fields[-1-i]
+    FuncProto *proto = nullptr;   // Function
+};
+
+struct Stmt {
+    enum Kind { Local, Assign, CallStmt, Do, While, Repeat, If, NumFor, GenFor, Return, Break, LocalFunction } kind;
+    int line = 0;
+    std::vector<int> slots;               // Local / NumFor(var) / GenFor(vars) / LocalFunction
+    std::vector<std::string> names;
+    std::vector<ExprP> targets;           // Assign
+    std::vector<ExprP> exprs;             // Local / Assign / Return / NumFor(start,stop[,step]) / GenFor explist
+    ExprP call;                           // CallStmt
+    Block body;                           // Do / While / Repeat / NumFor / GenFor
+    ExprP cond;                           // While / Repeat
+    std::vector<std::pair<ExprP, Block>> clauses;   // If: (cond, block); else has null cond
+};
+
+struct UpvalDesc { bool from_parent_local; int index; std::string name; };
+
+struct FuncProto {
+    std::string name;                     // for messages / emitted symbol
+    int line = 0;
+    int id = 0;
+    int nparams = 0;
+    bool is_vararg = false;
+    int nslots = 0;                       // local slots (params first)
+    std::vector<std::string> slot_names;
+    std::vector<UpvalDesc> upvals;
+    Block body;
+    FuncProto *parent = nullptr;
+};
+
+struct Chunk {
+    std::string name;
+    std::vector<std::unique_ptr<FuncProto>> protos;   // protos[0] = main
+    FuncProto *main() const { return protos[0].get(); }
+};
+
+std::shared_ptr<Chunk> parse(const std::string &src, const std::string &chunkname);
+
+// ---- runtime values --------------------------------------------------------------------------
+struct Table;
+struct Closure;
+struct Interp;
+struct Value;
+using Values = std::vector<Value>;
+using BuiltinFn = std::function<void(Interp &, const Values &args, Values &rets)>;
+struct Builtin { std::string name; BuiltinFn fn; };
+
+struct Value {
+    enum T { NIL, BOOL, NUM, STR, TABLE, FUNC, BUILTIN } t = NIL;
+    double n = 0;
+    bool b = false;
+    std::shared_ptr<std::string> s;
+    std::shared_ptr<Table> tab;
+    std::shared_ptr<Closure> fn;
+    std::shared_ptr<Builtin> bi;
+
+    static Value nil() { return Value(); }
+    static Value boolean(bool v) { Value x; x.t = BOOL; x.b = v; return x; }
+    static Value number(double v) { Value x; x.t = NUM; x.n = v; return x; }
+    static Value string(const std::string &v) { Value x; x.t = STR; x.s = std::make_shared<std::string>(v); return x; }
+    bool truthy() const { return !(t == NIL || (t == BOOL && !b)); }
+    bool is_function() const { return t == FUNC || t == BUILTIN; }
+    const char *type_name() const;
+};
+
+struct Table {
+    std::vector<Value> arr;                 // t[1..n]
+    std::map<double, Value> nhash;          // other numeric keys
+    std::map<std::string, Value> shash;
+    Value get(const Value &k) const;
+    void set(const Value &k, const Value &v);
+    size_t length() const { return arr.size(); }
+};
+
+struct Closure {
+    FuncProto *proto = nullptr;
+    std::shared_ptr<Chunk> chunk;           // keeps the AST alive
+    std::vector<std::shared_ptr<Value>> upvals;
+};
+
+struct Interp {
+    explicit Interp(const MathLib &m);
+    const MathLib *math;                    // swappable: platform libm (reference-faithful) or bkm.h
+    std::map<std::string, Value> globals;
+    long steps = 0, max_steps = 200000000;  // runaway-script guard
+    int depth = 0;
+    std::function<void(const std::string &)> print_sink;   // `print` output (Con_Printf)
+
+    Value get_global(const std::string &name) const;
+    void set_global(const std::string &name, const Value &v);
+    void register_builtin(const std::string &name, BuiltinFn fn);
+    // run a chunk (luaL_loadbuffer + lua_pcall)
+    void run(const std::string &src, const std::string &chunkname);
+    // call any function value (lua_call with LUA_MULTRET)
+    Values call(const Value &f, const Values &args);
+    std::string tostring(const Value &v) const;
+};
+
+}  // namespace bklua

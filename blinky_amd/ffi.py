@@ -22,6 +22,7 @@ lib = C.CDLL(LIB_PATH)
 
 MAX_PLATES = 6
 NULL_OFFSET = 0xFFFFFFFF
+DEVICE_NONE = -2
 OK = 0
 MAP_NONE, MAP_INVERSE, MAP_FORWARD = 0, 1, 2
 ZOOM_NONE, ZOOM_FOV, ZOOM_VFOV, ZOOM_COVER, ZOOM_CONTAIN = range(5)
@@ -69,6 +70,12 @@ _SIGS = {
     "bk_version": (C.c_char_p, []),
     "bk_set_apply_variant": (_i, [_vp, _i]),
     "bk_last_build_ms": (_d, [_vp]),
+    "bk_globe_pitch": (_i, [_vp]),
+    "bk_debug_kernel_source": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), _i]),
+    "bk_debug_eval": (_i, [_vp, _i, C.POINTER(_d), _i, C.POINTER(_d), C.POINTER(_i)]),
+    "bk_script_console": (C.c_char_p, [_vp]),
+    "bk_set_host_math": (_i, [_vp, _i]),
+    "bk_debug_eval_device": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch
@@ -217,6 +224,52 @@ class Context:
             pal = np.ascontiguousarray(pal, dtype=np.uint8)
         self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
                                       int(rubix_on), _ptr(pal)))
+
+    def globe_pitch(self):
+        return lib.bk_globe_pitch(self._h)
+
+    def kernel_source(self, compile=False):
+        need = _sz()
+        self._chk(lib.bk_debug_kernel_source(self._h, None, 0, C.byref(need), 0))
+        buf = C.create_string_buffer(need.value)
+        self._chk(lib.bk_debug_kernel_source(self._h, buf, need.value, None, int(compile)))
+        return buf.value.decode()
+
+    def eval_host(self, which, *args):
+        """which: 0 lens_inverse(x,y), 1 lens_forward(x,y,z), 2 globe_plate(x,y,z) -> tuple or None (nil)"""
+        a = (_d * len(args))(*args)
+        out = (_d * 8)()
+        n = _i()
+        self._chk(lib.bk_debug_eval(self._h, which, a, len(args), out, C.byref(n)))
+        return None if n.value < 0 else tuple(out[: n.value])
+
+    def eval_device(self, which, args):
+        """args: float64 array [n, nargs] -> (out [n, 8] float64, nout [n] int32)"""
+        args = np.ascontiguousarray(args, dtype=np.float64)
+        n, nargs = args.shape
+        out = np.empty((n, 8), np.float64)
+        nout = np.empty(n, np.int32)
+        self._chk(lib.bk_debug_eval_device(self._h, which, _ptr(args), nargs, n, _ptr(out), _ptr(nout)))
+        return out, nout
+
+    def eval_host_many(self, which, args):
+        args = np.ascontiguousarray(args, dtype=np.float64)
+        out = np.full((len(args), 8), np.nan)
+        nout = np.empty(len(args), np.int32)
+        for i, a in enumerate(args):
+            r = self.eval_host(which, *a)
+            if r is None:
+                nout[i] = -1
+            else:
+                nout[i] = len(r)
+                out[i, : len(r)] = r
+        return out, nout
+
+    def set_host_math(self, portable):
+        self._chk(lib.bk_set_host_math(self._h, int(portable)))
+
+    def console(self):
+        return lib.bk_script_console(self._h).decode()
 
     def set_apply_variant(self, v):
         self._chk(lib.bk_set_apply_variant(self._h, v))

@@ -32,6 +32,7 @@ extern "C" {
 
 #define BK_MAX_PLATES   6             /* MAX_PLATES, fisheye.c:352 */
 #define BK_NULL_OFFSET  0xFFFFFFFFu
+#define BK_DEVICE_NONE  (-2)          /* bk_create: host-only context (scripts, zoom, code generation) */
 
 enum {
     BK_OK = 0,
@@ -67,7 +68,7 @@ typedef struct {
 /* ---- lifecycle -------------------------------------------------------------------
  * replaces: the three malloc blocks and static state of fisheye.c (306-528, 712-727),
  * init_lua / lua_close (fisheye.c:1222-1265, 678-681). */
-bk_ctx     *bk_create(int device);            /* device < 0: current HIP device */
+bk_ctx     *bk_create(int device);            /* -1: current HIP device; BK_DEVICE_NONE: no device at all */
 void        bk_destroy(bk_ctx *ctx);
 const char *bk_last_error(const bk_ctx *ctx); /* ctx may be NULL: error of the last failed bk_create */
 int         bk_set_stream(bk_ctx *ctx, void *hip_stream);   /* hipStream_t; NULL = default stream */
@@ -112,7 +113,12 @@ int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints);
  * bk_upload_plate replaces render_plate's row memcpy loop (fisheye.c:2441-2449):
  * ps rows of ps bytes from src (pitch src_pitch) into plate `plate` of globe `frame`. */
 int   bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch);
-void *bk_globe_device_ptr(bk_ctx *ctx, int frame);   /* device address of globe `frame` (6*ps*ps bytes) */
+/* Device layout of a globe: uint8 [6 plates][ps rows][pitch], pitch = bk_globe_pitch() =
+ * round_up(ps, 64) so that every plate row starts on a 64-byte boundary (the apply kernel
+ * stages plate rows with 16-byte loads).  Lensmap entries cross this ABI in the reference
+ * layout (pitch ps); the library converts. */
+void *bk_globe_device_ptr(bk_ctx *ctx, int frame);   /* device address of globe `frame` (6*ps*pitch bytes) */
+int   bk_globe_pitch(const bk_ctx *ctx);
 /* synthetic plates: the SURVEY.md 8(d) LCG stream generated on the device */
 int   bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t seed_frame);
 
@@ -139,6 +145,21 @@ const char *bk_version(void);
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);
+/* the HIP translation unit generated for the current lens + globe scripts (needed = strlen+1);
+ * compile != 0 also runs it through hiprtc (works on a BK_DEVICE_NONE context) */
+int         bk_debug_kernel_source(bk_ctx *ctx, char *buf, size_t cap, size_t *needed, int compile);
+/* evaluate a callback with the HOST interpreter, for diagnosing a script: which 0 = lens_inverse(x,y),
+ * 1 = lens_forward(x,y,z), 2 = globe_plate(x,y,z); *nout = number of results, -1 for a single nil */
+int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs, double out[8], int *nout);
+/* the same on the DEVICE (the generated code), over n argument tuples of nargs doubles: out gets 8
+ * doubles per tuple, nout the result count (-1 = a single nil, <= -100 = runtime error bits) */
+int         bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout);
+/* host-side script arithmetic (chunk execution, calc_zoom, globe loading): 0 = the platform libm,
+ * which is what the reference's Lua VM calls (default: scale, lens_width, plates bit-identical to the
+ * reference on the same machine); 1 = the portable bkm.h functions the GPU kernels use */
+int         bk_set_host_math(bk_ctx *ctx, int portable);
+/* text the scripts print()ed since the context was created (the reference sends it to stdout) */
+const char *bk_script_console(bk_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,34 @@
  * what a real Lua VM would evaluate with a libm call at run time */
 static double (*volatile lua_pow)(double, double) = pow;
 static double (*volatile lua_sqrt)(double) = sqrt;
+/* A Lua VM makes one libm call per math.xxx; gcc -O2 would fuse sin(x)/cos(x) pairs of the
+ * transliterations into sincos(), whose glibc results differ from sin()/cos() in the last bit
+ * for ~0.1 % of arguments.  Route every call through a volatile pointer to keep them separate.
+ * (oracle.c, which restates the reference's own C code, is deliberately left to gcc: there
+ * the reference binary gets the same fusion - oracle/_ref arbitrates.) */
+static double (*volatile lua_sin)(double) = sin;
+static double (*volatile lua_cos)(double) = cos;
+static double (*volatile lua_tan)(double) = tan;
+static double (*volatile lua_asin)(double) = asin;
+static double (*volatile lua_acos)(double) = acos;
+static double (*volatile lua_atan)(double) = atan;
+static double (*volatile lua_atan2)(double, double) = atan2;
+static double (*volatile lua_sinh)(double) = sinh;
+static double (*volatile lua_cosh)(double) = cosh;
+static double (*volatile lua_tanh)(double) = tanh;
+static double (*volatile lua_exp)(double) = exp;
+#define sin lua_sin
+#define cos lua_cos
+#define tan lua_tan
+#define asin lua_asin
+#define acos lua_acos
+#define atan lua_atan
+#define atan2 lua_atan2
+#define sinh lua_sinh
+#define cosh lua_cosh
+#define tanh lua_tanh
+#define exp lua_exp
+#define sqrt lua_sqrt
 
 /* The three C functions a script may call (fisheye.c:1257-1264) are reached
  * through ok_host so that the same transliterations run both inside the oracle

@@ -63,3 +63,29 @@ void okpy_palmap(const uint8_t *basepal, uint8_t *out /* [6][256] */)
     ok_create_palmap(&s, basepal);
     for (i = 0; i < OK_MAX_PLATES; ++i) memcpy(out + 256 * i, s.plates[i].palette, 256);
 }
+
+/* evaluate a hand-transliterated callback: which 0 = lens_inverse(x,y), 1 = lens_forward(x,y,z).
+ * returns 1 values written, 0 nil, -1 unknown lens / missing callback */
+int okpy_eval(const char *lens, int which, double x, double y, double z, double *out)
+{
+    ok_state s;
+    ok_lens_def d;
+    memset(&s, 0, sizeof s);
+    ok_default_host(&s);
+    if (!ok_find_lens(lens, &d)) return -1;
+    if (which == 0) { if (!d.inverse) return -1; return d.inverse(&s.host, x, y, out); }
+    if (!d.forward) return -1;
+    return d.forward(&s.host, x, y, z, &out[0], &out[1]);
+}
+
+int okpy_lens_def(const char *lens, int *has_inverse, int *has_forward, int *max_fov, int *max_vfov,
+                  double *width, double *height, char *onload, int cap)
+{
+    ok_lens_def d;
+    if (!ok_find_lens(lens, &d)) return 0;
+    *has_inverse = d.inverse != NULL; *has_forward = d.forward != NULL;
+    *max_fov = d.max_fov; *max_vfov = d.max_vfov; *width = d.width; *height = d.height;
+    strncpy(onload, d.onload ? d.onload : "", (size_t)cap - 1);
+    onload[cap - 1] = 0;
+    return 1;
+}

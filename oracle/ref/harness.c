@@ -181,6 +181,30 @@ int ref_run(const char *globe_name, const char *lens_name, const char *zoomcmd, 
     return built;
 }
 
+/* Time the reference's own render_lensmap() (fisheye.c:2406-2424) on the state the last ref_run
+ * left behind: LCG plates, rubix off.  Returns total seconds over `reps` calls; *best_ms = fastest. */
+#include <time.h>
+double ref_time_apply(int reps, double *best_ms)
+{
+    size_t ps2 = (size_t)globe.platesize * globe.platesize;
+    struct timespec a, b;
+    double total = 0, best = 1e30;
+    int p, i;
+    for (p = 0; p < globe.numplates; ++p) lcg_fill(globe.pixels + ps2 * p, ps2, p, 0);
+    rubix.enabled = false;
+    for (i = 0; i < reps; ++i) {
+        double dt;
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        render_lensmap();
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        dt = (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
+        total += dt;
+        if (dt < best) best = dt;
+    }
+    if (best_ms) *best_ms = best * 1e3;
+    return total;
+}
+
 /* the reference's rubix palette LUTs (create_palmap ran in F_Init) */
 void ref_palettes(uint8_t out[6][256])
 {

@@ -130,3 +130,28 @@ def ref_palettes():
     out = np.empty((6, 256), np.uint8)
     _r.ref_palettes(_p(out))
     return out
+
+
+_o.okpy_eval.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+
+
+def eval_lens(lens, which, x, y, z=0.0):
+    """hand-transliterated callback (platform libm): tuple of results, None for nil"""
+    out = np.zeros(3)
+    rc = _o.okpy_eval(lens.encode(), which, x, y, z, _p(out))
+    if rc < 0:
+        raise KeyError(lens)
+    if rc == 0:
+        return None
+    return tuple(out[:3] if which == 0 else out[:2])
+
+
+def lens_def(lens):
+    hi, hf, mf, mv = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    w, h = C.c_double(), C.c_double()
+    buf = C.create_string_buffer(128)
+    _o.okpy_lens_def.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double)] * 2 + [C.c_char_p, C.c_int]
+    if not _o.okpy_lens_def(lens.encode(), C.byref(hi), C.byref(hf), C.byref(mf), C.byref(mv), C.byref(w), C.byref(h), buf, 128):
+        raise KeyError(lens)
+    return dict(has_inverse=hi.value, has_forward=hf.value, max_fov=mf.value, max_vfov=mv.value,
+                lens_width=w.value, lens_height=h.value, onload=buf.value.decode())

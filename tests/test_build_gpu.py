@@ -1,0 +1,175 @@
+"""Parity of the HIP lensmap BUILD (bk_build, replacing create_lensmap / resume_lensmap_inverse /
+resume_lensmap_forward, fisheye.c:2084-2397) against the CPU oracle and the reference goldens.
+Offsets, tints, display flags and scale must be bit-identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scripts as S
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "lensmaps.json")))["lensmaps"]
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import blinky_amd
+    return blinky_amd
+
+
+def build(bk, globe, lens, zoom, W, H, rows=None, grid=None):
+    ctx = bk.Context()
+    if grid:
+        ctx.set_rubixgrid(*grid)
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    if rows:
+        ctx.set_rows(*rows)
+    display, scale = ctx.build()
+    off, tin = ctx.read_lensmap()
+    return ctx, display, scale, off, tin
+
+
+@pytest.mark.parametrize("rec", GOLD, ids=lambda r: f"{r['globe']}-{r['lens']}-{r['zoom']}-{r['W']}x{r['H']}")
+def test_build_equals_reference_golden(bk, rec):
+    """every golden recorded from the unmodified reference, BASELINE.json's full 4K sizes included"""
+    ctx, display, scale, off, tin = build(bk, rec["globe"], rec["lens"], rec["zoom"], rec["W"], rec["H"])
+    nplates = len(rec["display"])
+    assert repr(scale) == rec["scale"]
+    assert display[:nplates] == rec["display"]
+    assert int((off != O.NULL).sum()) == rec["nonnull"]
+    assert O.fnv(off) == rec["fnv_offsets"]
+    assert O.fnv(tin) == rec["fnv_tints"]
+    # and the whole path: GPU-built map applied on the GPU to the LCG globe == the reference's frame
+    for p in range(nplates):
+        ctx.fill_plate_lcg(0, p, 0)
+    frame = ctx.apply(np.zeros((rec["H"], rec["W"]), np.uint8))
+    assert O.fnv(frame) == rec["fnv_frame"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    ("cube", "panini", "f_fov 90", 200, 150),
+    ("cube", "panini", "f_vfov 100", 257, 129),
+    ("trism", "stereographic", "f_fov 200", 320, 240),
+    ("trism", "hammer", "f_cover", 300, 300),
+    ("trism", "quincuncial", None, 256, 256),
+    ("trism", "eckert5", None, 200, 120),           # forward map
+    ("cube", "eckert5", "f_cover", 160, 120),
+    ("cube", "stereographic", None, 1, 1),          # degenerate sizes
+    ("cube", "hammer", None, 7, 3),
+])
+def test_build_equals_oracle_arrays(bk, cfg):
+    lm = O.lensmap(*cfg)
+    ctx, display, scale, off, tin = build(bk, *cfg)
+    assert scale == lm.scale
+    assert display[: lm.numplates] == lm.display
+    np.testing.assert_array_equal(off, lm.offsets)
+    np.testing.assert_array_equal(tin, lm.tints)
+    ctx.close()
+
+
+def test_rubixgrid_variants(bk):
+    for grid in [(3, 2.0, 1.0), (10, 4.0, 1.0), (5, 1.0, 0.5)]:
+        lm = O.lensmap("cube", "panini", None, 320, 240, grid=grid)
+        ctx, _, _, off, tin = build(bk, "cube", "panini", None, 320, 240, grid=grid)
+        np.testing.assert_array_equal(tin, lm.tints)
+        np.testing.assert_array_equal(off, lm.offsets)
+        ctx.close()
+
+
+@pytest.mark.parametrize("lens", ["hammer", "eckert5"])       # inverse and forward (stripe-filtered commit)
+def test_row_stripes_build_the_same_table(bk, lens):
+    W, H = 480, 270
+    lm = O.lensmap("cube", lens, None, W, H)
+    bounds = [0, 33, 34, 200, 270]
+    alldisp = [0] * 6
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        ctx, display, _, off, tin = build(bk, "cube", lens, None, W, H, rows=(r0, r1))
+        np.testing.assert_array_equal(off, lm.offsets.reshape(H, W)[r0:r1].ravel())
+        np.testing.assert_array_equal(tin, lm.tints.reshape(H, W)[r0:r1].ravel())
+        alldisp = [a | b for a, b in zip(alldisp, display)]
+        ctx.close()
+    assert alldisp == lm.display                   # the OR over stripes is the reference's display[]
+
+
+@pytest.mark.parametrize("lens", S.LENSES)
+def test_device_callbacks_bit_equal_host_interpreter(bk, lens):
+    """The generated device code and the host interpreter walk the same AST with the same portable
+    libm: raw callback results must be bit-identical for every shipped lens (also checks bkm.h
+    device == host)."""
+    ctx = bk.Context()
+    ctx.set_host_math(True)
+    info = S.configure(ctx, "cube", lens, None, (640, 480))
+    rng = np.random.default_rng(5)
+    if info.has_inverse:
+        w = info.lens_width or 6.0
+        h = info.lens_height or 4.0
+        args = np.concatenate([rng.uniform(-0.6, 0.6, (700, 2)) * [w, h], [[0.0, 0.0], [w / 2, 0.0], [0.0, h / 2], [1e-9, -1e-9]]])
+        d_out, d_n = ctx.eval_device(0, args)
+        h_out, h_n = ctx.eval_host_many(0, args)
+        np.testing.assert_array_equal(d_n, h_n)
+        assert d_out.view(np.uint64).tolist() == h_out.view(np.uint64).tolist() or \
+            np.array_equal(d_out[~np.isnan(h_out)].view(np.uint64), h_out[~np.isnan(h_out)].view(np.uint64))
+    if info.has_forward:
+        v = rng.normal(size=(600, 3))
+        v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+        d_out, d_n = ctx.eval_device(1, v)
+        h_out, h_n = ctx.eval_host_many(1, v)
+        np.testing.assert_array_equal(d_n, h_n)
+        m = ~np.isnan(h_out)
+        np.testing.assert_array_equal(np.isnan(d_out), np.isnan(h_out))
+        assert np.array_equal(d_out[m].view(np.uint64), h_out[m].view(np.uint64))
+    ctx.close()
+
+
+def test_globe_plate_override_fast_globe(bk):
+    """fast.lua's globe_plate (nil for z <= 0) runs on the device; check against the host interpreter
+    evaluating the same script for plate choice, then the table for structure."""
+    ctx = bk.Context()
+    ctx.set_host_math(True)
+    S.configure(ctx, "fast", "panini", "f_fov 200", (320, 200))
+    rng = np.random.default_rng(9)
+    v = rng.normal(size=(500, 3))
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    d_out, d_n = ctx.eval_device(2, v)
+    h_out, h_n = ctx.eval_host_many(2, v)
+    np.testing.assert_array_equal(d_n, h_n)
+    assert (d_n[v[:, 2] <= 0] == -1).all()
+    m = h_n == 1
+    np.testing.assert_array_equal(d_out[m, 0], h_out[m, 0])
+    display, _ = ctx.build()
+    off, _ = ctx.read_lensmap()
+    assert display[:2] == [1, 1]
+    mapped = off != O.NULL
+    assert 0 < mapped.sum() < off.size              # fov 200: rays behind the viewer stay NULL
+    assert (off[mapped] // (200 * 200) <= 1).all()
+    ctx.close()
+
+
+def test_script_runtime_errors_surface_as_errors(bk):
+    ctx = bk.Context()
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens("lens_width = 2 lens_height = 2 function lens_inverse(x,y) return x, y end", "two.lua")   # 2 values
+    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match="malformed result"):
+        ctx.build()
+    off, _ = ctx.read_lensmap()
+    assert (off == O.NULL).all()
+    ctx.load_lens("lens_width = 2 lens_height = 2 function lens_inverse(x,y) return x + undefined_global, 0, 1 end", "nil.lua")
+    with pytest.raises(bk.BlinkyError, match="arithmetic on a non-number"):
+        ctx.build()
+    ctx.load_lens("lens_width = 2 lens_height = 2 function lens_inverse(x,y) while true do end end", "loop.lua")
+    with pytest.raises(bk.BlinkyError, match="iteration budget"):
+        ctx.build()
+    # and an invalid zoom leaves an empty map, like the reference (create_lensmap returns early)
+    S.configure(ctx, "cube", "quincuncial", "f_fov 90")
+    with pytest.raises(bk.BlinkyError, match="max_fov"):
+        ctx.build()
+    assert (ctx.read_lensmap()[0] == O.NULL).all()
+    ctx.close()

@@ -1,0 +1,241 @@
+"""Host logic of the script surface, on a BK_DEVICE_NONE context (no GPU needed): the Lua-subset
+front-end, LUA_load_lens / LUA_load_globe / calc_zoom restatements, and the HIP code generator
+(every shipped lens must translate and compile with hiprtc)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scripts as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "lensmaps.json")))["lensmaps"]
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import blinky_amd
+    return blinky_amd
+
+
+def host_ctx(bk):
+    return bk.Context(bk.ffi.DEVICE_NONE)
+
+
+def lens_ctx(bk, body, globe="cube"):
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", globe), globe)
+    ctx.load_lens(body, "test.lua")
+    return ctx
+
+
+# ---- the reference's loaders ------------------------------------------------------------------
+
+def test_all_shipped_scripts_load(bk):
+    forward_only = {"eckert1", "eckert5", "gins8", "kavrayskiy7", "larrivee", "polyconic", "sinusoidal", "wagner6",
+                    "winkel1", "winkel2"}
+    for lens in S.LENSES:
+        ctx = host_ctx(bk)
+        info = S.configure(ctx, "cube", lens)
+        assert info.map_type == (bk.ffi.MAP_FORWARD if lens in forward_only else bk.ffi.MAP_INVERSE), lens
+        assert info.onload.decode().split()[0] in ("f_fov", "f_contain", "f_cover"), lens
+    for globe, n in [("cube", 6), ("cube_edge", 6), ("cube_corner", 6), ("trism", 5), ("tetra", 4), ("fast", 2)]:
+        ctx = host_ctx(bk)
+        ctx.load_globe(S.script("globes", globe), globe)
+        assert len(ctx.globe()) == n
+    # tetra.lua print()s its fov (tetra.lua:19); the reference sends that to stdout
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "tetra"), "tetra")
+    assert ctx.console().startswith("142.05755873")
+
+
+@pytest.mark.parametrize("lens", ["panini", "stereographic", "hammer", "quincuncial", "eckert5"])
+def test_lens_globals_equal_hand_transliteration(bk, lens):
+    ctx = host_ctx(bk)
+    info = S.configure(ctx, "cube", lens)
+    want = O.lens_def(lens)
+    assert (info.has_inverse, info.has_forward, info.max_fov, info.max_vfov) == (
+        want["has_inverse"], want["has_forward"], want["max_fov"], want["max_vfov"])
+    assert info.lens_width == want["lens_width"] and info.lens_height == want["lens_height"]   # bit-equal doubles
+    assert info.onload.decode() == want["onload"]
+
+
+@pytest.mark.parametrize("globe", ["cube", "trism"])
+def test_globe_plates_equal_oracle(bk, globe):
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", globe), globe)
+    want = O.globe_plates(globe)
+    got = ctx.globe()
+    assert len(got) == len(want)
+    for p, w in zip(got, want):
+        vec = np.array(list(p.forward) + list(p.right) + list(p.up) + [p.fov, p.dist], np.float32)
+        assert vec.tobytes() == w[:11].tobytes()
+
+
+@pytest.mark.parametrize("rec", GOLD, ids=lambda r: f"{r['globe']}-{r['lens']}-{r['zoom']}-{r['W']}x{r['H']}")
+def test_calc_zoom_equals_reference_scale(bk, rec):
+    ctx = host_ctx(bk)
+    S.configure(ctx, rec["globe"], rec["lens"], rec["zoom"], (rec["W"], rec["H"]))
+    assert repr(ctx.calc_zoom()) == rec["scale"]
+
+
+def test_calc_zoom_failures(bk):
+    ctx = host_ctx(bk)
+    S.configure(ctx, "cube", "quincuncial", "f_fov 90", (64, 48))      # no lens_forward, no max_fov
+    with pytest.raises(bk.BlinkyError, match="max_fov & max_vfov not specified"):
+        ctx.calc_zoom()
+    S.configure(ctx, "cube", "panini", "f_fov 400", (64, 48))
+    with pytest.raises(bk.BlinkyError, match="fov must be less than 360"):
+        ctx.calc_zoom()
+    S.configure(ctx, "cube", "panini", "f_contain", (64, 48))           # panini has no lens_width/height
+    with pytest.raises(bk.BlinkyError, match="neither lens_height nor lens_width"):
+        ctx.calc_zoom()
+
+
+def test_globals_leak_between_lenses_like_the_reference(bk):
+    """fisheye.c:1880-1903 clears only eight names; 'd' set by panini.lua survives into the next lens."""
+    ctx = host_ctx(bk)
+    S.configure(ctx, "cube", "panini")
+    ctx.load_lens("function lens_inverse(x,y) return d, numplates, 0 end", "probe.lua")
+    assert ctx.eval_host(0, 0.0, 0.0) == (1.0, 6.0, 0.0)
+    assert ctx.lens_info().max_fov == 0          # but max_fov was cleared
+
+
+# ---- interpreter == independent hand transliteration (platform libm on both sides) ---------------
+
+@pytest.mark.parametrize("lens", ["panini", "stereographic", "hammer", "quincuncial"])
+def test_interpreter_inverse_bit_equals_hand_c(bk, lens):
+    ctx = host_ctx(bk)
+    S.configure(ctx, "cube", lens)
+    rng = np.random.default_rng(11)
+    for x, y in rng.uniform(-3, 3, (1500, 2)):
+        a, b = ctx.eval_host(0, x, y), O.eval_lens(lens, 0, x, y)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array(a).tobytes() == np.array(b).tobytes(), (lens, x, y)
+
+
+@pytest.mark.parametrize("lens", ["panini", "stereographic", "hammer", "eckert5"])
+def test_interpreter_forward_bit_equals_hand_c(bk, lens):
+    ctx = host_ctx(bk)
+    S.configure(ctx, "cube", lens)
+    rng = np.random.default_rng(12)
+    for v in rng.normal(size=(1000, 3)):
+        v = (v / np.linalg.norm(v)).astype(np.float32).astype(np.float64)
+        a, b = ctx.eval_host(1, *v), O.eval_lens(lens, 1, *v)
+        assert np.array(a).tobytes() == np.array(b).tobytes(), (lens, v)
+
+
+# ---- Lua semantics ----------------------------------------------------------------------------------
+
+def ev(bk, body, *args):
+    return lens_ctx(bk, body).eval_host(0, *args)
+
+
+def test_operator_precedence_and_associativity(bk):
+    assert ev(bk, "function lens_inverse(x,y) return 2^3^2, -2^2, 2*3+4/2-1 end", 0, 0) == (512.0, -4.0, 7.0)
+    assert ev(bk, "function lens_inverse(x,y) return 7 % 3, -7 % 3, 7 % -3 end", 0, 0) == (1.0, 2.0, -2.0)
+    assert ev(bk, "function lens_inverse(x,y) if 1 < 2 and not (2 < 1) or false then return 1,1,1 end return 0,0,0 end", 0, 0) == (1, 1, 1)
+    assert ev(bk, "function lens_inverse(x,y) return 1 and 2, nil or 3, false and 9 or 4 end", 0, 0) == (2.0, 3.0, 4.0)
+    assert ev(bk, "function lens_inverse(x,y) return .25, 1.e-10, 0x10 end", 0, 0) == (0.25, 1e-10, 16.0)
+
+
+def test_control_flow(bk):
+    body = """
+    function lens_inverse(x,y)
+      local s = 0
+      for i=1,10 do s = s + i end           -- 55
+      for i=10,1,-3 do s = s + i end        -- 10+7+4+1
+      local n = 0
+      while true do n = n + 1; if n >= 5 then break end end
+      local m = 0
+      repeat local k = m + 1; m = k until k >= 3     -- until sees the body's local
+      return s, n, m
+    end"""
+    assert ev(bk, body, 0, 0) == (77.0, 5.0, 3.0)
+
+
+def test_multiple_assignment_and_returns(bk):
+    body = """
+    function two() return 1, 2 end
+    function lens_inverse(x,y)
+      local a, b, c = two()          -- c = nil
+      local d, e = (two())           -- parenthesised: one value
+      a, b = b, a                    -- swap: right side evaluated first
+      local t = {two(), two()}       -- {1, 1, 2}
+      if c == nil and e == nil then return a, b, #t end
+      return 0, 0, 0
+    end"""
+    assert ev(bk, body, 0, 0) == (2.0, 1.0, 3.0)
+    # call results are expanded only in the last position (gins8.lua:21 relies on it)
+    assert ev(bk, "function f(a,b,c) return a,b,c end function g() return 5,6 end function lens_inverse(x,y) return f(g(), g()) end", 0, 0) == (5.0, 5.0, 6.0)
+
+
+def test_closures_upvalues_tables_strings_comments(bk):
+    body = """
+    --[[ long
+    comment ]] local base = 10   -- chunk-level local captured below
+    local function add(v) return v + base end
+    cfg = { scale = 2, [3] = 30, 'a', "b" }
+    function lens_inverse(x,y)
+      local s = "x\\65\\n"          --[==[ another ]==]
+      return add(x) * cfg.scale, cfg[3], #cfg + #s
+    end"""
+    assert ev(bk, body, 1.0, 0) == (22.0, 30.0, 6.0)   # #cfg == 3: luaH_getn continues into the hash part
+
+
+def test_math_library(bk):
+    r = ev(bk, "function lens_inverse(x,y) local i,f = math.modf(-3.75) return i, f, math.max(1,5,3) + math.min(4,2) end", 0, 0)
+    assert r == (-3.0, -0.75, 7.0)
+    r = ev(bk, "function lens_inverse(x,y) return math.log(8, 2), log10(1000), tau / pi end", 0, 0)
+    assert r == (3.0, 3.0, 2.0)
+
+
+def test_script_errors_are_reported(bk):
+    ctx = host_ctx(bk)
+    with pytest.raises(bk.BlinkyError, match=r"bad\.lua:2: .*expected"):
+        ctx.load_lens("x = 1\nfunction (", "bad.lua")
+    with pytest.raises(bk.BlinkyError, match="attempt to call a nil value \\(global 'nosuch'\\)"):
+        ctx.load_lens("nosuch()", "bad.lua")
+    with pytest.raises(bk.BlinkyError, match="attempt to perform arithmetic on a nil value"):
+        ctx.load_lens("y = undefined_thing + 1", "bad.lua")
+    with pytest.raises(bk.BlinkyError, match="Unsupported map function"):
+        ctx.load_lens('map = "sideways"', "bad.lua")
+    with pytest.raises(bk.BlinkyError, match="plates must be an array"):
+        ctx.load_globe("plates = 3", "bad.lua")
+    with pytest.raises(bk.BlinkyError, match="fov must > 0"):
+        ctx.load_globe("plates = {{{0,0,1},{0,1,0},-5}}", "bad.lua")
+    with pytest.raises(bk.BlinkyError, match="execution budget"):
+        ctx.load_lens("while true do end", "bad.lua")
+
+
+# ---- code generation ------------------------------------------------------------------------------------
+
+def test_every_shipped_lens_translates_and_compiles(bk):
+    for lens in S.LENSES:
+        ctx = host_ctx(bk)
+        S.configure(ctx, "cube", lens, None, (640, 480))
+        src = ctx.kernel_source(compile=True)           # hiprtc, gfx950, no GPU needed
+        assert "bk_build_kernels.h" in src, lens
+
+
+def test_globe_plate_override_and_mutable_globals_translate(bk):
+    ctx = host_ctx(bk)
+    S.configure(ctx, "fast", "panini", None, (320, 240))
+    src = ctx.kernel_source(compile=True)
+    assert "BK_HAS_GLOBE_PLATE" in src
+    ctx = host_ctx(bk)
+    S.configure(ctx, "cube", "eckert4", None, (320, 240))      # get_max_x caches in globals lasty / maxx
+    src = ctx.kernel_source(compile=True)
+    assert "g_lasty" in src and "g_maxx" in src
+
+
+def test_unsupported_gpu_constructs_are_named(bk):
+    ctx = lens_ctx(bk, "function lens_inverse(x,y) local s = 'a' .. 'b' return 0,0,1 end")
+    with pytest.raises(bk.BlinkyError, match="not supported in a GPU callback: string"):
+        ctx.kernel_source()
+    ctx = lens_ctx(bk, "function f(n) if n < 1 then return 1 end return f(n-1) end function lens_inverse(x,y) return f(3),0,1 end")
+    with pytest.raises(bk.BlinkyError, match="recursion"):
+        ctx.kernel_source()
