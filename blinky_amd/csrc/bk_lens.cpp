@@ -496,11 +496,11 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
 
 static const char *err_text(int bits)
 {
-    if (bits & BK_ERR_RESULT) return "a lens callback returned a malformed result (not 3 numbers / 2 numbers / a single nil)";
+    if (bits & BK_ERR_LOOP) return "a lens callback exceeded the per-pixel iteration budget (infinite loop?)";
     if (bits & BK_ERR_ARITH) return "a lens callback performed arithmetic on a non-number (nil?)";
     if (bits & BK_ERR_COMPARE) return "a lens callback compared non-numbers with < or <=";
     if (bits & BK_ERR_INDEX) return "a lens callback stored outside a table's bounds";
-    if (bits & BK_ERR_LOOP) return "a lens callback exceeded the per-pixel iteration budget (infinite loop?)";
+    if (bits & BK_ERR_RESULT) return "a lens callback returned a malformed result (not 3 numbers / 2 numbers / a single nil)";
     return "unknown device error";
 }
 

@@ -18,6 +18,18 @@
 #define M_PI 3.14159265358979323846   /* include/mathlib.h:56-57 */
 #endif
 
+#ifdef OK_PORTABLE_LIBM
+/* liboracle_bkm.so: same algorithm, libm calls routed to the portable functions the GPU kernels
+ * are built from.  Lets the tests separate "algorithm differs" from "platform libm last bit". */
+#include "../blinky_amd/csrc/bkm.h"
+#define sin bkm_sin
+#define cos bkm_cos
+#define tan bkm_tan
+#define atan2 bkm_atan2
+#define sqrt bkm_sqrt
+#define fmod bkm_fmod
+#endif
+
 /* ---- mathlib.c restatements ------------------------------------------------- */
 
 /* include/mathlib.h:70  DotProduct macro on vec_t=float operands */

@@ -18,6 +18,22 @@
 
 /* calls through volatile pointers so gcc cannot constant-fold / strength-reduce
  * what a real Lua VM would evaluate with a libm call at run time */
+#ifdef OK_PORTABLE_LIBM   /* liboracle_bkm.so, see oracle.c */
+#include "../blinky_amd/csrc/bkm.h"
+#define pow bkm_pow
+#define sqrt bkm_sqrt
+#define sin bkm_sin
+#define cos bkm_cos
+#define tan bkm_tan
+#define asin bkm_asin
+#define acos bkm_acos
+#define atan bkm_atan
+#define atan2 bkm_atan2
+#define sinh bkm_sinh
+#define cosh bkm_cosh
+#define tanh bkm_tanh
+#define exp bkm_exp
+#endif
 static double (*volatile lua_pow)(double, double) = pow;
 static double (*volatile lua_sqrt)(double) = sqrt;
 /* A Lua VM makes one libm call per math.xxx; gcc -O2 would fuse sin(x)/cos(x) pairs of the
@@ -36,6 +52,20 @@ static double (*volatile lua_sinh)(double) = sinh;
 static double (*volatile lua_cosh)(double) = cosh;
 static double (*volatile lua_tanh)(double) = tanh;
 static double (*volatile lua_exp)(double) = exp;
+#undef sin
+#undef cos
+#undef tan
+#undef asin
+#undef acos
+#undef atan
+#undef atan2
+#undef sinh
+#undef cosh
+#undef tanh
+#undef exp
+#undef sqrt
+#undef pow
+#define pow lua_pow
 #define sin lua_sin
 #define cos lua_cos
 #define tan lua_tan

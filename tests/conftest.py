@@ -19,7 +19,7 @@ def _built():
     """Make sure the oracle (checker) and the HIP library (product) are built.
     Building the checker is not using it; the GPU box normally receives prebuilt files."""
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so", "liboracle_bkm.so"])
     if not os.path.exists(os.path.join(ROOT, "blinky_amd", "libblinkyhip.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "blinky_amd", "csrc")])
     yield

