@@ -39,6 +39,10 @@ extern "C" bk_ctx *bk_create(int device)
     }
     bk_ctx *ctx = new bk_ctx();
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
+    }
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc((void **)&ctx->d_pal, BK_MAX_PLATES * 256) != hipSuccess ||
         hipMalloc((void **)&ctx->d_display, (BK_MAX_PLATES + 2) * sizeof(int)) != hipSuccess) {
@@ -208,6 +212,31 @@ extern "C" int bk_set_apply_variant(bk_ctx *ctx, int variant)
     if (!ctx) return BK_E_INVALID;
     ctx->apply_variant = variant;
     return BK_OK;
+}
+
+extern "C" int bk_debug_set_ablation(bk_ctx *ctx, int bits)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (int r = ensure_device(ctx)) return r;
+    return bk::set_ablation(ctx, bits);
+}
+
+extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (lw >= 100) { ctx->apply_wgs_per_cu = lw - 100; return BK_OK; }      // developer knob: 100+n = n workgroups per CU
+    if (lw != 0 && (lw < 3 || lw > 5)) return BK_E_INVALID;
+    ctx->tile_shape = lw;
+    bk::tilemap_invalidate(ctx);
+    return BK_OK;
+}
+
+extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
+{
+    if (!ctx || !out) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "no lensmap");
+    if (int r = ensure_device(ctx)) return r;
+    return bk::tilemap_stats(ctx, out);
 }
 
 extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }

@@ -166,6 +166,7 @@ int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pit
 {
     const int rows = ctx->rows();
     if (rows <= 0 || nframes <= 0) return BK_OK;
+    if (ctx->apply_variant != 0) return launch_apply_tiled(ctx, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
     const size_t gstride = ctx->globe_stride();
     const int fchunk = nframes < 8 ? nframes : 8;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
@@ -225,7 +226,5 @@ int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_padded)
     return BK_OK;
 }
 
-void tilemap_invalidate(bk_ctx *) {}
-void tilemap_free(TileMap *) {}
 
 }  // namespace bk

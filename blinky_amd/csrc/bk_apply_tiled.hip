@@ -1,0 +1,583 @@
+// bk_apply_tiled.hip -- lensmap APPLY, variant 1: tiled lensmap + LDS-staged plate regions.
+//
+// The lensmap is frame-invariant, so after every build it is "compiled" once into a form the
+// per-frame gather can stream at full width:
+//   * the screen is cut into tiles of 32x8 pixels, one wavefront (64 lanes x 4 px) per tile;
+//   * for each tile a wave discovers, with ballots and shuffle reductions, which plates its
+//     pixels read and the bounding box of the texels inside each plate (<= 3 regions: a cube
+//     corner); the box is widened to 16-byte columns of the padded globe rows;
+//   * each pixel's 32-bit globe offset is replaced by a 16-bit address inside the tile's LDS
+//     staging area (0xFFFF = unmapped), stored tile-major so a wave reads its 512 B in one go.
+// Per frame a wave then (1) copies its regions HBM -> LDS with coalesced 16-byte row loads,
+// (2) gathers its 256 texels from LDS (ds_read_u8: ~8x the rate of the texture addresser's
+// byte gathers), (3) stores 4 packed pixels per lane.  Tiles whose regions do not fit
+// (BK_TILE_LDS_CAP) fall back to direct global gathers through the 32-bit table.
+// Four horizontally adjacent tiles form a workgroup (a 128x8 pixel strip: full 128-byte lines
+// are written by one CU), and workgroup b is mapped to a horizontal screen band chosen by
+// b % 8 so that each XCD's L2 keeps its own slice of the index stream and shares source rows.
+//
+// replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
+#include "bk_internal.h"
+
+namespace bk {
+
+// A tile is always 256 px = 64 lanes x 4 consecutive pixels; its SHAPE is chosen per lensmap:
+// lw = log2(lanes per tile row): 3 -> 32x8, 4 -> 64x4, 5 -> 128x2 pixels.  A workgroup (4 waves)
+// always covers a 128x8 pixel block; its tiles are stored contiguously (t = block*4 + wave).
+constexpr int TILE_PX = 256, BLOCK_W = 128, BLOCK_H = 8;
+constexpr int BK_TILE_LDS_CAP = 12288;                             // bytes of LDS per wave-tile
+constexpr uint32_t F_ALL = 1, F_SLOW = 2, F_EMPTY = 4;
+
+struct TileHdr {              // 32 bytes
+    uint32_t src[3];          // byte offset of region r inside one globe frame (16-byte aligned)
+    uint16_t w16[3];          // region width in 16-byte chunks
+    uint16_t rows[3];         // region height
+    uint16_t nreg;
+    uint16_t flags;
+    uint16_t lds16;           // LDS bytes / 16 the regions need
+    uint16_t pad;
+};
+
+struct TileMap {
+    TileHdr *d_hdr = nullptr;
+    uint16_t *d_idx = nullptr;      // [ntiles][256]
+    uint8_t *d_tint = nullptr;      // [ntiles][256] tile-major tints (rubix)
+    uint32_t *d_stats = nullptr;    // [0] max LDS bytes, [1] >3-region tiles, [2] empty tiles, [3] 128-B lines staged,
+                                    // [4..36) LDS-need histogram (512 B bins)
+    int blocks_x = 0, blocks_y = 0; // 128x8-pixel workgroup blocks
+    int lw = 3;                     // tile shape (see above)
+    int lds_bytes = 0;              // per wave, rounded up
+    uint32_t stats[40] = {0};
+    int slow_tiles = 0;
+    bool valid = false;
+    size_t alloc_tiles = 0;
+};
+
+// tile t = block*4 + wave; wave w sits at (w % per_row, w / per_row) inside the 128x8 block
+__device__ __forceinline__ void tile_origin(int t, int lw, int blocks_x, int *ox, int *oy)
+{
+    const int blk = t >> 2, w = t & 3;
+    const int by = blk / blocks_x, bx = blk - by * blocks_x;
+    const int tw = 4 << lw, th = 64 >> lw, per_row = BLOCK_W / tw;
+    *ox = bx * BLOCK_W + (w % per_row) * tw;
+    *oy = by * BLOCK_H + (w / per_row) * th;
+}
+
+__device__ __forceinline__ int wave_min(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// compile: one wave per tile
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
+                                                           int W, int rows, int ps, int gp, int blocks_x, int lw, int ntiles,
+                                                           TileHdr *__restrict__ hdr, uint16_t *__restrict__ idx,
+                                                           uint8_t *__restrict__ tint_t, uint32_t *__restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    int ox, oy;
+    tile_origin(t, lw, blocks_x, &ox, &oy);
+    const int ry = lane >> lw, cx = lane & ((1 << lw) - 1);
+    const int row = oy + ry, x0 = ox + cx * 4;
+
+    uint32_t o[4];
+    uint8_t tn[4];
+    int plate[4], px[4], py[4];
+    const uint32_t plate_stride = (uint32_t)gp * (uint32_t)ps;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool in = row < rows && x0 + k < W;
+        o[k] = in ? lmap[(size_t)row * W + x0 + k] : BK_NULL_OFFSET;
+        tn[k] = in ? tints[(size_t)row * W + x0 + k] : 255;
+        plate[k] = -1; px[k] = 0; py[k] = 0;
+        if (o[k] != BK_NULL_OFFSET) {
+            const uint32_t p = o[k] / plate_stride, rem = o[k] - p * plate_stride;
+            plate[k] = (int)p;
+            py[k] = (int)(rem / (uint32_t)gp);
+            px[k] = (int)(rem - (uint32_t)py[k] * (uint32_t)gp);
+        }
+    }
+    const bool all = __all(plate[0] >= 0 && plate[1] >= 0 && plate[2] >= 0 && plate[3] >= 0);
+    const bool any = __any(plate[0] >= 0 || plate[1] >= 0 || plate[2] >= 0 || plate[3] >= 0);
+
+    // regions: one per plate present in the tile (ballot), bounding box by shuffle reduction
+    int nreg = 0, lds16 = 0, lines = 0;
+    int r_plate[3] = {-1, -1, -1}, r_x0[3] = {0, 0, 0}, r_y0[3] = {0, 0, 0}, r_w16[3] = {0, 0, 0}, r_rows[3] = {0, 0, 0}, r_base16[3] = {0, 0, 0};
+    bool slow = false;
+    for (int p = 0; p < BK_MAX_PLATES; ++p) {
+        const bool mine = plate[0] == p || plate[1] == p || plate[2] == p || plate[3] == p;
+        if (__ballot(mine) == 0) continue;                       // wave-uniform
+        int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (plate[k] == p) { mnx = min(mnx, px[k]); mxx = max(mxx, px[k]); mny = min(mny, py[k]); mxy = max(mxy, py[k]); }
+        mnx = wave_min(mnx); mxx = wave_max(mxx); mny = wave_min(mny); mxy = wave_max(mxy);
+        if (nreg == 3) { slow = true; break; }
+        const int xa = mnx & ~15, w16 = (mxx - xa) / 16 + 1, nrows = mxy - mny + 1, pitch16 = w16 | 1;
+        r_plate[nreg] = p; r_x0[nreg] = xa; r_y0[nreg] = mny; r_w16[nreg] = w16; r_rows[nreg] = nrows; r_base16[nreg] = lds16;
+        lds16 += nrows * pitch16;
+        lines += nrows * (((xa + w16 * 16 + 127) >> 7) - (xa >> 7));      // 128-byte lines the staging touches
+        ++nreg;
+    }
+    if (lds16 * 16 > BK_TILE_LDS_CAP || lds16 * 16 > 0xFFF0) slow = true;
+
+    uint16_t a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = 0xFFFF;
+        if (plate[k] >= 0) {
+            a[k] = 0;
+            if (!slow)
+                for (int r = 0; r < 3; ++r)
+                    if (r_plate[r] == plate[k])
+                        a[k] = (uint16_t)((r_base16[r] + (py[k] - r_y0[r]) * (r_w16[r] | 1)) * 16 + (px[k] - r_x0[r]));
+        }
+    }
+    *reinterpret_cast<uint2 *>(idx + (size_t)t * TILE_PX + lane * 4) =
+        make_uint2((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16));
+    *reinterpret_cast<uint32_t *>(tint_t + (size_t)t * TILE_PX + lane * 4) =
+        (uint32_t)tn[0] | ((uint32_t)tn[1] << 8) | ((uint32_t)tn[2] << 16) | ((uint32_t)tn[3] << 24);
+    if (lane == 0) {
+        TileHdr h;
+        for (int r = 0; r < 3; ++r) {
+            h.src[r] = r < nreg ? (uint32_t)r_plate[r] * plate_stride + (uint32_t)r_y0[r] * (uint32_t)gp + (uint32_t)r_x0[r] : 0u;
+            h.w16[r] = (uint16_t)(r < nreg && !slow ? r_w16[r] : 0);
+            h.rows[r] = (uint16_t)(r < nreg && !slow ? r_rows[r] : 0);
+        }
+        h.nreg = (uint16_t)(slow ? 0 : nreg);
+        h.flags = (uint16_t)((all ? F_ALL : 0) | (slow ? F_SLOW : 0) | (any ? 0 : F_EMPTY));
+        h.lds16 = (uint16_t)(slow ? 0 : lds16);
+        h.pad = 0;
+        hdr[t] = h;
+        if (!slow && any) {
+            atomicMax(&stats[0], (uint32_t)lds16 * 16u);
+            atomicAdd(&stats[4 + min(31, (lds16 * 16 + 511) / 512)], 1u);     // histogram of LDS need
+            atomicAdd(&stats[3], (uint32_t)lines);
+        }
+        if (slow) atomicAdd(&stats[1], 1u);
+        if (!any) atomicAdd(&stats[2], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply
+// ---------------------------------------------------------------------------------------------
+// The hot path: every pixel of the tile mapped, regions <= NQ*1 KiB, aligned destination; the loop
+// body is branch-free.  (A register prefetch of frame f+1's chunks was measured and bought nothing:
+// with 24-32 waves per CU the memory system, not per-wave latency, is the limiter.)
+// developer ablation switch (tools/apply_probe.py): bit0 skip region loads, bit1 skip stores,
+// bit2 skip the LDS gather, bit3 skip the LDS writes.  0 in normal operation.
+__device__ int g_ablate = 0;
+
+template <int NQ>
+__device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
+                                           int f_begin, int f_end, uint8_t *__restrict__ out0, size_t frame_stride,
+                                           uint8_t *lds, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
+                                           uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
+                                           bool k0, bool k1, bool k2, bool k3,
+                                           uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
+{
+    // (explicit scalars, not arrays: the four chunks must stay in VGPRs)
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+    const int abl = g_ablate;
+    if (abl) {     // ablated copy of the loop, for attributing time; results are wrong by design
+        for (int f = f_begin; f < f_end; ++f) {
+            const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+            if (!(abl & 1)) {
+                q0 = *reinterpret_cast<const uint4 *>(gl + s0);
+                if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
+                if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
+                if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
+            }
+            if (!(abl & 8)) {
+                if (k0) *reinterpret_cast<uint4 *>(lds + d0) = q0;
+                if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(lds + d1) = q1;
+                if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(lds + d2) = q2;
+                if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(lds + d3) = q3;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t v0 = a0 + q0.x, v1 = a1, v2 = a2, v3 = a3;
+            if (!(abl & 4)) { v0 = lds[a0]; v1 = lds[a1]; v2 = lds[a2]; v3 = lds[a3]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t w = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+            if (!(abl & 2) || w == 0x12345678u) *reinterpret_cast<uint32_t *>(out0 + (size_t)f * frame_stride) = w;
+        }
+        return;
+    }
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        q0 = *reinterpret_cast<const uint4 *>(gl + s0);
+        if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
+        if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
+        if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
+        if (k0) *reinterpret_cast<uint4 *>(lds + d0) = q0;
+        if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(lds + d1) = q1;
+        if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(lds + d2) = q2;
+        if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(lds + d3) = q3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t v0 = lds[a0], v1 = lds[a1], v2 = lds[a2], v3 = lds[a3];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<uint32_t *>(out0 + (size_t)f * frame_stride) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+    }
+}
+
+// What a wave fetches ahead for its NEXT tile while it works on the current one: the 32-byte
+// header (as two vector loads, so that it is tracked by vmcnt like everything else - an s_load
+// would share lgkmcnt with the LDS traffic and stall the gathers), its 4 LDS indices and tints.
+struct TilePrefetch {
+    uint4 h0, h1;
+    uint2 iw;
+    uint32_t t4;
+};
+
+template <bool RUBIX>
+__device__ __forceinline__ TilePrefetch tile_fetch(const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx,
+                                                   const uint8_t *__restrict__ tint_t, int t, int lane)
+{
+    TilePrefetch p;
+    int tv;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tv) : "s"(t));     // make the address a VGPR: vector loads
+    const uint4 *hp = reinterpret_cast<const uint4 *>(hdr) + 2 * (size_t)tv;
+    p.h0 = hp[0];
+    p.h1 = hp[1];
+    p.iw = *reinterpret_cast<const uint2 *>(idx + (size_t)t * TILE_PX + lane * 4);
+    p.t4 = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + (size_t)t * TILE_PX + lane * 4) : 0xFFFFFFFFu;
+    return p;
+}
+
+template <bool RUBIX>
+__device__ __forceinline__ void tile_process(
+    const TilePrefetch &pf, int t, int lane, uint8_t *lds, const uint8_t *pal_s,
+    const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
+    int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp, int lw,
+    int blocks_x, int f_begin, int f_end, int lds_per_wave)
+{
+    // header words -> SGPRs (the values are wave-uniform)
+    const uint32_t h_src[3] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h0.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h0.y),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h0.z)};
+    const uint32_t w01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h0.w), w2r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h1.x);
+    const uint32_t r12 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h1.y), nf = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h1.z);
+    const uint32_t l16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h1.w) & 0xFFFFu;
+    const uint32_t h_w16[3] = {w01 & 0xFFFFu, w01 >> 16, w2r0 & 0xFFFFu};
+    const uint32_t h_rows[3] = {w2r0 >> 16, r12 & 0xFFFFu, r12 >> 16};
+    const uint32_t h_nreg = nf & 0xFFFFu, h_flags = nf >> 16;
+    if (h_flags & F_EMPTY) return;
+
+    const uint32_t a[4] = {pf.iw.x & 0xFFFFu, pf.iw.x >> 16, pf.iw.y & 0xFFFFu, pf.iw.y >> 16};
+    const uint32_t t4 = pf.t4;
+    int ox, oy;
+    tile_origin(t, lw, blocks_x, &ox, &oy);
+    const int ry = lane >> lw, cx = lane & ((1 << lw) - 1);
+    const int row = oy + ry, x = ox + cx * 4;
+    // a tile whose regions exceed this launch's LDS budget takes the direct-gather path
+    const bool slow = (h_flags & F_SLOW) != 0 || (int)l16 * 16 > lds_per_wave;
+    uint32_t so[4] = {BK_NULL_OFFSET, BK_NULL_OFFSET, BK_NULL_OFFSET, BK_NULL_OFFSET};
+    if (slow) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (row < rows && x + k < W) so[k] = lmap[(size_t)row * W + x + k];
+    }
+    const bool fast_store = (h_flags & F_ALL) && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & 3u) == 0;
+
+    // Frame-invariant staging plan: the 16-byte chunks of all regions are numbered row-major and
+    // chunk c = lane + 64 j is lane's j-th: 16 bytes at globe offset q_src[j] -> LDS offset q_lds[j].
+    // Tiles with <= MAXQ chunks per lane (regions <= 4 KiB) take the hot loop.  (A shift/mask "row
+    // pass" plan without the division was tried: its idle lanes cost more load instructions than
+    // the ALU it saved.)
+    constexpr int MAXQ = 4;
+    uint32_t q_src[MAXQ], q_lds[MAXQ];
+    bool q_ok[MAXQ];
+    uint32_t total_chunks = 0;
+    {
+        uint32_t base16 = 0, cbase = 0;
+#pragma unroll
+        for (int j = 0; j < MAXQ; ++j) { q_ok[j] = false; q_src[j] = 0; q_lds[j] = 0; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (slow || r >= (int)h_nreg) break;
+            const uint32_t w16 = h_w16[r], nrows = h_rows[r], pitch16 = w16 | 1u, total = w16 * nrows;
+            const uint32_t magic = w16 > 1 ? 0xFFFFFFFFu / w16 + 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const uint32_t c = (uint32_t)lane + 64u * j;          // chunk number across all regions
+                if (c >= cbase && c < cbase + total) {
+                    const uint32_t cc = c - cbase;
+                    const uint32_t yy = w16 > 1 ? __umulhi(cc, magic) : cc, xx = cc - yy * w16;
+                    q_ok[j] = true;
+                    q_src[j] = h_src[r] + yy * (uint32_t)gp + xx * 16u;
+                    q_lds[j] = (base16 + yy * pitch16 + xx) * 16u;
+                }
+            }
+            base16 += nrows * pitch16;
+            cbase += total;
+        }
+        total_chunks = cbase;
+    }
+    const bool piped = !slow && total_chunks <= 64u * MAXQ;
+
+    if (!RUBIX && piped && fast_store) {
+        uint8_t *out0 = dst + (size_t)row * dst_pitch + x;
+        const uint32_t nq = (total_chunks + 63u) >> 6;       // wave-uniform
+        if (nq <= 1) hot_frames<1>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
+        else if (nq == 2) hot_frames<2>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
+        else if (nq == 3) hot_frames<3>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
+        else hot_frames<4>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
+        return;
+    }
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        uint32_t v[4];
+        if (!slow) {
+            // general staged path: stage chunk by chunk (rows of the padded globe are 64-byte aligned)
+            int base16 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (r >= (int)h_nreg) break;
+                const uint32_t w16 = h_w16[r], nrows = h_rows[r], pitch16 = w16 | 1u, total = w16 * nrows;
+                const uint32_t magic = w16 > 1 ? 0xFFFFFFFFu / w16 + 1u : 0u;
+                const uint8_t *src = gl + h_src[r];
+                for (uint32_t c = lane; c < total; c += 64) {
+                    const uint32_t yy = w16 > 1 ? __umulhi(c, magic) : c, xx = c - yy * w16;
+                    const uint4 qq = *reinterpret_cast<const uint4 *>(src + (size_t)yy * gp + xx * 16);
+                    *reinterpret_cast<uint4 *>(lds + (size_t)(base16 + yy * pitch16 + xx) * 16) = qq;
+                }
+                base16 += nrows * pitch16;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = a[k] != 0xFFFFu ? lds[a[k]] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = so[k] != BK_NULL_OFFSET ? gl[so[k]] : 0u;
+        }
+        if (RUBIX) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t tt = (t4 >> (8 * k)) & 0xFFu;
+                if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+            }
+        }
+        uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row * dst_pitch + x;
+        if (fast_store) {
+            *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
+        }
+    }
+}
+
+// Persistent launch: the grid holds at most a few workgroups per CU; every wave walks a strided
+// sequence of tiles inside its XCD's band and fetches the header / indices of its next tile before
+// it starts on the current one, so a tile costs one dependent memory latency (its region rows),
+// not two.
+template <bool RUBIX>
+__global__ __launch_bounds__(256) void apply_tiled_kernel(
+    const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
+    const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
+    int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp, int lw,
+    int blocks_x, int nblocks, int nframes, int fchunk, int lds_per_wave, const uint8_t *__restrict__ pal)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *pal_s = smem + 4 * lds_per_wave;
+    if (RUBIX) {
+        for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += 256) pal_s[i] = pal[i];
+        __syncthreads();
+    }
+    uint8_t *lds = smem + wave * lds_per_wave;
+    // XCD-banded mapping: workgroup b runs on XCD b % 8 (observed dispatch order); XCD k owns the
+    // contiguous band [k*per, (k+1)*per) of 128x8 blocks.  Correctness does not depend on it.
+    const int per = (nblocks + 7) / 8;
+    const int band = (int)(blockIdx.x & 7);
+    const int wg_in_band = (int)(blockIdx.x >> 3), wgs_per_band = (int)(gridDim.x >> 3);
+    const int l_end = min(nblocks, (band + 1) * per);
+    int l = band * per + wg_in_band;
+    if (l >= l_end) return;
+    const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);
+
+    int t = __builtin_amdgcn_readfirstlane(l * 4 + wave);
+    TilePrefetch cur = tile_fetch<RUBIX>(hdr, idx, tint_t, t, lane);
+    for (;;) {
+        const int l_next = l + wgs_per_band;
+        const bool has_next = l_next < l_end;
+        const int t_next = __builtin_amdgcn_readfirstlane(l_next * 4 + wave);
+        TilePrefetch nxt = cur;
+        if (has_next) nxt = tile_fetch<RUBIX>(hdr, idx, tint_t, t_next, lane);
+        tile_process<RUBIX>(cur, t, lane, lds, pal_s, lmap, globe, globe_stride, globe_frames, frame0, dst, dst_pitch,
+                            frame_stride, W, rows, gp, lw, blocks_x, f_begin, f_end, lds_per_wave);
+        if (!has_next) break;
+        l = l_next;
+        t = t_next;
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void tilemap_free(TileMap *tm)
+{
+    if (!tm) return;
+    (void)hipFree(tm->d_hdr);
+    (void)hipFree(tm->d_idx);
+    (void)hipFree(tm->d_tint);
+    (void)hipFree(tm->d_stats);
+    delete tm;
+}
+
+void tilemap_invalidate(bk_ctx *ctx)
+{
+    if (ctx->tilemap) ctx->tilemap->valid = false;
+}
+
+// compile the tilemap for one tile shape and read back its statistics
+static int compile_shape(bk_ctx *ctx, TileMap *tm, int lw, size_t ntiles, double *cost_ps)
+{
+    const int rows = ctx->rows();
+    BK_HIP(ctx, hipMemsetAsync(tm->d_stats, 0, 40 * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(tile_compile_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, ctx->stream, ctx->d_offsets,
+                       ctx->d_tints, ctx->W, rows, ctx->ps, ctx->gp, tm->blocks_x, lw, (int)ntiles, tm->d_hdr, tm->d_idx,
+                       tm->d_tint, tm->d_stats);
+    BK_HIP(ctx, hipGetLastError());
+    BK_HIP(ctx, hipMemcpyAsync(tm->stats, tm->d_stats, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // LDS budget per wave, chosen by a small cost model over the histogram of per-tile needs: tiles
+    // above the budget take the direct-gather path (~3x the time of a staged tile) while a larger
+    // budget lowers occupancy for everyone (workgroups per CU = min(6, 160 KiB / (4 * budget));
+    // 6 is what the kernel's SGPR count admits).
+    uint64_t staged_all = 0;
+    for (int b = 0; b < 32; ++b) staged_all += tm->stats[4 + b];
+    int best_bin = 1;
+    double best_c = -1;
+    for (int bin = 1; bin * 512 <= BK_TILE_LDS_CAP; ++bin) {
+        uint64_t fit = 0;
+        for (int b = 0; b <= bin; ++b) fit += tm->stats[4 + b];
+        const uint64_t over = staged_all - fit;
+        int wgs = (160 * 1024) / (4 * bin * 512);
+        if (wgs > 6) wgs = 6;
+        if (wgs < 1) wgs = 1;
+        const double c = ((double)fit + 3.0 * (double)over) * 6.0 / wgs;
+        if (best_c < 0 || c < best_c) { best_c = c; best_bin = bin; }
+    }
+    const int cap = best_bin * 512;
+    uint64_t over = 0;
+    for (int b = best_bin + 1; b < 32; ++b) over += tm->stats[4 + b];
+    const uint64_t staged = staged_all;
+    tm->lds_bytes = cap;
+    tm->slow_tiles = (int)(tm->stats[1] + over);
+    tm->lw = lw;
+    // cost model fitted to the rocprof ablations in profiles/ (ps per frame): a staged 128-byte line,
+    // a store segment (one per tile row), a tile on the direct-gather path; LDS budgets above 4 KiB
+    // cost occupancy.
+    const double nonempty = (double)(staged + tm->stats[1]);
+    double c = 8.6 * tm->stats[3] + 15.0 * (64 >> lw) * nonempty + 742.0 * tm->slow_tiles;
+    if (cap > 4096) c *= 1.0 + (cap - 4096) / 8192.0;
+    *cost_ps = c;
+    return BK_OK;
+}
+
+static int ensure_tilemap(bk_ctx *ctx)
+{
+    if (!ctx->tilemap) ctx->tilemap = new TileMap();
+    TileMap *tm = ctx->tilemap;
+    if (tm->valid) return BK_OK;
+    const int rows = ctx->rows();
+    tm->blocks_x = (ctx->W + BLOCK_W - 1) / BLOCK_W;
+    tm->blocks_y = (rows + BLOCK_H - 1) / BLOCK_H;
+    const size_t ntiles = (size_t)tm->blocks_x * tm->blocks_y * 4;
+    if (ntiles > tm->alloc_tiles) {
+        (void)hipFree(tm->d_hdr); (void)hipFree(tm->d_idx); (void)hipFree(tm->d_tint);
+        tm->d_hdr = nullptr; tm->d_idx = nullptr; tm->d_tint = nullptr;
+        BK_HIP(ctx, hipMalloc((void **)&tm->d_hdr, ntiles * sizeof(TileHdr)));
+        BK_HIP(ctx, hipMalloc((void **)&tm->d_idx, ntiles * TILE_PX * sizeof(uint16_t)));
+        BK_HIP(ctx, hipMalloc((void **)&tm->d_tint, ntiles * TILE_PX));
+        tm->alloc_tiles = ntiles;
+    }
+    if (!tm->d_stats) BK_HIP(ctx, hipMalloc((void **)&tm->d_stats, 40 * sizeof(uint32_t)));
+    // try the three tile shapes (each compile is a few microseconds of GPU time) and keep the cheapest
+    int best = ctx->tile_shape;
+    if (best < 3 || best > 5) {
+        double best_cost = 0;
+        best = -1;
+        for (int lw = 5; lw >= 3; --lw) {
+            double c = 0;
+            if (int r = compile_shape(ctx, tm, lw, ntiles, &c)) return r;
+            if (best < 0 || c < best_cost) { best = lw; best_cost = c; }
+        }
+    }
+    double c = 0;
+    if (tm->lw != best || ctx->tile_shape >= 3)
+        if (int r = compile_shape(ctx, tm, best, ntiles, &c)) return r;
+    tm->valid = true;
+    return BK_OK;
+}
+
+int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on)
+{
+    const int rows = ctx->rows();
+    if (rows <= 0 || nframes <= 0) return BK_OK;
+    if (int r = ensure_tilemap(ctx)) return r;
+    TileMap *tm = ctx->tilemap;
+    const int blocks_x = tm->blocks_x, nblocks = blocks_x * tm->blocks_y;
+    const int fchunk = nframes < 8 ? nframes : 8;
+    const int fblocks = (nframes + fchunk - 1) / fchunk;
+    const int per = (nblocks + 7) / 8;
+    // persistent grid: enough workgroups to fill the chip (the kernel's registers / LDS admit <= 6-8
+    // per CU); each walks its XCD band with a stride, prefetching its next tile's header.
+    int wgs_per_band = per;
+    const int resident_per_band = ctx->num_cus * ctx->apply_wgs_per_cu / 8;
+    if (fblocks * wgs_per_band > resident_per_band) wgs_per_band = (resident_per_band + fblocks - 1) / fblocks;
+    if (wgs_per_band < 1) wgs_per_band = 1;
+    if (wgs_per_band > per) wgs_per_band = per;
+    dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
+    const size_t shmem = (size_t)4 * tm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
+    if (rubix_on)
+        hipLaunchKernelGGL(apply_tiled_kernel<true>, grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,
+                           ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride,
+                           ctx->W, rows, ctx->gp, tm->lw, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal);
+    else
+        hipLaunchKernelGGL(apply_tiled_kernel<false>, grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,
+                           ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride,
+                           ctx->W, rows, ctx->gp, tm->lw, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal);
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+int set_ablation(bk_ctx *ctx, int bits)
+{
+    BK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &bits, sizeof(int)));
+    return BK_OK;
+}
+
+int tilemap_stats(bk_ctx *ctx, int out[6])
+{
+    if (int r = ensure_tilemap(ctx)) return r;
+    TileMap *tm = ctx->tilemap;
+    out[0] = tm->blocks_x * tm->blocks_y * 4; out[1] = tm->slow_tiles; out[2] = (int)tm->stats[2]; out[3] = tm->lds_bytes;
+    out[4] = 4 << tm->lw; out[5] = (int)tm->stats[3];
+    return BK_OK;
+}
+
+}  // namespace bk

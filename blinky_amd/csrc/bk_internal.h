@@ -65,6 +65,9 @@ struct bk_ctx {
     bool spans_valid = false;
 
     int apply_variant = -1;          // -1 auto
+    int num_cus = 256;               // multiProcessorCount of the device
+    int apply_wgs_per_cu = 16;       // persistent apply grid: workgroups per CU (tunable, bk_debug_set_tile_shape)
+    int tile_shape = 0;              // 0 = choose by cost model; 3/4/5 = force 32x8 / 64x4 / 128x2 tiles
     bk::TileMap *tilemap = nullptr;       // owned; freed with bk::tilemap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
@@ -100,6 +103,10 @@ int launch_mask(bk_ctx *ctx);                 // d_offsets -> d_mask
 int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed);   // one plate, padded rows
 int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_padded);   // reference <-> padded layout
 void tilemap_invalidate(bk_ctx *ctx);
+int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,
+                       size_t frame_stride, int rubix_on);
+int tilemap_stats(bk_ctx *ctx, int out[6]);
+int set_ablation(bk_ctx *ctx, int bits);      // developer timing ablations of the tiled apply   // tiles, slow tiles, empty tiles, LDS bytes per wave
 void tilemap_free(TileMap *);
 
 // bk_lens.cpp

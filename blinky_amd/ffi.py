@@ -71,6 +71,9 @@ _SIGS = {
     "bk_set_apply_variant": (_i, [_vp, _i]),
     "bk_last_build_ms": (_d, [_vp]),
     "bk_globe_pitch": (_i, [_vp]),
+    "bk_debug_tile_stats": (_i, [_vp, C.POINTER(_i)]),
+    "bk_debug_set_ablation": (_i, [_vp, _i]),
+    "bk_debug_set_tile_shape": (_i, [_vp, _i]),
     "bk_debug_kernel_source": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), _i]),
     "bk_debug_eval": (_i, [_vp, _i, C.POINTER(_d), _i, C.POINTER(_d), C.POINTER(_i)]),
     "bk_script_console": (C.c_char_p, [_vp]),
@@ -224,6 +227,17 @@ class Context:
             pal = np.ascontiguousarray(pal, dtype=np.uint8)
         self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
                                       int(rubix_on), _ptr(pal)))
+
+    def set_ablation(self, bits):
+        self._chk(lib.bk_debug_set_ablation(self._h, bits))
+
+    def tile_stats(self):
+        out = (_i * 6)()
+        self._chk(lib.bk_debug_tile_stats(self._h, out))
+        return dict(tiles=out[0], slow=out[1], empty=out[2], lds_bytes_per_wave=out[3], tile_w=out[4], lines=out[5])
+
+    def set_tile_shape(self, lw):
+        self._chk(lib.bk_debug_set_tile_shape(self._h, lw))
 
     def globe_pitch(self):
         return lib.bk_globe_pitch(self._h)

@@ -143,6 +143,14 @@ int         bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesi
 const char *bk_version(void);
 /* selects the apply kernel: 0 = direct gather, 1 = tiled/LDS-staged (default: best available) */
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
+/* developer only: timing ablations of the tiled apply (bit0 no region loads, bit1 no stores, bit2 no
+ * LDS gather, bit3 no LDS writes); results are wrong while non-zero.  0 restores normal operation. */
+int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
+/* tiled apply statistics of the current lensmap: out = {tiles, tiles on the direct-gather fallback,
+ * empty tiles, LDS bytes per wavefront, tile width in pixels, 128-byte lines staged per frame} */
+int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
+/* force the tile shape of the tiled apply: 0 = cost model (default), 3 / 4 / 5 = 32x8 / 64x4 / 128x2 px */
+int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);
 /* the HIP translation unit generated for the current lens + globe scripts (needed = strlen+1);

@@ -23,17 +23,27 @@ variants = [int(v) for v in sys.argv[5:]] or [0]
 t = time.time()
 lm = O.lensmap("cube", lens, None, W, H)
 print(f"oracle lensmap {lens} {W}x{H}: {time.time()-t:.2f}s nonnull={lm.nonnull}", flush=True)
+RING = int(os.environ.get("BK_RING", str(F)))       # resident globes (1 = every frame reads the same globe)
+SAMEOUT = int(os.environ.get("BK_SAMEOUT", "0"))       # 1 = every frame writes the same output buffer
 ctx = blinky_amd.Context()
-ctx.set_frames(F)
+ctx.set_frames(RING)
 ctx.resize(W, H)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-for f in range(F):
+for f in range(RING):
     for p in range(6):
         ctx.fill_plate_lcg(f, p, f)
 ctx.set_lensmap(lm.offsets, lm.tints)
 out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
-for v in variants:
+ABL = [int(x) for x in os.environ.get("BK_ABLATE", "0").split(",")]
+SHAPES = [int(x) for x in os.environ.get("BK_SHAPES", "0").split(",")]
+WGS = [int(x) for x in os.environ.get("BK_WGS", "6").split(",")]
+for v, abl, shp, wg in [(v, a, sh, wg) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])]:
     ctx.set_apply_variant(v)
+    if v != 0:
+        ctx.set_tile_shape(shp)
+        ctx.set_tile_shape(100 + wg)
+        ctx.set_ablation(abl)
+        print(f"shape {shp} ablation {abl} wgs/cu {wg}; tile stats:", ctx.tile_stats(), flush=True)
     for nf in sorted(set([1, F])):
         for _ in range(3):
             ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)
@@ -42,7 +52,7 @@ for v in variants:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for r in range(reps):
-            ctx.apply_device(out.data_ptr(), W, H * W, (r * nf) % F, nf)
+            ctx.apply_device(out.data_ptr(), W, 0 if SAMEOUT else H * W, (r * nf) % F, nf)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
