@@ -159,13 +159,14 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
         h.lds16 = (uint16_t)(slow ? 0 : lds16);
         h.pad = 0;
         hdr[t] = h;
+        uint32_t *st = stats + (t & 63) * 40;       // 64 replicas: 32 400 tiles must not serialise on one word
         if (!slow && any) {
-            atomicMax(&stats[0], (uint32_t)lds16 * 16u);
-            atomicAdd(&stats[4 + min(31, (lds16 * 16 + 511) / 512)], 1u);     // histogram of LDS need
-            atomicAdd(&stats[3], (uint32_t)lines);
+            atomicMax(&st[0], (uint32_t)lds16 * 16u);
+            atomicAdd(&st[4 + min(31, (lds16 * 16 + 511) / 512)], 1u);        // histogram of LDS need
+            atomicAdd(&st[3], (uint32_t)lines);
         }
-        if (slow) atomicAdd(&stats[1], 1u);
-        if (!any) atomicAdd(&stats[2], 1u);
+        if (slow) atomicAdd(&st[1], 1u);
+        if (!any) atomicAdd(&st[2], 1u);
     }
 }
 
@@ -278,6 +279,10 @@ __device__ __forceinline__ void tile_process(
     const uint32_t h_rows[3] = {w2r0 >> 16, r12 & 0xFFFFu, r12 >> 16};
     const uint32_t h_nreg = nf & 0xFFFFu, h_flags = nf >> 16;
     if (h_flags & F_EMPTY) return;
+    if (g_ablate & 16) {                       // developer ablation: header + indices only
+        if (pf.iw.x == 0x12345678u && h_src[0] == 0xFFFFFFFFu) dst[0] = 1;
+        return;
+    }
 
     const uint32_t a[4] = {pf.iw.x & 0xFFFFu, pf.iw.x >> 16, pf.iw.y & 0xFFFFu, pf.iw.y >> 16};
     const uint32_t t4 = pf.t4;
@@ -304,10 +309,24 @@ __device__ __forceinline__ void tile_process(
     uint32_t q_src[MAXQ], q_lds[MAXQ];
     bool q_ok[MAXQ];
     uint32_t total_chunks = 0;
-    {
-        uint32_t base16 = 0, cbase = 0;
 #pragma unroll
-        for (int j = 0; j < MAXQ; ++j) { q_ok[j] = false; q_src[j] = 0; q_lds[j] = 0; }
+    for (int j = 0; j < MAXQ; ++j) { q_ok[j] = false; q_src[j] = 0; q_lds[j] = 0; }
+    if (!slow && h_nreg == 1) {
+        // the common case (one plate under the tile): one division per chunk actually needed
+        const uint32_t w16 = h_w16[0], pitch16 = w16 | 1u, total = w16 * h_rows[0];
+        const uint32_t magic = w16 > 1 ? 0xFFFFFFFFu / w16 + 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < MAXQ; ++j) {
+            if (64u * j >= total) break;                              // wave-uniform
+            const uint32_t c = (uint32_t)lane + 64u * j;
+            const uint32_t yy = w16 > 1 ? __umulhi(c, magic) : c, xx = c - yy * w16;
+            q_ok[j] = c < total;
+            q_src[j] = q_ok[j] ? h_src[0] + yy * (uint32_t)gp + xx * 16u : 0u;
+            q_lds[j] = (yy * pitch16 + xx) * 16u;
+        }
+        total_chunks = total;
+    } else {
+        uint32_t base16 = 0, cbase = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             if (slow || r >= (int)h_nreg) break;
@@ -456,13 +475,19 @@ void tilemap_invalidate(bk_ctx *ctx)
 static int compile_shape(bk_ctx *ctx, TileMap *tm, int lw, size_t ntiles, double *cost_ps)
 {
     const int rows = ctx->rows();
-    BK_HIP(ctx, hipMemsetAsync(tm->d_stats, 0, 40 * sizeof(uint32_t), ctx->stream));
+    BK_HIP(ctx, hipMemsetAsync(tm->d_stats, 0, 64 * 40 * sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(tile_compile_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, ctx->stream, ctx->d_offsets,
                        ctx->d_tints, ctx->W, rows, ctx->ps, ctx->gp, tm->blocks_x, lw, (int)ntiles, tm->d_hdr, tm->d_idx,
                        tm->d_tint, tm->d_stats);
     BK_HIP(ctx, hipGetLastError());
-    BK_HIP(ctx, hipMemcpyAsync(tm->stats, tm->d_stats, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    static thread_local uint32_t rep[64 * 40];
+    BK_HIP(ctx, hipMemcpyAsync(rep, tm->d_stats, sizeof rep, hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 40; ++k) tm->stats[k] = 0;
+    for (int r = 0; r < 64; ++r) {
+        tm->stats[0] = rep[r * 40] > tm->stats[0] ? rep[r * 40] : tm->stats[0];
+        for (int k = 1; k < 40; ++k) tm->stats[k] += rep[r * 40 + k];
+    }
     // LDS budget per wave, chosen by a small cost model over the histogram of per-tile needs: tiles
     // above the budget take the direct-gather path (~3x the time of a staged tile) while a larger
     // budget lowers occupancy for everyone (workgroups per CU = min(6, 160 KiB / (4 * budget));
@@ -515,21 +540,24 @@ static int ensure_tilemap(bk_ctx *ctx)
         BK_HIP(ctx, hipMalloc((void **)&tm->d_tint, ntiles * TILE_PX));
         tm->alloc_tiles = ntiles;
     }
-    if (!tm->d_stats) BK_HIP(ctx, hipMalloc((void **)&tm->d_stats, 40 * sizeof(uint32_t)));
+    if (!tm->d_stats) BK_HIP(ctx, hipMalloc((void **)&tm->d_stats, 64 * 40 * sizeof(uint32_t)));
     // try the three tile shapes (each compile is a few microseconds of GPU time) and keep the cheapest
-    int best = ctx->tile_shape;
+    int best = ctx->tile_shape, compiled = -1;
+    if (best == 0) best = 3;     // 32x8 won on every shipped lens (profiles/): skip the search unless asked (-1)
     if (best < 3 || best > 5) {
         double best_cost = 0;
         best = -1;
         for (int lw = 5; lw >= 3; --lw) {
             double c = 0;
             if (int r = compile_shape(ctx, tm, lw, ntiles, &c)) return r;
+            compiled = lw;
             if (best < 0 || c < best_cost) { best = lw; best_cost = c; }
         }
     }
-    double c = 0;
-    if (tm->lw != best || ctx->tile_shape >= 3)
+    if (compiled != best) {
+        double c = 0;
         if (int r = compile_shape(ctx, tm, best, ntiles, &c)) return r;
+    }
     tm->valid = true;
     return BK_OK;
 }
