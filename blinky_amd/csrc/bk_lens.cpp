@@ -275,6 +275,24 @@ extern "C" int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char
     return BK_OK;
 }
 
+// "not a valid lens" / "not a valid globe" (fisheye.c:1080-1083, 1157-1160): the host could not even
+// read the script; the next bk_build then clears the map and reports the invalid state
+extern "C" int bk_clear_lens(bk_ctx *ctx)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (ctx->prog) { ctx->prog->lens_valid = false; ctx->prog->lens_inverse = ctx->prog->lens_forward = Value(); }
+    return BK_OK;
+}
+
+extern "C" int bk_clear_globe(bk_ctx *ctx)
+{
+    if (!ctx) return BK_E_INVALID;
+    ctx->globe_valid = false;
+    ctx->numplates = 0;
+    if (ctx->prog) ctx->prog->globe_plate = Value();
+    return BK_OK;
+}
+
 extern "C" int bk_get_lens_info(const bk_ctx *ctx, bk_lens_info *out)
 {
     if (!ctx || !out) return BK_E_INVALID;

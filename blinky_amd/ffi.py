@@ -48,6 +48,8 @@ _SIGS = {
     "bk_synchronize": (_i, [_vp]),
     "bk_load_globe": (_i, [_vp, C.c_char_p, _sz, C.c_char_p]),
     "bk_load_lens": (_i, [_vp, C.c_char_p, _sz, C.c_char_p]),
+    "bk_clear_lens": (_i, [_vp]),
+    "bk_clear_globe": (_i, [_vp]),
     "bk_get_lens_info": (_i, [_vp, C.POINTER(LensInfo)]),
     "bk_get_globe": (_i, [_vp, C.POINTER(Plate), C.POINTER(_i)]),
     "bk_set_globe_plates": (_i, [_vp, C.POINTER(Plate), _i]),

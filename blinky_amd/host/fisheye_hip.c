@@ -1,0 +1,412 @@
+/*
+ * fisheye_hip.c -- drop-in replacement of engine/NQ/fisheye.c for TyrQuake: same public face
+ * (engine/include/fisheye.h:4-9: fisheye_enabled, F_Init, F_Shutdown, F_RenderView,
+ * F_WriteConfig, plus fisheye_plate_fov read by common/r_main.c:417-418), same console commands
+ * (fisheye.c:651-665) and script locations (fisheye.c:1666, 1759) -- but the lensmap build and the
+ * per-frame lensmap apply run on an MI355X through libblinkyhip's C ABI (include/blinky_hip.h).
+ * The six scene renders per frame stay in the engine's software rasteriser (R_RenderView).
+ *
+ * Host code stays C, as in the reference.  Every function names the reference lines it stands in for.
+ */
+#include "engine_iface.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/blinky_hip.h"
+
+/* ---- globals the rest of the engine reads (fisheye.c:293-299) ---------------------------------- */
+qboolean fisheye_enabled;
+qboolean shortcutkeys_enabled;
+double fisheye_plate_fov;
+
+/* ---- state (fisheye.c:334-528, without the buffers: those live in HBM) --------------------------- */
+static bk_ctx *bk;
+static struct { char name[50]; qboolean valid, changed; } globe, lens;
+static struct { qboolean changed; int type, fov; } zoom;
+static struct { qboolean enabled; int numcells; double cell_size, pad_size; } rubix;
+static bk_plate plates[BK_MAX_PLATES];
+static int numplates;
+static int display[BK_MAX_PLATES];
+static unsigned char palettes[BK_MAX_PLATES][256];
+static int lensmap_ok;
+
+#define VBUFFER(x, y) (vid.buffer + (x) + (y) * vid.rowbytes)      /* fisheye.c:634 */
+
+static char *read_script(const char *kind, const char *name, size_t *len)
+{
+    char path[1024];
+    FILE *f;
+    long n;
+    char *buf;
+    snprintf(path, sizeof path, "%s/lua-scripts/%s/%s.lua", com_basedir, kind, name);   /* fisheye.c:1666, 1759 */
+    f = fopen(path, "rb");
+    if (!f) {
+        Con_Printf("could not loadfile (%s)\n", path);
+        return NULL;
+    }
+    fseek(f, 0, SEEK_END);
+    n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf = (char *)malloc((size_t)n + 1);
+    if (!buf || fread(buf, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(buf); return NULL; }
+    fclose(f);
+    buf[n] = 0;
+    *len = (size_t)n;
+    return buf;
+}
+
+/* LUA_load_lens (fisheye.c:1659-1750) */
+static qboolean load_lens(void)
+{
+    size_t len;
+    char *src, chunk[80];
+    int rc;
+    if (!bk) return false;
+    src = read_script("lenses", lens.name, &len);
+    if (!src) { bk_clear_lens(bk); return false; }
+    snprintf(chunk, sizeof chunk, "%s.lua", lens.name);
+    rc = bk_load_lens(bk, src, len, chunk);
+    free(src);
+    if (rc != BK_OK) { Con_Printf("%s\n", bk_last_error(bk)); return false; }
+    return true;
+}
+
+/* LUA_load_globe (fisheye.c:1752-1875) */
+static qboolean load_globe(void)
+{
+    size_t len;
+    char *src, chunk[80];
+    int rc;
+    numplates = 0;
+    if (!bk) return false;
+    src = read_script("globes", globe.name, &len);
+    if (!src) { bk_clear_globe(bk); return false; }
+    snprintf(chunk, sizeof chunk, "%s.lua", globe.name);
+    rc = bk_load_globe(bk, src, len, chunk);
+    free(src);
+    if (rc != BK_OK) { Con_Printf("%s\n", bk_last_error(bk)); return false; }
+    bk_get_globe(bk, plates, &numplates);
+    return true;
+}
+
+/* ---- console commands (fisheye.c:916-1176) -------------------------------------------------------- */
+
+static void clear_zoom(void)                        /* fisheye.c:1273-1278 */
+{
+    zoom.type = BK_ZOOM_NONE;
+    zoom.fov = 0;
+    zoom.changed = true;
+}
+
+static void print_zoom(void)                        /* fisheye.c:1280-1291 */
+{
+    Con_Printf("Zoom currently: ");
+    switch (zoom.type) {
+    case BK_ZOOM_FOV: Con_Printf("f_fov %d", zoom.fov); break;
+    case BK_ZOOM_VFOV: Con_Printf("f_vfov %d", zoom.fov); break;
+    case BK_ZOOM_COVER: Con_Printf("f_cover"); break;
+    case BK_ZOOM_CONTAIN: Con_Printf("f_contain"); break;
+    default: Con_Printf("none");
+    }
+    Con_Printf("\n");
+}
+
+static void cmd_dumppal(void)                       /* fisheye.c:916-931 */
+{
+    int i;
+    byte *pal = host_basepal;
+    FILE *f = fopen("palette", "w");
+    if (!f) { Con_Printf("could not open \"palette\" for writing\n"); return; }
+    for (i = 0; i < 256; ++i, pal += 3) fprintf(f, "%d, %d, %d,\n", pal[0], pal[1], pal[2]);
+    fclose(f);
+}
+
+static void cmd_rubix(void)                         /* fisheye.c:933-937 */
+{
+    rubix.enabled = !rubix.enabled;
+    Con_Printf("Rubix is %s\n", rubix.enabled ? "ON" : "OFF");
+}
+
+static void cmd_rubixgrid(void)                     /* fisheye.c:939-953 */
+{
+    if (Cmd_Argc() == 4) {
+        rubix.numcells = (int)Q_atof(Cmd_Argv(1));
+        rubix.cell_size = Q_atof(Cmd_Argv(2));
+        rubix.pad_size = Q_atof(Cmd_Argv(3));
+        lens.changed = true;                        /* need to recompute lens to update grid */
+    } else {
+        Con_Printf("RubixGrid <numcells> <cellsize> <padsize>\n");
+        Con_Printf("   numcells (default 10) = %d\n", rubix.numcells);
+        Con_Printf("   cellsize (default  4) = %f\n", rubix.cell_size);
+        Con_Printf("   padsize  (default  1) = %f\n", rubix.pad_size);
+    }
+}
+
+static void cmd_cover(void) { clear_zoom(); zoom.type = BK_ZOOM_COVER; }       /* fisheye.c:955-959 */
+static void cmd_contain(void) { clear_zoom(); zoom.type = BK_ZOOM_CONTAIN; }   /* fisheye.c:961-965 */
+
+static void cmd_fisheye(void)                       /* fisheye.c:967-977 */
+{
+    if (Cmd_Argc() < 2) {
+        Con_Printf("Currently: ");
+        Con_Printf("fisheye %d\n", fisheye_enabled);
+        Con_Printf("\nTry F_HELP for more options and commands.\n");
+        return;
+    }
+    fisheye_enabled = Q_atoi(Cmd_Argv(1)) ? true : false;
+    vid.recalc_refdef = true;
+}
+
+static void cmd_shortcutkeys(void)                  /* fisheye.c:979-1016 */
+{
+    static const char *lens_keys[9] = {"panini", "stereographic", "hammer", "winkeltripel", "fisheye1",
+                                       "mercator", "quincuncial", "cube", "debug"};
+    static const char *globe_keys[5][2] = {{"y", "cube"}, {"u", "cube_edge"}, {"i", "trism"}, {"o", "tetra"}, {"p", "fast"}};
+    char cmd[96];
+    int i;
+    shortcutkeys_enabled = !shortcutkeys_enabled;
+    if (shortcutkeys_enabled) {
+        Con_Printf("Enabled Fisheye shortcut keys: 1-9 = Lenses, Y,U,I,O,P = Globes\n");
+        for (i = 0; i < 9; ++i) {
+            snprintf(cmd, sizeof cmd, "bind %d \"f_lens %s\"", i + 1, lens_keys[i]);
+            Cmd_ExecuteString(cmd, src_command);
+        }
+        for (i = 0; i < 5; ++i) {
+            snprintf(cmd, sizeof cmd, "bind %s \"f_globe %s\"", globe_keys[i][0], globe_keys[i][1]);
+            Cmd_ExecuteString(cmd, src_command);
+        }
+    } else {
+        Con_Printf("Disabled Fisheye shortcut keys\n");
+        for (i = 1; i <= 8; ++i) {
+            snprintf(cmd, sizeof cmd, "bind %d \"impulse %d\"", i, i);
+            Cmd_ExecuteString(cmd, src_command);
+        }
+        Cmd_ExecuteString("unbind 9", src_command);
+        for (i = 0; i < 5; ++i) {
+            snprintf(cmd, sizeof cmd, "unbind %s", globe_keys[i][0]);
+            Cmd_ExecuteString(cmd, src_command);
+        }
+    }
+}
+
+static void cmd_help(void)                          /* fisheye.c:1018-1030 */
+{
+    Con_Printf("-----------------------------\n");
+    Con_Printf("Welcome to the FISHEYE ADDON!\n");
+    Con_Printf("-> fisheye 1    (ENABLE)\n");
+    Con_Printf("-> fisheye 0    (DISABLE)\n");
+    Con_Printf("\n");
+    Con_Printf("-> f_lens <tab>    (CHANGE LENS)\n");
+    Con_Printf("-> f_fov <degrees> (SET FOV)\n");
+    Con_Printf("\n");
+    Con_Printf("-> f_<tab>         (MORE COMMANDS)\n");
+    Con_Printf("-----------------------------\n");
+}
+
+static void cmd_fov(void)                           /* fisheye.c:1032-1044 */
+{
+    if (Cmd_Argc() < 2) {
+        Con_Printf("f_fov <degrees>: set horizontal FOV\n");
+        print_zoom();
+        return;
+    }
+    clear_zoom();
+    zoom.type = BK_ZOOM_FOV;
+    zoom.fov = (int)Q_atof(Cmd_Argv(1));
+}
+
+static void cmd_vfov(void)                          /* fisheye.c:1046-1058 */
+{
+    if (Cmd_Argc() < 2) {
+        Con_Printf("f_vfov <degrees>: set vertical FOV\n");
+        print_zoom();
+        return;
+    }
+    clear_zoom();
+    zoom.type = BK_ZOOM_VFOV;
+    zoom.fov = (int)Q_atof(Cmd_Argv(1));
+}
+
+static void cmd_lens(void)                          /* fisheye.c:1061-1103 */
+{
+    bk_lens_info info;
+    if (Cmd_Argc() < 2) {
+        Con_Printf("f_lens <name>: use a new lens\n");
+        Con_Printf("Currently: %s\n", lens.name);
+        return;
+    }
+    lens.changed = true;
+    snprintf(lens.name, sizeof lens.name, "%s", Cmd_Argv(1));
+    Con_Printf("f_lens %s", lens.name);
+    lens.valid = load_lens();
+    if (!lens.valid) {
+        strcpy(lens.name, "");
+        Con_Printf("not a valid lens\n");
+    }
+    /* the lens' onload command string gives a friendly default view (e.g. "f_fov 180") */
+    if (lens.valid && bk_get_lens_info(bk, &info) == BK_OK && info.onload[0]) {
+        Cmd_ExecuteString(info.onload, src_command);
+        Con_Printf("; %s\n", info.onload);
+    } else {
+        Con_Printf("\n");
+    }
+}
+
+static void cmd_saveglobe(void)                     /* fisheye.c:1120-1136; PCX export is not on the warp path */
+{
+    Con_Printf("f_saveglobe: not available in the HIP build (plates live in GPU memory)\n");
+}
+
+static void cmd_globe(void)                         /* fisheye.c:1138-1161 */
+{
+    if (Cmd_Argc() < 2) {
+        Con_Printf("f_globe <name>: use a new globe\n");
+        Con_Printf("Currently: %s\n", globe.name);
+        return;
+    }
+    globe.changed = true;
+    snprintf(globe.name, sizeof globe.name, "%s", Cmd_Argv(1));
+    Con_Printf("f_globe %s\n", globe.name);
+    globe.valid = load_globe();
+    if (!globe.valid) {
+        strcpy(globe.name, "");
+        Con_Printf("not a valid globe\n");
+    }
+}
+
+/* ---- public functions (engine/include/fisheye.h) ----------------------------------------------------- */
+
+void F_Init(void)                                   /* fisheye.c:642-676 */
+{
+    const char *dev = getenv("BLINKY_HIP_DEVICE");
+    rubix.enabled = false;
+    /* init_lua's counterpart: the script interpreter lives inside the context */
+    bk = bk_create(dev && !strcmp(dev, "none") ? BK_DEVICE_NONE : (dev ? atoi(dev) : -1));
+    if (!bk) Con_Printf("fisheye: %s\n", bk_last_error(NULL));
+
+    Cmd_AddCommand("fisheye", cmd_fisheye);
+    Cmd_AddCommand("f_help", cmd_help);
+    Cmd_AddCommand("f_dumppal", cmd_dumppal);
+    Cmd_AddCommand("f_rubix", cmd_rubix);
+    Cmd_AddCommand("f_rubixgrid", cmd_rubixgrid);
+    Cmd_AddCommand("f_cover", cmd_cover);
+    Cmd_AddCommand("f_contain", cmd_contain);
+    Cmd_AddCommand("f_fov", cmd_fov);
+    Cmd_AddCommand("f_vfov", cmd_vfov);
+    Cmd_AddCommand("f_lens", cmd_lens);
+    Cmd_AddCommand("f_globe", cmd_globe);
+    Cmd_AddCommand("f_saveglobe", cmd_saveglobe);
+    Cmd_AddCommand("f_shortcutkeys", cmd_shortcutkeys);
+
+    /* defaults */
+    Cmd_ExecuteString("fisheye 1", src_command);
+    Cmd_ExecuteString("f_globe cube", src_command);
+    Cmd_ExecuteString("f_lens panini", src_command);
+    Cmd_ExecuteString("f_fov 180", src_command);
+    Cmd_ExecuteString("f_rubixgrid 10 4 1", src_command);
+
+    if (host_basepal) bk_create_palmap(host_basepal, palettes);      /* create_palmap, fisheye.c:857-908 */
+    if (!bk) fisheye_enabled = false;
+}
+
+void F_Shutdown(void)                               /* fisheye.c:678-681 */
+{
+    bk_destroy(bk);
+    bk = NULL;
+}
+
+void F_WriteConfig(FILE *f)                         /* fisheye.c:683-696 */
+{
+    fprintf(f, "fisheye %d\n", fisheye_enabled);
+    fprintf(f, "f_lens \"%s\"\n", lens.name);
+    fprintf(f, "f_globe \"%s\"\n", globe.name);
+    fprintf(f, "f_rubixgrid %d %f %f\n", rubix.numcells, rubix.cell_size, rubix.pad_size);
+    switch (zoom.type) {
+    case BK_ZOOM_FOV: fprintf(f, "f_fov %d\n", zoom.fov); break;
+    case BK_ZOOM_VFOV: fprintf(f, "f_vfov %d\n", zoom.fov); break;
+    case BK_ZOOM_COVER: fprintf(f, "f_cover\n"); break;
+    case BK_ZOOM_CONTAIN: fprintf(f, "f_contain\n"); break;
+    default: break;
+    }
+}
+
+/* render_plate (fisheye.c:2427-2450): the engine renders the view, its rows go to the GPU */
+static void render_plate(int plate_index, vec3_t forward, vec3_t right, vec3_t up)
+{
+    VectorCopy(forward, r_refdef.forward);
+    VectorCopy(right, r_refdef.right);
+    VectorCopy(up, r_refdef.up);
+    R_PushDlights();
+    R_RenderView();
+    if (bk_upload_plate(bk, 0, plate_index, VBUFFER(scr_vrect.x, scr_vrect.y), vid.rowbytes) != BK_OK)
+        Con_Printf("fisheye: %s\n", bk_last_error(bk));
+}
+
+void F_RenderView(void)                             /* fisheye.c:698-811 */
+{
+    static int pwidth = -1, pheight = -1;
+    int width_px = scr_vrect.width, height_px = scr_vrect.height;
+    int sizechange = (pwidth != width_px) || (pheight != height_px);
+    vec3_t forward, right, up;
+    vrect_t vrect;
+    int i;
+
+    if (!bk) return;
+    if (sizechange && bk_resize(bk, width_px, height_px) != BK_OK) {        /* fisheye.c:712-727; no exit(1) */
+        Con_Printf("Quake-Lenses: %s\n", bk_last_error(bk));
+        return;
+    }
+    if (sizechange || zoom.changed || lens.changed || globe.changed) {      /* fisheye.c:730-743 */
+        int rc;
+        /* the lens is loaded again so that variables depending on the globe (numplates) are fresh */
+        lens.valid = lens.name[0] ? load_lens() : false;
+        if (!lens.name[0]) bk_clear_lens(bk);
+        if (!lens.valid) {
+            strcpy(lens.name, "");
+            Con_Printf("not a valid lens\n");
+        }
+        bk_set_zoom(bk, zoom.type, zoom.fov);
+        bk_set_rubixgrid(bk, rubix.numcells, rubix.cell_size, rubix.pad_size);
+        for (i = 0; i < BK_MAX_PLATES; ++i) display[i] = 0;
+        rc = bk_build(bk, display, NULL);                                   /* create_lensmap, fisheye.c:2367-2397 */
+        lensmap_ok = rc == BK_OK;
+        if (rc != BK_OK && lens.valid && globe.valid) Con_Printf("%s\n", bk_last_error(bk));
+    }
+
+    AngleVectors(r_refdef.viewangles, forward, right, up);                  /* fisheye.c:750 */
+    vrect.x = 0;
+    vrect.y = 0;
+    vrect.width = vid.width;
+    vrect.height = vid.height;
+    vrect.pnext = NULL;
+    R_SetVrect(&vrect, &scr_vrect, sb_lines);
+
+    for (i = 0; i < numplates; ++i) {                                        /* fisheye.c:764-794 */
+        if (display[i]) {
+            vec3_t r = {0, 0, 0}, u = {0, 0, 0}, f = {0, 0, 0};
+            fisheye_plate_fov = plates[i].fov;
+            R_ViewChanged(&vrect, sb_lines, vid.aspect);
+            VectorMA(r, plates[i].right[0], right, r);
+            VectorMA(r, plates[i].right[1], up, r);
+            VectorMA(r, plates[i].right[2], forward, r);
+            VectorMA(u, plates[i].up[0], right, u);
+            VectorMA(u, plates[i].up[1], up, u);
+            VectorMA(u, plates[i].up[2], forward, u);
+            VectorMA(f, plates[i].forward[0], right, f);
+            VectorMA(f, plates[i].forward[1], up, f);
+            VectorMA(f, plates[i].forward[2], forward, f);
+            render_plate(i, f, r, u);
+        }
+    }
+
+    Draw_TileClear(0, 0, vid.width, vid.height);                             /* fisheye.c:802 */
+    /* render_lensmap, fisheye.c:2406-2424 */
+    if (bk_apply(bk, 0, vid.buffer, vid.rowbytes, scr_vrect.x, scr_vrect.y, rubix.enabled, palettes) != BK_OK && lensmap_ok)
+        Con_Printf("fisheye: %s\n", bk_last_error(bk));
+
+    pwidth = width_px;
+    pheight = height_px;
+    lens.changed = globe.changed = zoom.changed = false;                    /* fisheye.c:810 */
+}

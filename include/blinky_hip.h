@@ -81,6 +81,8 @@ int         bk_synchronize(bk_ctx *ctx);
  * loads exactly as in the reference (only the names of fisheye.c:1880-1903 are cleared). */
 int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
+int bk_clear_lens(bk_ctx *ctx);    /* lens.valid = false ("not a valid lens", fisheye.c:1080-1083) */
+int bk_clear_globe(bk_ctx *ctx);   /* globe.valid = false (fisheye.c:1157-1160) */
 int bk_get_lens_info(const bk_ctx *ctx, bk_lens_info *out);
 int bk_get_globe(const bk_ctx *ctx, bk_plate plates[BK_MAX_PLATES], int *numplates);
 /* bypass the script for the globe (plates already in LUA_load_globe's float form) */

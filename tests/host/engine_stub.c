@@ -1,0 +1,171 @@
+/*
+ * engine_stub.c -- TEST INFRASTRUCTURE: a stand-in for the TyrQuake services that
+ * blinky_amd/host/fisheye_hip.c links against (see blinky_amd/host/engine_iface.h), plus a small
+ * driver API for the Python tests.  The "scene renderer" R_RenderView paints the view rectangle
+ * with the SURVEY.md 8(d) LCG stream of the plate being rendered.
+ */
+#include "../../blinky_amd/host/engine_iface.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* fisheye_hip.c's public face (engine/include/fisheye.h) */
+extern qboolean fisheye_enabled;
+extern double fisheye_plate_fov;
+void F_Init(void);
+void F_Shutdown(void);
+void F_RenderView(void);
+void F_WriteConfig(FILE *f);
+
+viddef_t vid;
+refdef_t r_refdef;
+vrect_t scr_vrect;
+int sb_lines;
+byte *host_basepal;
+char com_basedir[1024];
+
+static byte basepal[768];
+static char console[1 << 16];
+static size_t console_len;
+static int plate_order[8], plate_count, plate_next, frame_index;
+static double plate_fovs[8];
+static int bg_value;
+
+/* ---- console / commands ------------------------------------------------------------------------ */
+void Con_Printf(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    if (console_len < sizeof console - 1)
+        console_len += (size_t)vsnprintf(console + console_len, sizeof console - console_len, fmt, ap);
+    if (console_len >= sizeof console) console_len = sizeof console - 1;
+    va_end(ap);
+}
+#define MAX_CMDS 64
+static struct { const char *name; xcommand_t fn; } cmds[MAX_CMDS];
+static int ncmds, argc_;
+static char argbuf[1024], *argv_[16];
+void Cmd_AddCommand(const char *cmd_name, xcommand_t function) { cmds[ncmds].name = cmd_name; cmds[ncmds].fn = function; ncmds++; }
+void Cmd_SetCompletion(const char *cmd_name, cmd_arg_f completion) { (void)cmd_name; (void)completion; }
+int Cmd_Argc(void) { return argc_; }
+const char *Cmd_Argv(int arg) { return arg < argc_ ? argv_[arg] : ""; }
+void Cmd_ExecuteString(const char *text, cmd_source_t src)
+{
+    char *p;
+    int i;
+    (void)src;
+    strncpy(argbuf, text, sizeof argbuf - 1);
+    argbuf[sizeof argbuf - 1] = 0;
+    argc_ = 0;
+    p = argbuf;
+    while (*p && argc_ < 16) {
+        while (*p == ' ' || *p == '\t' || *p == '\n') p++;
+        if (!*p) break;
+        if (*p == '"') { argv_[argc_++] = ++p; while (*p && *p != '"') p++; }
+        else { argv_[argc_++] = p; while (*p && *p != ' ' && *p != '\t' && *p != '\n') p++; }
+        if (*p) *p++ = 0;
+    }
+    if (!argc_) return;
+    for (i = 0; i < ncmds; ++i)
+        if (!strcmp(cmds[i].name, argv_[0])) { cmds[i].fn(); return; }
+    Con_Printf("[engine] %s\n", text);            /* bind / unbind / impulse ...: record them */
+}
+float Q_atof(const char *str) { return (float)atof(str); }
+int Q_atoi(const char *str) { return atoi(str); }
+
+/* ---- math ----------------------------------------------------------------------------------------- */
+void VectorMA(const vec3_t veca, const float scale, const vec3_t vecb, vec3_t vecc)
+{
+    vecc[0] = veca[0] + scale * vecb[0];
+    vecc[1] = veca[1] + scale * vecb[1];
+    vecc[2] = veca[2] + scale * vecb[2];
+}
+void AngleVectors(const vec3_t angles, vec3_t forward, vec3_t right, vec3_t up)
+{
+    /* Quake convention: angles = (pitch, yaw, roll) in degrees */
+    float sy = sinf(angles[1] * (float)(M_PI / 180)), cy = cosf(angles[1] * (float)(M_PI / 180));
+    float sp = sinf(angles[0] * (float)(M_PI / 180)), cp = cosf(angles[0] * (float)(M_PI / 180));
+    float sr = sinf(angles[2] * (float)(M_PI / 180)), cr = cosf(angles[2] * (float)(M_PI / 180));
+    forward[0] = cp * cy; forward[1] = cp * sy; forward[2] = -sp;
+    right[0] = -1 * sr * sp * cy + -1 * cr * -sy; right[1] = -1 * sr * sp * sy + -1 * cr * cy; right[2] = -1 * sr * cp;
+    up[0] = cr * sp * cy + -sr * -sy; up[1] = cr * sp * sy + -sr * cy; up[2] = cr * cp;
+}
+
+/* ---- renderer hooks ---------------------------------------------------------------------------------- */
+void R_PushDlights(void) {}
+void R_ViewChanged(vrect_t *pvrect, int lineadj, float aspect) { (void)pvrect; (void)lineadj; (void)aspect; }
+void R_SetVrect(const vrect_t *pvrectin, vrect_t *pvrect, int lineadj) { (void)pvrectin; (void)pvrect; (void)lineadj; }
+void Draw_TileClear(int x, int y, int w, int h)
+{
+    int r;
+    for (r = 0; r < h; ++r) memset(vid.buffer + x + (size_t)(y + r) * vid.rowbytes, bg_value, (size_t)w);
+}
+void R_RenderView(void)
+{
+    /* paint the square plate view with the LCG stream of the plate the host is rendering */
+    int ps = scr_vrect.width < scr_vrect.height ? scr_vrect.width : scr_vrect.height;
+    int p = plate_next < plate_count ? plate_order[plate_next] : 0;
+    uint32_t st = 0x9E3779B9u * (uint32_t)(p + 1 + 6 * frame_index);
+    int x, y;
+    if (plate_next < 8) plate_fovs[plate_next] = fisheye_plate_fov;
+    plate_next++;
+    for (y = 0; y < ps; ++y) {
+        byte *row = vid.buffer + scr_vrect.x + (size_t)(scr_vrect.y + y) * vid.rowbytes;
+        for (x = 0; x < ps; ++x) { st = st * 1664525u + 1013904223u; row[x] = (byte)(st >> 24); }
+    }
+}
+
+/* ---- driver API for the tests -------------------------------------------------------------------------- */
+int hosttest_init(const char *basedir)
+{
+    int i;
+    for (i = 0; i < 768; ++i) basepal[i] = (byte)((i * 37) % 256);
+    host_basepal = basepal;
+    snprintf(com_basedir, sizeof com_basedir, "%s", basedir);
+    console_len = 0; console[0] = 0;
+    F_Init();
+    return fisheye_enabled;
+}
+void hosttest_resize(int W, int H, int x0, int y0, int extra_pitch)
+{
+    free(vid.buffer);
+    vid.width = W + x0 + 3; vid.height = H + y0 + 2;
+    vid.rowbytes = vid.width + extra_pitch;
+    vid.buffer = (pixel_t *)calloc((size_t)vid.rowbytes * vid.height, 1);
+    vid.aspect = 1;
+    scr_vrect.x = x0; scr_vrect.y = y0; scr_vrect.width = W; scr_vrect.height = H;
+}
+void hosttest_cmd(const char *text) { Cmd_ExecuteString(text, src_command); }
+/* one frame: plates are painted in `order` (the display[] flags, ascending); returns how many the host rendered */
+int hosttest_frame(const int *order, int n, int frame, int bg, uint8_t *out)
+{
+    int i;
+    plate_count = n; plate_next = 0; frame_index = frame; bg_value = bg;
+    for (i = 0; i < n && i < 8; ++i) plate_order[i] = order[i];
+    memset(vid.buffer, bg, (size_t)vid.rowbytes * vid.height);
+    F_RenderView();
+    if (out) memcpy(out, vid.buffer, (size_t)vid.rowbytes * vid.height);
+    return plate_next;
+}
+int hosttest_rowbytes(void) { return vid.rowbytes; }
+int hosttest_vidheight(void) { return vid.height; }
+double hosttest_plate_fov(int i) { return plate_fovs[i]; }
+const char *hosttest_console(void) { return console; }
+void hosttest_console_clear(void) { console_len = 0; console[0] = 0; }
+int hosttest_writeconfig(char *buf, int cap)
+{
+    FILE *f = tmpfile();
+    size_t n;
+    if (!f) return -1;
+    F_WriteConfig(f);
+    fflush(f);
+    rewind(f);
+    n = fread(buf, 1, (size_t)cap - 1, f);
+    buf[n] = 0;
+    fclose(f);
+    return (int)n;
+}
+void hosttest_shutdown(void) { F_Shutdown(); }
