@@ -91,6 +91,7 @@ def main():
 
     import blinky_amd
     import scripts as S
+    from blinky_amd import multigpu
 
     F = args.frames
     ctx = blinky_amd.Context(local_rank)
@@ -98,7 +99,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     ctx.set_frames(F)
     S.configure(ctx, GLOBE, LENS, ZOOM, (W, H))
-    bounds = [H * r // world for r in range(world + 1)]
+    bounds = multigpu.stripe_bounds(H, world)
     r0, r1 = bounds[rank], bounds[rank + 1]
     ctx.set_rows(r0, r1)
     if args.variant >= 0:
@@ -110,6 +111,7 @@ def main():
     build_first_wall_ms = (time.time() - t0) * 1e3
     t0 = time.time()
     display, scale = ctx.build()                  # module cached: emit + launch only
+    display = multigpu.or_display(display, world, dev)   # which plates the whole frame reads
     build_wall_ms = (time.time() - t0) * 1e3
     build_kernel_ms = ctx.last_build_ms()
     t0 = time.time()
@@ -124,12 +126,13 @@ def main():
     stripe = torch.zeros((F, rows, W), dtype=torch.uint8, device=dev)       # Draw_TileClear stand-in: 0
     gather_list = None
     if world > 1 and rank == 0:
-        gather_list = [torch.empty((F, bounds[r + 1] - bounds[r], W), dtype=torch.uint8, device=dev) for r in range(world)]
+        hmax = max(bounds[r + 1] - bounds[r] for r in range(world))
+        gather_list = [torch.empty((F, hmax, W), dtype=torch.uint8, device=dev) for r in range(world)]
 
     def step(i):
         ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=(i * F) % F, nframes=F)
         if world > 1:
-            dist.gather(stripe, gather_list, dst=0)
+            multigpu.gather_stripes(stripe, bounds, rank, world, 0, gather_list)
 
     def barrier():
         torch.cuda.synchronize()
