@@ -89,3 +89,50 @@ int okpy_lens_def(const char *lens, int *has_inverse, int *has_forward, int *max
     onload[cap - 1] = 0;
     return 1;
 }
+
+/* Generic-lens variant: the lens callbacks are supplied by the caller (the tests pass ctypes
+ * callbacks that evaluate the real Lua script with an interpreter on the platform libm), the rest -
+ * globe, zoom, build, grid - is the fisheye.c restatement above.  Lens globals come as arguments. */
+typedef int (*okpy_inv_cb)(double x, double y, double *out3);                 /* 1 values, 0 nil, -1 error */
+typedef int (*okpy_fwd_cb)(double x, double y, double z, double *out2);
+static okpy_inv_cb g_inv_cb;
+static okpy_fwd_cb g_fwd_cb;
+static int cb_inverse(void *ud, double x, double y, double ray[3]) { (void)ud; return g_inv_cb(x, y, ray); }
+static int cb_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double o[2];
+    int rc = g_fwd_cb(x, y, z, o);
+    (void)ud;
+    *ox = o[0]; *oy = o[1];
+    return rc;
+}
+
+int okpy_lensmap_cb(const char *globe, okpy_inv_cb inv, okpy_fwd_cb fwd, int map_type, int max_fov, int max_vfov,
+                    double lens_width, double lens_height, const char *zoomcmd, int W, int H,
+                    uint32_t *offsets, uint8_t *tints, int *display, double *scale, int *numplates)
+{
+    ok_state s;
+    int i, ok;
+    memset(&s, 0, sizeof s);
+    ok_default_host(&s);
+    s.rubix_numcells = 10; s.rubix_cell = 4; s.rubix_pad = 1;
+    if (!ok_use_globe(&s, globe)) return -1;
+    g_inv_cb = inv; g_fwd_cb = fwd;
+    s.inverse = inv ? cb_inverse : NULL;
+    s.forward = fwd ? cb_forward : NULL;
+    s.ud = &s.host;
+    s.map_type = map_type; s.max_fov = max_fov; s.max_vfov = max_vfov;
+    s.width = lens_width; s.height = lens_height;
+    s.zoom_type = OK_ZOOM_NONE; s.zoom_fov = 0;
+    if (zoomcmd && !strncmp(zoomcmd, "f_fov ", 6)) { s.zoom_type = OK_ZOOM_FOV; s.zoom_fov = (int)atof(zoomcmd + 6); }
+    else if (zoomcmd && !strncmp(zoomcmd, "f_vfov ", 7)) { s.zoom_type = OK_ZOOM_VFOV; s.zoom_fov = (int)atof(zoomcmd + 7); }
+    else if (zoomcmd && !strcmp(zoomcmd, "f_cover")) s.zoom_type = OK_ZOOM_COVER;
+    else if (zoomcmd && !strcmp(zoomcmd, "f_contain")) s.zoom_type = OK_ZOOM_CONTAIN;
+    s.width_px = W; s.height_px = H;
+    s.platesize = W < H ? W : H;
+    s.offsets = offsets; s.tints = tints;
+    ok = ok_create_lensmap(&s);
+    for (i = 0; i < OK_MAX_PLATES; ++i) display[i] = i < s.numplates ? s.plates[i].display : 0;
+    *scale = s.scale; *numplates = s.numplates;
+    return ok;
+}

@@ -161,3 +161,46 @@ def lens_def(lens):
         raise KeyError(lens)
     return dict(has_inverse=hi.value, has_forward=hf.value, max_fov=mf.value, max_vfov=mv.value,
                 lens_width=w.value, lens_height=h.value, onload=buf.value.decode())
+
+
+_INV_CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double))
+_FWD_CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double))
+
+
+def lensmap_with_callbacks(globe, info, eval_inverse, eval_forward, zoom, W, H):
+    """The oracle's fisheye.c restatement (platform libm) driven by arbitrary lens callbacks:
+    eval_inverse(x, y) -> (rx, ry, rz) | None;  eval_forward(x, y, z) -> (x, y) | None.
+    `info` carries the lens globals (map_type, max_fov, max_vfov, lens_width, lens_height)."""
+    def inv(x, y, out):
+        r = eval_inverse(x, y)
+        if r is None:
+            return 0
+        if len(r) != 3:
+            return -1
+        out[0], out[1], out[2] = r
+        return 1
+
+    def fwd(x, y, z, out):
+        r = eval_forward(x, y, z)
+        if r is None:
+            return 0
+        if len(r) != 2:
+            return -1
+        out[0], out[1] = r
+        return 1
+
+    inv_c = _INV_CB(inv) if eval_inverse else _INV_CB()
+    fwd_c = _FWD_CB(fwd) if eval_forward else _FWD_CB()
+    off = np.empty(W * H, np.uint32)
+    tin = np.empty(W * H, np.uint8)
+    disp = (C.c_int * 6)()
+    scale, npl = C.c_double(), C.c_int()
+    _o.okpy_lensmap_cb.argtypes = [C.c_char_p, _INV_CB, _FWD_CB, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    rc = _o.okpy_lensmap_cb(globe.encode(), inv_c, fwd_c, info.map_type, info.max_fov, info.max_vfov,
+                            info.lens_width, info.lens_height, zoom.encode() if zoom else None, W, H,
+                            _p(off), _p(tin), disp, C.byref(scale), C.byref(npl))
+    if rc < 0:
+        raise KeyError(globe)
+    return Lensmap(W, H, off, tin, list(disp)[: npl.value], scale.value, npl.value, info.map_type, rc == 1)
