@@ -2,30 +2,28 @@
 //
 // The lensmap is frame-invariant, so after every build it is "compiled" once into a form the
 // per-frame gather can stream at full width:
-//   * the screen is cut into tiles of 32x8 pixels, one wavefront (64 lanes x 4 px) per tile;
+//   * the screen is cut into tiles of 32 x (8*RG) pixels, one wavefront per tile (64 lanes, each
+//     RG groups of 4 consecutive pixels; RG = 1, 2 or 4, default 2);
 //   * for each tile a wave discovers, with ballots and shuffle reductions, which plates its
 //     pixels read and the bounding box of the texels inside each plate (<= 3 regions: a cube
 //     corner); the box is widened to 16-byte columns of the padded globe rows;
 //   * each pixel's 32-bit globe offset is replaced by a 16-bit address inside the tile's LDS
-//     staging area (0xFFFF = unmapped), stored tile-major so a wave reads its 512 B in one go.
+//     staging area (0xFFFF = unmapped), stored tile-major so a wave reads its slab in one go.
 // Per frame a wave then (1) copies its regions HBM -> LDS with coalesced 16-byte row loads,
-// (2) gathers its 256 texels from LDS (ds_read_u8: ~8x the rate of the texture addresser's
-// byte gathers), (3) stores 4 packed pixels per lane.  Tiles whose regions do not fit
-// (BK_TILE_LDS_CAP) fall back to direct global gathers through the 32-bit table.
-// Four horizontally adjacent tiles form a workgroup (a 128x8 pixel strip: full 128-byte lines
-// are written by one CU), and workgroup b is mapped to a horizontal screen band chosen by
-// b % 8 so that each XCD's L2 keeps its own slice of the index stream and shares source rows.
+// (2) gathers its texels from LDS (ds_read_u8: several times the rate of the texture
+// addresser's byte gathers), (3) stores 4 packed pixels per lane and row group.  Tiles whose
+// regions do not fit the LDS budget fall back to direct global gathers through the 32-bit table.
+// Four horizontally adjacent tiles form a workgroup (a 128-pixel-wide strip: full 128-byte lines
+// are written by one CU); the launch is persistent and workgroup b walks tiles of the horizontal
+// screen band b % 8, so each XCD's L2 keeps its own slice of the index stream and shares plate rows.
 //
 // replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
 #include "bk_internal.h"
 
 namespace bk {
 
-// A tile is always 256 px = 64 lanes x 4 consecutive pixels; its SHAPE is chosen per lensmap:
-// lw = log2(lanes per tile row): 3 -> 32x8, 4 -> 64x4, 5 -> 128x2 pixels.  A workgroup (4 waves)
-// always covers a 128x8 pixel block; its tiles are stored contiguously (t = block*4 + wave).
-constexpr int TILE_PX = 256, BLOCK_W = 128, BLOCK_H = 8;
-constexpr int BK_TILE_LDS_CAP = 12288;                             // bytes of LDS per wave-tile
+constexpr int TILE_W = 32, BLOCK_W = 128;                         // tile height = 8 * RG
+constexpr int BK_TILE_LDS_CAP = 12288;                            // max bytes of LDS per wave-tile
 constexpr uint32_t F_ALL = 1, F_SLOW = 2, F_EMPTY = 4;
 
 struct TileHdr {              // 32 bytes
@@ -40,27 +38,31 @@ struct TileHdr {              // 32 bytes
 
 struct TileMap {
     TileHdr *d_hdr = nullptr;
-    uint16_t *d_idx = nullptr;      // [ntiles][256]
-    uint8_t *d_tint = nullptr;      // [ntiles][256] tile-major tints (rubix)
-    uint32_t *d_stats = nullptr;    // [0] max LDS bytes, [1] >3-region tiles, [2] empty tiles, [3] 128-B lines staged,
-                                    // [4..36) LDS-need histogram (512 B bins)
-    int blocks_x = 0, blocks_y = 0; // 128x8-pixel workgroup blocks
-    int lw = 3;                     // tile shape (see above)
-    int lds_bytes = 0;              // per wave, rounded up
+    uint16_t *d_idx = nullptr;      // [ntiles][RG][256]
+    uint8_t *d_tint = nullptr;      // [ntiles][RG][256] tile-major tints (rubix)
+    uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max LDS bytes, [1] >3-region tiles, [2] empty tiles,
+                                    // [3] 128-B lines staged, [4..36) LDS-need histogram (512 B bins)
+    int blocks_x = 0, blocks_y = 0; // workgroup blocks of 128 x (8*RG) pixels
+    int rg = 2;                     // row groups per lane (tile height / 8)
+    int lds_bytes = 0;              // LDS budget per wave of the apply launch
     uint32_t stats[40] = {0};
     int slow_tiles = 0;
     bool valid = false;
-    size_t alloc_tiles = 0;
+    size_t alloc_px = 0;
 };
 
-// tile t = block*4 + wave; wave w sits at (w % per_row, w / per_row) inside the 128x8 block
-__device__ __forceinline__ void tile_origin(int t, int lw, int blocks_x, int *ox, int *oy)
+// developer ablation switch (tools/apply_probe.py): bit0 skip region loads, bit1 skip stores,
+// bit2 skip the LDS gather, bit3 skip the LDS writes, bit4 header/index fetch only.  0 normally;
+// results are wrong by design while it is non-zero.
+__device__ int g_ablate = 0;
+
+// tile t = block*4 + wave; wave w is the w-th 32-pixel column of the 128-pixel-wide block
+__device__ __forceinline__ void tile_origin(int t, int rg, int blocks_x, int *ox, int *oy)
 {
     const int blk = t >> 2, w = t & 3;
     const int by = blk / blocks_x, bx = blk - by * blocks_x;
-    const int tw = 4 << lw, th = 64 >> lw, per_row = BLOCK_W / tw;
-    *ox = bx * BLOCK_W + (w % per_row) * tw;
-    *oy = by * BLOCK_H + (w / per_row) * th;
+    *ox = bx * BLOCK_W + w * TILE_W;
+    *oy = by * 8 * rg;
 }
 
 __device__ __forceinline__ int wave_min(int v)
@@ -77,50 +79,55 @@ __device__ __forceinline__ int wave_max(int v)
 // ---------------------------------------------------------------------------------------------
 // compile: one wave per tile
 // ---------------------------------------------------------------------------------------------
+template <int RG>
 __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
-                                                           int W, int rows, int ps, int gp, int blocks_x, int lw, int ntiles,
+                                                           int W, int rows, int ps, int gp, int blocks_x, int ntiles,
                                                            TileHdr *__restrict__ hdr, uint16_t *__restrict__ idx,
                                                            uint8_t *__restrict__ tint_t, uint32_t *__restrict__ stats)
 {
+    constexpr int NP = 4 * RG;                  // pixels per lane
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= ntiles) return;
     int ox, oy;
-    tile_origin(t, lw, blocks_x, &ox, &oy);
-    const int ry = lane >> lw, cx = lane & ((1 << lw) - 1);
-    const int row = oy + ry, x0 = ox + cx * 4;
+    tile_origin(t, RG, blocks_x, &ox, &oy);
+    const int ry = lane >> 3, cx = lane & 7;
+    const int x0 = ox + cx * 4;
 
-    uint32_t o[4];
-    uint8_t tn[4];
-    int plate[4], px[4], py[4];
+    uint32_t o[NP];
+    uint8_t tn[NP];
+    int plate[NP], px[NP], py[NP];
     const uint32_t plate_stride = (uint32_t)gp * (uint32_t)ps;
+    bool all_l = true, any_l = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool in = row < rows && x0 + k < W;
-        o[k] = in ? lmap[(size_t)row * W + x0 + k] : BK_NULL_OFFSET;
-        tn[k] = in ? tints[(size_t)row * W + x0 + k] : 255;
-        plate[k] = -1; px[k] = 0; py[k] = 0;
-        if (o[k] != BK_NULL_OFFSET) {
-            const uint32_t p = o[k] / plate_stride, rem = o[k] - p * plate_stride;
-            plate[k] = (int)p;
-            py[k] = (int)(rem / (uint32_t)gp);
-            px[k] = (int)(rem - (uint32_t)py[k] * (uint32_t)gp);
+    for (int i = 0; i < NP; ++i) {
+        const int row = oy + (i >> 2) * 8 + ry, x = x0 + (i & 3);
+        const bool in = row < rows && x < W;
+        o[i] = in ? lmap[(size_t)row * W + x] : BK_NULL_OFFSET;
+        tn[i] = in ? tints[(size_t)row * W + x] : 255;
+        plate[i] = -1; px[i] = 0; py[i] = 0;
+        if (o[i] != BK_NULL_OFFSET) {
+            const uint32_t p = o[i] / plate_stride, rem = o[i] - p * plate_stride;
+            plate[i] = (int)p;
+            py[i] = (int)(rem / (uint32_t)gp);
+            px[i] = (int)(rem - (uint32_t)py[i] * (uint32_t)gp);
         }
+        all_l = all_l && plate[i] >= 0;
+        any_l = any_l || plate[i] >= 0;
     }
-    const bool all = __all(plate[0] >= 0 && plate[1] >= 0 && plate[2] >= 0 && plate[3] >= 0);
-    const bool any = __any(plate[0] >= 0 || plate[1] >= 0 || plate[2] >= 0 || plate[3] >= 0);
+    const bool all = __all(all_l), any = __any(any_l);
 
     // regions: one per plate present in the tile (ballot), bounding box by shuffle reduction
     int nreg = 0, lds16 = 0, lines = 0;
     int r_plate[3] = {-1, -1, -1}, r_x0[3] = {0, 0, 0}, r_y0[3] = {0, 0, 0}, r_w16[3] = {0, 0, 0}, r_rows[3] = {0, 0, 0}, r_base16[3] = {0, 0, 0};
     bool slow = false;
     for (int p = 0; p < BK_MAX_PLATES; ++p) {
-        const bool mine = plate[0] == p || plate[1] == p || plate[2] == p || plate[3] == p;
-        if (__ballot(mine) == 0) continue;                       // wave-uniform
+        bool mine = false;
         int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (plate[k] == p) { mnx = min(mnx, px[k]); mxx = max(mxx, px[k]); mny = min(mny, py[k]); mxy = max(mxy, py[k]); }
+        for (int i = 0; i < NP; ++i)
+            if (plate[i] == p) { mine = true; mnx = min(mnx, px[i]); mxx = max(mxx, px[i]); mny = min(mny, py[i]); mxy = max(mxy, py[i]); }
+        if (__ballot(mine) == 0) continue;                       // wave-uniform
         mnx = wave_min(mnx); mxx = wave_max(mxx); mny = wave_min(mny); mxy = wave_max(mxy);
         if (nreg == 3) { slow = true; break; }
         const int xa = mnx & ~15, w16 = (mxx - xa) / 16 + 1, nrows = mxy - mny + 1, pitch16 = w16 | 1;
@@ -131,22 +138,26 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
     }
     if (lds16 * 16 > BK_TILE_LDS_CAP || lds16 * 16 > 0xFFF0) slow = true;
 
-    uint16_t a[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        a[k] = 0xFFFF;
-        if (plate[k] >= 0) {
-            a[k] = 0;
-            if (!slow)
-                for (int r = 0; r < 3; ++r)
-                    if (r_plate[r] == plate[k])
-                        a[k] = (uint16_t)((r_base16[r] + (py[k] - r_y0[r]) * (r_w16[r] | 1)) * 16 + (px[k] - r_x0[r]));
+    for (int r = 0; r < RG; ++r) {
+        uint32_t a[4], tw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = r * 4 + k;
+            a[k] = 0xFFFFu;
+            if (plate[i] >= 0) {
+                a[k] = 0;
+                if (!slow)
+                    for (int q = 0; q < 3; ++q)
+                        if (r_plate[q] == plate[i])
+                            a[k] = (uint32_t)((r_base16[q] + (py[i] - r_y0[q]) * (r_w16[q] | 1)) * 16 + (px[i] - r_x0[q]));
+            }
+            tw |= (uint32_t)tn[i] << (8 * k);
         }
+        const size_t slab = ((size_t)t * RG + r) * 256 + lane * 4;
+        *reinterpret_cast<uint2 *>(idx + slab) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+        *reinterpret_cast<uint32_t *>(tint_t + slab) = tw;
     }
-    *reinterpret_cast<uint2 *>(idx + (size_t)t * TILE_PX + lane * 4) =
-        make_uint2((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16));
-    *reinterpret_cast<uint32_t *>(tint_t + (size_t)t * TILE_PX + lane * 4) =
-        (uint32_t)tn[0] | ((uint32_t)tn[1] << 8) | ((uint32_t)tn[2] << 16) | ((uint32_t)tn[3] << 24);
     if (lane == 0) {
         TileHdr h;
         for (int r = 0; r < 3; ++r) {
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
         h.lds16 = (uint16_t)(slow ? 0 : lds16);
         h.pad = 0;
         hdr[t] = h;
-        uint32_t *st = stats + (t & 63) * 40;       // 64 replicas: 32 400 tiles must not serialise on one word
+        uint32_t *st = stats + (t & 63) * 40;       // 64 replicas: thousands of tiles must not serialise on one word
         if (!slow && any) {
             atomicMax(&st[0], (uint32_t)lds16 * 16u);
             atomicAdd(&st[4 + min(31, (lds16 * 16 + 511) / 512)], 1u);        // histogram of LDS need
@@ -173,100 +184,93 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
 // ---------------------------------------------------------------------------------------------
 // apply
 // ---------------------------------------------------------------------------------------------
-// The hot path: every pixel of the tile mapped, regions <= NQ*1 KiB, aligned destination; the loop
-// body is branch-free.  (A register prefetch of frame f+1's chunks was measured and bought nothing:
-// with 24-32 waves per CU the memory system, not per-wave latency, is the limiter.)
-// developer ablation switch (tools/apply_probe.py): bit0 skip region loads, bit1 skip stores,
-// bit2 skip the LDS gather, bit3 skip the LDS writes.  0 in normal operation.
-__device__ int g_ablate = 0;
-
-template <int NQ>
-__device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
-                                           int f_begin, int f_end, uint8_t *__restrict__ out0, size_t frame_stride,
-                                           uint8_t *lds, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
-                                           uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
-                                           bool k0, bool k1, bool k2, bool k3,
-                                           uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
-{
-    // (explicit scalars, not arrays: the four chunks must stay in VGPRs)
-    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-    const int abl = g_ablate;
-    if (abl) {     // ablated copy of the loop, for attributing time; results are wrong by design
-        for (int f = f_begin; f < f_end; ++f) {
-            const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
-            if (!(abl & 1)) {
-                q0 = *reinterpret_cast<const uint4 *>(gl + s0);
-                if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
-                if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
-                if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
-            }
-            if (!(abl & 8)) {
-                if (k0) *reinterpret_cast<uint4 *>(lds + d0) = q0;
-                if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(lds + d1) = q1;
-                if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(lds + d2) = q2;
-                if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(lds + d3) = q3;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t v0 = a0 + q0.x, v1 = a1, v2 = a2, v3 = a3;
-            if (!(abl & 4)) { v0 = lds[a0]; v1 = lds[a1]; v2 = lds[a2]; v3 = lds[a3]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t w = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-            if (!(abl & 2) || w == 0x12345678u) *reinterpret_cast<uint32_t *>(out0 + (size_t)f * frame_stride) = w;
-        }
-        return;
-    }
-    for (int f = f_begin; f < f_end; ++f) {
-        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
-        q0 = *reinterpret_cast<const uint4 *>(gl + s0);
-        if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
-        if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
-        if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
-        if (k0) *reinterpret_cast<uint4 *>(lds + d0) = q0;
-        if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(lds + d1) = q1;
-        if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(lds + d2) = q2;
-        if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(lds + d3) = q3;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t v0 = lds[a0], v1 = lds[a1], v2 = lds[a2], v3 = lds[a3];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<uint32_t *>(out0 + (size_t)f * frame_stride) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-    }
-}
+template <int RG>
+struct TileIdx {              // a lane's LDS addresses (two 16-bit per dword) and tints, per row group
+    uint2 iw[RG];
+    uint32_t t4[RG];
+};
 
 // What a wave fetches ahead for its NEXT tile while it works on the current one: the 32-byte
 // header (as two vector loads, so that it is tracked by vmcnt like everything else - an s_load
-// would share lgkmcnt with the LDS traffic and stall the gathers), its 4 LDS indices and tints.
+// would share lgkmcnt with the LDS traffic and stall the gathers), its LDS indices and tints.
+template <int RG>
 struct TilePrefetch {
     uint4 h0, h1;
-    uint2 iw;
-    uint32_t t4;
+    TileIdx<RG> ix;
 };
 
-template <bool RUBIX>
-__device__ __forceinline__ TilePrefetch tile_fetch(const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx,
-                                                   const uint8_t *__restrict__ tint_t, int t, int lane)
+template <bool RUBIX, int RG>
+__device__ __forceinline__ TilePrefetch<RG> tile_fetch(const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx,
+                                                       const uint8_t *__restrict__ tint_t, int t, int lane)
 {
-    TilePrefetch p;
+    TilePrefetch<RG> p;
     int tv;
     asm volatile("v_mov_b32 %0, %1" : "=v"(tv) : "s"(t));     // make the address a VGPR: vector loads
     const uint4 *hp = reinterpret_cast<const uint4 *>(hdr) + 2 * (size_t)tv;
     p.h0 = hp[0];
     p.h1 = hp[1];
-    p.iw = *reinterpret_cast<const uint2 *>(idx + (size_t)t * TILE_PX + lane * 4);
-    p.t4 = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + (size_t)t * TILE_PX + lane * 4) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const size_t slab = ((size_t)t * RG + r) * 256 + lane * 4;
+        p.ix.iw[r] = *reinterpret_cast<const uint2 *>(idx + slab);
+        p.ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + slab) : 0xFFFFFFFFu;
+    }
     return p;
 }
 
-template <bool RUBIX>
+// The hot path: every pixel of the tile mapped, regions <= NQ KiB, aligned destination; the loop
+// body is branch-free.  (Tried and measured without gain: a register prefetch of frame f+1's chunks,
+// and issuing several frames' loads before their stores - with 24 waves per CU the memory system,
+// not per-wave latency, is the limiter.)
+template <int NQ, int RG>
+__device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
+                                           int f_begin, int f_end, uint8_t *__restrict__ out0, int dst_pitch, size_t frame_stride,
+                                           uint8_t *lds, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
+                                           uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
+                                           bool k0, bool k1, bool k2, bool k3, const TileIdx<RG> ix)
+{
+    // (explicit scalars, not arrays: the four chunks must stay in VGPRs)
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+    const int abl = g_ablate;
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        if (!(abl & 1)) {
+            q0 = *reinterpret_cast<const uint4 *>(gl + s0);
+            if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
+            if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
+            if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
+        }
+        if (!(abl & 8)) {
+            if (k0) *reinterpret_cast<uint4 *>(lds + d0) = q0;
+            if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(lds + d1) = q1;
+            if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(lds + d2) = q2;
+            if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(lds + d3) = q3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t w[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            uint32_t v0 = ix.iw[r].x & 0xFFFFu, v1 = ix.iw[r].x >> 16, v2 = ix.iw[r].y & 0xFFFFu, v3 = ix.iw[r].y >> 16;
+            if (!(abl & 4)) { v0 = lds[v0]; v1 = lds[v1]; v2 = lds[v2]; v3 = lds[v3]; }
+            w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                *reinterpret_cast<uint32_t *>(out0 + (size_t)f * frame_stride + (size_t)(r * 8) * dst_pitch) = w[r];
+        }
+    }
+}
+
+template <bool RUBIX, int RG>
 __device__ __forceinline__ void tile_process(
-    const TilePrefetch &pf, int t, int lane, uint8_t *lds, const uint8_t *pal_s,
+    const TilePrefetch<RG> &pf, int t, int lane, uint8_t *lds, const uint8_t *pal_s,
     const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
-    int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp, int lw,
+    int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp,
     int blocks_x, int f_begin, int f_end, int lds_per_wave)
 {
     // header words -> SGPRs (the values are wave-uniform)
@@ -280,24 +284,16 @@ __device__ __forceinline__ void tile_process(
     const uint32_t h_nreg = nf & 0xFFFFu, h_flags = nf >> 16;
     if (h_flags & F_EMPTY) return;
     if (g_ablate & 16) {                       // developer ablation: header + indices only
-        if (pf.iw.x == 0x12345678u && h_src[0] == 0xFFFFFFFFu) dst[0] = 1;
+        if (pf.ix.iw[0].x == 0x12345678u && h_src[0] == 0xFFFFFFFFu) dst[0] = 1;
         return;
     }
 
-    const uint32_t a[4] = {pf.iw.x & 0xFFFFu, pf.iw.x >> 16, pf.iw.y & 0xFFFFu, pf.iw.y >> 16};
-    const uint32_t t4 = pf.t4;
     int ox, oy;
-    tile_origin(t, lw, blocks_x, &ox, &oy);
-    const int ry = lane >> lw, cx = lane & ((1 << lw) - 1);
-    const int row = oy + ry, x = ox + cx * 4;
+    tile_origin(t, RG, blocks_x, &ox, &oy);
+    const int ry = lane >> 3, cx = lane & 7;
+    const int row0 = oy + ry, x = ox + cx * 4;             // row group r covers row0 + 8 r
     // a tile whose regions exceed this launch's LDS budget takes the direct-gather path
     const bool slow = (h_flags & F_SLOW) != 0 || (int)l16 * 16 > lds_per_wave;
-    uint32_t so[4] = {BK_NULL_OFFSET, BK_NULL_OFFSET, BK_NULL_OFFSET, BK_NULL_OFFSET};
-    if (slow) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (row < rows && x + k < W) so[k] = lmap[(size_t)row * W + x + k];
-    }
     const bool fast_store = (h_flags & F_ALL) && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & 3u) == 0;
 
     // Frame-invariant staging plan: the 16-byte chunks of all regions are numbered row-major and
@@ -351,19 +347,34 @@ __device__ __forceinline__ void tile_process(
     const bool piped = !slow && total_chunks <= 64u * MAXQ;
 
     if (!RUBIX && piped && fast_store) {
-        uint8_t *out0 = dst + (size_t)row * dst_pitch + x;
+        uint8_t *out0 = dst + (size_t)row0 * dst_pitch + x;
         const uint32_t nq = (total_chunks + 63u) >> 6;       // wave-uniform
-        if (nq <= 1) hot_frames<1>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
-        else if (nq == 2) hot_frames<2>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
-        else if (nq == 3) hot_frames<3>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
-        else hot_frames<4>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, frame_stride, lds, q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3], q_ok[0], q_ok[1], q_ok[2], q_ok[3], a[0], a[1], a[2], a[3]);
+#define BK_HOT(N) hot_frames<N, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, dst_pitch, frame_stride, lds, \
+                                    q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3],            \
+                                    q_ok[0], q_ok[1], q_ok[2], q_ok[3], pf.ix)
+        if (nq <= 1) BK_HOT(1);
+        else if (nq == 2) BK_HOT(2);
+        else if (nq == 3) BK_HOT(3);
+        else BK_HOT(4);
+#undef BK_HOT
         return;
+    }
+
+    // general path: partially mapped tiles, rubix, large regions, the direct-gather fallback
+    uint32_t so[RG][4];
+    if (slow) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = row0 + r * 8;
+                so[r][k] = (row < rows && x + k < W) ? lmap[(size_t)row * W + x + k] : BK_NULL_OFFSET;
+            }
     }
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
-        uint32_t v[4];
         if (!slow) {
-            // general staged path: stage chunk by chunk (rows of the padded globe are 64-byte aligned)
+            // stage chunk by chunk (rows of the padded globe are 64-byte aligned)
             int base16 = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -381,41 +392,47 @@ __device__ __forceinline__ void tile_process(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = a[k] != 0xFFFFu ? lds[a[k]] : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = so[k] != BK_NULL_OFFSET ? gl[so[k]] : 0u;
         }
-        if (RUBIX) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const uint32_t a[4] = {pf.ix.iw[r].x & 0xFFFFu, pf.ix.iw[r].x >> 16, pf.ix.iw[r].y & 0xFFFFu, pf.ix.iw[r].y >> 16};
+            uint32_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t tt = (t4 >> (8 * k)) & 0xFFu;
-                if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+                if (slow) v[k] = so[r][k] != BK_NULL_OFFSET ? gl[so[r][k]] : 0u;
+                else v[k] = a[k] != 0xFFFFu ? lds[a[k]] : 0u;
+            }
+            if (RUBIX) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t tt = (pf.ix.t4[r] >> (8 * k)) & 0xFFu;
+                    if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+                }
+            }
+            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x;
+            if (fast_store) {
+                *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
             }
         }
-        uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row * dst_pitch + x;
-        if (fast_store) {
-            *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
+        if (!slow) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-// Persistent launch: the grid holds at most a few workgroups per CU; every wave walks a strided
-// sequence of tiles inside its XCD's band and fetches the header / indices of its next tile before
-// it starts on the current one, so a tile costs one dependent memory latency (its region rows),
-// not two.
-template <bool RUBIX>
+// Persistent launch: the grid holds a bounded number of workgroups per CU; every wave walks a
+// strided sequence of tiles inside its XCD's band and fetches the header / indices of its next tile
+// before it starts on the current one.
+template <bool RUBIX, int RG>
 __global__ __launch_bounds__(256) void apply_tiled_kernel(
     const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
     const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
-    int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp, int lw,
+    int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp,
     int blocks_x, int nblocks, int nframes, int fchunk, int lds_per_wave, const uint8_t *__restrict__ pal)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(256) void apply_tiled_kernel(
     }
     uint8_t *lds = smem + wave * lds_per_wave;
     // XCD-banded mapping: workgroup b runs on XCD b % 8 (observed dispatch order); XCD k owns the
-    // contiguous band [k*per, (k+1)*per) of 128x8 blocks.  Correctness does not depend on it.
+    // contiguous band [k*per, (k+1)*per) of workgroup blocks.  Correctness does not depend on it.
     const int per = (nblocks + 7) / 8;
     const int band = (int)(blockIdx.x & 7);
     const int wg_in_band = (int)(blockIdx.x >> 3), wgs_per_band = (int)(gridDim.x >> 3);
@@ -437,15 +454,15 @@ __global__ __launch_bounds__(256) void apply_tiled_kernel(
     const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);
 
     int t = __builtin_amdgcn_readfirstlane(l * 4 + wave);
-    TilePrefetch cur = tile_fetch<RUBIX>(hdr, idx, tint_t, t, lane);
+    TilePrefetch<RG> cur = tile_fetch<RUBIX, RG>(hdr, idx, tint_t, t, lane);
     for (;;) {
         const int l_next = l + wgs_per_band;
         const bool has_next = l_next < l_end;
         const int t_next = __builtin_amdgcn_readfirstlane(l_next * 4 + wave);
-        TilePrefetch nxt = cur;
-        if (has_next) nxt = tile_fetch<RUBIX>(hdr, idx, tint_t, t_next, lane);
-        tile_process<RUBIX>(cur, t, lane, lds, pal_s, lmap, globe, globe_stride, globe_frames, frame0, dst, dst_pitch,
-                            frame_stride, W, rows, gp, lw, blocks_x, f_begin, f_end, lds_per_wave);
+        TilePrefetch<RG> nxt = cur;
+        if (has_next) nxt = tile_fetch<RUBIX, RG>(hdr, idx, tint_t, t_next, lane);
+        tile_process<RUBIX, RG>(cur, t, lane, lds, pal_s, lmap, globe, globe_stride, globe_frames, frame0, dst, dst_pitch,
+                                frame_stride, W, rows, gp, blocks_x, f_begin, f_end, lds_per_wave);
         if (!has_next) break;
         l = l_next;
         t = t_next;
@@ -471,14 +488,20 @@ void tilemap_invalidate(bk_ctx *ctx)
     if (ctx->tilemap) ctx->tilemap->valid = false;
 }
 
-// compile the tilemap for one tile shape and read back its statistics
-static int compile_shape(bk_ctx *ctx, TileMap *tm, int lw, size_t ntiles, double *cost_ps)
+// compile the tilemap for one tile height and read back its statistics
+static int compile_shape(bk_ctx *ctx, TileMap *tm, int rg, double *cost_ps)
 {
     const int rows = ctx->rows();
+    tm->rg = rg;
+    tm->blocks_x = (ctx->W + BLOCK_W - 1) / BLOCK_W;
+    tm->blocks_y = (rows + 8 * rg - 1) / (8 * rg);
+    const size_t ntiles = (size_t)tm->blocks_x * tm->blocks_y * 4;
     BK_HIP(ctx, hipMemsetAsync(tm->d_stats, 0, 64 * 40 * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(tile_compile_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, ctx->stream, ctx->d_offsets,
-                       ctx->d_tints, ctx->W, rows, ctx->ps, ctx->gp, tm->blocks_x, lw, (int)ntiles, tm->d_hdr, tm->d_idx,
-                       tm->d_tint, tm->d_stats);
+    const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+#define BK_COMPILE(N) hipLaunchKernelGGL(tile_compile_kernel<N>, grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
+                                         ctx->ps, ctx->gp, tm->blocks_x, (int)ntiles, tm->d_hdr, tm->d_idx, tm->d_tint, tm->d_stats)
+    if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
+#undef BK_COMPILE
     BK_HIP(ctx, hipGetLastError());
     static thread_local uint32_t rep[64 * 40];
     BK_HIP(ctx, hipMemcpyAsync(rep, tm->d_stats, sizeof rep, hipMemcpyDeviceToHost, ctx->stream));
@@ -509,15 +532,12 @@ static int compile_shape(bk_ctx *ctx, TileMap *tm, int lw, size_t ntiles, double
     const int cap = best_bin * 512;
     uint64_t over = 0;
     for (int b = best_bin + 1; b < 32; ++b) over += tm->stats[4 + b];
-    const uint64_t staged = staged_all;
     tm->lds_bytes = cap;
     tm->slow_tiles = (int)(tm->stats[1] + over);
-    tm->lw = lw;
-    // cost model fitted to the rocprof ablations in profiles/ (ps per frame): a staged 128-byte line,
-    // a store segment (one per tile row), a tile on the direct-gather path; LDS budgets above 4 KiB
-    // cost occupancy.
-    const double nonempty = (double)(staged + tm->stats[1]);
-    double c = 8.6 * tm->stats[3] + 15.0 * (64 >> lw) * nonempty + 742.0 * tm->slow_tiles;
+    // cost model (ps per frame) for comparing tile heights: a staged 128-byte line, per-tile fixed work,
+    // a tile on the direct-gather path (per pixel group)
+    const double nonempty = (double)(staged_all + tm->stats[1]);
+    double c = 8.6 * tm->stats[3] + 120.0 * nonempty + 742.0 * rg * tm->slow_tiles;
     if (cap > 4096) c *= 1.0 + (cap - 4096) / 8192.0;
     *cost_ps = c;
     return BK_OK;
@@ -529,34 +549,35 @@ static int ensure_tilemap(bk_ctx *ctx)
     TileMap *tm = ctx->tilemap;
     if (tm->valid) return BK_OK;
     const int rows = ctx->rows();
-    tm->blocks_x = (ctx->W + BLOCK_W - 1) / BLOCK_W;
-    tm->blocks_y = (rows + BLOCK_H - 1) / BLOCK_H;
-    const size_t ntiles = (size_t)tm->blocks_x * tm->blocks_y * 4;
-    if (ntiles > tm->alloc_tiles) {
+    // buffers sized for the shortest tiles (most tiles); every height covers <= that many pixels + padding
+    const size_t bx = (ctx->W + BLOCK_W - 1) / BLOCK_W;
+    const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
+    const size_t max_tiles = bx * 4 * (size_t)((rows + 7) / 8);
+    if (max_px > tm->alloc_px) {
         (void)hipFree(tm->d_hdr); (void)hipFree(tm->d_idx); (void)hipFree(tm->d_tint);
         tm->d_hdr = nullptr; tm->d_idx = nullptr; tm->d_tint = nullptr;
-        BK_HIP(ctx, hipMalloc((void **)&tm->d_hdr, ntiles * sizeof(TileHdr)));
-        BK_HIP(ctx, hipMalloc((void **)&tm->d_idx, ntiles * TILE_PX * sizeof(uint16_t)));
-        BK_HIP(ctx, hipMalloc((void **)&tm->d_tint, ntiles * TILE_PX));
-        tm->alloc_tiles = ntiles;
+        BK_HIP(ctx, hipMalloc((void **)&tm->d_hdr, max_tiles * sizeof(TileHdr)));
+        BK_HIP(ctx, hipMalloc((void **)&tm->d_idx, max_px * sizeof(uint16_t)));
+        BK_HIP(ctx, hipMalloc((void **)&tm->d_tint, max_px));
+        tm->alloc_px = max_px;
     }
     if (!tm->d_stats) BK_HIP(ctx, hipMalloc((void **)&tm->d_stats, 64 * 40 * sizeof(uint32_t)));
-    // try the three tile shapes (each compile is a few microseconds of GPU time) and keep the cheapest
+    // ctx->tile_shape: 0 = default height (RG 2), 1/2/4 = force RG, -1 = compile all three and keep the cheapest
     int best = ctx->tile_shape, compiled = -1;
-    if (best == 0) best = 3;     // 32x8 won on every shipped lens (profiles/): skip the search unless asked (-1)
-    if (best < 3 || best > 5) {
+    if (best == 0) best = 2;
+    if (best != 1 && best != 2 && best != 4) {
         double best_cost = 0;
         best = -1;
-        for (int lw = 5; lw >= 3; --lw) {
+        for (int rg = 4; rg >= 1; rg >>= 1) {
             double c = 0;
-            if (int r = compile_shape(ctx, tm, lw, ntiles, &c)) return r;
-            compiled = lw;
-            if (best < 0 || c < best_cost) { best = lw; best_cost = c; }
+            if (int r = compile_shape(ctx, tm, rg, &c)) return r;
+            compiled = rg;
+            if (best < 0 || c < best_cost) { best = rg; best_cost = c; }
         }
     }
     if (compiled != best) {
         double c = 0;
-        if (int r = compile_shape(ctx, tm, best, ntiles, &c)) return r;
+        if (int r = compile_shape(ctx, tm, best, &c)) return r;
     }
     tm->valid = true;
     return BK_OK;
@@ -572,8 +593,8 @@ int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int d
     const int fchunk = nframes < 8 ? nframes : 8;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     const int per = (nblocks + 7) / 8;
-    // persistent grid: enough workgroups to fill the chip (the kernel's registers / LDS admit <= 6-8
-    // per CU); each walks its XCD band with a stride, prefetching its next tile's header.
+    // persistent grid: enough workgroups to fill the chip a few times over; each walks its XCD band
+    // with a stride, prefetching its next tile's header.
     int wgs_per_band = per;
     const int resident_per_band = ctx->num_cus * ctx->apply_wgs_per_cu / 8;
     if (fblocks * wgs_per_band > resident_per_band) wgs_per_band = (resident_per_band + fblocks - 1) / fblocks;
@@ -581,14 +602,12 @@ int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int d
     if (wgs_per_band > per) wgs_per_band = per;
     dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
     const size_t shmem = (size_t)4 * tm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
-    if (rubix_on)
-        hipLaunchKernelGGL(apply_tiled_kernel<true>, grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,
-                           ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride,
-                           ctx->W, rows, ctx->gp, tm->lw, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal);
-    else
-        hipLaunchKernelGGL(apply_tiled_kernel<false>, grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,
-                           ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride,
-                           ctx->W, rows, ctx->gp, tm->lw, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal);
+#define BK_APPLY(RBX, N) hipLaunchKernelGGL((apply_tiled_kernel<RBX, N>), grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,      \
+                                            ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride, \
+                                            ctx->W, rows, ctx->gp, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal)
+    if (rubix_on) { if (tm->rg == 1) BK_APPLY(true, 1); else if (tm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
+    else { if (tm->rg == 1) BK_APPLY(false, 1); else if (tm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
+#undef BK_APPLY
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;
 }
@@ -604,7 +623,7 @@ int tilemap_stats(bk_ctx *ctx, int out[6])
     if (int r = ensure_tilemap(ctx)) return r;
     TileMap *tm = ctx->tilemap;
     out[0] = tm->blocks_x * tm->blocks_y * 4; out[1] = tm->slow_tiles; out[2] = (int)tm->stats[2]; out[3] = tm->lds_bytes;
-    out[4] = 4 << tm->lw; out[5] = (int)tm->stats[3];
+    out[4] = 8 * tm->rg; out[5] = (int)tm->stats[3];
     return BK_OK;
 }
 

@@ -67,7 +67,7 @@ struct bk_ctx {
     int apply_variant = -1;          // -1 auto
     int num_cus = 256;               // multiProcessorCount of the device
     int apply_wgs_per_cu = 16;       // persistent apply grid: workgroups per CU (tunable, bk_debug_set_tile_shape)
-    int tile_shape = 0;              // 0 = choose by cost model; 3/4/5 = force 32x8 / 64x4 / 128x2 tiles
+    int tile_shape = 0;              // tiled apply: 0 = default tile height (rg 2), 1/2/4 = force rg, -1 = search by cost model
     bk::TileMap *tilemap = nullptr;       // owned; freed with bk::tilemap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;

@@ -236,7 +236,7 @@ class Context:
     def tile_stats(self):
         out = (_i * 6)()
         self._chk(lib.bk_debug_tile_stats(self._h, out))
-        return dict(tiles=out[0], slow=out[1], empty=out[2], lds_bytes_per_wave=out[3], tile_w=out[4], lines=out[5])
+        return dict(tiles=out[0], slow=out[1], empty=out[2], lds_bytes_per_wave=out[3], tile_h=out[4], lines=out[5])
 
     def set_tile_shape(self, lw):
         self._chk(lib.bk_debug_set_tile_shape(self._h, lw))

@@ -149,10 +149,10 @@ int         bk_set_apply_variant(bk_ctx *ctx, int variant);
  * LDS gather, bit3 no LDS writes); results are wrong while non-zero.  0 restores normal operation. */
 int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
 /* tiled apply statistics of the current lensmap: out = {tiles, tiles on the direct-gather fallback,
- * empty tiles, LDS bytes per wavefront, tile width in pixels, 128-byte lines staged per frame} */
+ * empty tiles, LDS bytes per wavefront, tile height in pixels, 128-byte lines staged per frame} */
 int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
-/* tile shape of the tiled apply: 0 = default (32x8 px), 3 / 4 / 5 = force 32x8 / 64x4 / 128x2 px,
- * -1 = compile all three and keep the cheapest by the cost model */
+/* tile height of the tiled apply (tiles are 32 pixels wide, 8*rg tall): 0 = default (rg 2 = 32x16 px),
+ * 1 / 2 / 4 = force rg, -1 = compile all three and keep the cheapest by the cost model */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);
