@@ -225,7 +225,7 @@ extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
 {
     if (!ctx) return BK_E_INVALID;
     if (lw >= 100) { ctx->apply_wgs_per_cu = lw - 100; return BK_OK; }      // developer knob: 100+n = n workgroups per CU
-    if (lw != 0 && lw != -1 && lw != 1 && lw != 2 && lw != 4) return BK_E_INVALID;
+    if (lw != 0 && lw != -1 && lw != 1 && lw != 2 && lw != 4 && lw != 9 && lw != 10) return BK_E_INVALID;
     ctx->tile_shape = lw;
     bk::tilemap_invalidate(ctx);
     return BK_OK;

@@ -22,7 +22,7 @@
 
 namespace bk {
 
-constexpr int TILE_W = 32, BLOCK_W = 128;                         // tile height = 8 * RG
+// tile = (32*XG) x (8*RG) pixels; a lane owns, in each of RG row groups, 4*XG consecutive pixels
 constexpr int BK_TILE_LDS_CAP = 12288;                            // max bytes of LDS per wave-tile
 constexpr uint32_t F_ALL = 1, F_SLOW = 2, F_EMPTY = 4;
 
@@ -43,7 +43,7 @@ struct TileMap {
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max LDS bytes, [1] >3-region tiles, [2] empty tiles,
                                     // [3] 128-B lines staged, [4..36) LDS-need histogram (512 B bins)
     int blocks_x = 0, blocks_y = 0; // workgroup blocks of 128 x (8*RG) pixels
-    int rg = 2;                     // row groups per lane (tile height / 8)
+    int rg = 2, xg = 1;             // row groups per lane (tile height / 8), x groups per lane (tile width / 32)
     int lds_bytes = 0;              // LDS budget per wave of the apply launch
     uint32_t stats[40] = {0};
     int slow_tiles = 0;
@@ -56,12 +56,12 @@ struct TileMap {
 // results are wrong by design while it is non-zero.
 __device__ int g_ablate = 0;
 
-// tile t = block*4 + wave; wave w is the w-th 32-pixel column of the 128-pixel-wide block
-__device__ __forceinline__ void tile_origin(int t, int rg, int blocks_x, int *ox, int *oy)
+// tile t = block*4 + wave; wave w is the w-th column of tiles in the (128*XG)-pixel-wide block
+__device__ __forceinline__ void tile_origin(int t, int rg, int xg, int blocks_x, int *ox, int *oy)
 {
     const int blk = t >> 2, w = t & 3;
     const int by = blk / blocks_x, bx = blk - by * blocks_x;
-    *ox = bx * BLOCK_W + w * TILE_W;
+    *ox = (bx * 4 + w) * 32 * xg;
     *oy = by * 8 * rg;
 }
 
@@ -79,20 +79,20 @@ __device__ __forceinline__ int wave_max(int v)
 // ---------------------------------------------------------------------------------------------
 // compile: one wave per tile
 // ---------------------------------------------------------------------------------------------
-template <int RG>
+template <int RG, int XG>
 __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
                                                            int W, int rows, int ps, int gp, int blocks_x, int ntiles,
                                                            TileHdr *__restrict__ hdr, uint16_t *__restrict__ idx,
                                                            uint8_t *__restrict__ tint_t, uint32_t *__restrict__ stats)
 {
-    constexpr int NP = 4 * RG;                  // pixels per lane
+    constexpr int NG = RG * XG, NP = 4 * NG;    // pixel groups / pixels per lane; group g = (row group g / XG, x half g % XG)
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= ntiles) return;
     int ox, oy;
-    tile_origin(t, RG, blocks_x, &ox, &oy);
+    tile_origin(t, RG, XG, blocks_x, &ox, &oy);
     const int ry = lane >> 3, cx = lane & 7;
-    const int x0 = ox + cx * 4;
+    const int x0 = ox + cx * 4 * XG;
 
     uint32_t o[NP];
     uint8_t tn[NP];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
     bool all_l = true, any_l = false;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int row = oy + (i >> 2) * 8 + ry, x = x0 + (i & 3);
+        const int row = oy + ((i >> 2) / XG) * 8 + ry, x = x0 + ((i >> 2) % XG) * 4 + (i & 3);
         const bool in = row < rows && x < W;
         o[i] = in ? lmap[(size_t)row * W + x] : BK_NULL_OFFSET;
         tn[i] = in ? tints[(size_t)row * W + x] : 255;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
     if (lds16 * 16 > BK_TILE_LDS_CAP || lds16 * 16 > 0xFFF0) slow = true;
 
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
+    for (int r = 0; r < NG; ++r) {
         uint32_t a[4], tw = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
             }
             tw |= (uint32_t)tn[i] << (8 * k);
         }
-        const size_t slab = ((size_t)t * RG + r) * 256 + lane * 4;
+        // per row group: lane-major, 4*XG entries per lane (one 8- or 16-byte load in the apply kernel)
+        const size_t slab = ((size_t)t * RG + r / XG) * (256 * XG) + (size_t)lane * (4 * XG) + (r % XG) * 4;
         *reinterpret_cast<uint2 *>(idx + slab) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
         *reinterpret_cast<uint32_t *>(tint_t + slab) = tw;
     }
@@ -184,26 +185,26 @@ __global__ __launch_bounds__(256) void tile_compile_kernel(const uint32_t *__res
 // ---------------------------------------------------------------------------------------------
 // apply
 // ---------------------------------------------------------------------------------------------
-template <int RG>
-struct TileIdx {              // a lane's LDS addresses (two 16-bit per dword) and tints, per row group
-    uint2 iw[RG];
-    uint32_t t4[RG];
+template <int NG>
+struct TileIdx {              // a lane's LDS addresses (two 16-bit per dword) and tints, per pixel group
+    uint2 iw[NG];
+    uint32_t t4[NG];
 };
 
 // What a wave fetches ahead for its NEXT tile while it works on the current one: the 32-byte
 // header (as two vector loads, so that it is tracked by vmcnt like everything else - an s_load
 // would share lgkmcnt with the LDS traffic and stall the gathers), its LDS indices and tints.
-template <int RG>
+template <int NG>
 struct TilePrefetch {
     uint4 h0, h1;
-    TileIdx<RG> ix;
+    TileIdx<NG> ix;
 };
 
-template <bool RUBIX, int RG>
-__device__ __forceinline__ TilePrefetch<RG> tile_fetch(const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx,
+template <bool RUBIX, int RG, int XG>
+__device__ __forceinline__ TilePrefetch<RG * XG> tile_fetch(const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx,
                                                        const uint8_t *__restrict__ tint_t, int t, int lane)
 {
-    TilePrefetch<RG> p;
+    TilePrefetch<RG * XG> p;
     int tv;
     asm volatile("v_mov_b32 %0, %1" : "=v"(tv) : "s"(t));     // make the address a VGPR: vector loads
     const uint4 *hp = reinterpret_cast<const uint4 *>(hdr) + 2 * (size_t)tv;
@@ -211,9 +212,18 @@ __device__ __forceinline__ TilePrefetch<RG> tile_fetch(const TileHdr *__restrict
     p.h1 = hp[1];
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
-        const size_t slab = ((size_t)t * RG + r) * 256 + lane * 4;
-        p.ix.iw[r] = *reinterpret_cast<const uint2 *>(idx + slab);
-        p.ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + slab) : 0xFFFFFFFFu;
+        const size_t slab = ((size_t)t * RG + r) * (256 * XG) + (size_t)lane * (4 * XG);
+        if (XG == 1) {
+            p.ix.iw[r] = *reinterpret_cast<const uint2 *>(idx + slab);
+            p.ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + slab) : 0xFFFFFFFFu;
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4 *>(idx + slab);
+            p.ix.iw[r * XG] = make_uint2(v.x, v.y);
+            p.ix.iw[r * XG + XG - 1] = make_uint2(v.z, v.w);
+            const uint2 tt = RUBIX ? *reinterpret_cast<const uint2 *>(tint_t + slab) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            p.ix.t4[r * XG] = tt.x;
+            p.ix.t4[r * XG + XG - 1] = tt.y;
+        }
     }
     return p;
 }
@@ -222,12 +232,12 @@ __device__ __forceinline__ TilePrefetch<RG> tile_fetch(const TileHdr *__restrict
 // body is branch-free.  (Tried and measured without gain: a register prefetch of frame f+1's chunks,
 // and issuing several frames' loads before their stores - with 24 waves per CU the memory system,
 // not per-wave latency, is the limiter.)
-template <int NQ, int RG>
+template <int NQ, int RG, int XG>
 __device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
                                            int f_begin, int f_end, uint8_t *__restrict__ out0, int dst_pitch, size_t frame_stride,
                                            uint8_t *lds, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
                                            uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
-                                           bool k0, bool k1, bool k2, bool k3, const TileIdx<RG> ix)
+                                           bool k0, bool k1, bool k2, bool k3, const TileIdx<RG * XG> ix)
 {
     // (explicit scalars, not arrays: the four chunks must stay in VGPRs)
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
@@ -249,9 +259,9 @@ __device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, si
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t w[RG];
+        uint32_t w[RG * XG];
 #pragma unroll
-        for (int r = 0; r < RG; ++r) {
+        for (int r = 0; r < RG * XG; ++r) {
             uint32_t v0 = ix.iw[r].x & 0xFFFFu, v1 = ix.iw[r].x >> 16, v2 = ix.iw[r].y & 0xFFFFu, v3 = ix.iw[r].y >> 16;
             if (!(abl & 4)) { v0 = lds[v0]; v1 = lds[v1]; v2 = lds[v2]; v3 = lds[v3]; }
             w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
@@ -260,15 +270,18 @@ __device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, si
         __builtin_amdgcn_wave_barrier();
         if (!(abl & 2)) {
 #pragma unroll
-            for (int r = 0; r < RG; ++r)
-                *reinterpret_cast<uint32_t *>(out0 + (size_t)f * frame_stride + (size_t)(r * 8) * dst_pitch) = w[r];
+            for (int r = 0; r < RG; ++r) {
+                uint8_t *o = out0 + (size_t)f * frame_stride + (size_t)(r * 8) * dst_pitch;
+                if (XG == 1) *reinterpret_cast<uint32_t *>(o) = w[r];
+                else *reinterpret_cast<uint2 *>(o) = make_uint2(w[r * XG], w[r * XG + XG - 1]);
+            }
         }
     }
 }
 
-template <bool RUBIX, int RG>
+template <bool RUBIX, int RG, int XG>
 __device__ __forceinline__ void tile_process(
-    const TilePrefetch<RG> &pf, int t, int lane, uint8_t *lds, const uint8_t *pal_s,
+    const TilePrefetch<RG * XG> &pf, int t, int lane, uint8_t *lds, const uint8_t *pal_s,
     const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
     int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp,
     int blocks_x, int f_begin, int f_end, int lds_per_wave)
@@ -289,12 +302,12 @@ __device__ __forceinline__ void tile_process(
     }
 
     int ox, oy;
-    tile_origin(t, RG, blocks_x, &ox, &oy);
+    tile_origin(t, RG, XG, blocks_x, &ox, &oy);
     const int ry = lane >> 3, cx = lane & 7;
-    const int row0 = oy + ry, x = ox + cx * 4;             // row group r covers row0 + 8 r
+    const int row0 = oy + ry, x = ox + cx * 4 * XG;        // group g covers row0 + 8 (g / XG), x + 4 (g % XG)
     // a tile whose regions exceed this launch's LDS budget takes the direct-gather path
     const bool slow = (h_flags & F_SLOW) != 0 || (int)l16 * 16 > lds_per_wave;
-    const bool fast_store = (h_flags & F_ALL) && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & 3u) == 0;
+    const bool fast_store = (h_flags & F_ALL) && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & (uintptr_t)(4 * XG - 1)) == 0;
 
     // Frame-invariant staging plan: the 16-byte chunks of all regions are numbered row-major and
     // chunk c = lane + 64 j is lane's j-th: 16 bytes at globe offset q_src[j] -> LDS offset q_lds[j].
@@ -349,7 +362,7 @@ __device__ __forceinline__ void tile_process(
     if (!RUBIX && piped && fast_store) {
         uint8_t *out0 = dst + (size_t)row0 * dst_pitch + x;
         const uint32_t nq = (total_chunks + 63u) >> 6;       // wave-uniform
-#define BK_HOT(N) hot_frames<N, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, dst_pitch, frame_stride, lds, \
+#define BK_HOT(N) hot_frames<N, RG, XG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, dst_pitch, frame_stride, lds, \
                                     q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3],            \
                                     q_ok[0], q_ok[1], q_ok[2], q_ok[3], pf.ix)
         if (nq <= 1) BK_HOT(1);
@@ -361,14 +374,15 @@ __device__ __forceinline__ void tile_process(
     }
 
     // general path: partially mapped tiles, rubix, large regions, the direct-gather fallback
-    uint32_t so[RG][4];
+    constexpr int NG = RG * XG;
+    uint32_t so[NG][4];
     if (slow) {
 #pragma unroll
-        for (int r = 0; r < RG; ++r)
+        for (int r = 0; r < NG; ++r)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int row = row0 + r * 8;
-                so[r][k] = (row < rows && x + k < W) ? lmap[(size_t)row * W + x + k] : BK_NULL_OFFSET;
+                const int row = row0 + (r / XG) * 8, xx = x + (r % XG) * 4 + k;
+                so[r][k] = (row < rows && xx < W) ? lmap[(size_t)row * W + xx] : BK_NULL_OFFSET;
             }
     }
     for (int f = f_begin; f < f_end; ++f) {
@@ -394,7 +408,7 @@ __device__ __forceinline__ void tile_process(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #pragma unroll
-        for (int r = 0; r < RG; ++r) {
+        for (int r = 0; r < NG; ++r) {
             const uint32_t a[4] = {pf.ix.iw[r].x & 0xFFFFu, pf.ix.iw[r].x >> 16, pf.ix.iw[r].y & 0xFFFFu, pf.ix.iw[r].y >> 16};
             uint32_t v[4];
 #pragma unroll
@@ -409,7 +423,7 @@ __device__ __forceinline__ void tile_process(
                     if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
                 }
             }
-            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x;
+            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + (r / XG) * 8) * dst_pitch + x + (r % XG) * 4;
             if (fast_store) {
                 *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
             } else {
@@ -428,7 +442,7 @@ __device__ __forceinline__ void tile_process(
 // Persistent launch: the grid holds a bounded number of workgroups per CU; every wave walks a
 // strided sequence of tiles inside its XCD's band and fetches the header / indices of its next tile
 // before it starts on the current one.
-template <bool RUBIX, int RG>
+template <bool RUBIX, int RG, int XG>
 __global__ __launch_bounds__(256) void apply_tiled_kernel(
     const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
     const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
@@ -454,14 +468,14 @@ __global__ __launch_bounds__(256) void apply_tiled_kernel(
     const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);
 
     int t = __builtin_amdgcn_readfirstlane(l * 4 + wave);
-    TilePrefetch<RG> cur = tile_fetch<RUBIX, RG>(hdr, idx, tint_t, t, lane);
+    TilePrefetch<RG * XG> cur = tile_fetch<RUBIX, RG, XG>(hdr, idx, tint_t, t, lane);
     for (;;) {
         const int l_next = l + wgs_per_band;
         const bool has_next = l_next < l_end;
         const int t_next = __builtin_amdgcn_readfirstlane(l_next * 4 + wave);
-        TilePrefetch<RG> nxt = cur;
-        if (has_next) nxt = tile_fetch<RUBIX, RG>(hdr, idx, tint_t, t_next, lane);
-        tile_process<RUBIX, RG>(cur, t, lane, lds, pal_s, lmap, globe, globe_stride, globe_frames, frame0, dst, dst_pitch,
+        TilePrefetch<RG * XG> nxt = cur;
+        if (has_next) nxt = tile_fetch<RUBIX, RG, XG>(hdr, idx, tint_t, t_next, lane);
+        tile_process<RUBIX, RG, XG>(cur, t, lane, lds, pal_s, lmap, globe, globe_stride, globe_frames, frame0, dst, dst_pitch,
                                 frame_stride, W, rows, gp, blocks_x, f_begin, f_end, lds_per_wave);
         if (!has_next) break;
         l = l_next;
@@ -489,18 +503,21 @@ void tilemap_invalidate(bk_ctx *ctx)
 }
 
 // compile the tilemap for one tile height and read back its statistics
-static int compile_shape(bk_ctx *ctx, TileMap *tm, int rg, double *cost_ps)
+static int compile_shape(bk_ctx *ctx, TileMap *tm, int shape, double *cost_ps)
 {
     const int rows = ctx->rows();
+    const int rg = shape & 7, xg = shape >= 8 ? 2 : 1;       // shape = rg + 8 * (xg - 1)
     tm->rg = rg;
-    tm->blocks_x = (ctx->W + BLOCK_W - 1) / BLOCK_W;
+    tm->xg = xg;
+    tm->blocks_x = (ctx->W + 128 * xg - 1) / (128 * xg);
     tm->blocks_y = (rows + 8 * rg - 1) / (8 * rg);
     const size_t ntiles = (size_t)tm->blocks_x * tm->blocks_y * 4;
     BK_HIP(ctx, hipMemsetAsync(tm->d_stats, 0, 64 * 40 * sizeof(uint32_t), ctx->stream));
     const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-#define BK_COMPILE(N) hipLaunchKernelGGL(tile_compile_kernel<N>, grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
-                                         ctx->ps, ctx->gp, tm->blocks_x, (int)ntiles, tm->d_hdr, tm->d_idx, tm->d_tint, tm->d_stats)
-    if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
+#define BK_COMPILE(N, X) hipLaunchKernelGGL((tile_compile_kernel<N, X>), grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
+                                            ctx->ps, ctx->gp, tm->blocks_x, (int)ntiles, tm->d_hdr, tm->d_idx, tm->d_tint, tm->d_stats)
+    if (xg == 1) { if (rg == 1) BK_COMPILE(1, 1); else if (rg == 2) BK_COMPILE(2, 1); else BK_COMPILE(4, 1); }
+    else { if (rg == 1) BK_COMPILE(1, 2); else BK_COMPILE(2, 2); }
 #undef BK_COMPILE
     BK_HIP(ctx, hipGetLastError());
     static thread_local uint32_t rep[64 * 40];
@@ -537,7 +554,7 @@ static int compile_shape(bk_ctx *ctx, TileMap *tm, int rg, double *cost_ps)
     // cost model (ps per frame) for comparing tile heights: a staged 128-byte line, per-tile fixed work,
     // a tile on the direct-gather path (per pixel group)
     const double nonempty = (double)(staged_all + tm->stats[1]);
-    double c = 8.6 * tm->stats[3] + 120.0 * nonempty + 742.0 * rg * tm->slow_tiles;
+    double c = 8.6 * tm->stats[3] + 120.0 * nonempty + 742.0 * rg * xg * tm->slow_tiles;
     if (cap > 4096) c *= 1.0 + (cap - 4096) / 8192.0;
     *cost_ps = c;
     return BK_OK;
@@ -550,7 +567,7 @@ static int ensure_tilemap(bk_ctx *ctx)
     if (tm->valid) return BK_OK;
     const int rows = ctx->rows();
     // buffers sized for the shortest tiles (most tiles); every height covers <= that many pixels + padding
-    const size_t bx = (ctx->W + BLOCK_W - 1) / BLOCK_W;
+    const size_t bx = (ctx->W + 127) / 128 + 1;
     const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
     const size_t max_tiles = bx * 4 * (size_t)((rows + 7) / 8);
     if (max_px > tm->alloc_px) {
@@ -562,17 +579,21 @@ static int ensure_tilemap(bk_ctx *ctx)
         tm->alloc_px = max_px;
     }
     if (!tm->d_stats) BK_HIP(ctx, hipMalloc((void **)&tm->d_stats, 64 * 40 * sizeof(uint32_t)));
-    // ctx->tile_shape: 0 = default height (RG 2), 1/2/4 = force RG, -1 = compile all three and keep the cheapest
+    // ctx->tile_shape: 0 = default (32x16), shape = rg + 8*(xg-1): 1/2/4 = 32x8/16/32, 9/10 = 64x8/16;
+    // -1 = compile every shape and keep the cheapest by the cost model
+    static const int shapes[5] = {1, 2, 4, 9, 10};
     int best = ctx->tile_shape, compiled = -1;
     if (best == 0) best = 2;
-    if (best != 1 && best != 2 && best != 4) {
+    bool known = false;
+    for (int sh : shapes) known = known || sh == best;
+    if (!known) {
         double best_cost = 0;
         best = -1;
-        for (int rg = 4; rg >= 1; rg >>= 1) {
+        for (int sh : shapes) {
             double c = 0;
-            if (int r = compile_shape(ctx, tm, rg, &c)) return r;
-            compiled = rg;
-            if (best < 0 || c < best_cost) { best = rg; best_cost = c; }
+            if (int r = compile_shape(ctx, tm, sh, &c)) return r;
+            compiled = sh;
+            if (best < 0 || c < best_cost) { best = sh; best_cost = c; }
         }
     }
     if (compiled != best) {
@@ -602,11 +623,16 @@ int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int d
     if (wgs_per_band > per) wgs_per_band = per;
     dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
     const size_t shmem = (size_t)4 * tm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
-#define BK_APPLY(RBX, N) hipLaunchKernelGGL((apply_tiled_kernel<RBX, N>), grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,      \
+#define BK_APPLY(RBX, N, X) hipLaunchKernelGGL((apply_tiled_kernel<RBX, N, X>), grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,      \
                                             ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride, \
                                             ctx->W, rows, ctx->gp, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal)
-    if (rubix_on) { if (tm->rg == 1) BK_APPLY(true, 1); else if (tm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
-    else { if (tm->rg == 1) BK_APPLY(false, 1); else if (tm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
+    if (tm->xg == 1) {
+        if (rubix_on) { if (tm->rg == 1) BK_APPLY(true, 1, 1); else if (tm->rg == 2) BK_APPLY(true, 2, 1); else BK_APPLY(true, 4, 1); }
+        else { if (tm->rg == 1) BK_APPLY(false, 1, 1); else if (tm->rg == 2) BK_APPLY(false, 2, 1); else BK_APPLY(false, 4, 1); }
+    } else {
+        if (rubix_on) { if (tm->rg == 1) BK_APPLY(true, 1, 2); else BK_APPLY(true, 2, 2); }
+        else { if (tm->rg == 1) BK_APPLY(false, 1, 2); else BK_APPLY(false, 2, 2); }
+    }
 #undef BK_APPLY
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;
@@ -623,7 +649,7 @@ int tilemap_stats(bk_ctx *ctx, int out[6])
     if (int r = ensure_tilemap(ctx)) return r;
     TileMap *tm = ctx->tilemap;
     out[0] = tm->blocks_x * tm->blocks_y * 4; out[1] = tm->slow_tiles; out[2] = (int)tm->stats[2]; out[3] = tm->lds_bytes;
-    out[4] = 8 * tm->rg; out[5] = (int)tm->stats[3];
+    out[4] = 8 * tm->rg + 1000 * 32 * tm->xg; out[5] = (int)tm->stats[3];       // width*1000 + height
     return BK_OK;
 }
 
