@@ -80,6 +80,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipFree(ctx->d_pal);
     hipFree(ctx->d_display);
     bk::tilemap_free(ctx->tilemap);
+    bk::coopmap_free(ctx->coopmap);
     bk::lensprogram_free(ctx->prog);
     delete ctx;
 }
@@ -224,6 +225,9 @@ extern "C" int bk_debug_set_ablation(bk_ctx *ctx, int bits)
 extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
 {
     if (!ctx) return BK_E_INVALID;
+    if (lw >= 400) { ctx->apply_lds_kb = lw - 400; bk::tilemap_invalidate(ctx); return BK_OK; }
+    if (lw >= 300) { ctx->apply_fchunk = lw - 300; return BK_OK; }
+    if (lw >= 200) { ctx->apply_flags = lw - 200; return BK_OK; }
     if (lw >= 100) { ctx->apply_wgs_per_cu = lw - 100; return BK_OK; }      // developer knob: 100+n = n workgroups per CU
     if (lw != 0 && lw != -1 && lw != 1 && lw != 2 && lw != 4 && lw != 9 && lw != 10) return BK_E_INVALID;
     ctx->tile_shape = lw;
@@ -236,7 +240,7 @@ extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
     if (!ctx || !out) return BK_E_INVALID;
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "no lensmap");
     if (int r = ensure_device(ctx)) return r;
-    return bk::tilemap_stats(ctx, out);
+    return ctx->apply_variant == 1 ? bk::tilemap_stats(ctx, out) : bk::coopmap_stats(ctx, out);
 }
 
 extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }

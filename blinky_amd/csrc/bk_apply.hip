@@ -166,7 +166,8 @@ int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pit
 {
     const int rows = ctx->rows();
     if (rows <= 0 || nframes <= 0) return BK_OK;
-    if (ctx->apply_variant != 0) return launch_apply_tiled(ctx, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
+    if (ctx->apply_variant == 1) return launch_apply_tiled(ctx, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
+    if (ctx->apply_variant != 0) return launch_apply_coop(ctx, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
     const size_t gstride = ctx->globe_stride();
     const int fchunk = nframes < 8 ? nframes : 8;
     const int fblocks = (nframes + fchunk - 1) / fchunk;

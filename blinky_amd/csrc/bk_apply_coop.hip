@@ -1,0 +1,571 @@
+// blinky-hip: workgroup-cooperative LDS-staged apply kernel (variant 2, the default) for gfx950.
+//
+// The per-wave tiled kernel (variant 1, bk_apply_tiled.hip) stages, per wave, the bounding boxes of
+// the plate texels under a 32-pixel-wide tile.  Counters on MI355X show what limits it: a 128-byte
+// globe line spans ~3.5 such tiles and screen rows are slanted in plate space, so the same lines are
+// requested over and over (TCP->TCC read requests = 5-6x the unique lines, L1 hit rate ~23 %,
+// TCP_PENDING_STALL ~2/3 of the kernel's cycles; kernel time tracks that request count) and, because
+// waves drift apart in time, part of those requests goes to HBM again (TCC_EA0_RDREQ = 1.6x unique).
+//
+// Here the unit of staging is the workgroup block of 128 x (8*RG) pixels and what is staged is the
+// EXACT set of 16-byte globe chunks the block's pixels read - no bounding boxes.  `coop_compile_kernel`
+// sorts the block's chunk numbers (bitonic sort in LDS), keeps the unique ones in ascending address
+// order as the block's chunk list, and rewrites every pixel's lensmap entry as a 16-bit LDS address
+// (slot * 16 + byte).  Per frame the 256 threads copy chunk list entry i to LDS slot i (neighbouring
+// lanes fetch neighbouring chunks of a line: one request per line and block), meet at one
+// s_barrier, and every wave gathers its 32-pixel column from the shared copy (ds_read_u8) and
+// stores 4 pixels per lane.  Two LDS buffers alternate, so one barrier per frame is enough: the
+// buffer a wave overwrites for frame f+2 was last read before the barrier of frame f+1.
+//
+// Same launch shape as variant 1: persistent grid, XCD-banded block order, next block's header,
+// chunk list head and indices prefetched, a batch launch re-uses a block's plan for up to 8 frames.
+// The chunk list is layout-agnostic: it holds byte offsets into a globe frame.
+//
+// replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
+#include "bk_internal.h"
+
+namespace bk {
+
+constexpr int BK_COOP_LDS_CAP = 49152;                 // max bytes of one staging buffer (3072 chunks)
+constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's column fully mapped / empty
+constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
+constexpr int BK_COOP_STATS = 128;                     // words per stats replica
+
+struct CoopHdr {              // 8 bytes per block
+    uint32_t nchunks;         // entries of the block's chunk list (0 for direct-gather / empty blocks)
+    uint32_t flags;
+};
+
+struct CoopMap {
+    CoopHdr *d_hdr = nullptr;
+    uint32_t *d_list = nullptr;     // [nblocks][256*4*RG] byte offsets (16-byte aligned) into a globe frame, ascending
+    uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][256] LDS addresses, 0xFFFF = unmapped
+    uint8_t *d_tint = nullptr;      // same order (rubix)
+    uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
+                                    // [3] 128-B lines staged, [4] chunks staged, [8..57) blocks by LDS need (1 KiB bins),
+                                    // [64..113) 128-B lines of those blocks
+    int blocks_x = 0, blocks_y = 0;
+    int rg = 4;
+    int lds_bytes = 0;              // bytes of ONE staging buffer of the apply launch
+    uint32_t stats[BK_COOP_STATS] = {0};
+    int slow_blocks = 0;
+    bool valid = false;
+    size_t alloc_px = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// compile: one workgroup per block
+// ---------------------------------------------------------------------------------------------
+template <int RG>
+__global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
+                                                           int W, int rows, int blocks_x, int nblocks,
+                                                           CoopHdr *__restrict__ hdr, uint32_t *__restrict__ list,
+                                                           uint16_t *__restrict__ idx, uint8_t *__restrict__ tint_t,
+                                                           uint32_t *__restrict__ stats)
+{
+    constexpr int NP = 4 * RG, N = 256 * NP;      // pixels per thread / per block
+    __shared__ uint32_t key[N];                   // chunk numbers, sorted in place
+    __shared__ uint32_t uniq[N];                  // unique chunk numbers, ascending
+    __shared__ uint32_t s_wsum[4], s_wlines[4];
+    __shared__ uint32_t s_flags;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x;
+    const int by = blk / blocks_x, bx = blk - by * blocks_x;
+    const int ox = (bx * 4 + wave) * 32, oy = by * 8 * RG;
+    const int ry = lane >> 3, cx = lane & 7;
+    const int x0 = ox + cx * 4;
+    if (threadIdx.x == 0) s_flags = 0;
+
+    uint32_t o[NP];
+    uint8_t tn[NP];
+    bool all_l = true, any_l = false;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = oy + (i >> 2) * 8 + ry, x = x0 + (i & 3);
+        const bool in = row < rows && x < W;
+        o[i] = in ? lmap[(size_t)row * W + x] : BK_NULL_OFFSET;
+        tn[i] = in ? tints[(size_t)row * W + x] : 255;
+        key[threadIdx.x * NP + i] = o[i] == BK_NULL_OFFSET ? 0xFFFFFFFFu : o[i] >> 4;
+        all_l = all_l && o[i] != BK_NULL_OFFSET;
+        any_l = any_l || o[i] != BK_NULL_OFFSET;
+    }
+    const bool all = __all(all_l), any = __any(any_l);
+    __syncthreads();
+    if (lane == 0) atomicOr(&s_flags, (all ? CF_ALL << wave : 0u) | (any ? 0u : CF_NONE << wave));
+
+    // bitonic sort of the N chunk numbers, ascending (unmapped = 0xFFFFFFFF sorts last)
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < N / 2; t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const uint32_t a = key[i], b = key[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { key[i] = b; key[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // unique: thread t owns sorted positions [t*NP, t*NP+NP)
+    uint32_t cnt = 0, lcnt = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = threadIdx.x * NP + i;
+        const uint32_t v = key[p], prev = p > 0 ? key[p - 1] : 0xFFFFFFFFu;
+        const bool first = v != 0xFFFFFFFFu && (p == 0 || v != prev);
+        cnt += first ? 1u : 0u;
+        lcnt += (first && (p == 0 || (v >> 3) != (prev >> 3))) ? 1u : 0u;       // a new 128-byte line
+    }
+    uint32_t incl = cnt, lsum = lcnt;
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t u = __shfl_up(incl, m);
+        if (lane >= m) incl += u;
+    }
+    for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m);
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_wlines[wave] = lsum;
+    __syncthreads();
+    uint32_t base = incl - cnt;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    const uint32_t nchunks = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const uint32_t lines = s_wlines[0] + s_wlines[1] + s_wlines[2] + s_wlines[3];
+    const bool slow = nchunks * 16u > (uint32_t)BK_COOP_LDS_CAP;
+    {
+        uint32_t k = base;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = threadIdx.x * NP + i;
+            const uint32_t v = key[p];
+            if (v != 0xFFFFFFFFu && (p == 0 || v != key[p - 1])) {
+                uniq[k] = v;
+                if (!slow) list[(size_t)blk * N + k] = v << 4;
+                ++k;
+            }
+        }
+    }
+    __syncthreads();
+
+    // every pixel: slot of its chunk (binary search in the unique list) -> 16-bit LDS address
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        uint32_t a[4], tw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = r * 4 + k;
+            a[k] = 0xFFFFu;
+            if (o[i] != BK_NULL_OFFSET) {
+                a[k] = 0;
+                if (!slow) {
+                    const uint32_t c = o[i] >> 4;
+                    uint32_t lo = 0, hi = nchunks;              // first slot with uniq[slot] >= c
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (uniq[mid] < c) lo = mid + 1; else hi = mid;
+                    }
+                    a[k] = lo * 16u + (o[i] & 15u);
+                }
+            }
+            tw |= (uint32_t)tn[i] << (8 * k);
+        }
+        const size_t slab = (((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4;
+        *reinterpret_cast<uint2 *>(idx + slab) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+        *reinterpret_cast<uint32_t *>(tint_t + slab) = tw;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t wflags = s_flags;
+        const bool any_blk = nchunks != 0;
+        CoopHdr h;
+        h.nchunks = slow ? 0u : nchunks;
+        h.flags = wflags | (slow ? CF_SLOW : 0u) | (any_blk ? 0u : CF_EMPTY);
+        hdr[blk] = h;
+        uint32_t *st = stats + (blk & 63) * BK_COOP_STATS;
+        if (!slow && any_blk) {
+            atomicMax(&st[0], nchunks);
+            const uint32_t bin = min(48u, (nchunks * 16u + 1023u) / 1024u);
+            atomicAdd(&st[8 + bin], 1u);
+            atomicAdd(&st[64 + bin], lines);
+            atomicAdd(&st[3], lines);
+            atomicAdd(&st[4], nchunks);
+        }
+        if (slow) atomicAdd(&st[1], 1u);
+        if (!any_blk) atomicAdd(&st[2], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply
+// ---------------------------------------------------------------------------------------------
+template <int RG>
+struct CoopIdx {              // a lane's LDS addresses (two 16-bit per dword) and tints, per row group
+    uint2 iw[RG];
+    uint32_t t4[RG];
+};
+// What a thread fetches ahead for its workgroup's NEXT block: the header (a vector load, so that it
+// is tracked by vmcnt like everything else), its first four chunk-list entries, its LDS indices.
+template <int RG>
+struct CoopPrefetch {
+    uint2 h;
+    uint32_t c[4];
+    CoopIdx<RG> ix;
+};
+
+template <bool RUBIX, int RG>
+__device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list,
+                                                      const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
+                                                      int blk, int wave, int lane)
+{
+    constexpr int N = 1024 * RG;
+    CoopPrefetch<RG> p;
+    int bv;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bv) : "s"(blk));     // make the address a VGPR: vector load
+    p.h = *(reinterpret_cast<const uint2 *>(hdr) + (size_t)bv);
+    const uint32_t *lp = list + (size_t)blk * N + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.c[j] = 256 * j < N ? lp[256 * j] : 0u;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const size_t slab = (((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4;
+        p.ix.iw[r] = *reinterpret_cast<const uint2 *>(idx + slab);
+        p.ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + slab) : 0xFFFFFFFFu;
+    }
+    return p;
+}
+
+// Frames of one staged block.  A thread's first four chunks (16 KiB per block) are in registers;
+// blocks with more read the rest of their list each frame (it stays in L2).
+template <int NQ, bool RUBIX, int RG>
+__device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
+                                            int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
+                                            uint8_t *lds0, uint32_t lds_buf, uint32_t &par, const uint32_t *__restrict__ blist,
+                                            uint32_t nchunks, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
+                                            bool k0, bool k1, bool k2, bool k3, const CoopIdx<RG> ix, bool fast_store,
+                                            bool tile_empty, const uint8_t *pal_s, int row0, int x, int kflags)
+{
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;     // (scalars, not an array: they must stay in VGPRs)
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        uint8_t *buf = lds0 + par * lds_buf;
+        uint8_t *mine = buf + threadIdx.x * 16u;
+        if (!(kflags & 2)) {
+            q0 = *reinterpret_cast<const uint4 *>(gl + s0);
+            if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
+            if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
+            if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
+        }
+        if (k0) *reinterpret_cast<uint4 *>(mine) = q0;
+        if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(mine + 4096) = q1;
+        if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(mine + 8192) = q2;
+        if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(mine + 12288) = q3;
+        if (NQ > 3) {
+            for (uint32_t c0 = 1024; c0 < nchunks; c0 += 1024) {      // blocks above 16 KiB: rounds of four loads
+                const uint32_t c = c0 + threadIdx.x;
+                const bool m0 = c < nchunks, m1 = c + 256u < nchunks, m2 = c + 512u < nchunks, m3 = c + 768u < nchunks;
+                const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
+                               a3 = m3 ? blist[c + 768u] : 0u;
+                q0 = *reinterpret_cast<const uint4 *>(gl + a0);
+                q1 = *reinterpret_cast<const uint4 *>(gl + a1);
+                q2 = *reinterpret_cast<const uint4 *>(gl + a2);
+                q3 = *reinterpret_cast<const uint4 *>(gl + a3);
+                uint8_t *md = mine + (size_t)c0 * 16u;
+                if (m0) *reinterpret_cast<uint4 *>(md) = q0;
+                if (m1) *reinterpret_cast<uint4 *>(md + 4096) = q1;
+                if (m2) *reinterpret_cast<uint4 *>(md + 8192) = q2;
+                if (m3) *reinterpret_cast<uint4 *>(md + 12288) = q3;
+            }
+        }
+        __syncthreads();                      // the block's chunks are in `buf`
+        par ^= 1u;
+        if (tile_empty) continue;
+        if (!RUBIX && fast_store) {
+            uint32_t w[RG];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const uint32_t v0 = buf[ix.iw[r].x & 0xFFFFu], v1 = buf[ix.iw[r].x >> 16], v2 = buf[ix.iw[r].y & 0xFFFFu], v3 = buf[ix.iw[r].y >> 16];
+                w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+            }
+            if (!(kflags & 4)) {
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+                    *reinterpret_cast<uint32_t *>(dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x) = w[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
+                    if (RUBIX) {
+                        const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
+                        if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+                    }
+                }
+                uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x;
+                if (fast_store) {
+                    *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
+                }
+            }
+        }
+    }
+}
+
+// direct-gather frames of a block whose chunk list does not fit the staging buffer
+template <bool RUBIX, int RG>
+__device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
+                                              int globe_frames, int frame0, int f_begin, int f_end, uint8_t *__restrict__ dst,
+                                              int dst_pitch, size_t frame_stride, int W, int rows, const CoopIdx<RG> ix,
+                                              const uint8_t *pal_s, int row0, int x)
+{
+    uint32_t so[RG][4];
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = row0 + r * 8, xx = x + k;
+            so[r][k] = (row < rows && xx < W) ? lmap[(size_t)row * W + xx] : BK_NULL_OFFSET;
+        }
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (so[r][k] == BK_NULL_OFFSET) continue;
+                uint32_t v = gl[so[r][k]];
+                if (RUBIX) {
+                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
+                    if (tt != 255u) v = pal_s[tt * 256 + v];
+                }
+                out[k] = (uint8_t)v;
+            }
+        }
+    }
+}
+
+template <bool RUBIX, int RG>
+__global__ __launch_bounds__(256) void apply_coop_kernel(
+    const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list, const uint16_t *__restrict__ idx,
+    const uint8_t *__restrict__ tint_t, const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe,
+    size_t globe_stride, int globe_frames, int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
+    int W, int rows, int blocks_x, int nblocks, int nframes, int fchunk, int lds_buf, const uint8_t *__restrict__ pal, int kflags)
+{
+    constexpr int N = 1024 * RG;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *pal_s = smem + 2 * lds_buf;
+    if (RUBIX) {
+        for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += 256) pal_s[i] = pal[i];
+        __syncthreads();
+    }
+    // XCD-banded mapping: workgroup b runs on XCD b % 8 (observed dispatch order); XCD k owns the
+    // contiguous band [k*per, (k+1)*per) of blocks.  Correctness does not depend on it.
+    const int per = (nblocks + 7) / 8;
+    const int band = (int)(blockIdx.x & 7);
+    const int wg_in_band = (int)(blockIdx.x >> 3), wgs_per_band = (int)(gridDim.x >> 3);
+    const int l_end = min(nblocks, (band + 1) * per);
+    int l = band * per + wg_in_band;
+    if (l >= l_end) return;
+    const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & 3u) == 0;
+    const int ry = lane >> 3, cx = lane & 7;
+    uint32_t par = 0;
+
+    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l, wave, lane);
+    for (;;) {
+        const int l_next = l + wgs_per_band;
+        const bool has_next = l_next < l_end;
+        CoopPrefetch<RG> nxt = cur;
+        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l_next, wave, lane);
+
+        const uint32_t nchunks = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.x);      // wave-uniform values -> SGPRs
+        const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.y);
+        if (!(flags & CF_EMPTY)) {
+            const int by = l / blocks_x, bx = l - by * blocks_x;
+            const int row0 = by * 8 * RG + ry, x = (bx * 4 + wave) * 32 + cx * 4;
+            const bool tile_all = (flags >> wave) & 1u, tile_empty = (flags >> (4 + wave)) & 1u;
+            // a block whose chunk list exceeds this launch's staging buffer takes the direct-gather path
+            const bool slow = (flags & CF_SLOW) != 0 || (int)(nchunks * 16u) > lds_buf;
+            if (slow) {
+                if (!tile_empty)
+                    coop_slow_frames<RUBIX, RG>(lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch,
+                                                frame_stride, W, rows, cur.ix, pal_s, row0, x);
+            } else {
+                const bool k0 = threadIdx.x < nchunks, k1 = threadIdx.x + 256u < nchunks, k2 = threadIdx.x + 512u < nchunks,
+                           k3 = threadIdx.x + 768u < nchunks;
+                const uint32_t s0 = k0 ? cur.c[0] : 0u, s1 = k1 ? cur.c[1] : 0u, s2 = k2 ? cur.c[2] : 0u, s3 = k3 ? cur.c[3] : 0u;
+                const bool fast_store = tile_all && aligned;
+                const uint32_t nq = (nchunks + 255u) >> 8;
+#define BK_COOP(NQ_) coop_frames<NQ_, RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, smem, \
+                                                (uint32_t)lds_buf, par, list + (size_t)l * N, nchunks, s0, s1, s2, s3, k0, k1, k2, k3,    \
+                                                cur.ix, fast_store, tile_empty, pal_s, row0, x, kflags)
+                if (nq <= 1) BK_COOP(1);
+                else if (nq == 2) BK_COOP(2);
+                else if (nq == 3) BK_COOP(3);
+                else BK_COOP(4);
+#undef BK_COOP
+            }
+        }
+        if (!has_next) break;
+        l = l_next;
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void coopmap_free(CoopMap *cm)
+{
+    if (!cm) return;
+    (void)hipFree(cm->d_hdr);
+    (void)hipFree(cm->d_list);
+    (void)hipFree(cm->d_idx);
+    (void)hipFree(cm->d_tint);
+    (void)hipFree(cm->d_stats);
+    delete cm;
+}
+
+void coopmap_invalidate(bk_ctx *ctx)
+{
+    if (ctx->coopmap) ctx->coopmap->valid = false;
+}
+
+static int coop_compile(bk_ctx *ctx, CoopMap *cm, int rg)
+{
+    const int rows = ctx->rows();
+    cm->rg = rg;
+    cm->blocks_x = (ctx->W + 127) / 128;
+    cm->blocks_y = (rows + 8 * rg - 1) / (8 * rg);
+    const int nblocks = cm->blocks_x * cm->blocks_y;
+    BK_HIP(ctx, hipMemsetAsync(cm->d_stats, 0, 64 * BK_COOP_STATS * sizeof(uint32_t), ctx->stream));
+    const dim3 grid((unsigned)nblocks), block(256);
+#define BK_COMPILE(N) hipLaunchKernelGGL((coop_compile_kernel<N>), grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
+                                         cm->blocks_x, nblocks, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, cm->d_stats)
+    if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
+#undef BK_COMPILE
+    BK_HIP(ctx, hipGetLastError());
+    static thread_local uint32_t rep[64 * BK_COOP_STATS];
+    BK_HIP(ctx, hipMemcpyAsync(rep, cm->d_stats, sizeof rep, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < BK_COOP_STATS; ++k) cm->stats[k] = 0;
+    for (int r = 0; r < 64; ++r) {
+        cm->stats[0] = rep[r * BK_COOP_STATS] > cm->stats[0] ? rep[r * BK_COOP_STATS] : cm->stats[0];
+        for (int k = 1; k < BK_COOP_STATS; ++k) cm->stats[k] += rep[r * BK_COOP_STATS + k];
+    }
+    return BK_OK;
+}
+
+// Cost model (ns per frame, fitted to MI355X measurements of four lenses x three block
+// heights x five buffer sizes): a staged 128-byte line costs ~13 ps on top of ~0.5 ps per pixel, a block on
+// the direct-gather path ~16 ns per row group, and fewer resident workgroups per CU (two staging
+// buffers each; registers allow `vg`) stretch everything.  Returns the best buffer size in KiB.
+static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, double *cost_ns)
+{
+    static const double pen[7] = {2.0, 2.0, 1.29, 1.11, 1.04, 1.0, 1.0};
+    const int vg = rg == 4 ? 4 : 6;
+    int best_bin = 1;
+    double best_c = -1;
+    for (int bin = 1; bin * 1024 <= BK_COOP_LDS_CAP; ++bin) {
+        uint64_t over = 0, lines_fit = 0;
+        for (int b = 0; b <= 48; ++b) {
+            if (b <= bin) lines_fit += cm->stats[64 + b];
+            else over += cm->stats[8 + b];
+        }
+        int wgs = (160 * 1024) / (2 * bin * 1024 + BK_MAX_PLATES * 256);
+        if (wgs > vg) wgs = vg;
+        if (wgs < 1) wgs = 1;
+        const double c = (0.013 * (double)lines_fit + 0.00048 * npixels) * pen[wgs] + 16.0 * rg * (double)(over + cm->stats[1]);
+        if (best_c < 0 || c < best_c) { best_c = c; best_bin = bin; }
+    }
+    *cost_ns = best_c;
+    return best_bin;
+}
+
+static int ensure_coopmap(bk_ctx *ctx)
+{
+    if (!ctx->coopmap) ctx->coopmap = new CoopMap();
+    CoopMap *cm = ctx->coopmap;
+    if (cm->valid) return BK_OK;
+    const int rows = ctx->rows();
+    const int forced = ctx->tile_shape == 1 || ctx->tile_shape == 2 || ctx->tile_shape == 4 ? ctx->tile_shape : 0;   // developer knob
+    const size_t bx = (ctx->W + 127) / 128;
+    const size_t max_blocks = bx * (size_t)((rows + 7) / 8);
+    const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
+    if (max_px > cm->alloc_px) {
+        (void)hipFree(cm->d_hdr); (void)hipFree(cm->d_list); (void)hipFree(cm->d_idx); (void)hipFree(cm->d_tint);
+        cm->d_hdr = nullptr; cm->d_list = nullptr; cm->d_idx = nullptr; cm->d_tint = nullptr;
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_hdr, max_blocks * sizeof(CoopHdr)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_list, max_px * sizeof(uint32_t)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_idx, max_px * sizeof(uint16_t)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_tint, max_px));
+        cm->alloc_px = max_px;
+    }
+    if (!cm->d_stats) BK_HIP(ctx, hipMalloc((void **)&cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t)));
+    // block height: the cheapest of 128x8 / 128x16 / 128x32 by the cost model, unless forced
+    int cand[3] = {4, 2, 1}, ncand = 3;
+    if (forced) { cand[0] = forced; ncand = 1; }
+    int best_rg = cand[0], best_kb = 1, compiled = 0;
+    double best_cost = -1;
+    for (int i = 0; i < ncand; ++i) {
+        if (int r = coop_compile(ctx, cm, cand[i])) return r;
+        compiled = cand[i];
+        double c = 0;
+        const int kb = coop_choose_buffer(cm, cand[i], (double)ctx->W * rows, &c);
+        if (best_cost < 0 || c < best_cost) { best_cost = c; best_rg = cand[i]; best_kb = kb; }
+    }
+    if (compiled != best_rg)
+        if (int r = coop_compile(ctx, cm, best_rg)) return r;
+    if (ctx->apply_lds_kb > 0) best_kb = ctx->apply_lds_kb > BK_COOP_LDS_CAP / 1024 ? BK_COOP_LDS_CAP / 1024 : ctx->apply_lds_kb;   // developer knob
+    uint64_t over = 0;
+    for (int b = best_kb + 1; b <= 48; ++b) over += cm->stats[8 + b];
+    cm->lds_bytes = best_kb * 1024;
+    cm->slow_blocks = (int)(cm->stats[1] + over);
+    cm->valid = true;
+    return BK_OK;
+}
+
+int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on)
+{
+    const int rows = ctx->rows();
+    if (rows <= 0 || nframes <= 0) return BK_OK;
+    if (int r = ensure_coopmap(ctx)) return r;
+    CoopMap *cm = ctx->coopmap;
+    const int blocks_x = cm->blocks_x, nblocks = blocks_x * cm->blocks_y;
+    const int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : 8;
+    const int fchunk = nframes < fmax ? nframes : fmax;
+    const int fblocks = (nframes + fchunk - 1) / fchunk;
+    const int per = (nblocks + 7) / 8;
+    int wgs_per_band = per;
+    const int resident_per_band = ctx->num_cus * ctx->apply_wgs_per_cu / 8;
+    if (fblocks * wgs_per_band > resident_per_band) wgs_per_band = (resident_per_band + fblocks - 1) / fblocks;
+    if (wgs_per_band < 1) wgs_per_band = 1;
+    if (wgs_per_band > per) wgs_per_band = per;
+    dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
+    const size_t shmem = (size_t)2 * cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
+#define BK_APPLY(RBX, N) hipLaunchKernelGGL((apply_coop_kernel<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
+                                           cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
+                                           dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, cm->lds_bytes,     \
+                                           ctx->d_pal, ctx->apply_flags)
+    if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
+    else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
+#undef BK_APPLY
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+int coopmap_stats(bk_ctx *ctx, int out[6])
+{
+    if (int r = ensure_coopmap(ctx)) return r;
+    CoopMap *cm = ctx->coopmap;
+    out[0] = cm->blocks_x * cm->blocks_y; out[1] = cm->slow_blocks; out[2] = (int)cm->stats[2]; out[3] = cm->lds_bytes;
+    out[4] = 8 * cm->rg + 1000 * 128; out[5] = (int)cm->stats[3];
+    return BK_OK;
+}
+
+}  // namespace bk

@@ -237,12 +237,13 @@ __device__ __forceinline__ void hot_frames(const uint8_t *__restrict__ globe, si
                                            int f_begin, int f_end, uint8_t *__restrict__ out0, int dst_pitch, size_t frame_stride,
                                            uint8_t *lds, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
                                            uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
-                                           bool k0, bool k1, bool k2, bool k3, const TileIdx<RG * XG> ix)
+                                           bool k0, bool k1, bool k2, bool k3, const TileIdx<RG * XG> ix, bool wg_sync)
 {
     // (explicit scalars, not arrays: the four chunks must stay in VGPRs)
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
     const int abl = g_ablate;
     for (int f = f_begin; f < f_end; ++f) {
+        if (wg_sync) __builtin_amdgcn_s_barrier();
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
         if (!(abl & 1)) {
             q0 = *reinterpret_cast<const uint4 *>(gl + s0);
@@ -284,7 +285,7 @@ __device__ __forceinline__ void tile_process(
     const TilePrefetch<RG * XG> &pf, int t, int lane, uint8_t *lds, const uint8_t *pal_s,
     const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
     int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp,
-    int blocks_x, int f_begin, int f_end, int lds_per_wave)
+    int blocks_x, int f_begin, int f_end, int lds_per_wave, bool wg_sync)
 {
     // header words -> SGPRs (the values are wave-uniform)
     const uint32_t h_src[3] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h0.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.h0.y),
@@ -295,7 +296,11 @@ __device__ __forceinline__ void tile_process(
     const uint32_t h_w16[3] = {w01 & 0xFFFFu, w01 >> 16, w2r0 & 0xFFFFu};
     const uint32_t h_rows[3] = {w2r0 >> 16, r12 & 0xFFFFu, r12 >> 16};
     const uint32_t h_nreg = nf & 0xFFFFu, h_flags = nf >> 16;
-    if (h_flags & F_EMPTY) return;
+    if (h_flags & F_EMPTY) {
+        // (wg_sync: the four waves of a workgroup meet once per frame, whatever path their tile takes)
+        if (wg_sync) for (int f = f_begin; f < f_end; ++f) __builtin_amdgcn_s_barrier();
+        return;
+    }
     if (g_ablate & 16) {                       // developer ablation: header + indices only
         if (pf.ix.iw[0].x == 0x12345678u && h_src[0] == 0xFFFFFFFFu) dst[0] = 1;
         return;
@@ -364,7 +369,7 @@ __device__ __forceinline__ void tile_process(
         const uint32_t nq = (total_chunks + 63u) >> 6;       // wave-uniform
 #define BK_HOT(N) hot_frames<N, RG, XG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, out0, dst_pitch, frame_stride, lds, \
                                     q_src[0], q_src[1], q_src[2], q_src[3], q_lds[0], q_lds[1], q_lds[2], q_lds[3],            \
-                                    q_ok[0], q_ok[1], q_ok[2], q_ok[3], pf.ix)
+                                    q_ok[0], q_ok[1], q_ok[2], q_ok[3], pf.ix, wg_sync)
         if (nq <= 1) BK_HOT(1);
         else if (nq == 2) BK_HOT(2);
         else if (nq == 3) BK_HOT(3);
@@ -374,6 +379,8 @@ __device__ __forceinline__ void tile_process(
     }
 
     // general path: partially mapped tiles, rubix, large regions, the direct-gather fallback
+    if ((g_ablate & 32) && !slow) return;      // developer ablations: skip staged-general / direct-gather tiles
+    if ((g_ablate & 64) && slow) return;
     constexpr int NG = RG * XG;
     uint32_t so[NG][4];
     if (slow) {
@@ -386,9 +393,12 @@ __device__ __forceinline__ void tile_process(
             }
     }
     for (int f = f_begin; f < f_end; ++f) {
+        if (wg_sync) __builtin_amdgcn_s_barrier();
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
         if (!slow) {
-            // stage chunk by chunk (rows of the padded globe are 64-byte aligned)
+            // stage the regions in rounds of 4 chunks per lane: the four 16-byte loads of a round are
+            // issued back to back before their LDS stores (one exposed memory latency per round, not
+            // per chunk; rows of the padded globe are 64-byte aligned)
             int base16 = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -396,10 +406,22 @@ __device__ __forceinline__ void tile_process(
                 const uint32_t w16 = h_w16[r], nrows = h_rows[r], pitch16 = w16 | 1u, total = w16 * nrows;
                 const uint32_t magic = w16 > 1 ? 0xFFFFFFFFu / w16 + 1u : 0u;
                 const uint8_t *src = gl + h_src[r];
-                for (uint32_t c = lane; c < total; c += 64) {
-                    const uint32_t yy = w16 > 1 ? __umulhi(c, magic) : c, xx = c - yy * w16;
-                    const uint4 qq = *reinterpret_cast<const uint4 *>(src + (size_t)yy * gp + xx * 16);
-                    *reinterpret_cast<uint4 *>(lds + (size_t)(base16 + yy * pitch16 + xx) * 16) = qq;
+                for (uint32_t c0 = 0; c0 < total; c0 += 256) {
+                    uint4 qq[4];
+                    uint32_t dd[4];
+                    bool okk[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t c = c0 + (uint32_t)lane + 64u * j;
+                        okk[j] = c < total;
+                        const uint32_t cc = okk[j] ? c : 0u;
+                        const uint32_t yy = w16 > 1 ? __umulhi(cc, magic) : cc, xx = cc - yy * w16;
+                        qq[j] = *reinterpret_cast<const uint4 *>(src + (size_t)yy * gp + xx * 16);
+                        dd[j] = (uint32_t)(base16 + yy * pitch16 + xx) * 16u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (okk[j]) *reinterpret_cast<uint4 *>(lds + dd[j]) = qq[j];
                 }
                 base16 += nrows * pitch16;
             }
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(256) void apply_tiled_kernel(
     const TileHdr *__restrict__ hdr, const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
     const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames,
     int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int gp,
-    int blocks_x, int nblocks, int nframes, int fchunk, int lds_per_wave, const uint8_t *__restrict__ pal)
+    int blocks_x, int nblocks, int nframes, int fchunk, int lds_per_wave, const uint8_t *__restrict__ pal, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(256) void apply_tiled_kernel(
         TilePrefetch<RG * XG> nxt = cur;
         if (has_next) nxt = tile_fetch<RUBIX, RG, XG>(hdr, idx, tint_t, t_next, lane);
         tile_process<RUBIX, RG, XG>(cur, t, lane, lds, pal_s, lmap, globe, globe_stride, globe_frames, frame0, dst, dst_pitch,
-                                frame_stride, W, rows, gp, blocks_x, f_begin, f_end, lds_per_wave);
+                                frame_stride, W, rows, gp, blocks_x, f_begin, f_end, lds_per_wave, (flags & 1) != 0);
         if (!has_next) break;
         l = l_next;
         t = t_next;
@@ -500,6 +522,7 @@ void tilemap_free(TileMap *tm)
 void tilemap_invalidate(bk_ctx *ctx)
 {
     if (ctx->tilemap) ctx->tilemap->valid = false;
+    coopmap_invalidate(ctx);
 }
 
 // compile the tilemap for one tile height and read back its statistics
@@ -611,7 +634,8 @@ int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int d
     if (int r = ensure_tilemap(ctx)) return r;
     TileMap *tm = ctx->tilemap;
     const int blocks_x = tm->blocks_x, nblocks = blocks_x * tm->blocks_y;
-    const int fchunk = nframes < 8 ? nframes : 8;
+    const int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : 8;
+    const int fchunk = nframes < fmax ? nframes : fmax;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     const int per = (nblocks + 7) / 8;
     // persistent grid: enough workgroups to fill the chip a few times over; each walks its XCD band
@@ -625,7 +649,7 @@ int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int d
     const size_t shmem = (size_t)4 * tm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
 #define BK_APPLY(RBX, N, X) hipLaunchKernelGGL((apply_tiled_kernel<RBX, N, X>), grid, dim3(256), shmem, ctx->stream, tm->d_hdr, tm->d_idx, tm->d_tint,      \
                                             ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst, dst_pitch, frame_stride, \
-                                            ctx->W, rows, ctx->gp, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal)
+                                            ctx->W, rows, ctx->gp, blocks_x, nblocks, nframes, fchunk, tm->lds_bytes, ctx->d_pal, ctx->apply_flags)
     if (tm->xg == 1) {
         if (rubix_on) { if (tm->rg == 1) BK_APPLY(true, 1, 1); else if (tm->rg == 2) BK_APPLY(true, 2, 1); else BK_APPLY(true, 4, 1); }
         else { if (tm->rg == 1) BK_APPLY(false, 1, 1); else if (tm->rg == 2) BK_APPLY(false, 2, 1); else BK_APPLY(false, 4, 1); }

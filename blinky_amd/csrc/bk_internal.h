@@ -20,6 +20,7 @@ struct Span { int row, x0, x1; };
 struct Rubix { int numcells = 10; double cell = 4, pad = 1; };   // defaults: fisheye.c:672
 
 struct LensProgram;   // bk_lens.cpp: parsed scripts + hiprtc modules
+struct CoopMap;       // bk_apply_coop.hip: per-block staging plans of the workgroup-cooperative apply kernel
 struct TileMap;       // bk_apply.hip: compact tiled lensmap for the staged apply kernel
 
 }  // namespace bk
@@ -64,11 +65,15 @@ struct bk_ctx {
     std::vector<bk::Span> spans;     // mapped spans of the owned rows
     bool spans_valid = false;
 
-    int apply_variant = -1;          // -1 auto
+    int apply_variant = -1;          // -1 auto (= 2); 0 direct gather, 1 per-wave LDS tiles, 2 workgroup-cooperative LDS blocks
     int num_cus = 256;               // multiProcessorCount of the device
+    int apply_flags = 0;             // developer knobs (bk_debug_set_tile_shape 200+v): bit0 = workgroup barrier per frame
+    int apply_lds_kb = 0;            // coop apply: force the staging buffer size in KiB (0 = cost model; knob 400+n)
+    int apply_fchunk = 0;            // frames a wave keeps a tile for (0 = default 8; knob 300+n)
     int apply_wgs_per_cu = 16;       // persistent apply grid: workgroups per CU (tunable, bk_debug_set_tile_shape)
     int tile_shape = 0;              // tiled apply: 0 = default tile height (rg 2), 1/2/4 = force rg, -1 = search by cost model
     bk::TileMap *tilemap = nullptr;       // owned; freed with bk::tilemap_free
+    bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
 
@@ -108,6 +113,12 @@ int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_
 int tilemap_stats(bk_ctx *ctx, int out[6]);
 int set_ablation(bk_ctx *ctx, int bits);      // developer timing ablations of the tiled apply   // tiles, slow tiles, empty tiles, LDS bytes per wave
 void tilemap_free(TileMap *);
+// bk_apply_coop.hip
+void coopmap_invalidate(bk_ctx *ctx);
+int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,
+                      size_t frame_stride, int rubix_on);
+int coopmap_stats(bk_ctx *ctx, int out[6]);   // blocks, direct-gather blocks, empty blocks, LDS bytes per buffer
+void coopmap_free(CoopMap *);
 
 // bk_lens.cpp
 void lensprogram_free(LensProgram *);

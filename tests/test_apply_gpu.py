@@ -35,7 +35,7 @@ def upload_globe(ctx, globe, frame=0):
         ctx.upload_plate(frame, p, globe[p])
 
 
-VARIANTS = [0, 1]
+VARIANTS = [0, 1, 2]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

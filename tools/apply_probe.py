@@ -37,18 +37,26 @@ out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
 ABL = [int(x) for x in os.environ.get("BK_ABLATE", "0").split(",")]
 SHAPES = [int(x) for x in os.environ.get("BK_SHAPES", "0").split(",")]
 WGS = [int(x) for x in os.environ.get("BK_WGS", "6").split(",")]
-for v, abl, shp, wg in [(v, a, sh, wg) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])]:
+FLAGS = [int(x) for x in os.environ.get("BK_FLAGS", "0").split(",")]     # bit0: workgroup barrier per frame
+FCH = [int(x) for x in os.environ.get("BK_FCHUNK", "0").split(",")]      # frames per tile visit (0 = default)
+REPS = int(os.environ.get("BK_REPS", "20"))
+LDSKB = [int(x) for x in os.environ.get("BK_LDSKB", "0").split(",")]    # coop apply: staging buffer KiB (0 = cost model)
+for v, abl, shp, wg, fl, fc, kb in [(v, a, sh, wg, fl, fc, kb) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])
+                               for fl in (FLAGS if v != 0 else [0]) for fc in (FCH if v != 0 else [0]) for kb in (LDSKB if v == 2 else [0])]:
     ctx.set_apply_variant(v)
     if v != 0:
         ctx.set_tile_shape(shp)
         ctx.set_tile_shape(100 + wg)
         ctx.set_ablation(abl)
-        print(f"shape {shp} ablation {abl} wgs/cu {wg}; tile stats:", ctx.tile_stats(), flush=True)
+        ctx.set_tile_shape(200 + fl)
+        ctx.set_tile_shape(300 + fc)
+        ctx.set_tile_shape(400 + kb)
+        print(f"shape {shp} ablation {abl} wgs/cu {wg} flags {fl} fchunk {fc} ldskb {kb}; tile stats:", ctx.tile_stats(), flush=True)
     for nf in sorted(set([1, F])):
         for _ in range(3):
             ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)
         torch.cuda.synchronize()
-        reps = 20
+        reps = REPS
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for r in range(reps):

@@ -1,0 +1,64 @@
+// Calibration probe (developer tool, not part of the library): streaming read / write / copy rates
+// of this GPU with 16-byte accesses, and a known byte count for checking the FETCH_SIZE /
+// WRITE_SIZE counter units under rocprofv3 --pmc.   hipcc --offload-arch=gfx950 -O3 membw_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void probe_read(const uint4 *__restrict__ a, size_t n, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 v = a[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
+__global__ __launch_bounds__(256) void probe_write(uint4 *__restrict__ a, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        a[i] = make_uint4((uint32_t)i, 1, 2, 3);
+}
+__global__ __launch_bounds__(256) void probe_copy(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+// the apply kernel's traffic mix: read 13 bytes, write 8 (per 21)
+__global__ __launch_bounds__(256) void probe_mix(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 v = a[i];
+        if ((i & 7) < 5) b[i] = v; else if (v.x == 0x12345679u) b[0] = v;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const size_t bytes = (argc > 1 ? (size_t)atol(argv[1]) : 1024) << 20;
+    const size_t n = bytes / 16;
+    uint4 *a, *b; uint32_t *sink;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int grids[] = {256 * 4, 256 * 8, 256 * 16, 256 * 32};
+    for (int g : grids) {
+        for (int k = 0; k < 4; ++k) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; ++rep) {
+                CK(hipEventRecord(e0));
+                if (k == 0) hipLaunchKernelGGL(probe_read, dim3(g), dim3(256), 0, 0, a, n, sink);
+                if (k == 1) hipLaunchKernelGGL(probe_write, dim3(g), dim3(256), 0, 0, b, n);
+                if (k == 2) hipLaunchKernelGGL(probe_copy, dim3(g), dim3(256), 0, 0, a, b, n);
+                if (k == 3) hipLaunchKernelGGL(probe_mix, dim3(g), dim3(256), 0, 0, a, b, n);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            const double moved = k == 2 ? 2.0 * bytes : k == 3 ? bytes * (1.0 + 5.0 / 8.0) : (double)bytes;
+            printf("%-5s grid %5d: %8.3f ms  %7.2f TB/s (bytes moved %.0f MiB)\n",
+                   k == 0 ? "read" : k == 1 ? "write" : k == 2 ? "copy" : "mix", g, best, moved / best / 1e9, moved / 1048576.0);
+        }
+    }
+    return 0;
+}

@@ -33,7 +33,25 @@ def pmc_table(path):
         print(f"{c:12s} grid {g:9d} calls {n:4d} avg {avg:14.2f} min {mn:14.2f} max {mx:14.2f}  {k[:90]}")
 
 
+def pmc_sequence(path, like="%apply_tiled%"):
+    """per-dispatch counter values in launch order (for probes that step through configurations)"""
+    con = sqlite3.connect(path)
+    print(f"== per-dispatch counters: {path}")
+    q = ("select dispatch_id, grid_size_x, grid_size_y, duration/1e3, counter_name, value from counters_collection "
+         "where kernel_name like ? order by dispatch_id, counter_name")
+    rows = {}
+    for d, gx, gy, dur, c, v in con.execute(q, (like,)):
+        rows.setdefault(d, [gx, gy, dur, {}])[3][c] = v
+    for d in sorted(rows):
+        gx, gy, dur, cs = rows[d]
+        print(f"{d:5d} grid {gx}x{gy} {dur:9.2f} us  " + "  ".join(f"{k}={v:.0f}" for k, v in cs.items()))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--seq":
+        for p in sys.argv[2:]:
+            pmc_sequence(p)
+        sys.exit(0)
     kernel_table(sys.argv[1])
     for p in sys.argv[2:]:
         pmc_table(p)
