@@ -242,16 +242,21 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                                             bool tile_empty, const uint8_t *pal_s, int row0, int x, int kflags)
 {
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;     // (scalars, not an array: they must stay in VGPRs)
+    const bool pipe = (kflags & 8) == 0;      // issue frame f+1's loads before frame f's gather (developer flag 8 turns it off)
+#define BK_COOP_LOADS(F)                                                                                   \
+    do {                                                                                                   \
+        const uint8_t *gl_ = globe + (size_t)((frame0 + (F)) % globe_frames) * globe_stride;              \
+        q0 = *reinterpret_cast<const uint4 *>(gl_ + s0);                                                   \
+        if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl_ + s1);                                       \
+        if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl_ + s2);                                       \
+        if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl_ + s3);                                       \
+    } while (0)
+    if (pipe && f_begin < f_end) BK_COOP_LOADS(f_begin);
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
         uint8_t *buf = lds0 + par * lds_buf;
         uint8_t *mine = buf + threadIdx.x * 16u;
-        if (!(kflags & 2)) {
-            q0 = *reinterpret_cast<const uint4 *>(gl + s0);
-            if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl + s1);
-            if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl + s2);
-            if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl + s3);
-        }
+        if (!pipe && !(kflags & 2)) BK_COOP_LOADS(f);
         if (k0) *reinterpret_cast<uint4 *>(mine) = q0;
         if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(mine + 4096) = q1;
         if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(mine + 8192) = q2;
@@ -275,6 +280,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
         }
         __syncthreads();                      // the block's chunks are in `buf`
         par ^= 1u;
+        if (pipe && f + 1 < f_end) BK_COOP_LOADS(f + 1);
         if (tile_empty) continue;
         if (!RUBIX && fast_store) {
             uint32_t w[RG];
@@ -313,6 +319,8 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
         }
     }
 }
+
+#undef BK_COOP_LOADS
 
 // direct-gather frames of a block whose chunk list does not fit the staging buffer
 template <bool RUBIX, int RG>

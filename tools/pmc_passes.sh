@@ -22,7 +22,7 @@ G[fetch]="FETCH_SIZE"
 G[write]="WRITE_SIZE"
 for g in "$@"; do
     rm -rf /tmp/pmc_$g
-    timeout ${PMC_TIMEOUT:-100} rocprofv3 --pmc ${G[$g]} --kernel-trace -d /tmp/pmc_$g -o pmc -- python $R/tools/apply_probe.py $LENS 3840 2160 16 1 > "$OUT/$g.log" 2>&1
+    timeout ${PMC_TIMEOUT:-100} rocprofv3 --pmc ${G[$g]} --kernel-trace -d /tmp/pmc_$g -o pmc -- python $R/tools/apply_probe.py $LENS 3840 2160 16 ${PROBE_VARIANT:-2} > "$OUT/$g.log" 2>&1
     db=$(find /tmp/pmc_$g -name "*.db" | head -1)
-    if [ -n "$db" ]; then { if [ -n "$PMC_SEQ" ]; then python $R/tools/prof_summary.py --seq "$db"; else python $R/tools/prof_summary.py "$db" "$db"; fi; } 2>&1 | grep -E "apply_tiled|^==|grid" > "$OUT/$g.txt"; else echo "no db (rc/pass failed)" > "$OUT/$g.txt"; tail -5 "$OUT/$g.log" >> "$OUT/$g.txt"; fi
+    if [ -n "$db" ]; then { if [ -n "$PMC_SEQ" ]; then python $R/tools/prof_summary.py --seq "$db"; else python $R/tools/prof_summary.py "$db" "$db"; fi; } 2>&1 | grep -E "apply_tiled|apply_coop|^==|grid" > "$OUT/$g.txt"; else echo "no db (rc/pass failed)" > "$OUT/$g.txt"; tail -5 "$OUT/$g.log" >> "$OUT/$g.txt"; fi
 done

@@ -33,7 +33,7 @@ def pmc_table(path):
         print(f"{c:12s} grid {g:9d} calls {n:4d} avg {avg:14.2f} min {mn:14.2f} max {mx:14.2f}  {k[:90]}")
 
 
-def pmc_sequence(path, like="%apply_tiled%"):
+def pmc_sequence(path, like="%apply_%"):
     """per-dispatch counter values in launch order (for probes that step through configurations)"""
     con = sqlite3.connect(path)
     print(f"== per-dispatch counters: {path}")
