@@ -8,7 +8,10 @@ the lensmap is built on the device from the bundled Lua scripts before the timed
 A *step* = one pass of the hot path over one batch: `frames` frames (distinct resident globes,
 one shared lensmap) warped by one bk_apply_device launch; with N > 1 ranks each rank owns a
 stripe of output rows (it builds and keeps only that stripe of the lensmap, holds a full globe
-replica) and the step ends with the RCCL gather of the stripes onto rank 0.
+replica) and the step ends with the frames' reassembly: one grouped RCCL send/recv in which frame f's
+stripes travel to rank f % N (blinky_amd.multigpu.exchange_rotating), overlapped with the next batch's
+warp.  (All frames gathered onto rank 0 - the single-display case, bounded by one GPU's xGMI ingest -
+is timed too and reported as `assembled_on_rank0_mpx_s`.)
 
 Prints ONE JSON line (rank 0).  `value` = whole-job Mpixels/s = W*H*frames*steps / time.
 """
@@ -78,6 +81,8 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="frames per step (batch warped by one launch)")
     ap.add_argument("--variant", type=int, default=-1, help="apply kernel variant (-1 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region, compare every reassembled frame this rank owns with a full-frame warp")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,7 +90,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # BLINKY_BENCH_BACKEND=gloo + BLINKY_BENCH_ONE_GPU=1: developer smoke of the N > 1 control flow on a
+        # single-GPU box (all ranks on cuda:0, stripes exchanged through host memory); never a measurement
+        dist.init_process_group(os.environ.get("BLINKY_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    host_exchange = world > 1 and dist.get_backend() == "gloo"
+    if os.environ.get("BLINKY_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -123,16 +133,46 @@ def main():
     torch.cuda.synchronize()
 
     rows = r1 - r0
-    stripe = torch.zeros((F, rows, W), dtype=torch.uint8, device=dev)       # Draw_TileClear stand-in: 0
+    # Draw_TileClear stand-in: 0.  Two stripe buffers, so that batch i+1 is warped while batch i's stripes travel.
+    stripes = [torch.zeros((F, rows, W), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    stripe = stripes[0]
+    nown = (F + world - 1) // world
+    xdev = torch.device("cpu") if host_exchange else dev
+    frames_out = [torch.zeros((nown, H, W), dtype=torch.uint8, device=xdev) for _ in range(2)] if world > 1 else None
+    pending = [[], []]
     gather_list = None
     if world > 1 and rank == 0:
         hmax = max(bounds[r + 1] - bounds[r] for r in range(world))
         gather_list = [torch.empty((F, hmax, W), dtype=torch.uint8, device=dev) for r in range(world)]
 
+    def origin(t):
+        # bk_apply_device takes the address of the frame's pixel (0,0) and writes the owned rows [r0, r1) only;
+        # a stripe buffer holds just those rows, so its frame origin lies r0 rows before it
+        return t.data_ptr() - r0 * W
+
     def step(i):
-        ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=(i * F) % F, nframes=F)
+        # one batch: warp this rank's stripe of F frames, then reassemble frame f on rank f % world (one grouped
+        # RCCL send/recv per batch; buffers alternate, the exchange of batch i overlaps the warp of batch i+1)
+        b = i & 1 if world > 1 else 0
+        for w in pending[b]:
+            w.wait()
+        pending[b] = []
+        ctx.apply_device(origin(stripes[b]), W, rows * W, frame0=(i * F) % F, nframes=F)
         if world > 1:
-            multigpu.gather_stripes(stripe, bounds, rank, world, 0, gather_list)
+            src = stripes[b].cpu() if host_exchange else stripes[b]
+            pending[b] = multigpu.exchange_rotating(src, bounds, rank, world, frames_out[b], wait=False)
+
+    def drain():
+        for b in range(2):
+            for w in pending[b]:
+                w.wait()
+            pending[b] = []
+
+    def step_root(i):
+        # the single-display variant: every frame of the batch gathered onto rank 0
+        ctx.apply_device(origin(stripe), W, rows * W, frame0=(i * F) % F, nframes=F)
+        multigpu.gather_stripes(stripe.cpu() if host_exchange else stripe, bounds, rank, world, 0,
+                                None if host_exchange else gather_list)
 
     def barrier():
         torch.cuda.synchronize()
@@ -142,23 +182,37 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    root_elapsed = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # extra (not `value`): all frames assembled on rank 0 - bounded by one GPU's xGMI ingest
+        nroot = max(3, args.steps // 5)
+        step_root(0)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(nroot):
+            step_root(i)
+        barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / nroot], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        root_elapsed = float(t.item())
 
     # ---- the dominant kernel alone, HIP events on the launch stream (roofline) ------------------------
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     e0.record(stream)
     for i in range(args.steps):
-        ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=0, nframes=F)
+        ctx.apply_device(origin(stripe), W, rows * W, frame0=0, nframes=F)
     e1.record(stream)
     torch.cuda.synchronize()
     kernel_ms = e0.elapsed_time(e1) / args.steps
@@ -173,10 +227,34 @@ def main():
     barrier()
     e0.record(stream)
     for i in range(args.steps):
-        ctx.apply_device(stripe.data_ptr(), W, rows * W, frame0=i % F, nframes=1)
+        ctx.apply_device(origin(stripe), W, rows * W, frame0=i % F, nframes=1)
     e1.record(stream)
     torch.cuda.synchronize()
     single_ms = e0.elapsed_time(e1) / args.steps
+
+    if args.check:
+        # every frame this rank ends up holding == the same frame warped whole by a full-height context
+        full_ctx = blinky_amd.Context(local_rank)
+        full_ctx.set_stream(stream.cuda_stream)
+        full_ctx.set_frames(F)
+        S.configure(full_ctx, GLOBE, LENS, ZOOM, (W, H))
+        full_ctx.build()
+        for f in range(F):
+            for p in range(6):
+                full_ctx.fill_plate_lcg(f, p, f)
+        full = torch.zeros((F, H, W), dtype=torch.uint8, device=dev)
+        full_ctx.apply_device(full.data_ptr(), W, H * W, frame0=0, nframes=F)
+        torch.cuda.synchronize()
+        if world > 1:
+            last = frames_out[(args.steps - 1) & 1]
+            bad = [f for f in multigpu.owned_frames(F, rank, world) if not torch.equal(last[f // world].to(dev), full[f])]
+        else:
+            ctx.apply_device(origin(stripe), W, rows * W, frame0=0, nframes=F)
+            torch.cuda.synchronize()
+            bad = [f for f in range(F) if not torch.equal(stripe[f], full[f])]
+        print(f"[check] rank {rank}: {'OK' if not bad else 'MISMATCH in frames ' + str(bad)}", file=sys.stderr, flush=True)
+        if bad:
+            sys.exit(3)
 
     if rank == 0:
         px_per_step = W * H * F
@@ -198,7 +276,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step (distinct resident globes, one lensmap)",
-                       "frames_per_step": F, "parallelism": f"row-stripes x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                       "frames_per_step": F, "parallelism": f"row-stripes x{world}" + (" + RCCL grouped send/recv: frame f reassembled on rank f%N" if world > 1 else ""),
                        "apply_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -208,6 +286,7 @@ def main():
             "lensmap_build_first_wall_ms_incl_hiprtc": round(build_first_wall_ms, 1),
             "lensmap_tilemap_compile_wall_ms": round(tilemap_wall_ms, 3), "tile_stats": tile_stats,
             "stripe_complete_mpx_s": round(stripe_complete_mpx, 1),
+            "assembled_on_rank0_mpx_s": round(W * H * F / root_elapsed / 1e6, 1) if root_elapsed else None,
             "single_frame_launch_us": round(single_ms * 1e3, 2),
             "single_frame_mpx_s": round(W * rows / (single_ms * 1e-3) / 1e6, 1),
             "lens_scale": scale,

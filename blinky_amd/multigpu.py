@@ -2,9 +2,17 @@
 
 Every output pixel is independent (SURVEY.md 8(e)): rank r owns rows [H*r//N, H*(r+1)//N), builds and
 keeps only that stripe of the lensmap (no exchange, ever), holds a full replica of the globe, warps
-its stripe, and the frame is reassembled by ONE collective: a gather of the stripes onto a root
-(RCCL over xGMI on GPUs; gloo in the CPU tests).  The only other exchange is a 6-int OR of the
-display[] flags after a build, so every rank knows which plates the whole frame reads."""
+its stripe, and the frame is reassembled by ONE grouped exchange per batch (RCCL over xGMI on GPUs;
+gloo in the CPU tests):
+
+* `gather_stripes`     - every frame onto one root (what a single display needs).  The root's xGMI
+                         ingest (7 links) bounds it: 7/8 of every frame's bytes enter one GPU.
+* `exchange_rotating`  - batches: frame f is reassembled on rank f % N (a gather whose root rotates),
+                         one grouped send/recv per batch, so all N*(N-1) links carry stripes at once and
+                         every GPU ends up holding whole frames (1/N of the batch each).
+
+The only other exchange is a 6-int OR of the display[] flags after a build, so every rank knows
+which plates the whole frame reads."""
 import torch
 import torch.distributed as dist
 
@@ -37,6 +45,41 @@ def gather_stripes(stripe, bounds, rank, world, dst=0, out_list=None):
         return [t[..., : heights[r], :] for r, t in enumerate(out_list)]
     dist.gather(send.contiguous(), None, dst=dst)
     return None
+
+
+def owned_frames(nframes, rank, world):
+    """frames of a batch that `exchange_rotating` assembles on `rank`: f = rank, rank + N, ..."""
+    return list(range(rank, nframes, world))
+
+
+def exchange_rotating(stripe, bounds, rank, world, out, wait=True):
+    """stripe: uint8 [F, rows_r, W] - this rank's rows of F frames.  out: uint8 [ceil(F/N), H, W].
+    Afterwards out[k] is the complete frame f = k*N + rank.  One grouped exchange (ncclGroup of
+    sends/recvs under RCCL): rank r sends its stripe of frame f to rank f % N and receives, for each
+    frame it owns, the other ranks' stripes straight into the rows they belong to (a row slice of a
+    frame is contiguous, so no staging copy and uneven stripes need no padding).
+    Returns the pending work handles when wait=False (the caller overlaps the next batch's warp)."""
+    F = stripe.shape[0]
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    for f in owned_frames(F, rank, world):
+        out[f // world, r0:r1, :].copy_(stripe[f])                      # my own rows of my frames
+    if world == 1:
+        return []
+    ops = []
+    for f in range(F):                                                   # same order on every rank (gloo matches in order)
+        owner = f % world
+        if owner == rank:
+            for src in range(world):
+                if src != rank:
+                    ops.append(dist.P2POp(dist.irecv, out[f // world, bounds[src]:bounds[src + 1], :], src))
+        else:
+            ops.append(dist.P2POp(dist.isend, stripe[f], owner))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if wait:
+        for w in works:
+            w.wait()
+        return []
+    return works
 
 
 def assemble(stripes):

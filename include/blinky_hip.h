@@ -130,7 +130,10 @@ int   bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t seed_frame);
  * bk_apply        dst is host memory (vid.buffer), pitch vid.rowbytes, origin scr_vrect.{x,y};
  *                 it is synchronous.  Only the owned rows are touched.
  * bk_apply_device dst is device memory holding nframes frames of frame_stride bytes each;
- *                 frame f is warped from globe (frame0+f) % nframes_resident.  Asynchronous on the stream. */
+ *                 frame f is warped from globe (frame0+f) % nframes_resident.  Asynchronous on the stream.
+ *                 dst addresses pixel (0,0) of frame 0 of the WHOLE view; only the owned rows
+ *                 [row0,row1) (bk_set_rows) are written, at dst + f*frame_stride + y*pitch + x.  A caller that
+ *                 keeps just its stripe (frame_stride = rows*pitch) passes stripe_base - row0*pitch. */
 int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int x0, int y0,
              int rubix_on, const uint8_t pal[BK_MAX_PLATES][256]);
 int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst_pitch,

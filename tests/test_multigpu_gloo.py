@@ -59,6 +59,16 @@ def _worker(rank, world, port, H, W, lens, out_path):
         open(out_path, "w").write("ok" if ok else "MISMATCH")
     else:
         assert got is None
+    # the batch exchange: frame f reassembled on rank f % world
+    mine = multigpu.owned_frames(F, rank, world)
+    outb = torch.zeros((max(1, (F + world - 1) // world), H, W), dtype=torch.uint8)
+    multigpu.exchange_rotating(torch.from_numpy(stripes), bounds, rank, world, outb)
+    ok2 = True
+    for f in mine:
+        want = np.zeros((H, W), np.uint8)
+        O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(ps, 6, f), want)
+        ok2 = ok2 and np.array_equal(outb[f // world].numpy(), want)
+    open(out_path + f".rot{rank}", "w").write("ok" if ok2 else "MISMATCH")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,6 +78,8 @@ def test_stripes_gather_to_the_full_frame(tmp_path, world, H):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), H, 480, "hammer", out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+    for r in range(world):
+        assert open(out + f".rot{r}").read() == "ok"        # every rank holds its frames of the batch, complete
 
 
 def test_stripe_bounds_cover_every_row_once():
