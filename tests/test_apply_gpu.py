@@ -181,6 +181,65 @@ def test_apply_4k_frame_hash_equals_reference_golden(bk, key, variant):
     ctx.close()
 
 
+def _scrambled_lensmap(W, H, ps, kind, seed):
+    """a lensmap no lens would produce: the apply must be exact for ANY table of offsets / NULLs / tints"""
+    rng = np.random.default_rng(seed)
+    n = W * H
+    if kind == "random":            # every pixel its own random texel: one chunk per pixel
+        off = rng.integers(0, 6 * ps * ps, n, dtype=np.uint32)
+    elif kind == "rows":            # long horizontal runs at random rows (few lines, many chunks)
+        y = rng.integers(0, ps, H)[:, None]
+        p = rng.integers(0, 6, H)[:, None]
+        x = (np.arange(W)[None, :] * 3 + rng.integers(0, ps, H)[:, None]) % ps
+        off = (p * ps * ps + y * ps + x).astype(np.uint32).reshape(-1)
+    else:                           # "columns": vertical runs (one texel column per pixel column)
+        x = rng.integers(0, ps, W)[None, :]
+        yy = (np.arange(H)[:, None] * 2 + rng.integers(0, ps, W)[None, :]) % ps
+        p = rng.integers(0, 6, W)[None, :]
+        off = (p * ps * ps + yy * ps + x).astype(np.uint32).reshape(-1)
+    off[rng.random(n) < 0.07] = O.NULL
+    tints = rng.integers(0, 6, n).astype(np.uint8)
+    tints[rng.random(n) < 0.5] = 255
+    return off, tints
+
+
+@pytest.mark.parametrize("kind", ["random", "rows", "columns"])
+@pytest.mark.parametrize("shape,ldskb", [(0, 0), (1, 0), (1, 48), (2, 48), (4, 48), (4, 8), (2, 1)])
+def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb):
+    """Variant 2 on arbitrary tables, with the block height and staging buffer forced so that blocks take the
+    register plan (<= 1024 chunks), the extra rounds (> 1024 chunks), and the direct-gather fallback (list larger
+    than the buffer); rubix on and off, unaligned pitch/origin, a batch longer than one frame chunk."""
+    import torch
+    W, H, ps, F = 517, 301, 301, 3
+    off, tints = _scrambled_lensmap(W, H, ps, kind, seed=shape * 100 + ldskb)
+    pal = O.palmap(O.synthetic_basepal())
+    ctx = bk.Context()
+    ctx.set_frames(F)
+    ctx.resize(W, H)
+    ctx.set_apply_variant(2)
+    ctx.set_tile_shape(shape)
+    ctx.set_tile_shape(400 + ldskb)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    globes = [O.lcg_globe(ps, 6, f) for f in range(F)]
+    for f in range(F):
+        upload_globe(ctx, globes[f], f)
+    ctx.set_lensmap(off, tints)
+    stats = ctx.tile_stats()
+    for rubix in (False, True):
+        for pitch, x0, y0 in ((W, 0, 0), (W + 5, 3, 2)):
+            out = torch.full((F, H + 4, pitch), 77, dtype=torch.uint8, device="cuda")
+            ctx.apply_device(out.data_ptr(), pitch, (H + 4) * pitch, frame0=1, nframes=F, x0=x0, y0=y0, rubix_on=rubix, pal=pal)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for f in range(F):
+                want = np.full((H + 4, pitch), 77, np.uint8)
+                O.apply(off, tints, W, H, globes[(1 + f) % F], want, pitch, x0, y0, rubix, pal)
+                np.testing.assert_array_equal(got[f], want, err_msg=f"{kind} shape {shape} ldskb {ldskb} rubix {rubix} frame {f} stats {stats}")
+    if kind == "random" and (shape, ldskb) == (2, 1):
+        assert stats["slow"] > 0            # 2048 chunks per block against a 1 KiB buffer: the fallback ran
+    ctx.close()
+
+
 def test_errors_are_reported_not_fatal(bk):
     ctx = bk.Context()
     with pytest.raises(bk.BlinkyError):
