@@ -66,7 +66,7 @@ static void free_maps(bk_ctx *ctx)
     ctx->map_px = 0;
     ctx->lensmap_valid = false;
     ctx->spans_valid = false;
-    bk::tilemap_invalidate(ctx);
+    bk::coopmap_invalidate(ctx);
 }
 
 extern "C" void bk_destroy(bk_ctx *ctx)
@@ -77,9 +77,9 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     free_maps(ctx);
     hipFree(ctx->d_globe);
+    hipFree(ctx->d_plate_stage);
     hipFree(ctx->d_pal);
     hipFree(ctx->d_display);
-    bk::tilemap_free(ctx->tilemap);
     bk::coopmap_free(ctx->coopmap);
     bk::lensprogram_free(ctx->prog);
     delete ctx;
@@ -124,7 +124,7 @@ static int alloc_maps(bk_ctx *ctx)
 
 static int alloc_globe(bk_ctx *ctx)
 {
-    const size_t need = (size_t)ctx->nframes * ctx->globe_stride();   // fisheye.c:718 per frame, rows padded to gp
+    const size_t need = (size_t)ctx->nframes * ctx->globe_stride();   // fisheye.c:718 per frame, plates padded to gp x ph
     if (need == ctx->globe_bytes && ctx->d_globe) return BK_OK;
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(ctx->d_globe);
@@ -143,6 +143,7 @@ extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
     if (width <= 0 || height <= 0) return ctx->fail(BK_E_INVALID, "bk_resize: bad size %dx%d", width, height);
     if (ctx->device < 0) {                      // host-only: geometry for calc_zoom / code generation
         ctx->W = width; ctx->H = height; ctx->ps = std::min(width, height); ctx->gp = (ctx->ps + 63) & ~63;
+        ctx->ph = (ctx->ps + 7) & ~7;
         ctx->row0 = 0; ctx->row1 = height;
         return BK_OK;
     }
@@ -150,10 +151,14 @@ extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
     if (width == ctx->W && height == ctx->H) return BK_OK;
     // (6*ps*ps and W*H must fit the uint32 lensmap entries)
     const int ps = std::min(width, height);                                  // fisheye.c:707
-    const int gp = (ps + 63) & ~63;
-    if ((uint64_t)BK_MAX_PLATES * gp * ps >= 0xFFFFFFFFull)
+    const int gp = (ps + 63) & ~63, ph = (ps + 7) & ~7;
+    if ((uint64_t)BK_MAX_PLATES * gp * ph >= 0xFFFFFFFFull)
         return ctx->fail(BK_E_INVALID, "bk_resize: platesize %d overflows 32-bit offsets", ps);
-    ctx->W = width; ctx->H = height; ctx->ps = ps; ctx->gp = gp;
+    ctx->W = width; ctx->H = height; ctx->ps = ps; ctx->gp = gp; ctx->ph = ph;
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_plate_stage);
+    ctx->d_plate_stage = nullptr;
+    BK_HIP(ctx, hipMalloc((void **)&ctx->d_plate_stage, (size_t)gp * ps));
     ctx->row0 = 0; ctx->row1 = height;
     ctx->lensmap_valid = false;
     if (int r = alloc_maps(ctx)) return r;
@@ -218,20 +223,19 @@ extern "C" int bk_set_apply_variant(bk_ctx *ctx, int variant)
 extern "C" int bk_debug_set_ablation(bk_ctx *ctx, int bits)
 {
     if (!ctx) return BK_E_INVALID;
-    if (int r = ensure_device(ctx)) return r;
-    return bk::set_ablation(ctx, bits);
+    ctx->apply_flags = bits;
+    return BK_OK;
 }
 
 extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
 {
     if (!ctx) return BK_E_INVALID;
-    if (lw >= 400) { ctx->apply_lds_kb = lw - 400; bk::tilemap_invalidate(ctx); return BK_OK; }
+    if (lw >= 400) { ctx->apply_lds_kb = lw - 400; bk::coopmap_invalidate(ctx); return BK_OK; }
     if (lw >= 300) { ctx->apply_fchunk = lw - 300; return BK_OK; }
-    if (lw >= 200) { ctx->apply_flags = lw - 200; return BK_OK; }
     if (lw >= 100) { ctx->apply_wgs_per_cu = lw - 100; return BK_OK; }      // developer knob: 100+n = n workgroups per CU
-    if (lw != 0 && lw != -1 && lw != 1 && lw != 2 && lw != 4 && lw != 9 && lw != 10) return BK_E_INVALID;
+    if (lw != 0 && lw != 1 && lw != 2 && lw != 4) return BK_E_INVALID;
     ctx->tile_shape = lw;
-    bk::tilemap_invalidate(ctx);
+    bk::coopmap_invalidate(ctx);
     return BK_OK;
 }
 
@@ -240,7 +244,7 @@ extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
     if (!ctx || !out) return BK_E_INVALID;
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "no lensmap");
     if (int r = ensure_device(ctx)) return r;
-    return ctx->apply_variant == 1 ? bk::tilemap_stats(ctx, out) : bk::coopmap_stats(ctx, out);
+    return bk::coopmap_stats(ctx, out);
 }
 
 extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }
@@ -260,7 +264,7 @@ extern "C" int bk_set_lensmap(bk_ctx *ctx, const uint32_t *offsets, const uint8_
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->lensmap_valid = true;
     ctx->spans_valid = false;
-    bk::tilemap_invalidate(ctx);
+    bk::coopmap_invalidate(ctx);
     return BK_OK;
 }
 
@@ -289,6 +293,12 @@ extern "C" void *bk_globe_device_ptr(bk_ctx *ctx, int frame)
 }
 
 extern "C" int bk_globe_pitch(const bk_ctx *ctx) { return ctx ? ctx->gp : 0; }
+extern "C" int bk_globe_rows(const bk_ctx *ctx) { return ctx ? ctx->ph : 0; }
+extern "C" uint32_t bk_globe_texel_offset(const bk_ctx *ctx, int plate, int px, int py)
+{
+    if (!ctx || plate < 0 || plate >= BK_MAX_PLATES || px < 0 || py < 0 || px >= ctx->ps || py >= ctx->ps) return BK_NULL_OFFSET;
+    return bk_texel_offset((uint32_t)ctx->gp, (uint32_t)ctx->ph, (uint32_t)plate, (uint32_t)px, (uint32_t)py);
+}
 
 extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch)
 {
@@ -299,8 +309,25 @@ extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t 
     if (int r = ensure_device(ctx)) return r;
     const size_t ps = ctx->ps;
     uint8_t *dst = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
-    // the row memcpy loop of render_plate, fisheye.c:2441-2449 (device rows are gp bytes apart)
-    BK_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)ctx->gp, src, (size_t)src_pitch, ps, ps, hipMemcpyHostToDevice, ctx->stream));
+    // the row memcpy loop of render_plate, fisheye.c:2441-2449: rows land in the staging buffer (gp bytes
+    // apart), one kernel moves them into the plate's 16x8 tiles
+    BK_HIP(ctx, hipMemcpy2DAsync(ctx->d_plate_stage, (size_t)ctx->gp, src, (size_t)src_pitch, ps, ps, hipMemcpyHostToDevice, ctx->stream));
+    if (int r = bk::launch_plate_retile(ctx, dst, 1)) return r;
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
+extern "C" int bk_download_plate(bk_ctx *ctx, int frame, int plate, uint8_t *dst_host, int dst_pitch)
+{
+    if (!ctx || !dst_host) return BK_E_INVALID;
+    if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_download_plate: call bk_resize first");
+    if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || dst_pitch < ctx->ps)
+        return ctx->fail(BK_E_INVALID, "bk_download_plate: bad frame/plate/pitch");
+    if (int r = ensure_device(ctx)) return r;
+    const size_t ps = ctx->ps;
+    uint8_t *src = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
+    if (int r = bk::launch_plate_retile(ctx, src, 0)) return r;
+    BK_HIP(ctx, hipMemcpy2DAsync(dst_host, (size_t)dst_pitch, ctx->d_plate_stage, (size_t)ctx->gp, ps, ps, hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BK_OK;
 }

@@ -112,10 +112,10 @@ __global__ __launch_bounds__(256) void mask_kernel(const uint32_t *__restrict__ 
 // synthetic plates: SURVEY.md 8(d)  s0 = seed, s <- s*1664525 + 1013904223, texel = s>>24.
 // Each thread jumps ahead to its first element by composing the affine map in O(log i).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, int ps, int gp, uint32_t seed)
+__global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, int ps, int gp, int ph, uint32_t seed)
 {
-    // texel i = py*ps + px of the stream lands at dst[py*gp + px]; each thread produces up to 16
-    // consecutive texels of one row
+    // texel i = py*ps + px of the stream lands at dst[bk_texel_offset(px, py)]; each thread produces
+    // up to 16 consecutive texels of one row = one 16-byte chunk of the tiled layout
     const int chunks_per_row = (ps + 15) / 16;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= chunks_per_row * ps) return;
@@ -134,27 +134,47 @@ __global__ __launch_bounds__(256) void lcg_kernel(uint8_t *__restrict__ dst, int
         s = s * 1664525u + 1013904223u;
         w[k >> 2] |= (s >> 24) << (8 * (k & 3));
     }
-    uint8_t *out = dst + (size_t)py * gp + px0;       // gp % 64 == 0 and px0 % 16 == 0: 16-byte aligned
+    uint8_t *out = dst + bk_texel_offset((uint32_t)gp, (uint32_t)ph, 0u, (uint32_t)px0, (uint32_t)py);   // px0 % 16 == 0: 16-byte aligned
     if (cnt == 16) *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
     else for (int k = 0; k < cnt; ++k) out[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
 }
 
 // ---------------------------------------------------------------------------------------
 // lensmap entries cross the ABI in the reference layout (plate*ps*ps + py*ps + px, GLOBEPIXEL
-// fisheye.c:349); on the device they address the padded globe (plate*gp*ps + py*gp + px)
+// fisheye.c:349); on the device they address the tiled globe (bk_texel_offset, bk_build_params.h)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void convert_offsets_kernel(uint32_t *__restrict__ buf, size_t n, uint32_t ps,
-                                                              uint32_t gp, int to_padded)
+                                                              uint32_t gp, uint32_t ph, int to_device)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t o = buf[i];
     if (o == BK_NULL_OFFSET) return;
-    const uint32_t pitch_in = to_padded ? ps : gp, pitch_out = to_padded ? gp : ps;
-    const uint32_t plate = o / (pitch_in * ps), rem = o - plate * (pitch_in * ps);
-    if (plate >= BK_MAX_PLATES) { buf[i] = BK_NULL_OFFSET; return; }    // never address outside the globe
-    const uint32_t py = rem / pitch_in, px = rem - py * pitch_in;
-    buf[i] = plate * (pitch_out * ps) + py * pitch_out + px;
+    uint32_t plate, px, py;
+    if (to_device) {
+        plate = o / (ps * ps);
+        const uint32_t rem = o - plate * (ps * ps);
+        py = rem / ps;
+        px = rem - py * ps;
+        buf[i] = plate < BK_MAX_PLATES ? bk_texel_offset(gp, ph, plate, px, py) : BK_NULL_OFFSET;   // never address outside the globe
+    } else {
+        bk_texel_coords(gp, ph, o, &plate, &px, &py);
+        buf[i] = plate * (ps * ps) + py * ps + px;
+    }
+}
+
+// one plate between the row-major staging buffer [ps][gp] and its tiled place in the globe: a thread
+// moves one 16-byte chunk (16 texels of a row)
+__global__ __launch_bounds__(256) void plate_retile_kernel(uint8_t *__restrict__ tiled, uint8_t *__restrict__ rowmajor,
+                                                           int ps, int gp, int ph, int to_tiled)
+{
+    const int cpr = gp >> 4;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= cpr * ps) return;
+    const int py = id / cpr, cx = id - py * cpr;
+    uint4 *t = reinterpret_cast<uint4 *>(tiled + bk_texel_offset((uint32_t)gp, (uint32_t)ph, 0u, (uint32_t)cx * 16u, (uint32_t)py));
+    uint4 *r = reinterpret_cast<uint4 *>(rowmajor + (size_t)py * gp + (size_t)cx * 16);
+    if (to_tiled) *t = *r; else *r = *t;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -166,7 +186,6 @@ int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pit
 {
     const int rows = ctx->rows();
     if (rows <= 0 || nframes <= 0) return BK_OK;
-    if (ctx->apply_variant == 1) return launch_apply_tiled(ctx, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
     if (ctx->apply_variant != 0) return launch_apply_coop(ctx, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
     const size_t gstride = ctx->globe_stride();
     const int fchunk = nframes < 8 ? nframes : 8;
@@ -213,16 +232,25 @@ int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed)
 {
     const int threads = ((ctx->ps + 15) / 16) * ctx->ps;
     hipLaunchKernelGGL(lcg_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                       plate_dst, ctx->ps, ctx->gp, seed);
+                       plate_dst, ctx->ps, ctx->gp, ctx->ph, seed);
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;
 }
 
-int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_padded)
+int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_device)
 {
     if (!n) return BK_OK;
     hipLaunchKernelGGL(convert_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       buf, n, (uint32_t)ctx->ps, (uint32_t)ctx->gp, to_padded);
+                       buf, n, (uint32_t)ctx->ps, (uint32_t)ctx->gp, (uint32_t)ctx->ph, to_device);
+    BK_HIP(ctx, hipGetLastError());
+    return BK_OK;
+}
+
+int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled)
+{
+    const int threads = (ctx->gp >> 4) * ctx->ps;
+    hipLaunchKernelGGL(plate_retile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                       plate_tiled, ctx->d_plate_stage, ctx->ps, ctx->gp, ctx->ph, to_tiled);
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;
 }

@@ -1,11 +1,11 @@
 // blinky-hip: workgroup-cooperative LDS-staged apply kernel (variant 2, the default) for gfx950.
 //
-// The per-wave tiled kernel (variant 1, bk_apply_tiled.hip) stages, per wave, the bounding boxes of
-// the plate texels under a 32-pixel-wide tile.  Counters on MI355X show what limits it: a 128-byte
-// globe line spans ~3.5 such tiles and screen rows are slanted in plate space, so the same lines are
-// requested over and over (TCP->TCC read requests = 5-6x the unique lines, L1 hit rate ~23 %,
-// TCP_PENDING_STALL ~2/3 of the kernel's cycles; kernel time tracks that request count) and, because
-// waves drift apart in time, part of those requests goes to HBM again (TCC_EA0_RDREQ = 1.6x unique).
+// A predecessor that staged, per wave, the bounding boxes of the plate texels under a 32-pixel-wide tile
+// (git history: bk_apply_tiled.hip; numbers in DESIGN.md 3.2) showed what limits this gather on MI355X:
+// with row-major plates a 128-byte line spans ~3.5 such tiles and screen rows are slanted in plate space,
+// so the same lines were requested over and over (TCP->TCC read requests = 5-6x the unique lines, L1
+// hit rate ~23 %, TCP_PENDING_STALL ~2/3 of the kernel's cycles; kernel time tracked that request count)
+// and, because waves drift apart in time, part of those requests went to HBM again.
 //
 // Here the unit of staging is the workgroup block of 128 x (8*RG) pixels and what is staged is the
 // EXACT set of 16-byte globe chunks the block's pixels read - no bounding boxes.  `coop_compile_kernel`
@@ -17,9 +17,10 @@
 // stores 4 pixels per lane.  Two LDS buffers alternate, so one barrier per frame is enough: the
 // buffer a wave overwrites for frame f+2 was last read before the barrier of frame f+1.
 //
-// Same launch shape as variant 1: persistent grid, XCD-banded block order, next block's header,
+// Persistent grid, XCD-banded block order, next block's header,
 // chunk list head and indices prefetched, a batch launch re-uses a block's plan for up to 8 frames.
-// The chunk list is layout-agnostic: it holds byte offsets into a globe frame.
+// The chunk list is layout-agnostic (byte offsets into a globe frame); with the globe stored as 16x8-texel
+// lines (bk_build_params.h) a block's slanted footprint touches about half the lines it did row-major.
 //
 // replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
 #include "bk_internal.h"
@@ -242,7 +243,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                                             bool tile_empty, const uint8_t *pal_s, int row0, int x, int kflags)
 {
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;     // (scalars, not an array: they must stay in VGPRs)
-    const bool pipe = (kflags & 8) == 0;      // issue frame f+1's loads before frame f's gather (developer flag 8 turns it off)
+    const bool pipe = (kflags & 8) == 0;      // issue frame f+1's loads before frame f's gather (ablation bit 8 turns it off)
 #define BK_COOP_LOADS(F)                                                                                   \
     do {                                                                                                   \
         const uint8_t *gl_ = globe + (size_t)((frame0 + (F)) % globe_frames) * globe_stride;              \

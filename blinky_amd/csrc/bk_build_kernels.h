@@ -48,7 +48,7 @@ BK_DEV bool bk_offgrid(const BkBuildParams &P, int px, int py)
 
 BK_DEV unsigned int bk_padded_offset(const BkBuildParams &P, int plate, int px, int py)
 {
-    return (unsigned int)plate * ((unsigned int)P.gp * (unsigned int)P.ps) + (unsigned int)py * (unsigned int)P.gp + (unsigned int)px;
+    return bk_texel_offset((unsigned int)P.gp, (unsigned int)P.ph, (unsigned int)plate, (unsigned int)px, (unsigned int)py);
 }
 
 __device__ __forceinline__ void bk_publish_flags(const int *s_disp, int *display, int serr, int *err)

@@ -13,12 +13,12 @@ typedef struct {
 typedef struct {
     int W, H;                /* lens.width_px / height_px */
     int row0, rows;          /* owned output rows [row0, row0+rows) */
-    int ps, gp;              /* platesize; padded row pitch of the device globe */
+    int ps, gp, ph;          /* platesize; padded plate width / height of the device globe (bk_texel_offset) */
     int numplates, has_globe_plate;
     double scale;            /* lens.scale */
     double rubix_block, rubix_pad, rubix_unit_px;   /* set_lensmap_grid constants (fisheye.c:1938-1948) */
     BkPlateDev plates[6];
-    unsigned int *offsets;   /* [rows][W] padded-layout offsets, 0xFFFFFFFF = NULL */
+    unsigned int *offsets;   /* [rows][W] device-layout offsets (bk_texel_offset), 0xFFFFFFFF = NULL */
     unsigned char *tints;    /* [rows][W] */
     int *display;            /* [6] */
     int *err;                /* [1] OR of BK_ERR_* bits */
@@ -28,6 +28,30 @@ typedef struct {
     int *corner_xy;          /* [numplates][ps+1][ps+1][2] screen coords of the texel corners */
     unsigned char *corner_ok;/* [numplates][ps+1][ps+1] */
 } BkBuildParams;
+
+/* Device globe layout.  A plate is gp = round_up(ps,64) texels wide and ph = round_up(ps,8) high and is
+ * stored as tiles of 16x8 texels = one 128-byte line each (tile rows 16 bytes apart, tiles row-major):
+ * the warp reads slanted footprints, and a line that covers a compact 2-D patch is shared by far fewer
+ * workgroup blocks than a 128x1 strip of a row.  16 consecutive texels of a row (x % 16 == 0) stay one
+ * aligned 16-byte chunk.  Byte offset of texel (plate, px, py) inside one globe frame: */
+#if defined(__HIP__) || defined(__HIPCC_RTC__)
+#define BK_LAYOUT_FN static __host__ __device__ inline __attribute__((always_inline))
+#else
+#define BK_LAYOUT_FN static inline
+#endif
+BK_LAYOUT_FN unsigned int bk_texel_offset(unsigned int gp, unsigned int ph, unsigned int plate, unsigned int px, unsigned int py)
+{
+    return plate * (gp * ph) + ((py >> 3) * (gp >> 4) + (px >> 4)) * 128u + (py & 7u) * 16u + (px & 15u);
+}
+/* inverse: offset -> plate, px, py */
+BK_LAYOUT_FN void bk_texel_coords(unsigned int gp, unsigned int ph, unsigned int off, unsigned int *plate, unsigned int *px, unsigned int *py)
+{
+    const unsigned int p = off / (gp * ph), rem = off - p * (gp * ph), tile = rem >> 7, tpr = gp >> 4;
+    const unsigned int ty = tile / tpr, tx = tile - ty * tpr;
+    *plate = p;
+    *px = tx * 16u + (rem & 15u);
+    *py = ty * 8u + ((rem >> 4) & 7u);
+}
 
 #define BK_ERR_ARITH 1       /* arithmetic on a non-number */
 #define BK_ERR_COMPARE 2     /* ordering comparison on non-numbers */

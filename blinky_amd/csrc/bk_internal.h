@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/blinky_hip.h"
+#include "bk_build_params.h"      // the device globe layout (bk_texel_offset)
 
 namespace bk {
 
@@ -21,7 +22,6 @@ struct Rubix { int numcells = 10; double cell = 4, pad = 1; };   // defaults: fi
 
 struct LensProgram;   // bk_lens.cpp: parsed scripts + hiprtc modules
 struct CoopMap;       // bk_apply_coop.hip: per-block staging plans of the workgroup-cooperative apply kernel
-struct TileMap;       // bk_apply.hip: compact tiled lensmap for the staged apply kernel
 
 }  // namespace bk
 
@@ -32,7 +32,7 @@ struct bk_ctx {
 
     // geometry (fisheye.c:704-708)
     int W = 0, H = 0, ps = 0;
-    int gp = 0;                      // padded row pitch of the device globe: round_up(ps, 64)
+    int gp = 0, ph = 0;              // padded plate width round_up(ps, 64) / height round_up(ps, 8) of the device globe
     int row0 = 0, row1 = 0;          // owned output rows
     int nframes = 1;
 
@@ -48,7 +48,8 @@ struct bk_ctx {
     bk::Rubix rubix;
 
     // device memory
-    uint8_t *d_globe = nullptr;      // [nframes][6][ps][gp]  (rows padded to gp bytes)
+    uint8_t *d_globe = nullptr;      // [nframes][6][ph/8][gp/16] tiles of 16x8 texels (bk_texel_offset, bk_build_params.h)
+    uint8_t *d_plate_stage = nullptr;  // [ps][gp] row-major staging of one plate for bk_upload_plate / bk_download_plate
     uint32_t *d_offsets = nullptr;   // [row1-row0][W]  offsets into the PADDED globe layout
     uint32_t *d_convert = nullptr;   // [row1-row0][W]  scratch for layout conversion at the ABI boundary
     uint8_t *d_tints = nullptr;      // [row1-row0][W]
@@ -65,14 +66,13 @@ struct bk_ctx {
     std::vector<bk::Span> spans;     // mapped spans of the owned rows
     bool spans_valid = false;
 
-    int apply_variant = -1;          // -1 auto (= 2); 0 direct gather, 1 per-wave LDS tiles, 2 workgroup-cooperative LDS blocks
+    int apply_variant = -1;          // -1 auto (= 2); 0 direct gather, 2 workgroup-cooperative LDS blocks
     int num_cus = 256;               // multiProcessorCount of the device
-    int apply_flags = 0;             // developer knobs (bk_debug_set_tile_shape 200+v): bit0 = workgroup barrier per frame
+    int apply_flags = 0;             // developer ablations of the coop apply (bk_debug_set_ablation): 2 no globe loads, 4 no stores, 8 no load pipelining
     int apply_lds_kb = 0;            // coop apply: force the staging buffer size in KiB (0 = cost model; knob 400+n)
-    int apply_fchunk = 0;            // frames a wave keeps a tile for (0 = default 8; knob 300+n)
+    int apply_fchunk = 0;            // frames a workgroup keeps a block for (0 = default 8; knob 300+n)
     int apply_wgs_per_cu = 16;       // persistent apply grid: workgroups per CU (tunable, bk_debug_set_tile_shape)
-    int tile_shape = 0;              // tiled apply: 0 = default tile height (rg 2), 1/2/4 = force rg, -1 = search by cost model
-    bk::TileMap *tilemap = nullptr;       // owned; freed with bk::tilemap_free
+    int tile_shape = 0;              // coop apply: 0 = block height by cost model, 1/2/4 = force 128x8 / 128x16 / 128x32
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
@@ -88,8 +88,8 @@ struct bk_ctx {
         return code;
     }
     int rows() const { return row1 - row0; }
-    size_t plate_bytes() const { return (size_t)gp * ps; }
-    size_t globe_stride() const { return (size_t)BK_MAX_PLATES * gp * ps; }
+    size_t plate_bytes() const { return (size_t)gp * ph; }
+    size_t globe_stride() const { return (size_t)BK_MAX_PLATES * gp * ph; }
 };
 
 #define BK_HIP(ctx, expr)                                                               \
@@ -106,13 +106,8 @@ int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_
                  size_t frame_stride, int rubix_on);
 int launch_mask(bk_ctx *ctx);                 // d_offsets -> d_mask
 int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed);   // one plate, padded rows
-int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_padded);   // reference <-> padded layout
-void tilemap_invalidate(bk_ctx *ctx);
-int launch_apply_tiled(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,
-                       size_t frame_stride, int rubix_on);
-int tilemap_stats(bk_ctx *ctx, int out[6]);
-int set_ablation(bk_ctx *ctx, int bits);      // developer timing ablations of the tiled apply   // tiles, slow tiles, empty tiles, LDS bytes per wave
-void tilemap_free(TileMap *);
+int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_device);   // reference <-> device (tiled) layout
+int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled);          // d_plate_stage (row-major) <-> a plate of the globe
 // bk_apply_coop.hip
 void coopmap_invalidate(bk_ctx *ctx);
 int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,

@@ -489,7 +489,7 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
     memset(bp, 0, sizeof *bp);
     bp->W = ctx->W; bp->H = ctx->H;
     bp->row0 = ctx->row0; bp->rows = ctx->rows();
-    bp->ps = ctx->ps; bp->gp = ctx->gp;
+    bp->ps = ctx->ps; bp->gp = ctx->gp; bp->ph = ctx->ph;
     bp->numplates = ctx->numplates;
     bp->has_globe_plate = ctx->prog->globe_plate.is_function();
     bp->scale = ctx->scale;
@@ -536,7 +536,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 2) * sizeof(int), ctx->stream));
     ctx->lensmap_valid = true;
     ctx->spans_valid = false;
-    bk::tilemap_invalidate(ctx);
+    bk::coopmap_invalidate(ctx);
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
     ctx->last_build_ms = 0;
 

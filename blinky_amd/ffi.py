@@ -73,6 +73,9 @@ _SIGS = {
     "bk_set_apply_variant": (_i, [_vp, _i]),
     "bk_last_build_ms": (_d, [_vp]),
     "bk_globe_pitch": (_i, [_vp]),
+    "bk_globe_rows": (_i, [_vp]),
+    "bk_globe_texel_offset": (C.c_uint32, [_vp, _i, _i, _i]),
+    "bk_download_plate": (_i, [_vp, _i, _i, _vp, _i]),
     "bk_debug_tile_stats": (_i, [_vp, C.POINTER(_i)]),
     "bk_debug_set_ablation": (_i, [_vp, _i]),
     "bk_debug_set_tile_shape": (_i, [_vp, _i]),
@@ -243,6 +246,18 @@ class Context:
 
     def globe_pitch(self):
         return lib.bk_globe_pitch(self._h)
+
+    def globe_rows(self):
+        return lib.bk_globe_rows(self._h)
+
+    def globe_texel_offset(self, plate, px, py):
+        return lib.bk_globe_texel_offset(self._h, plate, px, py)
+
+    def download_plate(self, frame, plate):
+        _, _, ps, _, _ = self.size()
+        out = np.empty((ps, ps), np.uint8)
+        self._chk(lib.bk_download_plate(self._h, frame, plate, _ptr(out), ps))
+        return out
 
     def kernel_source(self, compile=False):
         need = _sz()

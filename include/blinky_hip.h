@@ -115,12 +115,18 @@ int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints);
  * bk_upload_plate replaces render_plate's row memcpy loop (fisheye.c:2441-2449):
  * ps rows of ps bytes from src (pitch src_pitch) into plate `plate` of globe `frame`. */
 int   bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch);
-/* Device layout of a globe: uint8 [6 plates][ps rows][pitch], pitch = bk_globe_pitch() =
- * round_up(ps, 64) so that every plate row starts on a 64-byte boundary (the apply kernel
- * stages plate rows with 16-byte loads).  Lensmap entries cross this ABI in the reference
- * layout (pitch ps); the library converts. */
-void *bk_globe_device_ptr(bk_ctx *ctx, int frame);   /* device address of globe `frame` (6*ps*pitch bytes) */
-int   bk_globe_pitch(const bk_ctx *ctx);
+/* the way back (the plate copy cmd_saveglobe reads, fisheye.c:1396-1465): ps rows of ps bytes to dst_host */
+int   bk_download_plate(bk_ctx *ctx, int frame, int plate, uint8_t *dst_host, int dst_pitch);
+/* Device layout of a globe frame: 6 plates of bk_globe_pitch() = round_up(ps,64) by bk_globe_rows() =
+ * round_up(ps,8) texels, each stored as 16x8-texel tiles of 128 bytes (tiles row-major, rows of a tile
+ * 16 bytes apart): a 128-byte line covers a compact patch, so the slanted footprints of the warp touch
+ * about half as many lines as with row-major plates.  bk_globe_texel_offset gives the byte offset of a
+ * texel inside a frame (0xFFFFFFFF if out of range) for callers that fill plates on the device themselves.
+ * Lensmap entries cross this ABI in the reference layout (plate*ps*ps + py*ps + px); the library converts. */
+void    *bk_globe_device_ptr(bk_ctx *ctx, int frame);   /* device address of globe `frame` (6*pitch*rows bytes) */
+int      bk_globe_pitch(const bk_ctx *ctx);
+int      bk_globe_rows(const bk_ctx *ctx);
+uint32_t bk_globe_texel_offset(const bk_ctx *ctx, int plate, int px, int py);
 /* synthetic plates: the SURVEY.md 8(d) LCG stream generated on the device */
 int   bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t seed_frame);
 
@@ -146,16 +152,16 @@ void bk_create_palmap(const uint8_t *basepal, uint8_t pal_out[BK_MAX_PLATES][256
 /* ---- introspection (tests, bench) ------------------------------------------------------ */
 int         bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesize, int *row0, int *row1);
 const char *bk_version(void);
-/* selects the apply kernel: 0 = direct gather, 1 = tiled/LDS-staged (default: best available) */
+/* selects the apply kernel: 0 = direct gather, 2 = workgroup-cooperative LDS staging (default) */
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
-/* developer only: timing ablations of the tiled apply (bit0 no region loads, bit1 no stores, bit2 no
- * LDS gather, bit3 no LDS writes); results are wrong while non-zero.  0 restores normal operation. */
+/* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
+ * pipelining); results are wrong while bits 2/4 are set.  0 restores normal operation. */
 int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
-/* tiled apply statistics of the current lensmap: out = {tiles, tiles on the direct-gather fallback,
- * empty tiles, LDS bytes per wavefront, tile height in pixels, 128-byte lines staged per frame} */
+/* staged apply statistics of the current lensmap: out = {blocks, blocks on the direct-gather fallback,
+ * empty blocks, bytes of one LDS staging buffer, 128000 + block height in pixels, 128-byte lines staged per frame} */
 int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
-/* tile height of the tiled apply (tiles are 32 pixels wide, 8*rg tall): 0 = default (rg 2 = 32x16 px),
- * 1 / 2 / 4 = force rg, -1 = compile all three and keep the cheapest by the cost model */
+/* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
+ * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);

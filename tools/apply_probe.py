@@ -18,7 +18,7 @@ lens = sys.argv[1] if len(sys.argv) > 1 else "panini"
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 2160
 F = int(sys.argv[4]) if len(sys.argv) > 4 else 16
-variants = [int(v) for v in sys.argv[5:]] or [0]
+variants = [int(v) for v in sys.argv[5:]] or [2]
 
 t = time.time()
 lm = O.lensmap("cube", lens, None, W, H)
@@ -37,21 +37,19 @@ out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
 ABL = [int(x) for x in os.environ.get("BK_ABLATE", "0").split(",")]
 SHAPES = [int(x) for x in os.environ.get("BK_SHAPES", "0").split(",")]
 WGS = [int(x) for x in os.environ.get("BK_WGS", "6").split(",")]
-FLAGS = [int(x) for x in os.environ.get("BK_FLAGS", "0").split(",")]     # bit0: workgroup barrier per frame
 FCH = [int(x) for x in os.environ.get("BK_FCHUNK", "0").split(",")]      # frames per tile visit (0 = default)
 REPS = int(os.environ.get("BK_REPS", "20"))
 LDSKB = [int(x) for x in os.environ.get("BK_LDSKB", "0").split(",")]    # coop apply: staging buffer KiB (0 = cost model)
-for v, abl, shp, wg, fl, fc, kb in [(v, a, sh, wg, fl, fc, kb) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])
-                               for fl in (FLAGS if v != 0 else [0]) for fc in (FCH if v != 0 else [0]) for kb in (LDSKB if v == 2 else [0])]:
+for v, abl, shp, wg, fc, kb in [(v, a, sh, wg, fc, kb) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])
+                               for fc in (FCH if v != 0 else [0]) for kb in (LDSKB if v == 2 else [0])]:
     ctx.set_apply_variant(v)
     if v != 0:
         ctx.set_tile_shape(shp)
         ctx.set_tile_shape(100 + wg)
-        ctx.set_ablation(abl)
-        ctx.set_tile_shape(200 + fl)
+        ctx.set_ablation(abl)             # 2 no globe loads, 4 no stores, 8 no load pipelining
         ctx.set_tile_shape(300 + fc)
         ctx.set_tile_shape(400 + kb)
-        print(f"shape {shp} ablation {abl} wgs/cu {wg} flags {fl} fchunk {fc} ldskb {kb}; tile stats:", ctx.tile_stats(), flush=True)
+        print(f"shape {shp} ablation {abl} wgs/cu {wg} fchunk {fc} ldskb {kb}; tile stats:", ctx.tile_stats(), flush=True)
     for nf in sorted(set([1, F])):
         for _ in range(3):
             ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)
