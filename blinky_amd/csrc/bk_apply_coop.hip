@@ -23,6 +23,8 @@
 // lines (bk_build_params.h) a block's slanted footprint touches about half the lines it did row-major.
 //
 // replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
+#include <cmath>
+
 #include "bk_internal.h"
 
 namespace bk {
@@ -30,7 +32,7 @@ namespace bk {
 constexpr int BK_COOP_LDS_CAP = 49152;                 // max bytes of one staging buffer (3072 chunks)
 constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's column fully mapped / empty
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
-constexpr int BK_COOP_STATS = 128;                     // words per stats replica
+constexpr int BK_COOP_STATS = 192;                     // words per stats replica
 
 struct CoopHdr {              // 8 bytes per block
     uint32_t nchunks;         // entries of the block's chunk list (0 for direct-gather / empty blocks)
@@ -44,7 +46,7 @@ struct CoopMap {
     uint8_t *d_tint = nullptr;      // same order (rubix)
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
                                     // [3] 128-B lines staged, [4] chunks staged, [8..57) blocks by LDS need (1 KiB bins),
-                                    // [64..113) 128-B lines of those blocks
+                                    // [64..113) 128-B lines of those blocks, [128..177) chunks of those blocks
     int blocks_x = 0, blocks_y = 0;
     int rg = 4;
     int lds_bytes = 0;              // bytes of ONE staging buffer of the apply launch
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
             const uint32_t bin = min(48u, (nchunks * 16u + 1023u) / 1024u);
             atomicAdd(&st[8 + bin], 1u);
             atomicAdd(&st[64 + bin], lines);
+            atomicAdd(&st[128 + bin], nchunks);
             atomicAdd(&st[3], lines);
             atomicAdd(&st[4], nchunks);
         }
@@ -470,26 +473,30 @@ static int coop_compile(bk_ctx *ctx, CoopMap *cm, int rg)
     return BK_OK;
 }
 
-// Cost model (ns per frame, fitted to MI355X measurements of four lenses x three block
-// heights x five buffer sizes): a staged 128-byte line costs ~13 ps on top of ~0.5 ps per pixel, a block on
-// the direct-gather path ~16 ns per row group, and fewer resident workgroups per CU (two staging
-// buffers each; registers allow `vg`) stretch everything.  Returns the best buffer size in KiB.
-static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, double *cost_ns)
+// Cost model (ns per frame), fitted to MI355X measurements of five lenses x three block heights x five
+// buffer sizes.  Throughput side: a staged 128-byte line ~13 ps, a staged block ~0.08 ns, a pixel ~0.5 ps.
+// Latency side: a workgroup spends ~0.9 us per chunk-per-thread and frame on a block (load -> LDS -> barrier ->
+// gather -> store) plus ~0.1 us per row group, and a CU overlaps only as many blocks as it holds workgroups
+// (two staging buffers each; registers allow 7 / 6 / 4 for 128x8 / 128x16 / 128x32 blocks).  The two sides
+// combine as a 3-norm; a block on the direct-gather path adds ~16 ns per row group.  Returns the best
+// buffer size in KiB.
+static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns)
 {
-    static const double pen[7] = {2.0, 2.0, 1.29, 1.11, 1.04, 1.0, 1.0};
-    const int vg = rg == 4 ? 4 : 6;
+    const int vg = rg == 4 ? 4 : rg == 2 ? 6 : 7;
     int best_bin = 1;
     double best_c = -1;
     for (int bin = 1; bin * 1024 <= BK_COOP_LDS_CAP; ++bin) {
-        uint64_t over = 0, lines_fit = 0;
+        uint64_t over = 0, lines_fit = 0, blocks_fit = 0, chunks_fit = 0;
         for (int b = 0; b <= 48; ++b) {
-            if (b <= bin) lines_fit += cm->stats[64 + b];
+            if (b <= bin) { lines_fit += cm->stats[64 + b]; blocks_fit += cm->stats[8 + b]; chunks_fit += cm->stats[128 + b]; }
             else over += cm->stats[8 + b];
         }
         int wgs = (160 * 1024) / (2 * bin * 1024 + BK_MAX_PLATES * 256);
         if (wgs > vg) wgs = vg;
         if (wgs < 1) wgs = 1;
-        const double c = (0.013 * (double)lines_fit + 0.00048 * npixels) * pen[wgs] + 16.0 * rg * (double)(over + cm->stats[1]);
+        const double t_thr = 0.013 * (double)lines_fit + 0.08 * (double)blocks_fit + 0.00048 * npixels;
+        const double t_lat = (900.0 * (double)chunks_fit / 256.0 + 100.0 * rg * (double)blocks_fit) / ((double)num_cus * wgs);
+        const double c = cbrt(t_thr * t_thr * t_thr + t_lat * t_lat * t_lat) + 16.0 * rg * (double)(over + cm->stats[1]);
         if (best_c < 0 || c < best_c) { best_c = c; best_bin = bin; }
     }
     *cost_ns = best_c;
@@ -525,7 +532,7 @@ static int ensure_coopmap(bk_ctx *ctx)
         if (int r = coop_compile(ctx, cm, cand[i])) return r;
         compiled = cand[i];
         double c = 0;
-        const int kb = coop_choose_buffer(cm, cand[i], (double)ctx->W * rows, &c);
+        const int kb = coop_choose_buffer(cm, cand[i], (double)ctx->W * rows, ctx->num_cus, &c);
         if (best_cost < 0 || c < best_cost) { best_cost = c; best_rg = cand[i]; best_kb = kb; }
     }
     if (compiled != best_rg)
