@@ -265,6 +265,26 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_resolve(BkBuildPara
 }
 #endif
 
+/* The plate image f_saveglobe writes (WritePCXplate's pixel loop, fisheye.c:1438-1456): texel (j,i) of the
+ * plate, or 0xFE where the ray through (u=j/ps, v=i/ps) belongs to another plate (ray_to_plate_index, which
+ * may be the globe script's globe_plate) unless with_margins.  out = [ps][ps] row-major. */
+extern "C" __global__ __launch_bounds__(256) void bk_save_plate(BkBuildParams P, int plate, int with_margins,
+                                                                const unsigned char *globe_frame, unsigned char *out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= P.ps || i >= P.ps) return;
+    unsigned char col = globe_frame[bk_padded_offset(P, plate, j, i)];
+    if (!with_margins) {
+        const double v = ((double)i) / P.ps, u = ((double)j) / P.ps;                   /* :1439, 1441 */
+        float ray[3];
+        bk_plate_uv_to_ray(P, plate, u, v, ray);
+        BkState S;
+        bk_state_init(S, &P);
+        if (plate != bk_ray_to_plate_index(S, ray)) col = 0xFE;                        /* :1446 */
+    }
+    out[(size_t)i * P.ps + j] = col;
+}
+
 /* test / diagnosis hook: run one callback over an array of argument tuples and return the raw
  * double results (bk_debug_eval_device).  which: 0 lens_inverse, 1 lens_forward, 2 globe_plate.
  * nout[i] = number of results, -1 for a single nil, -100-err on a runtime error. */

@@ -609,6 +609,37 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
 
 // debug / test hook: run a callback on the DEVICE over n argument tuples (nargs doubles each);
 // out receives 8 doubles per tuple, nout the result count (-1 single nil, <= -100 runtime error)
+/* f_saveglobe's plate image (fisheye.c:1438-1456), computed on the device; the caller encodes the PCX */
+extern "C" int bk_save_plate(bk_ctx *ctx, int frame, int plate, int with_margins, uint8_t *dst_host, int dst_pitch)
+{
+    if (!ctx || !dst_host) return BK_E_INVALID;
+    if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_save_plate: this context has no device");
+    if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_save_plate: call bk_resize first");
+    if (!ctx->globe_valid || !ctx->prog) return ctx->fail(BK_E_STATE, "not a valid globe");
+    if (plate < 0 || plate >= ctx->numplates || frame < 0 || frame >= ctx->nframes || dst_pitch < ctx->ps)
+        return ctx->fail(BK_E_INVALID, "bk_save_plate: bad frame/plate/pitch");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    LensProgram *P = ctx->prog;
+    std::string src;
+    if (int r = generate_source(ctx, P, &src)) return r;
+    if (int r = compile_module(ctx, P, src)) return r;
+    hipFunction_t fn = nullptr;
+    BK_HIP(ctx, hipModuleGetFunction(&fn, P->module, "bk_save_plate"));
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    const uint8_t *globe = ctx->d_globe + (size_t)frame * ctx->globe_stride();
+    uint8_t *out = nullptr;
+    BK_HIP(ctx, hipMalloc((void **)&out, (size_t)ctx->ps * ctx->ps));
+    void *args[] = {&bp, &plate, &with_margins, &globe, &out};
+    hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((ctx->ps + 255) / 256), (unsigned)ctx->ps, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(dst_host, (size_t)dst_pitch, out, (size_t)ctx->ps, (size_t)ctx->ps, (size_t)ctx->ps, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(out);
+    if (e != hipSuccess) return ctx->fail(BK_E_HIP, "bk_save_plate failed: %s", hipGetErrorString(e));
+    return BK_OK;
+}
+
 extern "C" int bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout)
 {
     if (!ctx || !args || !out || !nout || nargs < 1 || nargs > 4 || n < 1) return BK_E_INVALID;

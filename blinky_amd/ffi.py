@@ -76,6 +76,7 @@ _SIGS = {
     "bk_globe_rows": (_i, [_vp]),
     "bk_globe_texel_offset": (C.c_uint32, [_vp, _i, _i, _i]),
     "bk_download_plate": (_i, [_vp, _i, _i, _vp, _i]),
+    "bk_save_plate": (_i, [_vp, _i, _i, _i, _vp, _i]),
     "bk_debug_tile_stats": (_i, [_vp, C.POINTER(_i)]),
     "bk_debug_set_ablation": (_i, [_vp, _i]),
     "bk_debug_set_tile_shape": (_i, [_vp, _i]),
@@ -252,6 +253,12 @@ class Context:
 
     def globe_texel_offset(self, plate, px, py):
         return lib.bk_globe_texel_offset(self._h, plate, px, py)
+
+    def save_plate(self, frame, plate, with_margins):
+        _, _, ps, _, _ = self.size()
+        out = np.empty((ps, ps), np.uint8)
+        self._chk(lib.bk_save_plate(self._h, frame, plate, int(with_margins), _ptr(out), ps))
+        return out
 
     def download_plate(self, frame, plate):
         _, _, ps, _, _ = self.size()

@@ -76,6 +76,10 @@ void R_RenderView(void);                                             /* include/
 void R_ViewChanged(vrect_t *pvrect, int lineadj, float aspect);      /* include/render.h:163 */
 void R_SetVrect(const vrect_t *pvrectin, vrect_t *pvrect, int lineadj);   /* include/render.h:211 */
 void Draw_TileClear(int x, int y, int w, int h);                     /* include/draw.h:42 */
+void *Hunk_TempAlloc(int size);                                      /* include/zone.h:112 */
+void COM_WriteFile(const char *filename, const void *data, int len); /* include/common.h:204 */
+void D_EnableBackBufferAccess(void);                                 /* include/d_iface.h:140 */
+void D_DisableBackBufferAccess(void);
 
 #define VectorCopy(a, b) do { (b)[0] = (a)[0]; (b)[1] = (a)[1]; (b)[2] = (a)[2]; } while (0)   /* mathlib.h:73 */
 #endif /* BLINKY_IN_ENGINE */

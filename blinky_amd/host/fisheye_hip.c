@@ -254,9 +254,80 @@ static void cmd_lens(void)                          /* fisheye.c:1061-1103 */
     }
 }
 
-static void cmd_saveglobe(void)                     /* fisheye.c:1120-1136; PCX export is not on the warp path */
+static struct { qboolean should; int with_margins; char name[32]; } save;       /* globe.save, fisheye.c:370-375 */
+
+static void cmd_saveglobe(void)                     /* fisheye.c:1120-1136 */
 {
-    Con_Printf("f_saveglobe: not available in the HIP build (plates live in GPU memory)\n");
+    if (Cmd_Argc() < 2) {
+        Con_Printf("f_saveglobe <name> [full flag=0]: screenshot the globe plates\n");
+        return;
+    }
+    strncpy(save.name, Cmd_Argv(1), 32);
+    save.name[31] = 0;
+    save.with_margins = Cmd_Argc() >= 3 ? Q_atoi(Cmd_Argv(2)) : 0;
+    save.should = true;
+}
+
+/* WritePCXplate, fisheye.c:1396-1465.  The plate image (texels, 0xFE outside the plate's own region unless
+ * with_margins) comes from the device (bk_save_plate); header, run-length escapes and palette are packed here
+ * exactly as the reference packs them (pcx_t, NQ/client.h:376-391; little-endian shorts). */
+static void write_pcx_plate(const char *filename, int plate_index, int with_margins)
+{
+    int platesize = 0, width, height, i, j, length;
+    byte *pcx, *pack, *img;
+    const byte *palette = host_basepal;
+    bk_get_size(bk, NULL, NULL, &platesize, NULL, NULL);
+    width = height = platesize;
+    pcx = (byte *)Hunk_TempAlloc(width * height * 2 + 1000);
+    img = (byte *)malloc((size_t)width * height);
+    if (pcx == NULL || img == NULL) {
+        Con_Printf("SCR_ScreenShot_f: not enough memory\n");
+        free(img);
+        return;
+    }
+    if (bk_save_plate(bk, 0, plate_index, with_margins, img, width) != BK_OK) {
+        Con_Printf("f_saveglobe: %s\n", bk_last_error(bk));
+        free(img);
+        return;
+    }
+    memset(pcx, 0, 128);
+    pcx[0] = 0x0a;                                    /* manufacturer: PCX id */
+    pcx[1] = 5;                                       /* version: 256 color */
+    pcx[2] = 1;                                       /* encoding */
+    pcx[3] = 8;                                       /* bits_per_pixel */
+    pcx[8] = (byte)((width - 1) & 0xFF);   pcx[9] = (byte)((width - 1) >> 8);      /* xmax */
+    pcx[10] = (byte)((height - 1) & 0xFF); pcx[11] = (byte)((height - 1) >> 8);    /* ymax */
+    pcx[12] = (byte)(width & 0xFF);        pcx[13] = (byte)(width >> 8);           /* hres */
+    pcx[14] = (byte)(height & 0xFF);       pcx[15] = (byte)(height >> 8);          /* vres */
+    pcx[65] = 1;                                      /* color_planes: chunky image */
+    pcx[66] = (byte)(width & 0xFF);        pcx[67] = (byte)(width >> 8);           /* bytes_per_line */
+    pcx[68] = 2;                                      /* palette_type: not a grey scale */
+    pack = pcx + 128;
+    for (i = 0; i < height; i++)
+        for (j = 0; j < width; j++) {
+            byte col = img[(size_t)i * width + j];
+            if ((col & 0xc0) == 0xc0) *pack++ = 0xc1;
+            *pack++ = col;
+        }
+    *pack++ = 0x0c;                                   /* palette ID byte */
+    for (i = 0; i < 768; i++) *pack++ = *palette++;
+    length = (int)(pack - pcx);
+    COM_WriteFile(filename, pcx, length);
+    free(img);
+}
+
+static void save_globe(int numplates)                /* fisheye.c:1467-1484 */
+{
+    int i;
+    char pcxname[32];
+    save.should = false;
+    D_EnableBackBufferAccess();
+    for (i = 0; i < numplates; ++i) {
+        snprintf(pcxname, 32, "%s%d.pcx", save.name, i);
+        write_pcx_plate(pcxname, i, save.with_margins);
+        Con_Printf("Wrote %s\n", pcxname);
+    }
+    D_DisableBackBufferAccess();
 }
 
 static void cmd_globe(void)                         /* fisheye.c:1138-1161 */
@@ -400,6 +471,8 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
             render_plate(i, f, r, u);
         }
     }
+
+    if (save.should) save_globe(numplates);                                  /* fisheye.c:797-799 */
 
     Draw_TileClear(0, 0, vid.width, vid.height);                             /* fisheye.c:802 */
     /* render_lensmap, fisheye.c:2406-2424 */

@@ -117,6 +117,10 @@ int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints);
 int   bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch);
 /* the way back (the plate copy cmd_saveglobe reads, fisheye.c:1396-1465): ps rows of ps bytes to dst_host */
 int   bk_download_plate(bk_ctx *ctx, int frame, int plate, uint8_t *dst_host, int dst_pitch);
+/* the plate image f_saveglobe encodes (WritePCXplate's pixel loop, fisheye.c:1438-1456): texel, or 0xFE where
+ * the ray through the texel belongs to another plate (ray_to_plate_index / the globe's globe_plate) unless
+ * with_margins.  Computed on the device; PCX packing is the caller's (blinky_amd/host/fisheye_hip.c). */
+int   bk_save_plate(bk_ctx *ctx, int frame, int plate, int with_margins, uint8_t *dst_host, int dst_pitch);
 /* Device layout of a globe frame: 6 plates of bk_globe_pitch() = round_up(ps,64) by bk_globe_rows() =
  * round_up(ps,8) texels, each stored as 16x8-texel tiles of 128 bytes (tiles row-major, rows of a tile
  * 16 bytes apart): a 128-byte line covers a compact patch, so the slanted footprints of the warp touch

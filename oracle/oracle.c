@@ -568,6 +568,48 @@ void ok_create_palmap(ok_state *s, const uint8_t *basepal)
 
 /* ---- test helpers ------------------------------------------------------------ */
 
+/* WritePCXplate, fisheye.c:1396-1465 (itself "copied from WritePCXfile in NQ/screen.c"); pcx_t is
+ * NQ/client.h:376-391: 128 header bytes, then the data.  Little-endian shorts (LittleShort). */
+int ok_write_pcx_plate(const ok_state *s, int plate, int with_margins, const uint8_t *plate_pixels,
+                       const uint8_t *basepal, uint8_t *out)
+{
+    const int width = s->platesize, height = s->platesize;                /* :1400-1405 */
+    const uint8_t *data = plate_pixels;
+    uint8_t *pack;
+    int i, j;
+    memset(out, 0, 128);
+    out[0] = 0x0a;                                  /* manufacturer: PCX id            :1419 */
+    out[1] = 5;                                     /* version: 256 color              :1420 */
+    out[2] = 1;                                     /* encoding                        :1421 */
+    out[3] = 8;                                     /* bits_per_pixel                  :1422 */
+    /* xmin, ymin = 0 */
+    out[8] = (uint8_t)((width - 1) & 0xFF);  out[9] = (uint8_t)(((width - 1) >> 8) & 0xFF);     /* xmax  :1425 */
+    out[10] = (uint8_t)((height - 1) & 0xFF); out[11] = (uint8_t)(((height - 1) >> 8) & 0xFF);  /* ymax  :1426 */
+    out[12] = (uint8_t)(width & 0xFF);  out[13] = (uint8_t)((width >> 8) & 0xFF);               /* hres  :1427 */
+    out[14] = (uint8_t)(height & 0xFF); out[15] = (uint8_t)((height >> 8) & 0xFF);              /* vres  :1428 */
+    /* palette[48] = 0, reserved = 0 (Hunk_TempAlloc memory; the reference leaves `reserved` unset) */
+    out[65] = 1;                                    /* color_planes: chunky image      :1430 */
+    out[66] = (uint8_t)(width & 0xFF); out[67] = (uint8_t)((width >> 8) & 0xFF);                /* bytes_per_line :1431 */
+    out[68] = 2; out[69] = 0;                       /* palette_type: not a grey scale  :1432 */
+    pack = out + 128;                               /* &pcx->data                      :1436 */
+    for (i = 0; i < height; i++) {
+        double v = ((double)i) / height;                                    /* :1439 */
+        for (j = 0; j < width; j++) {
+            double u = ((double)j) / width;                                 /* :1441 */
+            float ray[3];
+            uint8_t col;
+            ok_plate_uv_to_ray(s, plate, u, v, ray);
+            col = (with_margins || plate == ray_to_plate_index(s, ray)) ? *data : 0xFE;     /* :1446 */
+            if ((col & 0xc0) == 0xc0) *pack++ = 0xc1;                       /* :1448-1450 */
+            *pack++ = col;
+            data++;
+        }
+    }
+    *pack++ = 0x0c;                                 /* palette ID byte                 :1459 */
+    for (i = 0; i < 768; i++) *pack++ = basepal[i];
+    return (int)(pack - out);
+}
+
 uint64_t ok_fnv1a64(const void *data, size_t n)
 {
     const unsigned char *p = (const unsigned char *)data;

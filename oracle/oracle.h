@@ -112,6 +112,13 @@ void ok_apply(const ok_state *s, const uint8_t *globe, uint8_t *dst, int dst_pit
 /* rubix palette LUTs (fisheye.c:835-908); basepal = 768 bytes */
 void ok_create_palmap(ok_state *s, const uint8_t *basepal);
 
+/* f_saveglobe's plate file (WritePCXplate, fisheye.c:1396-1465): PCX header, the plate packed row by row
+ * (texels outside the plate's own region become 0xFE unless with_margins), palette.  `plate_pixels` = the
+ * plate's ps*ps texels; out must hold ps*ps*2 + 1000 bytes (the reference's Hunk_TempAlloc size).
+ * Returns the file length. */
+int  ok_write_pcx_plate(const ok_state *s, int plate, int with_margins, const uint8_t *plate_pixels,
+                        const uint8_t *basepal, uint8_t *out);
+
 /* helpers for tests */
 uint64_t ok_fnv1a64(const void *data, size_t n);
 void ok_lcg_fill_plate(uint8_t *dst, size_t n, int plate, int frame);   /* SURVEY 8(d) */

@@ -64,6 +64,17 @@ void okpy_palmap(const uint8_t *basepal, uint8_t *out /* [6][256] */)
     for (i = 0; i < OK_MAX_PLATES; ++i) memcpy(out + 256 * i, s.plates[i].palette, 256);
 }
 
+/* f_saveglobe: the PCX file of one plate of a named globe at platesize ps */
+int okpy_pcx_plate(const char *globe, int ps, int plate, int with_margins, const uint8_t *plate_pixels,
+                   const uint8_t *basepal, uint8_t *out)
+{
+    ok_state s;
+    memset(&s, 0, sizeof s);
+    if (!ok_use_globe(&s, globe)) return -1;
+    s.platesize = ps;
+    return ok_write_pcx_plate(&s, plate, with_margins, plate_pixels, basepal, out);
+}
+
 /* evaluate a hand-transliterated callback: which 0 = lens_inverse(x,y), 1 = lens_forward(x,y,z).
  * returns 1 values written, 0 nil, -1 unknown lens / missing callback */
 int okpy_eval(const char *lens, int which, double x, double y, double z, double *out)

@@ -87,7 +87,19 @@ void *Hunk_TempAlloc(int size) { return calloc(1, (size_t)size); }
 void STree_AllocInit(void) {}
 void COM_ScanDir(struct stree_root *root, const char *path, const char *pfx, const char *ext, qboolean stripext)
 { (void)root; (void)path; (void)pfx; (void)ext; (void)stripext; }
-void COM_WriteFile(const char *filename, const void *data, int len) { (void)filename; (void)data; (void)len; }
+/* files the reference writes (f_saveglobe's PCX plates) are kept in memory for the tests */
+#define REF_MAX_FILES 8
+static struct { char name[64]; unsigned char *data; int len; } ref_files[REF_MAX_FILES];
+static int ref_nfiles;
+void COM_WriteFile(const char *filename, const void *data, int len)
+{
+    if (ref_nfiles >= REF_MAX_FILES) return;
+    strncpy(ref_files[ref_nfiles].name, filename, sizeof ref_files[0].name - 1);
+    ref_files[ref_nfiles].data = (unsigned char *)malloc((size_t)len);
+    memcpy(ref_files[ref_nfiles].data, data, (size_t)len);
+    ref_files[ref_nfiles].len = len;
+    ++ref_nfiles;
+}
 
 /* ---- renderer hooks -------------------------------------------------------------- */
 void R_PushDlights(void) {}
@@ -203,6 +215,29 @@ double ref_time_apply(int reps, double *best_ms)
     }
     if (best_ms) *best_ms = best * 1e3;
     return total;
+}
+
+/* "f_saveglobe <name> <with_margins>" on the state the last ref_run left behind, plates = LCG(frame_index):
+ * runs the reference's own cmd_saveglobe + save_globe + WritePCXplate (fisheye.c:1120-1136, 1396-1484) and
+ * returns the bytes it handed to COM_WriteFile for plate `plate` (length, or -1; name_out gets the file name). */
+int ref_saveglobe(const char *name, int with_margins, int frame_index, int plate, unsigned char *out, int cap, char *name_out)
+{
+    char cmd[128];
+    size_t ps2 = (size_t)globe.platesize * globe.platesize;
+    int p, i, len = -1;
+    for (p = 0; p < globe.numplates; ++p) lcg_fill(globe.pixels + ps2 * p, ps2, p, frame_index);
+    for (i = 0; i < ref_nfiles; ++i) free(ref_files[i].data);
+    ref_nfiles = 0;
+    snprintf(cmd, sizeof cmd, "f_saveglobe %s %d", name, with_margins);
+    Cmd_ExecuteString(cmd, src_command);
+    if (!globe.save.should) return -1;
+    save_globe();
+    if (plate >= 0 && plate < ref_nfiles) {
+        len = ref_files[plate].len;
+        if (len <= cap) memcpy(out, ref_files[plate].data, (size_t)len);
+        if (name_out) strcpy(name_out, ref_files[plate].name);
+    }
+    return len;
 }
 
 /* the reference's rubix palette LUTs (create_palmap ran in F_Init) */

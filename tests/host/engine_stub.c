@@ -94,6 +94,43 @@ void AngleVectors(const vec3_t angles, vec3_t forward, vec3_t right, vec3_t up)
     up[0] = cr * sp * cy + -sr * -sy; up[1] = cr * sp * sy + -sr * cy; up[2] = cr * cp;
 }
 
+/* ---- zone / filesystem: files the host layer writes (f_saveglobe) are kept in memory ------------------- */
+void *Hunk_TempAlloc(int size)
+{
+    static void *last;
+    free(last);
+    last = calloc(1, (size_t)size);
+    return last;
+}
+#define MAX_FILES 8
+static struct { char name[64]; unsigned char *data; int len; } files[MAX_FILES];
+static int nfiles;
+void COM_WriteFile(const char *filename, const void *data, int len)
+{
+    if (nfiles >= MAX_FILES) return;
+    snprintf(files[nfiles].name, sizeof files[0].name, "%s", filename);
+    files[nfiles].data = (unsigned char *)malloc((size_t)len);
+    memcpy(files[nfiles].data, data, (size_t)len);
+    files[nfiles].len = len;
+    ++nfiles;
+}
+void D_EnableBackBufferAccess(void) {}
+void D_DisableBackBufferAccess(void) {}
+int hosttest_num_files(void) { return nfiles; }
+int hosttest_file(int i, char *name_out, unsigned char *out, int cap)
+{
+    if (i < 0 || i >= nfiles) return -1;
+    strcpy(name_out, files[i].name);
+    if (files[i].len <= cap) memcpy(out, files[i].data, (size_t)files[i].len);
+    return files[i].len;
+}
+void hosttest_clear_files(void)
+{
+    int i;
+    for (i = 0; i < nfiles; ++i) free(files[i].data);
+    nfiles = 0;
+}
+
 /* ---- renderer hooks ---------------------------------------------------------------------------------- */
 void R_PushDlights(void) {}
 void R_ViewChanged(vrect_t *pvrect, int lineadj, float aspect) { (void)pvrect; (void)lineadj; (void)aspect; }

@@ -138,6 +138,24 @@ def ref_palettes():
     return out
 
 
+def ref_saveglobe(name, with_margins, frame_index, plate, ps):
+    """the reference's own f_saveglobe (cmd_saveglobe + save_globe + WritePCXplate) on the state the last
+    ref_run left behind, plates = LCG(frame_index): (file name, file bytes) of plate `plate`"""
+    buf = np.empty(ps * ps * 2 + 1000, np.uint8)
+    nm = C.create_string_buffer(64)
+    n = _r.ref_saveglobe(name.encode(), int(with_margins), frame_index, plate, _p(buf), buf.size, nm)
+    return nm.value.decode(), (buf[:n].copy() if n >= 0 else None)
+
+
+def pcx_plate(globe, ps, plate, with_margins, plate_pixels, basepal):
+    """oracle restatement of WritePCXplate: the file bytes"""
+    out = np.empty(ps * ps * 2 + 1000, np.uint8)
+    n = _o.okpy_pcx_plate(globe.encode(), ps, plate, int(with_margins), _p(np.ascontiguousarray(plate_pixels, np.uint8)),
+                          _p(np.ascontiguousarray(basepal, np.uint8)), _p(out))
+    assert n > 0
+    return out[:n].copy()
+
+
 _o.okpy_eval.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
 
 
