@@ -93,6 +93,14 @@ def apply(offsets, tints, W, rows, globe, dst, pitch=None, x0=0, y0=0, rubix_on=
     return dst
 
 
+def time_apply_mt(offsets, tints, W, rows, globe, reps, nthreads):
+    """best wall seconds of the row-parallel (pthreads) restatement of render_lensmap over `reps` calls"""
+    dst = np.zeros((rows, W), np.uint8)
+    _o.okpy_time_apply_mt.restype = C.c_double
+    return _o.okpy_time_apply_mt(_p(np.ascontiguousarray(offsets, np.uint32)), _p(np.ascontiguousarray(tints, np.uint8)), W, rows,
+                                 _p(np.ascontiguousarray(globe)), _p(dst), W, reps, nthreads), dst
+
+
 def palmap(basepal):
     out = np.empty((6, 256), np.uint8)
     _o.okpy_palmap(_p(np.ascontiguousarray(basepal, np.uint8)), _p(out))
