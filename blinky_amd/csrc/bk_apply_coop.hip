@@ -361,7 +361,7 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
 }
 
 template <bool RUBIX, int RG>
-__global__ __launch_bounds__(256) void apply_coop_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(
     const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list, const uint16_t *__restrict__ idx,
     const uint8_t *__restrict__ tint_t, const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe,
     size_t globe_stride, int globe_frames, int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
@@ -477,12 +477,12 @@ static int coop_compile(bk_ctx *ctx, CoopMap *cm, int rg)
 // buffer sizes.  Throughput side: a staged 128-byte line ~13 ps, a staged block ~0.08 ns, a pixel ~0.5 ps.
 // Latency side: a workgroup spends ~0.9 us per chunk-per-thread and frame on a block (load -> LDS -> barrier ->
 // gather -> store) plus ~0.1 us per row group, and a CU overlaps only as many blocks as it holds workgroups
-// (two staging buffers each; registers allow 7 / 6 / 4 for 128x8 / 128x16 / 128x32 blocks).  The two sides
+// (two staging buffers each; registers allow 7 / 6 / 5 for 128x8 / 128x16 / 128x32 blocks).  The two sides
 // combine as a 3-norm; a block on the direct-gather path adds ~16 ns per row group.  Returns the best
 // buffer size in KiB.
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns)
 {
-    const int vg = rg == 4 ? 4 : rg == 2 ? 6 : 7;
+    const int vg = rg == 4 ? 5 : rg == 2 ? 6 : 7;
     int best_bin = 1;
     double best_c = -1;
     for (int bin = 1; bin * 1024 <= BK_COOP_LDS_CAP; ++bin) {
