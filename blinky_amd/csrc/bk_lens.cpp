@@ -4,6 +4,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstring>
+#include <unistd.h>
 
 #include "bk_build_params.h"
 #include "bk_emit.h"
@@ -24,6 +25,7 @@ struct LensProgram {
     // compiled build kernels, keyed by the generated source text
     std::string module_source;
     hipModule_t module = nullptr;
+    bool module_from_cache = false;      // the last compile_module() loaded its code object from BLINKY_HIP_CACHE
     hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr;
     std::string last_source;      // for bk_debug_kernel_source
     std::string console;          // print() output of the scripts
@@ -376,6 +378,52 @@ extern "C" int bk_calc_zoom(bk_ctx *ctx, double *scale_out)
 
 // ---- hiprtc ---------------------------------------------------------------------------------------------
 
+// Optional on-disk cache of compiled lens modules (opt-in: BLINKY_HIP_CACHE=<directory>).  hiprtc takes
+// 0.2-1.1 s per lens, which the engine would feel as a hitch on every first `f_lens`; a code object is keyed by
+// FNV-1a-64 over the generated source, the embedded headers, the target arch and the library version.
+static uint64_t fnv1a64(const void *data, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+static std::string cache_path(const std::string &source, const std::string &arch)
+{
+    const char *dir = getenv("BLINKY_HIP_CACHE");
+    if (!dir || !*dir) return std::string();
+    uint64_t h = fnv1a64(source.data(), source.size());
+    for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) h = fnv1a64(bk::kEmbeddedHeaders[i].text, strlen(bk::kEmbeddedHeaders[i].text), h);
+    h = fnv1a64(arch.data(), arch.size(), h);
+    const char *ver = bk_version();
+    h = fnv1a64(ver, strlen(ver), h);
+    char name[64];
+    snprintf(name, sizeof name, "/bk_lens_%016llx.hsaco", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+static bool cache_load(const std::string &path, std::vector<char> *code)
+{
+    if (path.empty()) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    bool ok = n > 0;
+    if (ok) { code->resize((size_t)n); ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n; }
+    fclose(f);
+    return ok;
+}
+static void cache_store(const std::string &path, const std::vector<char> &code)
+{
+    if (path.empty()) return;
+    const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                     // a cache that cannot be written is simply not used
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
 static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source)
 {
     if (P->module && source == P->module_source) return BK_OK;
@@ -386,28 +434,34 @@ static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source
         hnames.push_back(bk::kEmbeddedHeaders[i].name);
         htexts.push_back(bk::kEmbeddedHeaders[i].text);
     }
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, source.c_str(), "bk_lens_build.hip", (int)hnames.size(), htexts.data(), hnames.data()) != HIPRTC_SUCCESS)
-        return ctx->fail(BK_E_HIP, "hiprtcCreateProgram failed");
     hipDeviceProp_t prop;
     std::string arch = "--offload-arch=gfx950";
     if (ctx->device >= 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.gcnArchName[0])
         arch = std::string("--offload-arch=") + prop.gcnArchName;
-    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
-    hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
-    if (rc != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, 0);
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
+    std::vector<char> code;
+    const std::string cpath = cache_path(source, arch);
+    P->module_from_cache = cache_load(cpath, &code);
+    if (!P->module_from_cache) {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, source.c_str(), "bk_lens_build.hip", (int)hnames.size(), htexts.data(), hnames.data()) != HIPRTC_SUCCESS)
+            return ctx->fail(BK_E_HIP, "hiprtcCreateProgram failed");
+        const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+        hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+        if (rc != HIPRTC_SUCCESS) {
+            size_t n = 0;
+            hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n, 0);
+            if (n) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            return ctx->fail(BK_E_HIP, "hiprtc failed to compile the lens kernels: %s", log.c_str());
+        }
+        size_t cs = 0;
+        hiprtcGetCodeSize(prog, &cs);
+        code.resize(cs);
+        hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
-        return ctx->fail(BK_E_HIP, "hiprtc failed to compile the lens kernels: %s", log.c_str());
+        cache_store(cpath, code);
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
     if (ctx->device < 0) {              // host-only context: compiling is all we can do
         P->module_source = source;
         return BK_OK;
@@ -472,6 +526,9 @@ extern "C" int bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nar
     }
     return BK_OK;
 }
+
+/* test hook: 1 if the current lens module came from the BLINKY_HIP_CACHE directory instead of hiprtc */
+extern "C" int bk_debug_module_from_cache(const bk_ctx *ctx) { return ctx && ctx->prog && ctx->prog->module_from_cache ? 1 : 0; }
 
 extern "C" int bk_set_host_math(bk_ctx *ctx, int portable)
 {

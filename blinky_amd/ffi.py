@@ -71,6 +71,7 @@ _SIGS = {
     "bk_get_size": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "bk_version": (C.c_char_p, []),
     "bk_set_apply_variant": (_i, [_vp, _i]),
+    "bk_debug_module_from_cache": (_i, [_vp]),
     "bk_last_build_ms": (_d, [_vp]),
     "bk_globe_pitch": (_i, [_vp]),
     "bk_globe_rows": (_i, [_vp]),
@@ -308,6 +309,9 @@ class Context:
 
     def console(self):
         return lib.bk_script_console(self._h).decode()
+
+    def module_from_cache(self):
+        return bool(lib.bk_debug_module_from_cache(self._h))
 
     def set_apply_variant(self, v):
         self._chk(lib.bk_set_apply_variant(self._h, v))

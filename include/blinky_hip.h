@@ -158,6 +158,11 @@ int         bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesi
 const char *bk_version(void);
 /* selects the apply kernel: 0 = direct gather, 2 = workgroup-cooperative LDS staging (default) */
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
+/* Lens modules are compiled with hiprtc on first use (0.2-1.1 s per lens).  Setting the environment variable
+ * BLINKY_HIP_CACHE=<directory> keeps the compiled code objects there (keyed by generated source, embedded
+ * headers, GPU arch and library version) so that later runs load them in milliseconds.
+ * bk_debug_module_from_cache: 1 if the current module was loaded from that cache (test hook). */
+int         bk_debug_module_from_cache(const bk_ctx *ctx);
 /* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
  * pipelining); results are wrong while bits 2/4 are set.  0 restores normal operation. */
 int         bk_debug_set_ablation(bk_ctx *ctx, int bits);

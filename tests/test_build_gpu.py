@@ -215,6 +215,21 @@ def test_globe_plate_override_fast_globe(bk):
     ctx.close()
 
 
+def test_module_cache_round_trip_builds_the_same_table(bk, tmp_path, monkeypatch):
+    """a lens module loaded back from BLINKY_HIP_CACHE builds the identical lensmap"""
+    monkeypatch.setenv("BLINKY_HIP_CACHE", str(tmp_path))
+    tables = []
+    for i in range(2):
+        ctx = bk.Context()
+        S.configure(ctx, "cube", "quincuncial", None, (400, 300))
+        ctx.build()
+        assert ctx.module_from_cache() == (i == 1)
+        tables.append(ctx.read_lensmap())
+        ctx.close()
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
+
+
 def test_script_runtime_errors_surface_as_errors(bk):
     ctx = bk.Context()
     ctx.load_globe(S.script("globes", "cube"), "cube")

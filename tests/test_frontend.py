@@ -221,6 +221,36 @@ def test_every_shipped_lens_translates_and_compiles(bk):
         assert "bk_build_kernels.h" in src, lens
 
 
+def test_compiled_modules_are_cached_on_disk_when_asked(bk, tmp_path, monkeypatch):
+    """BLINKY_HIP_CACHE=<dir>: the first compile stores the code object, an identical program loads it back, a
+    different lens or size-independent change of the source does not hit it; without the variable nothing is kept."""
+    import time
+    monkeypatch.delenv("BLINKY_HIP_CACHE", raising=False)
+    ctx = host_ctx(bk)
+    S.configure(ctx, "cube", "hammer", None, (320, 240))
+    ctx.kernel_source(compile=True)
+    assert not ctx.module_from_cache()
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    monkeypatch.setenv("BLINKY_HIP_CACHE", str(cache))
+    t0 = time.time()
+    ctx.kernel_source(compile=True)
+    cold = time.time() - t0
+    assert not ctx.module_from_cache()
+    files = list(cache.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("bk_lens_") and files[0].suffix == ".hsaco" and files[0].stat().st_size > 1000
+    ctx2 = host_ctx(bk)
+    S.configure(ctx2, "cube", "hammer", None, (640, 480))       # the size is a kernel argument, not part of the source
+    t0 = time.time()
+    ctx2.kernel_source(compile=True)
+    warm = time.time() - t0
+    assert ctx2.module_from_cache() and warm < cold
+    ctx3 = host_ctx(bk)
+    S.configure(ctx3, "cube", "panini", None, (320, 240))
+    ctx3.kernel_source(compile=True)
+    assert not ctx3.module_from_cache() and len(list(cache.iterdir())) == 2
+
+
 def test_globe_plate_override_and_mutable_globals_translate(bk):
     ctx = host_ctx(bk)
     S.configure(ctx, "fast", "panini", None, (320, 240))
