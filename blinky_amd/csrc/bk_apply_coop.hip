@@ -74,9 +74,11 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = blockIdx.x;
     const int by = blk / blocks_x, bx = blk - by * blocks_x;
-    const int ox = (bx * 4 + wave) * 32, oy = by * 8 * RG;
-    const int ry = lane >> 3, cx = lane & 7;
-    const int x0 = ox + cx * 4;
+    // pixel -> lane: a wave spans the block's full 128-pixel width, 32 lanes x 4 pixels per row, two rows per
+    // row group (rows 2*wave, 2*wave+1 of each group of 8): its stores are whole 128-byte lines
+    const int oy = by * 8 * RG;
+    const int ry = wave * 2 + (lane >> 5);
+    const int x0 = bx * 128 + (lane & 31) * 4;
     if (threadIdx.x == 0) s_flags = 0;
 
     uint32_t o[NP];
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     if (l >= l_end) return;
     const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);
     const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & 3u) == 0;
-    const int ry = lane >> 3, cx = lane & 7;
+    const int ry = wave * 2 + (lane >> 5), cx = lane & 31;        // same pixel -> lane mapping as coop_compile_kernel
     uint32_t par = 0;
 
     CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l, wave, lane);
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.y);
         if (!(flags & CF_EMPTY)) {
             const int by = l / blocks_x, bx = l - by * blocks_x;
-            const int row0 = by * 8 * RG + ry, x = (bx * 4 + wave) * 32 + cx * 4;
+            const int row0 = by * 8 * RG + ry, x = bx * 128 + cx * 4;
             const bool tile_all = (flags >> wave) & 1u, tile_empty = (flags >> (4 + wave)) & 1u;
             // a block whose chunk list exceeds this launch's staging buffer takes the direct-gather path
             const bool slow = (flags & CF_SLOW) != 0 || (int)(nchunks * 16u) > lds_buf;
