@@ -74,11 +74,13 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = blockIdx.x;
     const int by = blk / blocks_x, bx = blk - by * blocks_x;
-    // pixel -> lane: a wave spans the block's full 128-pixel width, 32 lanes x 4 pixels per row, two rows per
-    // row group (rows 2*wave, 2*wave+1 of each group of 8): its stores are whole 128-byte lines
+    // pixel -> lane: a lane owns 4*RG consecutive pixels of ONE row (RG groups of 4), 32/RG lanes span the
+    // block's 128-pixel width and a wave covers 2*RG consecutive rows: every store instruction of the apply
+    // kernel writes whole 128-byte lines (one dword / dwordx2 / dwordx4 per lane)
+    constexpr int LPR = 32 / RG;                  // lanes per row
     const int oy = by * 8 * RG;
-    const int ry = wave * 2 + (lane >> 5);
-    const int x0 = bx * 128 + (lane & 31) * 4;
+    const int ry = wave * 2 * RG + lane / LPR;
+    const int x0 = bx * 128 + (lane % LPR) * 4 * RG;
     if (threadIdx.x == 0) s_flags = 0;
 
     uint32_t o[NP];
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     bool all_l = true, any_l = false;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int row = oy + (i >> 2) * 8 + ry, x = x0 + (i & 3);
+        const int row = oy + ry, x = x0 + i;
         const bool in = row < rows && x < W;
         o[i] = in ? lmap[(size_t)row * W + x] : BK_NULL_OFFSET;
         tn[i] = in ? tints[(size_t)row * W + x] : 255;
@@ -296,9 +298,10 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                 w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
             }
             if (!(kflags & 4)) {
-#pragma unroll
-                for (int r = 0; r < RG; ++r)
-                    *reinterpret_cast<uint32_t *>(dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x) = w[r];
+                uint8_t *o = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x;
+                if (RG == 1) *reinterpret_cast<uint32_t *>(o) = w[0];
+                else if (RG == 2) *reinterpret_cast<uint2 *>(o) = make_uint2(w[0], w[RG - 1]);
+                else *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1 % RG], w[2 % RG], w[3 % RG]);
             }
         } else {
 #pragma unroll
@@ -313,7 +316,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                         if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
                     }
                 }
-                uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x;
+                uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
                 if (fast_store) {
                     *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
                 } else {
@@ -340,14 +343,14 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
     for (int r = 0; r < RG; ++r)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int row = row0 + r * 8, xx = x + k;
+            const int row = row0, xx = x + 4 * r + k;
             so[r][k] = (row < rows && xx < W) ? lmap[(size_t)row * W + xx] : BK_NULL_OFFSET;
         }
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)(row0 + r * 8) * dst_pitch + x;
+            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (so[r][k] == BK_NULL_OFFSET) continue;
@@ -386,8 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     int l = band * per + wg_in_band;
     if (l >= l_end) return;
     const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);
-    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & 3u) == 0;
-    const int ry = wave * 2 + (lane >> 5), cx = lane & 31;        // same pixel -> lane mapping as coop_compile_kernel
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & (uintptr_t)(4 * RG - 1)) == 0;
+    constexpr int LPR = 32 / RG;                                   // same pixel -> lane mapping as coop_compile_kernel
+    const int ry = wave * 2 * RG + lane / LPR, cx = lane % LPR;
     uint32_t par = 0;
 
     CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l, wave, lane);
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.y);
         if (!(flags & CF_EMPTY)) {
             const int by = l / blocks_x, bx = l - by * blocks_x;
-            const int row0 = by * 8 * RG + ry, x = bx * 128 + cx * 4;
+            const int row0 = by * 8 * RG + ry, x = bx * 128 + cx * 4 * RG;
             const bool tile_all = (flags >> wave) & 1u, tile_empty = (flags >> (4 + wave)) & 1u;
             // a block whose chunk list exceeds this launch's staging buffer takes the direct-gather path
             const bool slow = (flags & CF_SLOW) != 0 || (int)(nchunks * 16u) > lds_buf;
