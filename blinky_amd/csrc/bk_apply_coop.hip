@@ -30,9 +30,11 @@
 namespace bk {
 
 constexpr int BK_COOP_LDS_CAP = 49152;                 // max bytes of one staging buffer (3072 chunks)
+constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
 constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's column fully mapped / empty
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
-constexpr int BK_COOP_STATS = 192;                     // words per stats replica
+constexpr uint32_t BK_COOP_BINS = 65;                  // LDS-need histogram: 1 KiB bins, 0..64 KiB
+constexpr int BK_COOP_STATS = 208;                     // words per stats replica
 
 struct CoopHdr {              // 8 bytes per block
     uint32_t nchunks;         // entries of the block's chunk list (0 for direct-gather / empty blocks)
@@ -45,8 +47,8 @@ struct CoopMap {
     uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][256] LDS addresses, 0xFFFF = unmapped
     uint8_t *d_tint = nullptr;      // same order (rubix)
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
-                                    // [3] 128-B lines staged, [4] chunks staged, [8..57) blocks by LDS need (1 KiB bins),
-                                    // [64..113) 128-B lines of those blocks, [128..177) chunks of those blocks
+                                    // [3] 128-B lines staged, [4] chunks staged, [8..73) blocks by LDS need (1 KiB bins),
+                                    // [73..138) 128-B lines of those blocks, [138..203) chunks of those blocks
     int blocks_x = 0, blocks_y = 0;
     int rg = 4;
     int lds_bytes = 0;              // bytes of ONE staging buffer of the apply launch
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     for (int w = 0; w < wave; ++w) base += s_wsum[w];
     const uint32_t nchunks = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     const uint32_t lines = s_wlines[0] + s_wlines[1] + s_wlines[2] + s_wlines[3];
-    const bool slow = nchunks * 16u > (uint32_t)BK_COOP_LDS_CAP;
+    const bool slow = nchunks > BK_COOP_MAX_CHUNKS;        // (only a 128x32 block whose 4096 pixels all read different chunks)
     {
         uint32_t k = base;
 #pragma unroll
@@ -188,10 +190,10 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         uint32_t *st = stats + (blk & 63) * BK_COOP_STATS;
         if (!slow && any_blk) {
             atomicMax(&st[0], nchunks);
-            const uint32_t bin = min(48u, (nchunks * 16u + 1023u) / 1024u);
+            const uint32_t bin = min(BK_COOP_BINS - 1u, (nchunks * 16u + 1023u) / 1024u);
             atomicAdd(&st[8 + bin], 1u);
-            atomicAdd(&st[64 + bin], lines);
-            atomicAdd(&st[128 + bin], nchunks);
+            atomicAdd(&st[8 + BK_COOP_BINS + bin], lines);
+            atomicAdd(&st[8 + 2 * BK_COOP_BINS + bin], nchunks);
             atomicAdd(&st[3], lines);
             atomicAdd(&st[4], nchunks);
         }
@@ -331,7 +333,79 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
 
 #undef BK_COOP_LOADS
 
-// direct-gather frames of a block whose chunk list does not fit the staging buffer
+// Frames of a block whose chunk list is larger than the launch's staging buffer: the list goes through
+// LDS in passes of lds_buf/16 chunks (buffers still alternate, one barrier per pass); a pixel picks its texel
+// up in the pass that holds its slot and the packed words are stored after the last pass.
+template <bool RUBIX, int RG>
+__device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
+                                                   int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
+                                                   uint8_t *lds0, uint32_t lds_buf, uint32_t *par_io, const uint32_t *__restrict__ blist,
+                                                   uint32_t nchunks, const CoopIdx<RG> ix, bool fast_store, bool tile_empty,
+                                                   const uint8_t *pal_s, int row0, int x)
+{
+    uint32_t par = *par_io;
+    const uint32_t cpb = lds_buf >> 4;                       // chunks per pass
+    for (int f = f_begin; f < f_end; ++f) {
+        const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
+        uint32_t w[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) w[r] = 0;
+        for (uint32_t base = 0; base < nchunks; base += cpb) {
+            uint8_t *buf = lds0 + par * lds_buf;
+            const uint32_t end = min(nchunks, base + cpb);
+            for (uint32_t c0 = base; c0 < end; c0 += 1024) {
+                const uint32_t c = c0 + threadIdx.x;
+                const bool m0 = c < end, m1 = c + 256u < end, m2 = c + 512u < end, m3 = c + 768u < end;
+                const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
+                               a3 = m3 ? blist[c + 768u] : 0u;
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(gl + a0), q1 = *reinterpret_cast<const uint4 *>(gl + a1),
+                            q2 = *reinterpret_cast<const uint4 *>(gl + a2), q3 = *reinterpret_cast<const uint4 *>(gl + a3);
+                uint8_t *md = buf + (size_t)(c - base) * 16u;
+                if (m0) *reinterpret_cast<uint4 *>(md) = q0;
+                if (m1) *reinterpret_cast<uint4 *>(md + 4096) = q1;
+                if (m2) *reinterpret_cast<uint4 *>(md + 8192) = q2;
+                if (m3) *reinterpret_cast<uint4 *>(md + 12288) = q3;
+            }
+            __syncthreads();
+            par ^= 1u;
+            if (tile_empty) continue;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t rel = a[k] - base * 16u;          // (0xFFFF = unmapped never lands inside: slots <= 4094)
+                    if (a[k] != 0xFFFFu && rel < (end - base) * 16u) w[r] |= (uint32_t)buf[rel] << (8 * k);
+                }
+            }
+        }
+        if (tile_empty) continue;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = (w[r] >> (8 * k)) & 0xFFu;
+                if (RUBIX) {
+                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
+                    if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+                }
+            }
+            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
+            if (fast_store) {
+                *reinterpret_cast<uint32_t *>(out) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
+            }
+        }
+    }
+    *par_io = par;
+}
+
+// direct-gather frames of a block that has no chunk list (more than 4095 unique chunks)
 template <bool RUBIX, int RG>
 __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
                                               int globe_frames, int frame0, int f_begin, int f_end, uint8_t *__restrict__ dst,
@@ -407,12 +481,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             const int by = l / blocks_x, bx = l - by * blocks_x;
             const int row0 = by * 8 * RG + ry, x = bx * 128 + cx * 4 * RG;
             const bool tile_all = (flags >> wave) & 1u, tile_empty = (flags >> (4 + wave)) & 1u;
-            // a block whose chunk list exceeds this launch's staging buffer takes the direct-gather path
-            const bool slow = (flags & CF_SLOW) != 0 || (int)(nchunks * 16u) > lds_buf;
-            if (slow) {
+            if (flags & CF_SLOW) {
                 if (!tile_empty)
                     coop_slow_frames<RUBIX, RG>(lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch,
                                                 frame_stride, W, rows, cur.ix, pal_s, row0, x);
+            } else if ((int)(nchunks * 16u) > lds_buf) {
+                // a chunk list larger than this launch's staging buffer goes through it in passes
+                coop_frames_multipass<RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
+                                                 smem, (uint32_t)lds_buf, &par, list + (size_t)l * N, nchunks, cur.ix, tile_all && aligned,
+                                                 tile_empty, pal_s, row0, x);
             } else {
                 const bool k0 = threadIdx.x < nchunks, k1 = threadIdx.x + 256u < nchunks, k2 = threadIdx.x + 512u < nchunks,
                            k3 = threadIdx.x + 768u < nchunks;
@@ -484,25 +561,31 @@ static int coop_compile(bk_ctx *ctx, CoopMap *cm, int rg)
 // Latency side: a workgroup spends ~0.9 us per chunk-per-thread and frame on a block (load -> LDS -> barrier ->
 // gather -> store) plus ~0.1 us per row group, and a CU overlaps only as many blocks as it holds workgroups
 // (two staging buffers each; registers allow 7 / 6 / 5 for 128x8 / 128x16 / 128x32 blocks).  The two sides
-// combine as a 3-norm; a block on the direct-gather path adds ~16 ns per row group.  Returns the best
-// buffer size in KiB.
+// combine as a 3-norm; a block larger than the buffer takes ceil(need/buffer) passes; a block on the direct-gather
+// path (no chunk list at all) adds ~16 ns per row group.  Returns the best buffer size in KiB.
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns)
 {
     const int vg = rg == 4 ? 5 : rg == 2 ? 6 : 7;
     int best_bin = 1;
     double best_c = -1;
     for (int bin = 1; bin * 1024 <= BK_COOP_LDS_CAP; ++bin) {
-        uint64_t over = 0, lines_fit = 0, blocks_fit = 0, chunks_fit = 0;
-        for (int b = 0; b <= 48; ++b) {
-            if (b <= bin) { lines_fit += cm->stats[64 + b]; blocks_fit += cm->stats[8 + b]; chunks_fit += cm->stats[128 + b]; }
-            else over += cm->stats[8 + b];
+        // blocks that need more than the buffer go through it in ceil(need / buffer) passes (slower per chunk:
+        // no register plan, the list is re-read every frame)
+        double lines_fit = 0, blocks_fit = 0, chunks_fit = 0, over_passes = 0;
+        for (int b = 0; b < (int)BK_COOP_BINS; ++b) {
+            const double passes = b <= bin ? 1.0 : (double)((b + bin - 1) / bin);
+            if (b > bin) over_passes += passes * cm->stats[8 + b];
+            lines_fit += cm->stats[8 + BK_COOP_BINS + b];
+            blocks_fit += passes * cm->stats[8 + b];
+            chunks_fit += (b <= bin ? 1.0 : 1.5) * cm->stats[8 + 2 * BK_COOP_BINS + b];
         }
         int wgs = (160 * 1024) / (2 * bin * 1024 + BK_MAX_PLATES * 256);
         if (wgs > vg) wgs = vg;
         if (wgs < 1) wgs = 1;
-        const double t_thr = 0.013 * (double)lines_fit + 0.08 * (double)blocks_fit + 0.00048 * npixels;
-        const double t_lat = (900.0 * (double)chunks_fit / 256.0 + 100.0 * rg * (double)blocks_fit) / ((double)num_cus * wgs);
-        const double c = cbrt(t_thr * t_thr * t_thr + t_lat * t_lat * t_lat) + 16.0 * rg * (double)(over + cm->stats[1]);
+        const double t_thr = 0.013 * lines_fit + 0.08 * blocks_fit + 0.00048 * npixels;
+        const double t_lat = (900.0 * chunks_fit / 256.0 + 100.0 * rg * blocks_fit) / ((double)num_cus * wgs);
+        // (multi-pass blocks are long-running stragglers of the persistent grid: charged ~12 ns per pass and row group)
+        const double c = cbrt(t_thr * t_thr * t_thr + t_lat * t_lat * t_lat) + 12.0 * rg * over_passes + 16.0 * rg * (double)cm->stats[1];
         if (best_c < 0 || c < best_c) { best_c = c; best_bin = bin; }
     }
     *cost_ns = best_c;
@@ -544,8 +627,8 @@ static int ensure_coopmap(bk_ctx *ctx)
     if (compiled != best_rg)
         if (int r = coop_compile(ctx, cm, best_rg)) return r;
     if (ctx->apply_lds_kb > 0) best_kb = ctx->apply_lds_kb > BK_COOP_LDS_CAP / 1024 ? BK_COOP_LDS_CAP / 1024 : ctx->apply_lds_kb;   // developer knob
-    uint64_t over = 0;
-    for (int b = best_kb + 1; b <= 48; ++b) over += cm->stats[8 + b];
+    uint64_t over = 0;                         // blocks that take more than one pass through the buffer
+    for (int b = best_kb + 1; b < (int)BK_COOP_BINS; ++b) over += cm->stats[8 + b];
     cm->lds_bytes = best_kb * 1024;
     cm->slow_blocks = (int)(cm->stats[1] + over);
     cm->valid = true;
