@@ -14,8 +14,9 @@
 // (slot * 16 + byte).  Per frame the 256 threads copy chunk list entry i to LDS slot i (neighbouring
 // lanes fetch neighbouring chunks of a line: one request per line and block), meet at one
 // s_barrier, and every wave gathers its 32-pixel column from the shared copy (ds_read_u8) and
-// stores 4 pixels per lane.  Two LDS buffers alternate, so one barrier per frame is enough: the
-// buffer a wave overwrites for frame f+2 was last read before the barrier of frame f+1.
+// stores its pixels.  One staging buffer, two barriers per frame (chunks visible / gather done): measured
+// against two alternating buffers with one barrier, the halved LDS footprint - more resident workgroups per
+// CU - wins whenever LDS limits occupancy and costs nothing when it does not.
 //
 // Persistent grid, XCD-banded block order, next block's header,
 // chunk list head and indices prefetched, a batch launch re-uses a block's plan for up to 8 frames.
@@ -29,7 +30,7 @@
 
 namespace bk {
 
-constexpr int BK_COOP_LDS_CAP = 49152;                 // max bytes of one staging buffer (3072 chunks)
+constexpr int BK_COOP_LDS_CAP = 65536;                 // max bytes of the staging buffer (a block has <= 4095 chunks)
 constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
 constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's column fully mapped / empty
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
@@ -51,7 +52,7 @@ struct CoopMap {
                                     // [73..138) 128-B lines of those blocks, [138..203) chunks of those blocks
     int blocks_x = 0, blocks_y = 0;
     int rg = 4;
-    int lds_bytes = 0;              // bytes of ONE staging buffer of the apply launch
+    int lds_bytes = 0;              // bytes of the staging buffer of the apply launch
     uint32_t stats[BK_COOP_STATS] = {0};
     int slow_blocks = 0;
     bool valid = false;
@@ -246,7 +247,7 @@ __device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict
 template <int NQ, bool RUBIX, int RG>
 __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
                                             int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
-                                            uint8_t *lds0, uint32_t lds_buf, uint32_t &par, const uint32_t *__restrict__ blist,
+                                            uint8_t *buf, const uint32_t *__restrict__ blist,
                                             uint32_t nchunks, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
                                             bool k0, bool k1, bool k2, bool k3, const CoopIdx<RG> ix, bool fast_store,
                                             bool tile_empty, const uint8_t *pal_s, int row0, int x, int kflags)
@@ -264,7 +265,6 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
     if (pipe && f_begin < f_end) BK_COOP_LOADS(f_begin);
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
-        uint8_t *buf = lds0 + par * lds_buf;
         uint8_t *mine = buf + threadIdx.x * 16u;
         if (!pipe && !(kflags & 2)) BK_COOP_LOADS(f);
         if (k0) *reinterpret_cast<uint4 *>(mine) = q0;
@@ -289,9 +289,8 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
             }
         }
         __syncthreads();                      // the block's chunks are in `buf`
-        par ^= 1u;
         if (pipe && f + 1 < f_end) BK_COOP_LOADS(f + 1);
-        if (tile_empty) continue;
+        if (tile_empty) { __syncthreads(); continue; }
         if (!RUBIX && fast_store) {
             uint32_t w[RG];
 #pragma unroll
@@ -328,22 +327,22 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                 }
             }
         }
+        __syncthreads();                      // every wave is done with `buf`
     }
 }
 
 #undef BK_COOP_LOADS
 
 // Frames of a block whose chunk list is larger than the launch's staging buffer: the list goes through
-// LDS in passes of lds_buf/16 chunks (buffers still alternate, one barrier per pass); a pixel picks its texel
-// up in the pass that holds its slot and the packed words are stored after the last pass.
+// LDS in passes of lds_buf/16 chunks; a pixel picks its texel up in the pass that holds its slot and the packed
+// words are stored after the last pass.
 template <bool RUBIX, int RG>
 __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
                                                    int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
-                                                   uint8_t *lds0, uint32_t lds_buf, uint32_t *par_io, const uint32_t *__restrict__ blist,
+                                                   uint8_t *buf, uint32_t lds_buf, const uint32_t *__restrict__ blist,
                                                    uint32_t nchunks, const CoopIdx<RG> ix, bool fast_store, bool tile_empty,
                                                    const uint8_t *pal_s, int row0, int x)
 {
-    uint32_t par = *par_io;
     const uint32_t cpb = lds_buf >> 4;                       // chunks per pass
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
@@ -351,7 +350,6 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
 #pragma unroll
         for (int r = 0; r < RG; ++r) w[r] = 0;
         for (uint32_t base = 0; base < nchunks; base += cpb) {
-            uint8_t *buf = lds0 + par * lds_buf;
             const uint32_t end = min(nchunks, base + cpb);
             for (uint32_t c0 = base; c0 < end; c0 += 1024) {
                 const uint32_t c = c0 + threadIdx.x;
@@ -367,17 +365,18 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                 if (m3) *reinterpret_cast<uint4 *>(md + 12288) = q3;
             }
             __syncthreads();
-            par ^= 1u;
-            if (tile_empty) continue;
+            if (!tile_empty) {
 #pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
+                for (int r = 0; r < RG; ++r) {
+                    const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t rel = a[k] - base * 16u;          // (0xFFFF = unmapped never lands inside: slots <= 4094)
-                    if (a[k] != 0xFFFFu && rel < (end - base) * 16u) w[r] |= (uint32_t)buf[rel] << (8 * k);
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t rel = a[k] - base * 16u;          // (0xFFFF = unmapped never lands inside: slots <= 4094)
+                        if (a[k] != 0xFFFFu && rel < (end - base) * 16u) w[r] |= (uint32_t)buf[rel] << (8 * k);
+                    }
                 }
             }
+            __syncthreads();
         }
         if (tile_empty) continue;
 #pragma unroll
@@ -402,7 +401,6 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
             }
         }
     }
-    *par_io = par;
 }
 
 // direct-gather frames of a block that has no chunk list (more than 4095 unique chunks)
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     constexpr int N = 1024 * RG;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint8_t *pal_s = smem + 2 * lds_buf;
+    uint8_t *pal_s = smem + lds_buf;
     if (RUBIX) {
         for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += 256) pal_s[i] = pal[i];
         __syncthreads();
@@ -466,7 +464,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & (uintptr_t)(4 * RG - 1)) == 0;
     constexpr int LPR = 32 / RG;                                   // same pixel -> lane mapping as coop_compile_kernel
     const int ry = wave * 2 * RG + lane / LPR, cx = lane % LPR;
-    uint32_t par = 0;
 
     CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l, wave, lane);
     for (;;) {
@@ -488,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             } else if ((int)(nchunks * 16u) > lds_buf) {
                 // a chunk list larger than this launch's staging buffer goes through it in passes
                 coop_frames_multipass<RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
-                                                 smem, (uint32_t)lds_buf, &par, list + (size_t)l * N, nchunks, cur.ix, tile_all && aligned,
+                                                 smem, (uint32_t)lds_buf, list + (size_t)l * N, nchunks, cur.ix, tile_all && aligned,
                                                  tile_empty, pal_s, row0, x);
             } else {
                 const bool k0 = threadIdx.x < nchunks, k1 = threadIdx.x + 256u < nchunks, k2 = threadIdx.x + 512u < nchunks,
@@ -497,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 const bool fast_store = tile_all && aligned;
                 const uint32_t nq = (nchunks + 255u) >> 8;
 #define BK_COOP(NQ_) coop_frames<NQ_, RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, smem, \
-                                                (uint32_t)lds_buf, par, list + (size_t)l * N, nchunks, s0, s1, s2, s3, k0, k1, k2, k3,    \
+                                                list + (size_t)l * N, nchunks, s0, s1, s2, s3, k0, k1, k2, k3,                    \
                                                 cur.ix, fast_store, tile_empty, pal_s, row0, x, kflags)
                 if (nq <= 1) BK_COOP(1);
                 else if (nq == 2) BK_COOP(2);
@@ -560,7 +557,7 @@ static int coop_compile(bk_ctx *ctx, CoopMap *cm, int rg)
 // buffer sizes.  Throughput side: a staged 128-byte line ~13 ps, a staged block ~0.08 ns, a pixel ~0.5 ps.
 // Latency side: a workgroup spends ~0.9 us per chunk-per-thread and frame on a block (load -> LDS -> barrier ->
 // gather -> store) plus ~0.1 us per row group, and a CU overlaps only as many blocks as it holds workgroups
-// (two staging buffers each; registers allow 7 / 6 / 5 for 128x8 / 128x16 / 128x32 blocks).  The two sides
+// (one staging buffer each; registers allow 7 / 6 / 5 for 128x8 / 128x16 / 128x32 blocks).  The two sides
 // combine as a 3-norm; a block larger than the buffer takes ceil(need/buffer) passes; a block on the direct-gather
 // path (no chunk list at all) adds ~16 ns per row group.  Returns the best buffer size in KiB.
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns)
@@ -579,7 +576,7 @@ static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num
             blocks_fit += passes * cm->stats[8 + b];
             chunks_fit += (b <= bin ? 1.0 : 1.5) * cm->stats[8 + 2 * BK_COOP_BINS + b];
         }
-        int wgs = (160 * 1024) / (2 * bin * 1024 + BK_MAX_PLATES * 256);
+        int wgs = (160 * 1024) / (bin * 1024 + BK_MAX_PLATES * 256);
         if (wgs > vg) wgs = vg;
         if (wgs < 1) wgs = 1;
         const double t_thr = 0.013 * lines_fit + 0.08 * blocks_fit + 0.00048 * npixels;
@@ -652,7 +649,7 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     if (wgs_per_band < 1) wgs_per_band = 1;
     if (wgs_per_band > per) wgs_per_band = per;
     dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
-    const size_t shmem = (size_t)2 * cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
+    const size_t shmem = (size_t)cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
 #define BK_APPLY(RBX, N) hipLaunchKernelGGL((apply_coop_kernel<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, cm->lds_bytes,     \
