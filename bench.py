@@ -298,6 +298,12 @@ def main():
             "lensmap_blockmap_first_wall_ms_incl_alloc": round(tilemap_first_wall_ms, 3), "tile_stats": tile_stats,
             "stripe_complete_mpx_s": round(stripe_complete_mpx, 1),
             "assembled_on_rank0_mpx_s": round(W * H * F / root_elapsed / 1e6, 1) if root_elapsed else None,
+            # what xGMI allows (one link per GPU pair, ~64 GB/s per direction): a rank receives (N-1)/N of every frame it
+            # owns, each peer's share over that peer's own link -> whole-job bound = N * N * link rate (1 B per pixel)
+            "exchange": None if world == 1 else {
+                "bytes_received_per_rank_per_step": int(len(multigpu.owned_frames(F, 0, world)) * (H - (bounds[1] - bounds[0])) * W),
+                "xgmi_link_GBps_assumed": 64, "bound_mpx_s": round(world * world * 64e9 / 1e6, 1),
+                "bound_all_on_rank0_mpx_s": round(64e9 * world / 1e6, 1)},
             "single_frame_launch_us": round(single_ms * 1e3, 2),
             "single_frame_mpx_s": round(W * rows / (single_ms * 1e-3) / 1e6, 1),
             "lens_scale": scale,
