@@ -362,13 +362,18 @@ struct Emitter {
             return;
         }
         if (bn == "math.max" || bn == "math.min") {
-            if (a.multi) unsupported(f.chunk, e.line, bn + " over an expanded call");
-            if (a.fixed.empty()) unsupported(f.chunk, e.line, bn + " without arguments");
+            if (a.fixed.empty() && !a.multi) unsupported(f.chunk, e.line, bn + " without arguments");
+            const std::string cmp = bn == "math.max" ? " > " : " < ";
             std::string m = tmp("m");
-            line(f, "double " + m + " = " + num(0) + ";");
+            line(f, "double " + m + " = " + num(0) + ";");           // (no value at all -> bk_tonum(nil) raises the script error)
             for (size_t i = 1; i < a.fixed.size(); ++i) {
                 std::string d = tmp("d");
-                line(f, "{ const double " + d + " = " + num(i) + "; if (" + d + (bn == "math.max" ? " > " : " < ") + m + ") " + m + " = " + d + "; }");
+                line(f, "{ const double " + d + " = " + num(i) + "; if (" + d + cmp + m + ") " + m + " = " + d + "; }");
+            }
+            if (a.multi) {                                           // the values a trailing call expands to, e.g. math.min(x, math.max(a, b))
+                std::string d = tmp("d");
+                line(f, "for (int q = " + std::string(a.fixed.empty() ? "1" : "0") + "; q < " + a.mcnt + "; ++q) { const double " + d + " = bk_tonum(S, " +
+                            a.marr + "[q]); if (" + d + cmp + m + ") " + m + " = " + d + "; }");
             }
             single("bk_num(" + m + ")");
             return;

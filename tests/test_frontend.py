@@ -251,6 +251,23 @@ def test_compiled_modules_are_cached_on_disk_when_asked(bk, tmp_path, monkeypatc
     assert not ctx3.module_from_cache() and len(list(cache.iterdir())) == 2
 
 
+def test_min_max_over_an_expanded_call_translate(bk):
+    """math.min(x, math.max(a, b)): the trailing call is in multi-value position (Lua expands it)"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens("""
+local function two(a) return a, a * 2 end
+function lens_inverse(x, y)
+  return math.min(x, math.max(y, 0.25)), math.max(two(x)), math.min(3, two(y))
+end
+""", "mm.lua")
+    ctx.resize(64, 48)
+    assert ctx.eval_host(0, 0.5, 0.1) == (0.25, 1.0, 0.1)
+    assert ctx.eval_host(0, -1.0, 2.0) == (-1.0, -1.0, 2.0)
+    src = ctx.kernel_source(compile=True)
+    assert "lens_inverse" in src
+
+
 def test_globe_plate_override_and_mutable_globals_translate(bk):
     ctx = host_ctx(bk)
     S.configure(ctx, "fast", "panini", None, (320, 240))

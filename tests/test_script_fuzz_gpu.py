@@ -1,0 +1,162 @@
+"""Differential fuzz of the script surface: random lens scripts inside the supported Lua subset are run by the
+host interpreter (portable libm) and by the generated device code; every raw result of lens_inverse /
+lens_forward must be bit-identical (values, NaNs, nil vs numbers, count of results).  The shipped lenses only
+exercise the constructs their authors happened to use; this walks the emitter through operator precedence,
+short-circuit and/or, nested functions with upvalues, numeric for / while / repeat loops, multiple assignment and
+multiple returns."""
+import numpy as np
+import pytest
+
+import scripts as S
+
+pytestmark = pytest.mark.gpu
+
+UNARY = ["math.sin", "math.cos", "math.atan", "math.sqrt", "math.abs", "math.exp", "math.floor", "math.ceil", "math.tanh",
+         "math.asin", "math.acos", "math.log", "math.tan", "math.sinh", "math.cosh"]
+BINARY_FN = ["math.atan2", "math.min", "math.max", "math.pow", "math.fmod"]
+BINOPS = ["+", "-", "*", "/", "%", "^"]
+CMPS = ["<", "<=", ">", ">=", "==", "~="]
+
+
+class Gen:
+    def __init__(self, seed):
+        self.r = np.random.default_rng(seed)
+        self.n = 0
+
+    def pick(self, xs):
+        return xs[int(self.r.integers(0, len(xs)))]
+
+    def num(self):
+        k = self.r.integers(0, 6)
+        if k == 0:
+            return str(int(self.r.integers(-3, 9)))
+        if k == 1:
+            return "math.pi"
+        if k == 2:
+            return f"{self.r.uniform(-2, 2):.6g}"
+        if k == 3:
+            return f"{10.0 ** self.r.uniform(-3, 3):.4e}"
+        return f"{self.r.uniform(0, 1):.9f}"
+
+    def expr(self, vars_, depth):
+        if depth <= 0 or self.r.random() < 0.2:
+            return self.pick(vars_) if self.r.random() < 0.65 else self.num()
+        k = self.r.integers(0, 10)
+        a = self.expr(vars_, depth - 1)
+        if k <= 3:
+            return f"({a} {self.pick(BINOPS)} {self.expr(vars_, depth - 1)})"
+        if k == 4:
+            return f"(- {a})"
+        if k == 5:
+            return f"{self.pick(UNARY)}({a})"
+        if k == 6:
+            return f"{self.pick(BINARY_FN)}({a}, {self.expr(vars_, depth - 1)})"
+        if k == 7:        # short-circuit value selection (the Lua idiom `c and a or b`)
+            return f"(({self.cond(vars_, depth - 1)}) and {a} or {self.expr(vars_, depth - 1)})"
+        if k == 8:
+            return f"helper({a}, {self.expr(vars_, depth - 1)})"
+        return f"(({a}) * 0.5 + {self.pick(vars_)})"
+
+    def cond(self, vars_, depth):
+        c = f"{self.expr(vars_, depth)} {self.pick(CMPS)} {self.expr(vars_, depth)}"
+        k = self.r.integers(0, 5)
+        if k == 0:
+            return f"not ({c})"
+        if k == 1:
+            return f"({c}) and ({self.expr(vars_, depth)} {self.pick(CMPS)} {self.num()})"
+        if k == 2:
+            return f"({c}) or ({self.expr(vars_, depth)} {self.pick(CMPS)} {self.num()})"
+        return c
+
+    def block(self, vars_, depth, indent):
+        out = []
+        vars_ = list(vars_)
+        for _ in range(int(self.r.integers(1, 4))):
+            k = self.r.integers(0, 8)
+            pad = "  " * indent
+            if k <= 2:
+                self.n += 1
+                v = f"v{self.n}"
+                out.append(f"{pad}local {v} = {self.expr(vars_, depth)}")
+                vars_.append(v)
+            elif k == 3 and len(vars_) > 2:
+                out.append(f"{pad}{self.pick(vars_[2:])} = {self.expr(vars_, depth)}")
+            elif k == 4:
+                out.append(f"{pad}if {self.cond(vars_, depth - 1)} then")
+                out += self.block(vars_, depth - 1, indent + 1)[0]
+                if self.r.random() < 0.5:
+                    out.append(f"{pad}elseif {self.cond(vars_, depth - 1)} then")
+                    out += self.block(vars_, depth - 1, indent + 1)[0]
+                if self.r.random() < 0.6:
+                    out.append(f"{pad}else")
+                    out += self.block(vars_, depth - 1, indent + 1)[0]
+                out.append(f"{pad}end")
+            elif k == 5:
+                self.n += 1
+                acc, i = f"acc{self.n}", f"i{self.n}"
+                out.append(f"{pad}local {acc} = {self.expr(vars_, 1)}")
+                step = self.pick(["", ", 2", ", -1"])
+                lo, hi = (1, int(self.r.integers(2, 7))) if step != ", -1" else (int(self.r.integers(2, 7)), 1)
+                out.append(f"{pad}for {i} = {lo}, {hi}{step} do {acc} = {acc} * 0.75 + {self.expr(vars_ + [i], 2)} end")
+                vars_.append(acc)
+            elif k == 6:
+                self.n += 1
+                w, c = f"w{self.n}", f"c{self.n}"
+                out.append(f"{pad}local {w}, {c} = {self.expr(vars_, 2)}, 0")
+                if self.r.random() < 0.5:
+                    out.append(f"{pad}while {c} < {int(self.r.integers(1, 6))} do {w} = math.cos({w}) + {self.pick(vars_)} * 0.125; {c} = {c} + 1 end")
+                else:
+                    out.append(f"{pad}repeat {w} = {w} * 0.5 + {self.expr(vars_, 1)}; {c} = {c} + 1 until {c} >= {int(self.r.integers(1, 5))} or {w} > 1e6")
+                vars_.append(w)
+            else:
+                self.n += 1
+                a, b = f"p{self.n}", f"q{self.n}"
+                out.append(f"{pad}local {a}, {b} = pair({self.expr(vars_, 2)}, {self.expr(vars_, 2)})")
+                vars_ += [a, b]
+        return out, vars_
+
+    def script(self, forward):
+        args = ["x", "y", "z"] if forward else ["x", "y"]
+        body, vars_ = self.block(args, 3, 1)
+        nres = 2 if forward else 3
+        rets = ", ".join(self.expr(vars_, 2) for _ in range(nres))
+        name = "lens_forward" if forward else "lens_inverse"
+        return "\n".join([
+            "local bias = 0.25",
+            "local function helper(a, b) if a > b then return a - b * bias end return (a + b) * 0.5 end",
+            "local function pair(a, b) return a + b, a * b - bias end",
+            f"function {name}({', '.join(args)})",
+            *body,
+            f"  if ({self.cond(vars_, 1)}) and {'z < -0.6' if forward else 'x > 1.5'} then return nil end",
+            f"  return {rets}",
+            "end",
+            "max_fov = 360", "max_vfov = 180", 'onload = "f_fov 90"',
+        ])
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_scripts_device_equals_host_interpreter(seed):
+    import blinky_amd
+    forward = seed % 3 == 2
+    src = Gen(1000 + seed).script(forward)
+    ctx = blinky_amd.Context()
+    ctx.set_host_math(True)
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(src, f"fuzz{seed}.lua")
+    ctx.resize(64, 48)
+    rng = np.random.default_rng(seed)
+    if forward:
+        a = rng.normal(size=(300, 3))
+        a = (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+        which = 1
+    else:
+        a = np.concatenate([rng.uniform(-3, 3, (280, 2)), [[0, 0], [1, -1], [1e-12, 2.5], [-3, 3]]])
+        which = 0
+    d_out, d_n = ctx.eval_device(which, a)
+    h_out, h_n = ctx.eval_host_many(which, a)
+    np.testing.assert_array_equal(d_n, h_n, err_msg=src)
+    nan_d, nan_h = np.isnan(d_out), np.isnan(h_out)
+    np.testing.assert_array_equal(nan_d, nan_h, err_msg=src)
+    assert np.array_equal(d_out[~nan_h].view(np.uint64), h_out[~nan_h].view(np.uint64)), src
+    assert (d_n > 0).any(), "degenerate script: every point returned nil\n" + src
+    ctx.close()
