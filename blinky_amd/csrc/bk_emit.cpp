@@ -309,6 +309,15 @@ struct Emitter {
         return {arr, cnt};
     }
 
+    // true for calls that always produce exactly one value: math.* except modf / frexp
+    bool single_valued_call(Fn &f, const Expr &e)
+    {
+        Value callee;
+        if (e.kind != Expr::Call || !static_value(f, *e.a, &callee) || callee.t != Value::BUILTIN) return false;
+        const std::string &bn = callee.bi->name;
+        return bn.compare(0, 5, "math.") == 0 && bn != "math.modf" && bn != "math.frexp";
+    }
+
     // a call in multi-value context: results land in *arr (bkv[BK_MAXRET]) with count *cnt
     void emit_call(Fn &f, const Expr &e, std::string *arr, std::string *cnt)
     {
@@ -444,7 +453,10 @@ struct Emitter {
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table) {
                 const Expr &t = *s.exprs[0];
                 if (!t.fields.empty()) unsupported(f.chunk, s.line, "table constructors with named fields");
-                for (auto &x : t.args) if (x->kind == Expr::Call && &x == &t.args.back()) unsupported(f.chunk, s.line, "call expansion inside a table constructor");
+                // a trailing call would expand to all its results; the table's size must be static, so only calls that
+                // always yield exactly one value are taken (the math library; `(f())` truncates any other call)
+                if (!t.args.empty() && t.args.back()->kind == Expr::Call && !single_valued_call(f, *t.args.back()))
+                    unsupported(f.chunk, s.line, "call expansion inside a table constructor (write '(f(...))' to keep one value)");
                 std::vector<std::string> vals;
                 for (auto &x : t.args) vals.push_back(emit_expr(f, *x));
                 int n = (int)vals.size();

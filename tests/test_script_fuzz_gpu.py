@@ -2,8 +2,8 @@
 host interpreter (portable libm) and by the generated device code; every raw result of lens_inverse /
 lens_forward must be bit-identical (values, NaNs, nil vs numbers, count of results).  The shipped lenses only
 exercise the constructs their authors happened to use; this walks the emitter through operator precedence,
-short-circuit and/or, nested functions with upvalues, numeric for / while / repeat loops, multiple assignment and
-multiple returns."""
+short-circuit and/or, script functions with upvalues, numeric for / while / repeat loops, local array tables,
+multiple assignment and multiple returns."""
 import numpy as np
 import pytest
 
@@ -72,7 +72,7 @@ class Gen:
         out = []
         vars_ = list(vars_)
         for _ in range(int(self.r.integers(1, 4))):
-            k = self.r.integers(0, 8)
+            k = self.r.integers(0, 9)
             pad = "  " * indent
             if k <= 2:
                 self.n += 1
@@ -108,6 +108,17 @@ class Gen:
                 else:
                     out.append(f"{pad}repeat {w} = {w} * 0.5 + {self.expr(vars_, 1)}; {c} = {c} + 1 until {c} >= {int(self.r.integers(1, 5))} or {w} > 1e6")
                 vars_.append(w)
+            elif k == 7:      # a local array table: constant and computed indices, element stores, the length operator
+                self.n += 1
+                t, i = f"t{self.n}", f"j{self.n}"
+                size = int(self.r.integers(2, 5))
+                elems = [self.expr(vars_, 2) for _ in range(size)]
+                if elems[-1].startswith("helper("):
+                    elems[-1] = f"({elems[-1]})"          # a script function in the last slot must be truncated to one value
+                out.append(f"{pad}local {t} = {{{', '.join(elems)}}}")
+                out.append(f"{pad}{t}[{int(self.r.integers(1, size + 1))}] = {self.expr(vars_, 2)}")
+                out.append(f"{pad}for {i} = 1, #{t} do {t}[{i}] = {t}[{i}] + {t}[({i} % #{t}) + 1] * 0.5 end")
+                vars_ += [f"{t}[{c}]" for c in range(1, size + 1)]
             else:
                 self.n += 1
                 a, b = f"p{self.n}", f"q{self.n}"
