@@ -370,7 +370,8 @@ extern "C" int bk_calc_zoom(bk_ctx *ctx, double *scale_out)
     } catch (const LuaError &e) {
         return ctx->fail(BK_E_SCRIPT, "lens_forward failed: %s", e.what());
     }
-    if (!(scale > 0)) return ctx->fail(BK_E_ZOOM, "init returned a scale of %f, which is  <= 0", scale);       /* :1380 */
+    // (as the reference writes it: a NaN scale - a lens_forward that returns NaN - is NOT rejected and builds an empty map)
+    if (scale <= 0) return ctx->fail(BK_E_ZOOM, "init returned a scale of %f, which is  <= 0", scale);          /* :1380 */
     ctx->scale = scale;
     if (scale_out) *scale_out = scale;
     return BK_OK;

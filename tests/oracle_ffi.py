@@ -193,8 +193,8 @@ _INV_CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double))
 _FWD_CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double))
 
 
-def lensmap_with_callbacks(globe, info, eval_inverse, eval_forward, zoom, W, H):
-    """The oracle's fisheye.c restatement (platform libm) driven by arbitrary lens callbacks:
+def lensmap_with_callbacks(globe, info, eval_inverse, eval_forward, zoom, W, H, portable=False):
+    """The oracle's fisheye.c restatement (platform libm; portable=True: the bkm.h build) driven by arbitrary lens callbacks:
     eval_inverse(x, y) -> (rx, ry, rz) | None;  eval_forward(x, y, z) -> (x, y) | None.
     `info` carries the lens globals (map_type, max_fov, max_vfov, lens_width, lens_height)."""
     def inv(x, y, out):
@@ -221,10 +221,11 @@ def lensmap_with_callbacks(globe, info, eval_inverse, eval_forward, zoom, W, H):
     tin = np.empty(W * H, np.uint8)
     disp = (C.c_int * 6)()
     scale, npl = C.c_double(), C.c_int()
-    _o.okpy_lensmap_cb.argtypes = [C.c_char_p, _INV_CB, _FWD_CB, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+    lib = _ob if portable else _o
+    lib.okpy_lensmap_cb.argtypes = [C.c_char_p, _INV_CB, _FWD_CB, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                    C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
                                    C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    rc = _o.okpy_lensmap_cb(globe.encode(), inv_c, fwd_c, info.map_type, info.max_fov, info.max_vfov,
+    rc = lib.okpy_lensmap_cb(globe.encode(), inv_c, fwd_c, info.map_type, info.max_fov, info.max_vfov,
                             info.lens_width, info.lens_height, zoom.encode() if zoom else None, W, H,
                             _p(off), _p(tin), disp, C.byref(scale), C.byref(npl))
     if rc < 0:

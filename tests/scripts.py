@@ -34,6 +34,14 @@ GLOBES = names("globes")
 ZOOM_CMD = {"f_fov": 1, "f_vfov": 2, "f_cover": 3, "f_contain": 4}
 
 
+def zoom_args(cmd):
+    """'f_fov 120' -> (zoom type, degrees) for Context.set_zoom; '' -> (0, 0)"""
+    parts = cmd.split()
+    if not parts:
+        return 0, 0
+    return ZOOM_CMD[parts[0]], int(float(parts[1])) if len(parts) > 1 else 0
+
+
 def configure(ctx, globe, lens, zoom=None, size=None):
     """'f_globe G; f_lens L; <zoom or the lens' onload>' on a blinky_amd Context"""
     ctx.load_globe(script("globes", globe), globe + ".lua")
