@@ -12,14 +12,18 @@
 // sorts the block's chunk numbers (bitonic sort in LDS), keeps the unique ones in ascending address
 // order as the block's chunk list, and rewrites every pixel's lensmap entry as a 16-bit LDS address
 // (slot * 16 + byte).  Per frame the 256 threads copy chunk list entry i to LDS slot i (neighbouring
-// lanes fetch neighbouring chunks of a line: one request per line and block), meet at one
-// s_barrier, and every wave gathers its 32-pixel column from the shared copy (ds_read_u8) and
-// stores its pixels.  One staging buffer, two barriers per frame (chunks visible / gather done): measured
-// against two alternating buffers with one barrier, the halved LDS footprint - more resident workgroups per
-// CU - wins whenever LDS limits occupancy and costs nothing when it does not.
+// lanes fetch neighbouring chunks of a line: one request per line and block), meet at an s_barrier, gather
+// their pixels from the shared copy (ds_read_u8) and store them.  A lane owns 4*RG consecutive pixels of one
+// row and 32/RG lanes span the block's width, so every store instruction of a wave writes whole 128-byte
+// lines (32-byte row segments per wave cost 1.3x in kernel time); the stores are non-temporal (the frame is
+// never read back; L2 stays with the globe lines blocks share).  One staging buffer, two barriers per frame
+// (chunks visible / gather done): measured against two alternating buffers with one barrier, the halved LDS
+// footprint - more resident workgroups per CU - wins whenever LDS limits occupancy and costs nothing when
+// it does not.  Lists larger than the buffer go through it in passes.
 //
-// Persistent grid, XCD-banded block order, next block's header,
-// chunk list head and indices prefetched, a batch launch re-uses a block's plan for up to 8 frames.
+// Two kernel forms: persistent (a workgroup walks a strided list of blocks in its XCD's band and prefetches the
+// next block's header, chunk list head and indices) and one-block-per-workgroup for launches whose whole grid
+// is resident at once (fewer registers).  A batch launch re-uses a block's plan for up to 8 frames.
 // The chunk list is layout-agnostic (byte offsets into a globe frame); with the globe stored as 16x8-texel
 // lines (bk_build_params.h) a block's slanted footprint touches about half the lines it did row-major.
 //
@@ -32,7 +36,7 @@ namespace bk {
 
 constexpr int BK_COOP_LDS_CAP = 65536;                 // max bytes of the staging buffer (a block has <= 4095 chunks)
 constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
-constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's column fully mapped / empty
+constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's rows of the block fully mapped / empty
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
 constexpr uint32_t BK_COOP_BINS = 65;                  // LDS-need histogram: 1 KiB bins, 0..64 KiB
 constexpr int BK_COOP_STATS = 208;                     // words per stats replica
@@ -45,7 +49,7 @@ struct CoopHdr {              // 8 bytes per block
 struct CoopMap {
     CoopHdr *d_hdr = nullptr;
     uint32_t *d_list = nullptr;     // [nblocks][256*4*RG] byte offsets (16-byte aligned) into a globe frame, ascending
-    uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][256] LDS addresses, 0xFFFF = unmapped
+    uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][64 lanes][4] LDS addresses, 0xFFFF = unmapped
     uint8_t *d_tint = nullptr;      // same order (rubix)
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
                                     // [3] 128-B lines staged, [4] chunks staged, [8..73) blocks by LDS need (1 KiB bins),
