@@ -676,7 +676,10 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     if (int r = ensure_coopmap(ctx)) return r;
     CoopMap *cm = ctx->coopmap;
     const int blocks_x = cm->blocks_x, nblocks = blocks_x * cm->blocks_y;
-    const int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : 8;
+    // frames per block visit: 8, but a batch of 8..15 frames is split in two groups so that the grid has more
+    // workgroups than one scheduling round holds (8 frames: 3.86 -> 3.70 us/frame)
+    int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : 8;
+    if (ctx->apply_fchunk <= 0 && nframes >= 8 && nframes < 16) fmax = (nframes + 1) / 2;
     const int fchunk = nframes < fmax ? nframes : fmax;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     const int per = (nblocks + 7) / 8;
