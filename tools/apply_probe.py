@@ -21,7 +21,8 @@ F = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 variants = [int(v) for v in sys.argv[5:]] or [2]
 
 t = time.time()
-lm = O.lensmap("cube", lens, None, W, H)
+GLOBE = os.environ.get("BK_GLOBE", "cube")
+lm = O.lensmap(GLOBE, lens, None, W, H)
 print(f"oracle lensmap {lens} {W}x{H}: {time.time()-t:.2f}s nonnull={lm.nonnull}", flush=True)
 RING = int(os.environ.get("BK_RING", str(F)))       # resident globes (1 = every frame reads the same globe)
 SAMEOUT = int(os.environ.get("BK_SAMEOUT", "0"))       # 1 = every frame writes the same output buffer
