@@ -80,6 +80,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipFree(ctx->d_plate_stage);
     hipFree(ctx->d_pal);
     hipFree(ctx->d_display);
+    hipFree(ctx->d_flag_list);
     bk::coopmap_free(ctx->coopmap);
     bk::lensprogram_free(ctx->prog);
     delete ctx;
@@ -148,21 +149,38 @@ extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
         return BK_OK;
     }
     if (int r = ensure_device(ctx)) return r;
-    if (width == ctx->W && height == ctx->H) return BK_OK;
+    if (width == ctx->W && height == ctx->H && ctx->d_offsets && ctx->d_globe && ctx->d_plate_stage) return BK_OK;
     // (6*ps*ps and W*H must fit the uint32 lensmap entries)
     const int ps = std::min(width, height);                                  // fisheye.c:707
     const int gp = (ps + 63) & ~63, ph = (ps + 7) & ~7;
     if ((uint64_t)BK_MAX_PLATES * gp * ph >= 0xFFFFFFFFull)
         return ctx->fail(BK_E_INVALID, "bk_resize: platesize %d overflows 32-bit offsets", ps);
+    // failure-atomic: should an allocation fail the context is left EMPTY (W = H = 0, every buffer freed, every
+    // device entry point answers BK_E_STATE) and a later bk_resize of the same size tries again; the reference
+    // exits the process instead (fisheye.c:723-726)
+    auto fail_empty = [&](int rc) {
+        const std::string msg = ctx->err;
+        free_maps(ctx);
+        (void)hipFree(ctx->d_globe); ctx->d_globe = nullptr; ctx->globe_bytes = 0;
+        (void)hipFree(ctx->d_plate_stage); ctx->d_plate_stage = nullptr;
+        ctx->W = ctx->H = ctx->ps = ctx->gp = ctx->ph = 0;
+        ctx->row0 = ctx->row1 = 0;
+        ctx->err = msg;
+        return rc;
+    };
     ctx->W = width; ctx->H = height; ctx->ps = ps; ctx->gp = gp; ctx->ph = ph;
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_plate_stage);
-    ctx->d_plate_stage = nullptr;
-    BK_HIP(ctx, hipMalloc((void **)&ctx->d_plate_stage, (size_t)gp * ps));
     ctx->row0 = 0; ctx->row1 = height;
     ctx->lensmap_valid = false;
-    if (int r = alloc_maps(ctx)) return r;
-    return alloc_globe(ctx);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_empty(ctx->fail(BK_E_HIP, "bk_resize: hipStreamSynchronize failed"));
+    (void)hipFree(ctx->d_plate_stage);
+    ctx->d_plate_stage = nullptr;
+    if (hipMalloc((void **)&ctx->d_plate_stage, (size_t)gp * ps) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_empty(ctx->fail(BK_E_NOMEM, "bk_resize: out of device memory (plate staging, %dx%d)", width, height));
+    }
+    if (int r = alloc_maps(ctx)) return fail_empty(r);
+    if (int r = alloc_globe(ctx)) return fail_empty(r);
+    return BK_OK;
 }
 
 extern "C" int bk_set_rows(bk_ctx *ctx, int row0, int row1)

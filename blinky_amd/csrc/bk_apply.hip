@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void apply_direct4(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t t = (t4 >> (8 * k)) & 0xFFu;
-                if (t != 255u) v[k] = s_pal[t * 256 + v[k]];
+                if (t < (uint32_t)BK_MAX_PLATES) v[k] = s_pal[t * 256 + v[k]];      // (255 = none; a caller's out-of-range tint never indexes past the LUT)
             }
         }
         if (all && ((reinterpret_cast<uintptr_t>(out) & 3u) == 0)) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void apply_direct1(
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
         uint32_t v = gl[o];
-        if (RUBIX && t != 255u) v = pal[t * 256 + v];
+        if (RUBIX && t < (uint32_t)BK_MAX_PLATES) v = pal[t * 256 + v];
         dst[(size_t)f * frame_stride + (size_t)row * dst_pitch + x] = (uint8_t)v;
     }
 }
@@ -177,6 +177,16 @@ __global__ __launch_bounds__(256) void plate_retile_kernel(uint8_t *__restrict__
     if (to_tiled) *t = *r; else *r = *t;
 }
 
+// sparse patches of a device table (the handful of lensmap entries / texel corners the host re-derives on the
+// platform libm after a build, bk_lens.cpp): dst[idx[i]] = val[i]
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_kernel(T *__restrict__ dst, const uint32_t *__restrict__ idx,
+                                                      const T *__restrict__ val, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -255,5 +265,27 @@ int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled)
     return BK_OK;
 }
 
+template <typename T>
+static int scatter_impl(bk_ctx *ctx, T *dst, const uint32_t *h_idx, const T *h_val, size_t n)
+{
+    if (!n) return BK_OK;
+    uint32_t *d_idx = nullptr;
+    T *d_val = nullptr;
+    BK_HIP(ctx, hipMalloc((void **)&d_idx, n * sizeof(uint32_t)));
+    hipError_t e = hipMalloc((void **)&d_val, n * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, h_idx, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_val, h_val, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(scatter_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst, d_idx, d_val, (uint32_t)n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the host arrays and the temporaries go away with the caller
+    (void)hipFree(d_idx);
+    (void)hipFree(d_val);
+    if (e != hipSuccess) return ctx->fail(BK_E_HIP, "scatter: %s", hipGetErrorString(e));
+    return BK_OK;
+}
+int launch_scatter32(bk_ctx *ctx, uint32_t *dst, const uint32_t *h_idx, const uint32_t *h_val, size_t n) { return scatter_impl<uint32_t>(ctx, dst, h_idx, h_val, n); }
+int launch_scatter8(bk_ctx *ctx, uint8_t *dst, const uint32_t *h_idx, const uint8_t *h_val, size_t n) { return scatter_impl<uint8_t>(ctx, dst, h_idx, h_val, n); }
 
 }  // namespace bk

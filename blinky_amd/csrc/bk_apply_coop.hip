@@ -60,7 +60,7 @@ struct CoopMap {
     uint32_t stats[BK_COOP_STATS] = {0};
     int slow_blocks = 0;
     bool valid = false;
-    size_t alloc_px = 0;
+    size_t alloc_px = 0, alloc_blocks = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -324,7 +324,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                     v[k] = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
                     if (RUBIX) {
                         const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                        if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+                        if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
                     }
                 }
                 uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
@@ -398,7 +398,7 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                 v[k] = (w[r] >> (8 * k)) & 0xFFu;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt != 255u) v[k] = pal_s[tt * 256 + v[k]];
+                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
                 }
             }
             uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
@@ -439,7 +439,7 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
                 uint32_t v = gl[so[r][k]];
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt != 255u) v = pal_s[tt * 256 + v];
+                    if (tt < (uint32_t)BK_MAX_PLATES) v = pal_s[tt * 256 + v];
                 }
                 out[k] = (uint8_t)v;
             }
@@ -636,14 +636,16 @@ static int ensure_coopmap(bk_ctx *ctx)
     const size_t bx = (ctx->W + 127) / 128;
     const size_t max_blocks = bx * (size_t)((rows + 7) / 8);
     const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
-    if (max_px > cm->alloc_px) {
+    if (max_px > cm->alloc_px || max_blocks > cm->alloc_blocks) {      // (the header count follows ceil(rows/8), the rest ceil(rows/32))
         (void)hipFree(cm->d_hdr); (void)hipFree(cm->d_list); (void)hipFree(cm->d_idx); (void)hipFree(cm->d_tint);
         cm->d_hdr = nullptr; cm->d_list = nullptr; cm->d_idx = nullptr; cm->d_tint = nullptr;
+        cm->alloc_px = cm->alloc_blocks = 0;
         BK_HIP(ctx, hipMalloc((void **)&cm->d_hdr, max_blocks * sizeof(CoopHdr)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_list, max_px * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_idx, max_px * sizeof(uint16_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_tint, max_px));
         cm->alloc_px = max_px;
+        cm->alloc_blocks = max_blocks;
     }
     if (!cm->d_stats) BK_HIP(ctx, hipMalloc((void **)&cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t)));
     // block height: the cheapest of 128x8 / 128x16 / 128x32 by the cost model, unless forced

@@ -9,6 +9,7 @@ BK_DEV void bk_state_init(BkState &S, const BkBuildParams *P)
     S.P = P;
     S.err = 0;
     S.steps = 0;
+    S.flag = 0;
     BK_INIT_GLOBALS(S)
 }
 
@@ -22,6 +23,7 @@ BK_DEV int bk_ray_to_plate_index(BkState &S, const float *ray)
     int n = LF_globe_plate(S, a, 3, r);
     if (n < 1 || !bk_isnum(r[n - 1])) return -1;            /* !lua_isnumber(lua,-1)  :1642 */
     double d = r[n - 1].n;                                  /* lua_tointeger: round to nearest (LUA_IEEE754TRICK) */
+    if (r[n - 1].e != 0.0 && !(bkm_rint(d - r[n - 1].e) == bkm_rint(d + r[n - 1].e))) S.flag = 1;
     if (!(d > -2147483648.0 && d < 2147483647.0)) return -1;
     int plate = (int)bkm_rint(d);
     if (plate < 0 || plate >= P.numplates) return -1;       /* the reference would index out of bounds */
@@ -49,6 +51,15 @@ BK_DEV bool bk_offgrid(const BkBuildParams &P, int px, int py)
 BK_DEV unsigned int bk_padded_offset(const BkBuildParams &P, int plate, int px, int py)
 {
     return bk_texel_offset((unsigned int)P.gp, (unsigned int)P.ph, (unsigned int)plate, (unsigned int)px, (unsigned int)py);
+}
+
+/* a pixel / corner / texel whose outcome the host has to re-derive on the platform libm */
+__device__ __forceinline__ void bk_push_flagged(const BkBuildParams &P, unsigned int id, unsigned int a, unsigned int b, unsigned int c)
+{
+    const unsigned int k = atomicAdd(P.flag_count, 1u);
+    if (k < P.flag_cap) {
+        P.flag_list[4 * k] = id; P.flag_list[4 * k + 1] = a; P.flag_list[4 * k + 2] = b; P.flag_list[4 * k + 3] = c;
+    }
 }
 
 __device__ __forceinline__ void bk_publish_flags(const int *s_disp, int *display, int serr, int *err)
@@ -83,9 +94,10 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
         bkv r[BK_MAXRET];
         const int n = LF_lens_inverse(S, a, 2, r);
         if (n == 3 && bk_isnum(r[0]) && bk_isnum(r[1]) && bk_isnum(r[2])) {
-            float ray[3] = {(float)r[0].n, (float)r[1].n, (float)r[2].n};   /* :1559-1561 */
+            float ray[3] = {bk_narrow(S, r[0].n, r[0].e), bk_narrow(S, r[1].n, r[1].e), bk_narrow(S, r[2].n, r[2].e)};   /* :1559-1561 */
             bk_vector_normalize(ray);                                        /* :1562 */
             const int plate = bk_ray_to_plate_index(S, ray);
+            /* from the float ray on, every step is an IEEE operation the reference performs identically */
             if (plate >= 0) {
                 const BkPlateDev &p = P.plates[plate];
                 const double px_ = (double)bk_dot3(p.right, ray);            /* :2055-2057 */
@@ -97,7 +109,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
                     const int px = bk_trunc_to_int(u * P.ps);                /* :1988 */
                     const int py = bk_trunc_to_int(v * P.ps);
                     if (px >= 0 && px < P.ps && py >= 0 && py < P.ps) {      /* :1971 */
-                        s_disp[plate] = 1;                                   /* :1976 */
+                        if (!S.flag) s_disp[plate] = 1;                      /* :1976 (a flagged pixel's plate is the host's to say) */
                         off = bk_padded_offset(P, plate, px, py);            /* :1979 */
                         if (bk_offgrid(P, px, py)) tint = (unsigned char)plate;   /* :1959 */
                     }
@@ -110,6 +122,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
         const size_t o = (size_t)lyl * P.W + lx;
         P.offsets[o] = off;
         P.tints[o] = tint;
+        if (S.flag) bk_push_flagged(P, (unsigned int)o, off, tint, 0u);
     }
     __syncthreads();
     bk_publish_flags(s_disp, P.display, err, P.err);
@@ -140,8 +153,11 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
     unsigned char ok = 0;
     int sx = 0, sy = 0;
     if (n == 2 && bk_isnum(r[0]) && bk_isnum(r[1])) {
-        sx = bk_trunc_to_int(r[0].n / P.scale + (double)(P.W / 2));          /* :2239 */
-        sy = bk_trunc_to_int(-r[1].n / P.scale + (double)(P.H / 2));         /* :2240 */
+        const double fx = r[0].n / P.scale + (double)(P.W / 2), fy = -r[1].n / P.scale + (double)(P.H / 2);
+        sx = bk_trunc_to_int(fx);                                            /* :2239 */
+        sy = bk_trunc_to_int(fy);                                            /* :2240 */
+        bk_need_same_trunc(S, fx, bk_eop(fx, r[0].e / P.scale));
+        bk_need_same_trunc(S, fy, bk_eop(fy, r[1].e / P.scale));
         ok = 1;
     } else if (!(n == 1 && r[0].t == BK_TNIL)) {
         S.err |= BK_ERR_RESULT;
@@ -149,6 +165,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
     P.corner_xy[2 * id] = sx;
     P.corner_xy[2 * id + 1] = sy;
     P.corner_ok[id] = ok;
+    if (S.flag) bk_push_flagged(P, (unsigned int)id, (unsigned int)sx, (unsigned int)sy, ok);
     if (S.err) atomicOr(P.err, S.err);
 }
 
@@ -226,7 +243,18 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
         bk_state_init(S, &P);
         float ray[3];
         bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
-        if (plate == bk_ray_to_plate_index(S, ray)) {                               /* :2196 */
+        bool own = plate == bk_ray_to_plate_index(S, ray);                          /* :2196 */
+#ifdef BK_HAS_GLOBE_PLATE
+        if (P.ovr_count) {                          /* second pass: the host's answers for the texels the first pass flagged */
+            unsigned int lo = 0, hi = P.ovr_count;
+            while (lo < hi) {
+                const unsigned int mid = (lo + hi) >> 1;
+                if ((P.ovr_list[mid] >> 1) < (unsigned int)id) lo = mid + 1; else hi = mid;
+            }
+            if (lo < P.ovr_count && (P.ovr_list[lo] >> 1) == (unsigned int)id) own = P.ovr_list[lo] & 1u;
+        } else if (S.flag) bk_push_flagged(P, (unsigned int)id, own ? 1u : 0u, 0u, 0u);
+#endif
+        if (own) {
             const int n1 = P.ps + 1;
             const long long base = (long long)plate * n1 * n1;
             const long long c_tl = base + (long long)py * n1 + px, c_bl = c_tl + n1;

@@ -27,6 +27,15 @@ typedef struct {
     unsigned int *fwd_key_tint;  /* [rows][W] same, over writers that were off the rubix grid */
     int *corner_xy;          /* [numplates][ps+1][ps+1][2] screen coords of the texel corners */
     unsigned char *corner_ok;/* [numplates][ps+1][ps+1] */
+    /* pixels / corners / texels whose discrete outcome depends on libm's last bits (bk_device_rt.h): their
+     * indices are appended here and re-evaluated by the host interpreter on the platform libm */
+    unsigned int *flag_list; /* [flag_cap][4]: id, then what the device derived (offset, tint, 0 | sx, sy, ok | own, 0, 0) */
+    unsigned int *flag_count;/* [1] total flagged (may exceed flag_cap: the host then retries with a larger list) */
+    unsigned int flag_cap;
+    /* forward build, second pass only: host-decided answers to "does this texel's ray select its own plate" for the
+     * texels the first pass flagged (globe_plate scripts): (texel id << 1 | answer), ascending */
+    const unsigned int *ovr_list;
+    unsigned int ovr_count;
 } BkBuildParams;
 
 /* Device globe layout.  A plate is gp = round_up(ps,64) texels wide and ph = round_up(ps,8) high and is

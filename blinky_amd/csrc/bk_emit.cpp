@@ -140,16 +140,16 @@ struct Emitter {
             unsupported(f.chunk, at.line, "table '" + hint + "' with non-array keys");
         std::string name = "GT" + std::to_string(++uid) + "_" + sanitize(hint);
         int n = (int)t->arr.size();
-        table_code << "static __device__ const bkv " << name << "[" << n + 1 << "] = {{0.0, BK_TNIL}";
+        table_code << "static __device__ const bkv " << name << "[" << n + 1 << "] = {{0.0, 0.0, BK_TNIL}";
         for (const Value &v : t->arr) {
             char buf[80];
             switch (v.t) {
             case Value::NUM:
                 if (v.n != v.n || std::isinf(v.n)) unsupported(f.chunk, at.line, "non-finite number in table '" + hint + "'");
-                snprintf(buf, sizeof buf, ", {%a, BK_TNUM}", v.n);
+                snprintf(buf, sizeof buf, ", {%a, 0.0, BK_TNUM}", v.n);
                 break;
-            case Value::BOOL: snprintf(buf, sizeof buf, ", {0.0, %s}", v.b ? "BK_TTRUE" : "BK_TFALSE"); break;
-            case Value::NIL: snprintf(buf, sizeof buf, ", {0.0, BK_TNIL}"); break;
+            case Value::BOOL: snprintf(buf, sizeof buf, ", {0.0, 0.0, %s}", v.b ? "BK_TTRUE" : "BK_TFALSE"); break;
+            case Value::NIL: snprintf(buf, sizeof buf, ", {0.0, 0.0, BK_TNIL}"); break;
             default: unsupported(f.chunk, at.line, std::string("table '") + hint + "' holding a " + v.type_name());
             }
             table_code << buf;
@@ -194,7 +194,7 @@ struct Emitter {
         case Expr::Index: {
             if (e.a->kind == Expr::Name && e.a->var == VarKind::Local && f.array_slots.count(e.a->slot)) {
                 std::string k = emit_expr(f, *e.b), t = tmp();
-                line(f, "bkv " + t + " = bk_aget(A" + std::to_string(e.a->slot) + ", " + std::to_string(f.array_slots[e.a->slot]) + ", " + k + ");");
+                line(f, "bkv " + t + " = bk_aget(S, A" + std::to_string(e.a->slot) + ", " + std::to_string(f.array_slots[e.a->slot]) + ", " + k + ");");
                 return t;
             }
             Value sv;
@@ -203,7 +203,7 @@ struct Emitter {
             if (static_value(f, *e.a, &o) && o.t == Value::TABLE) {
                 auto ct = const_table(f, e, o.tab, e.a->kind == Expr::Name ? e.a->str : "table");
                 std::string k = emit_expr(f, *e.b), t = tmp();
-                line(f, "bkv " + t + " = bk_aget(" + ct.first + ", " + std::to_string(ct.second) + ", " + k + ");");
+                line(f, "bkv " + t + " = bk_aget(S, " + ct.first + ", " + std::to_string(ct.second) + ", " + k + ");");
                 return t;
             }
             unsupported(f.chunk, e.line, "indexing this expression");
@@ -250,8 +250,8 @@ struct Emitter {
             else if (op == "/") call = "bk_div(S, " + a + ", " + b + ")";
             else if (op == "%") call = "bk_mod(S, " + a + ", " + b + ")";
             else if (op == "^") call = "bk_pow(S, " + a + ", " + b + ")";
-            else if (op == "==") call = "bk_eq(" + a + ", " + b + ")";
-            else if (op == "~=") call = "bk_ne(" + a + ", " + b + ")";
+            else if (op == "==") call = "bk_eq(S, " + a + ", " + b + ")";
+            else if (op == "~=") call = "bk_ne(S, " + a + ", " + b + ")";
             else if (op == "<") call = "bk_lt(S, " + a + ", " + b + ")";
             else if (op == "<=") call = "bk_le(S, " + a + ", " + b + ")";
             else if (op == ">") call = "bk_lt(S, " + b + ", " + a + ")";
@@ -347,50 +347,41 @@ struct Emitter {
         }
         Args a = emit_args(f, e.args);
         auto A = [&](size_t i) { return arg_at(a, i); };
-        auto num = [&](size_t i) { return "bk_tonum(S, " + A(i) + ")"; };
         auto single = [&](const std::string &expr) {
             line(f, "bkv " + *arr + "[1] = {" + expr + "}; const int " + *cnt + " = 1;");
         };
+        // the math library: value + error bound (bk_device_rt.h); one bkm.h call per Lua call, as in the interpreter
         static const std::map<std::string, std::string> unary = {
-            {"math.sin", "bkm_sin"}, {"math.cos", "bkm_cos"}, {"math.tan", "bkm_tan"}, {"math.asin", "bkm_asin"},
-            {"math.acos", "bkm_acos"}, {"math.atan", "bkm_atan"}, {"math.sinh", "bkm_sinh"}, {"math.cosh", "bkm_cosh"},
-            {"math.tanh", "bkm_tanh"}, {"math.exp", "bkm_exp"}, {"math.log10", "bkm_log10"}, {"math.sqrt", "bkm_sqrt"},
-            {"math.abs", "bkm_fabs"}, {"math.floor", "bkm_floor"}, {"math.ceil", "bkm_ceil"}};
+            {"math.sin", "bk_f_sin"}, {"math.cos", "bk_f_cos"}, {"math.tan", "bk_f_tan"}, {"math.asin", "bk_f_asin"},
+            {"math.acos", "bk_f_acos"}, {"math.atan", "bk_f_atan"}, {"math.sinh", "bk_f_sinh"}, {"math.cosh", "bk_f_cosh"},
+            {"math.tanh", "bk_f_tanh"}, {"math.exp", "bk_f_exp"}, {"math.log10", "bk_f_log10"}, {"math.sqrt", "bk_f_sqrt"},
+            {"math.abs", "bk_f_abs"}, {"math.floor", "bk_f_floor"}, {"math.ceil", "bk_f_ceil"}};
         auto u = unary.find(bn);
-        if (u != unary.end()) { single("bk_num(" + u->second + "(" + num(0) + "))"); return; }
-        if (bn == "math.atan2") { single("bk_num(bkm_atan2(" + num(0) + ", " + num(1) + "))"); return; }
-        if (bn == "math.pow") { single("bk_num(bkm_pow(" + num(0) + ", " + num(1) + "))"); return; }
-        if (bn == "math.fmod") { single("bk_num(bkm_fmod(" + num(0) + ", " + num(1) + "))"); return; }
-        if (bn == "math.deg") { single("bk_num(" + num(0) + " / (0x1.921fb54442d18p+1 / 180.0))"); return; }
-        if (bn == "math.rad") { single("bk_num(" + num(0) + " * (0x1.921fb54442d18p+1 / 180.0))"); return; }
+        if (u != unary.end()) { single(u->second + "(S, " + A(0) + ")"); return; }
+        if (bn == "math.atan2") { single("bk_f_atan2(S, " + A(0) + ", " + A(1) + ")"); return; }
+        if (bn == "math.pow") { single("bk_powv(S, " + A(0) + ", " + A(1) + ")"); return; }
+        if (bn == "math.fmod") { single("bk_f_fmod(S, " + A(0) + ", " + A(1) + ")"); return; }
+        if (bn == "math.deg") { single("bk_f_scale(S, " + A(0) + ", 0x1.921fb54442d18p+1 / 180.0, true)"); return; }
+        if (bn == "math.rad") { single("bk_f_scale(S, " + A(0) + ", 0x1.921fb54442d18p+1 / 180.0, false)"); return; }
         if (bn == "math.log") {
-            if (a.fixed.size() < 2 && !a.multi) { single("bk_num(bkm_log(" + num(0) + "))"); return; }
-            std::string x = tmp(), b = tmp();
-            line(f, "const double " + x + " = " + num(0) + "; const bkv " + b + " = " + A(1) + ";");
-            single(b + ".t == BK_TNIL ? bk_num(bkm_log(" + x + ")) : (bk_tonum(S, " + b + ") == 10.0 ? bk_num(bkm_log10(" + x + ")) : bk_num(bkm_log(" + x + ") / bkm_log(" + b + ".n)))");
+            if (a.fixed.size() < 2 && !a.multi) { single("bk_f_log(S, " + A(0) + ")"); return; }
+            single("bk_f_logb(S, " + A(0) + ", " + A(1) + ")");
             return;
         }
         if (bn == "math.max" || bn == "math.min") {
             if (a.fixed.empty() && !a.multi) unsupported(f.chunk, e.line, bn + " without arguments");
-            const std::string cmp = bn == "math.max" ? " > " : " < ";
+            const std::string want = bn == "math.max" ? "true" : "false";
             std::string m = tmp("m");
-            line(f, "double " + m + " = " + num(0) + ";");           // (no value at all -> bk_tonum(nil) raises the script error)
-            for (size_t i = 1; i < a.fixed.size(); ++i) {
-                std::string d = tmp("d");
-                line(f, "{ const double " + d + " = " + num(i) + "; if (" + d + cmp + m + ") " + m + " = " + d + "; }");
-            }
-            if (a.multi) {                                           // the values a trailing call expands to, e.g. math.min(x, math.max(a, b))
-                std::string d = tmp("d");
-                line(f, "for (int q = " + std::string(a.fixed.empty() ? "1" : "0") + "; q < " + a.mcnt + "; ++q) { const double " + d + " = bk_tonum(S, " +
-                            a.marr + "[q]); if (" + d + cmp + m + ") " + m + " = " + d + "; }");
-            }
-            single("bk_num(" + m + ")");
+            line(f, "bkv " + m + " = " + A(0) + "; (void)bk_tonum(S, " + m + ");");   // (no value at all -> bk_tonum(nil) raises the script error)
+            for (size_t i = 1; i < a.fixed.size(); ++i) line(f, m + " = bk_f_pick(S, " + m + ", " + A(i) + ", " + want + ");");
+            if (a.multi)                                             // the values a trailing call expands to, e.g. math.min(x, math.max(a, b))
+                line(f, "for (int q = " + std::string(a.fixed.empty() ? "1" : "0") + "; q < " + a.mcnt + "; ++q) " + m + " = bk_f_pick(S, " + m + ", " +
+                            a.marr + "[q], " + want + ");");
+            single(m);
             return;
         }
         if (bn == "math.modf") {
-            std::string x = tmp("x"), ip = tmp("ip");
-            line(f, "const double " + x + " = " + num(0) + ", " + ip + " = bkm_trunc(" + x + ");");
-            line(f, "bkv " + *arr + "[2] = {bk_num(" + ip + "), bk_num(bkm_isinf(" + x + ") ? bkm_copysign(0.0, " + x + ") : " + x + " - " + ip + ")}; const int " + *cnt + " = 2;");
+            line(f, "bkv " + *arr + "[2]; bk_f_modf(S, " + A(0) + ", " + *arr + "); const int " + *cnt + " = 2;");
             return;
         }
         if (bn == "latlon_to_ray") {
@@ -540,6 +531,7 @@ struct Emitter {
             std::string start = emit_expr(f, *s.exprs[0]), stop = emit_expr(f, *s.exprs[1]);
             std::string step = s.exprs.size() > 2 ? emit_expr(f, *s.exprs[2]) : "bk_num(1.0)";
             std::string st = tmp("step"), lim = tmp("lim"), idx = tmp("idx");
+            line(f, "bk_need_exact(S, " + start + "); bk_need_exact(S, " + stop + "); bk_need_exact(S, " + step + ");");   // loop trip count
             line(f, "const double " + st + " = bk_tonum(S, " + step + "), " + lim + " = bk_tonum(S, " + stop + ");");
             line(f, "double " + idx + " = bk_tonum(S, " + start + ") - " + st + ";");       // OP_FORPREP
             line(f, "for (;;) {");

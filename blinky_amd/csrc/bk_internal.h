@@ -56,7 +56,10 @@ struct bk_ctx {
     uint8_t *d_frame = nullptr;      // [row1-row0][W] staging for bk_apply (host dst)
     uint8_t *d_pal = nullptr;        // [6][256]
     uint64_t *d_mask = nullptr;      // mapped bits, 1 per pixel of the owned rows
-    int *d_display = nullptr;        // [6] display flags + [1] error bits written by the build kernels
+    int *d_display = nullptr;        // [6] display flags + [1] error bits + [1] flagged-entry count written by the build kernels
+    uint32_t *d_flag_list = nullptr; // entries a build flagged for re-evaluation on the platform libm (bk_device_rt.h)
+    size_t flag_cap = 0;
+    int last_flagged = 0, last_changed = 0;   // of the last bk_build: entries re-evaluated on the host / entries that changed
     uint8_t *h_frame = nullptr;      // pinned, [row1-row0][W]
     uint64_t *h_mask = nullptr;      // pinned
     size_t globe_bytes = 0;          // allocated size of d_globe
@@ -108,6 +111,8 @@ int launch_mask(bk_ctx *ctx);                 // d_offsets -> d_mask
 int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed);   // one plate, padded rows
 int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_device);   // reference <-> device (tiled) layout
 int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled);          // d_plate_stage (row-major) <-> a plate of the globe
+int launch_scatter32(bk_ctx *ctx, uint32_t *dst, const uint32_t *h_idx, const uint32_t *h_val, size_t n);   // dst[idx[i]] = val[i]; synchronous
+int launch_scatter8(bk_ctx *ctx, uint8_t *dst, const uint32_t *h_idx, const uint8_t *h_val, size_t n);
 // bk_apply_coop.hip
 void coopmap_invalidate(bk_ctx *ctx);
 int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,

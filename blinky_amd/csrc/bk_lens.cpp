@@ -3,6 +3,7 @@
 // LUA_load_lens (1659-1750), calc_zoom (1293-1386) and create_lensmap (2367-2397).
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cstring>
 #include <unistd.h>
 
@@ -568,6 +569,9 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
     bp->tints = ctx->d_tints;
     bp->display = ctx->d_display;
     bp->err = ctx->d_display + BK_MAX_PLATES;
+    bp->flag_count = (unsigned int *)(ctx->d_display + BK_MAX_PLATES + 1);
+    bp->flag_list = ctx->d_flag_list;
+    bp->flag_cap = (unsigned int)ctx->flag_cap;
 }
 
 static const char *err_text(int bits)
@@ -578,6 +582,132 @@ static const char *err_text(int bits)
     if (bits & BK_ERR_INDEX) return "a lens callback stored outside a table's bounds";
     if (bits & BK_ERR_RESULT) return "a lens callback returned a malformed result (not 3 numbers / 2 numbers / a single nil)";
     return "unknown device error";
+}
+
+// ---- host re-evaluation of the entries a build flagged ------------------------------------------------------
+// The device evaluates the callbacks on bkm.h; the reference's Lua VM calls the platform libm.  The kernels
+// flag every pixel / texel corner / texel whose DISCRETE outcome could depend on the last bits of a
+// transcendental (bk_device_rt.h) - a handful per 4K map - and the functions below re-derive exactly those
+// with this context's host interpreter (platform libm unless bk_set_host_math says otherwise: the same
+// evaluator calc_zoom and the globe loader use), restating fisheye.c's float/double tail, and patch the table.
+namespace {
+
+float h_dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }     /* mathlib.h:70 */
+int h_trunc_to_int(double v)                                                                          /* cvttsd2si */
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+/* ray_to_plate_index, fisheye.c:2023-2050 (same out-of-range handling as the kernel's) */
+int h_ray_to_plate_index(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, const float *ray)
+{
+    if (P->globe_plate.is_function()) {
+        Values r = P->interp.call(P->globe_plate, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
+                                                         Value::number((double)ray[2])});
+        if (r.empty() || r.back().t != Value::NUM) return -1;
+        const double d = r.back().n;
+        if (!(d > -2147483648.0 && d < 2147483647.0)) return -1;
+        const int plate = (int)__builtin_rint(d);
+        if (plate < 0 || plate >= bp.numplates) return -1;
+        return plate;
+    }
+    int plate_index = 0;
+    double max_dp = -2;
+    for (int i = 0; i < bp.numplates; ++i) {
+        const double dp = (double)h_dot3(ray, bp.plates[i].forward);
+        if (dp > max_dp) { max_dp = dp; plate_index = i; }
+    }
+    (void)ctx;
+    return plate_index;
+}
+
+bool h_offgrid(const BkBuildParams &bp, int px, int py)                                                /* fisheye.c:1922-1960 */
+{
+    const double ux = (double)px / bp.rubix_unit_px, uy = (double)py / bp.rubix_unit_px;
+    return !(__builtin_fmod(ux, bp.rubix_block) < bp.rubix_pad || __builtin_fmod(uy, bp.rubix_block) < bp.rubix_pad);
+}
+
+/* one pixel of resume_lensmap_inverse (fisheye.c:2084-2124, 1545-1588, 1995-2013); o = index inside the owned stripe */
+void h_inverse_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32_t o, uint32_t *off, uint8_t *tint,
+                     int *plate_shown, int *err)
+{
+    *off = BK_NULL_OFFSET; *tint = 255; *plate_shown = -1;
+    const int lyl = (int)(o / (uint32_t)bp.W), lx = (int)(o - (uint32_t)lyl * (uint32_t)bp.W), ly = bp.row0 + lyl;
+    const double y = (double)(-(ly - bp.H / 2)) * bp.scale, x = (double)(lx - bp.W / 2) * bp.scale;
+    Values r = P->interp.call(P->lens_inverse, Values{Value::number(x), Value::number(y)});
+    if (r.size() == 3 && r[0].t == Value::NUM && r[1].t == Value::NUM && r[2].t == Value::NUM) {
+        float ray[3] = {(float)r[0].n, (float)r[1].n, (float)r[2].n};
+        bk::h_vector_normalize(ray);
+        const int plate = h_ray_to_plate_index(ctx, P, bp, ray);
+        if (plate < 0) return;
+        const BkPlateDev &p = bp.plates[plate];
+        const double px_ = (double)h_dot3(p.right, ray), py_ = (double)h_dot3(p.up, ray), pz_ = (double)h_dot3(p.forward, ray);
+        const double u = px_ / pz_ * p.dist64 + 0.5, v = -py_ / pz_ * p.dist64 + 0.5;
+        if (u >= 0 && u <= 1 && v >= 0 && v <= 1) {
+            const int px = h_trunc_to_int(u * bp.ps), py = h_trunc_to_int(v * bp.ps);
+            if (px >= 0 && px < bp.ps && py >= 0 && py < bp.ps) {
+                *plate_shown = plate;
+                *off = bk_texel_offset((unsigned)bp.gp, (unsigned)bp.ph, (unsigned)plate, (unsigned)px, (unsigned)py);
+                if (h_offgrid(bp, px, py)) *tint = (uint8_t)plate;
+            }
+        }
+    } else if (!(r.size() == 1 && r[0].t == Value::NIL)) {
+        *err |= BK_ERR_RESULT;
+    }
+}
+
+/* one texel corner of the forward build: uv_to_screen, fisheye.c:2227-2243 */
+void h_corner_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32_t id, int *sx, int *sy, uint8_t *ok, int *err)
+{
+    const uint32_t n1 = (uint32_t)bp.ps + 1u;
+    const uint32_t plate = id / (n1 * n1), rem = id - plate * n1 * n1, j = rem / n1, i = rem - j * n1;
+    const double u = ((double)i - 0.5) / bp.ps, v = ((double)j - 0.5) / bp.ps;
+    float ray[3];
+    bk::h_plate_uv_to_ray(ctx->plates[plate], u, v, ray);
+    *sx = 0; *sy = 0; *ok = 0;
+    Values r = P->interp.call(P->lens_forward, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
+                                                      Value::number((double)ray[2])});
+    if (r.size() == 2 && r[0].t == Value::NUM && r[1].t == Value::NUM) {
+        *sx = h_trunc_to_int(r[0].n / bp.scale + (double)(bp.W / 2));
+        *sy = h_trunc_to_int(-r[1].n / bp.scale + (double)(bp.H / 2));
+        *ok = 1;
+    } else if (!(r.size() == 1 && r[0].t == Value::NIL)) {
+        *err |= BK_ERR_RESULT;
+    }
+}
+
+/* forward build: does the ray through texel `id` select its own plate (fisheye.c:2193-2196) */
+bool h_texel_owns(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32_t id)
+{
+    const uint32_t ps = (uint32_t)bp.ps, plate = id / (ps * ps), rem = id - plate * ps * ps, py = rem / ps, px = rem - py * ps;
+    float ray[3];
+    bk::h_plate_uv_to_ray(ctx->plates[plate], (double)px / bp.ps, (double)py / bp.ps, ray);
+    return (int)plate == h_ray_to_plate_index(ctx, P, bp, ray);
+}
+
+}  // namespace
+
+// the flag list a kernel just filled: grows the list and reports `retry` when it overflowed
+static int read_flagged(bk_ctx *ctx, unsigned int count, std::vector<uint32_t> *list, bool *retry)
+{
+    *retry = false;
+    list->clear();
+    if (count > ctx->flag_cap) {
+        (void)hipFree(ctx->d_flag_list);
+        ctx->d_flag_list = nullptr;
+        ctx->flag_cap = 0;
+        const size_t cap = (size_t)count + count / 4 + 1024;
+        BK_HIP(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 4 * sizeof(uint32_t)));
+        ctx->flag_cap = cap;
+        *retry = true;
+        return BK_OK;
+    }
+    if (!count) return BK_OK;
+    list->resize((size_t)count * 4);
+    BK_HIP(ctx, hipMemcpyAsync(list->data(), ctx->d_flag_list, (size_t)count * 16, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
 }
 
 extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out)
@@ -597,6 +727,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     bk::coopmap_invalidate(ctx);
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
     ctx->last_build_ms = 0;
+    ctx->last_flagged = ctx->last_changed = 0;
 
     LensProgram *P = ctx->prog;
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
@@ -607,6 +738,10 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     std::string src;
     if (int r = generate_source(ctx, P, &src)) return r;
     if (int r = compile_module(ctx, P, src)) return r;
+    if (!ctx->d_flag_list) {
+        BK_HIP(ctx, hipMalloc((void **)&ctx->d_flag_list, (size_t)65536 * 4 * sizeof(uint32_t)));
+        ctx->flag_cap = 65536;
+    }
 
     BkBuildParams bp;
     fill_params(ctx, &bp);
@@ -614,7 +749,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     hipEvent_t e0, e1;
     BK_HIP(ctx, hipEventCreate(&e0));
     BK_HIP(ctx, hipEventCreate(&e1));
-    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int rc = BK_OK;
     auto cleanup = [&]() {
         for (void *p : scratch) if (p) (void)hipFree(p);
@@ -622,46 +757,160 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         (void)hipEventDestroy(e1);
     };
 #define BK_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = ctx->fail(BK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
-
-    if (P->info.map_type == BK_MAP_INVERSE) {
-        if (!P->k_inverse) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_inverse (map = \"lens_inverse\" without the function)"); }
-        BK_HIP_C(hipEventRecord(e0, ctx->stream));
-        BK_HIP_C(hipModuleLaunchKernel(P->k_inverse, (unsigned)((ctx->W + 255) / 256), (unsigned)ctx->rows(), 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
-        BK_HIP_C(hipEventRecord(e1, ctx->stream));
-    } else {
-        if (!P->k_corners || !P->k_quads || !P->k_resolve) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_forward"); }
-        const size_t n1 = (size_t)ctx->ps + 1;
-        const size_t ncorner = (size_t)ctx->numplates * n1 * n1;
-        BK_HIP_C(hipMalloc(&scratch[0], ncorner * 2 * sizeof(int)));
-        BK_HIP_C(hipMalloc(&scratch[1], ncorner));
-        BK_HIP_C(hipMalloc(&scratch[2], px * 4));
-        BK_HIP_C(hipMalloc(&scratch[3], px * 4));
-        bp.corner_xy = (int *)scratch[0];
-        bp.corner_ok = (unsigned char *)scratch[1];
-        bp.fwd_key_px = (unsigned int *)scratch[2];
-        bp.fwd_key_tint = (unsigned int *)scratch[3];
-        BK_HIP_C(hipMemsetAsync(scratch[2], 0, px * 4, ctx->stream));
-        BK_HIP_C(hipMemsetAsync(scratch[3], 0, px * 4, ctx->stream));
-        const size_t ntexel = (size_t)ctx->numplates * ctx->ps * ctx->ps;
-        BK_HIP_C(hipEventRecord(e0, ctx->stream));
-        BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((ncorner + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
-        BK_HIP_C(hipModuleLaunchKernel(P->k_quads, (unsigned)((ntexel + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
-        BK_HIP_C(hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
-        BK_HIP_C(hipEventRecord(e1, ctx->stream));
-    }
+#define BK_RC_C(expr) do { rc = (expr); if (rc != BK_OK) { cleanup(); return rc; } } while (0)
     int flags[BK_MAX_PLATES + 2];
-    BK_HIP_C(hipMemcpyAsync(flags, ctx->d_display, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    int host_display[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
+    int host_err = 0;
+    std::vector<uint32_t> flagged;
+    auto reset_counters = [&]() -> hipError_t { return hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 2) * sizeof(int), ctx->stream); };
+    auto read_counters = [&]() -> hipError_t {
+        hipError_t e = hipMemcpyAsync(flags, ctx->d_display, sizeof flags, hipMemcpyDeviceToHost, ctx->stream);
+        return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+    };
+
+    try {
+        if (P->info.map_type == BK_MAP_INVERSE) {
+            if (!P->k_inverse) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_inverse (map = \"lens_inverse\" without the function)"); }
+            BK_HIP_C(hipEventRecord(e0, ctx->stream));
+            for (;;) {
+                BK_HIP_C(hipModuleLaunchKernel(P->k_inverse, (unsigned)((ctx->W + 255) / 256), (unsigned)ctx->rows(), 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                BK_HIP_C(read_counters());
+                bool retry = false;
+                BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
+                if (!retry) break;
+                fill_params(ctx, &bp);                       // (the list moved)
+                BK_HIP_C(reset_counters());
+            }
+            // re-derive the flagged pixels on the host and patch the ones that differ
+            std::vector<uint32_t> idx, voff;
+            std::vector<uint8_t> vtint;
+            for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
+                uint32_t off; uint8_t tint; int shown;
+                h_inverse_entry(ctx, P, bp, flagged[k], &off, &tint, &shown, &host_err);
+                if (shown >= 0) host_display[shown] = 1;
+                if (off != flagged[k + 1] || tint != (uint8_t)flagged[k + 2]) { idx.push_back(flagged[k]); voff.push_back(off); vtint.push_back(tint); }
+            }
+            ctx->last_flagged = (int)(flagged.size() / 4);
+            ctx->last_changed = (int)idx.size();
+            BK_RC_C(bk::launch_scatter32(ctx, ctx->d_offsets, idx.data(), voff.data(), idx.size()));
+            BK_RC_C(bk::launch_scatter8(ctx, ctx->d_tints, idx.data(), vtint.data(), idx.size()));
+            BK_HIP_C(hipEventRecord(e1, ctx->stream));
+        } else {
+            if (!P->k_corners || !P->k_quads || !P->k_resolve) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_forward"); }
+            const size_t n1 = (size_t)ctx->ps + 1;
+            const size_t ncorner = (size_t)ctx->numplates * n1 * n1;
+            BK_HIP_C(hipMalloc(&scratch[0], ncorner * 2 * sizeof(int)));
+            BK_HIP_C(hipMalloc(&scratch[1], ncorner));
+            BK_HIP_C(hipMalloc(&scratch[2], px * 4));
+            BK_HIP_C(hipMalloc(&scratch[3], px * 4));
+            bp.corner_xy = (int *)scratch[0];
+            bp.corner_ok = (unsigned char *)scratch[1];
+            bp.fwd_key_px = (unsigned int *)scratch[2];
+            bp.fwd_key_tint = (unsigned int *)scratch[3];
+            const size_t ntexel = (size_t)ctx->numplates * ctx->ps * ctx->ps;
+            BK_HIP_C(hipEventRecord(e0, ctx->stream));
+            // texel corners -> screen; the flagged ones re-derived on the host
+            for (;;) {
+                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((ncorner + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                BK_HIP_C(read_counters());
+                bool retry = false;
+                BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
+                if (!retry) break;
+                bp.flag_list = ctx->d_flag_list; bp.flag_cap = (unsigned)ctx->flag_cap;
+                BK_HIP_C(reset_counters());
+            }
+            int corner_err = flags[BK_MAX_PLATES];
+            {
+                std::vector<uint32_t> ixy, vxy, iok;
+                std::vector<uint8_t> vok;
+                for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
+                    int sx, sy; uint8_t ok;
+                    h_corner_entry(ctx, P, bp, flagged[k], &sx, &sy, &ok, &host_err);
+                    if ((uint32_t)sx != flagged[k + 1] || (uint32_t)sy != flagged[k + 2] || ok != (uint8_t)flagged[k + 3]) {
+                        ixy.push_back(2 * flagged[k]); vxy.push_back((uint32_t)sx);
+                        ixy.push_back(2 * flagged[k] + 1); vxy.push_back((uint32_t)sy);
+                        iok.push_back(flagged[k]); vok.push_back(ok);
+                    }
+                }
+                ctx->last_flagged = (int)(flagged.size() / 4);
+                ctx->last_changed = (int)iok.size();
+                BK_RC_C(bk::launch_scatter32(ctx, (uint32_t *)bp.corner_xy, ixy.data(), vxy.data(), ixy.size()));
+                BK_RC_C(bk::launch_scatter8(ctx, bp.corner_ok, iok.data(), vok.data(), iok.size()));
+            }
+            // quads; with a globe_plate script a texel's "own plate" test can be flagged too: the host answers those and
+            // the scatter runs once more with its answers
+            std::vector<uint32_t> ovr;
+            for (int pass = 0; pass < 2; ++pass) {
+                bool again = false;
+                for (;;) {
+                    BK_HIP_C(reset_counters());
+                    BK_HIP_C(hipMemsetAsync(scratch[2], 0, px * 4, ctx->stream));
+                    BK_HIP_C(hipMemsetAsync(scratch[3], 0, px * 4, ctx->stream));
+                    BK_HIP_C(hipModuleLaunchKernel(P->k_quads, (unsigned)((ntexel + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                    BK_HIP_C(read_counters());
+                    if (pass == 1) break;
+                    bool retry = false;
+                    BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
+                    if (!retry) break;
+                    bp.flag_list = ctx->d_flag_list; bp.flag_cap = (unsigned)ctx->flag_cap;
+                }
+                if (pass == 0 && !flagged.empty()) {
+                    std::vector<std::pair<uint32_t, uint32_t>> ans;
+                    for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
+                        const bool own = h_texel_owns(ctx, P, bp, flagged[k]);
+                        if ((own ? 1u : 0u) != flagged[k + 1]) { again = true; ++ctx->last_changed; }
+                        ans.push_back({flagged[k], own ? 1u : 0u});
+                    }
+                    ctx->last_flagged += (int)ans.size();
+                    if (again) {
+                        std::sort(ans.begin(), ans.end());
+                        for (auto &a : ans) { ovr.push_back((a.first << 1) | a.second); }
+                        BK_HIP_C(hipMalloc(&scratch[4], ovr.size() * 4));
+                        BK_HIP_C(hipMemcpyAsync(scratch[4], ovr.data(), ovr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                        bp.ovr_list = (const unsigned int *)scratch[4];
+                        bp.ovr_count = (unsigned)ovr.size();
+                    }
+                }
+                if (!again) break;
+            }
+            flags[BK_MAX_PLATES] |= corner_err;
+            BK_HIP_C(hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+            BK_HIP_C(hipEventRecord(e1, ctx->stream));
+        }
+    } catch (const LuaError &e) {
+        cleanup();
+        return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", e.what());
+    }
     BK_HIP_C(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     ctx->last_build_ms = ms;
     cleanup();
 #undef BK_HIP_C
+#undef BK_RC_C
     for (int i = 0; i < BK_MAX_PLATES; ++i) {
-        ctx->display[i] = i < ctx->numplates ? flags[i] : 0;
+        ctx->display[i] = i < ctx->numplates ? (flags[i] | host_display[i]) : 0;
         if (display_out) display_out[i] = ctx->display[i];
     }
-    if (flags[BK_MAX_PLATES]) return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(flags[BK_MAX_PLATES]));
+    const int errbits = flags[BK_MAX_PLATES] | host_err;
+    if (errbits) {
+        // The reference aborts the build at the first malformed callback result and keeps the rows done so far
+        // (fisheye.c:2113-2117); which rows those are depends on its scan order and time slicing.  Here a failed
+        // build leaves an EMPTY map (nothing is drawn) and reports the error.
+        BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
+        BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
+        return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
+    }
+    return BK_OK;
+}
+
+extern "C" int bk_last_build_fixups(const bk_ctx *ctx, int *flagged, int *changed)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (flagged) *flagged = ctx->last_flagged;
+    if (changed) *changed = ctx->last_changed;
     return BK_OK;
 }
 

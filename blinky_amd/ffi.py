@@ -60,6 +60,7 @@ _SIGS = {
     "bk_set_rubixgrid": (_i, [_vp, _i, _d, _d]),
     "bk_build": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
     "bk_calc_zoom": (_i, [_vp, C.POINTER(_d)]),
+    "bk_last_build_fixups": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "bk_set_lensmap": (_i, [_vp, _vp, _vp]),
     "bk_read_lensmap": (_i, [_vp, _vp, _vp]),
     "bk_upload_plate": (_i, [_vp, _i, _i, _vp, _i]),
@@ -188,6 +189,12 @@ class Context:
         scale = _d()
         self._chk(lib.bk_calc_zoom(self._h, C.byref(scale)))
         return scale.value
+
+    def last_build_fixups(self):
+        """(entries the last build re-derived on the host, entries that changed)"""
+        a, b = _i(), _i()
+        self._chk(lib.bk_last_build_fixups(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def last_build_ms(self):
         return lib.bk_last_build_ms(self._h)

@@ -104,9 +104,21 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * replaces: create_lensmap (fisheye.c:2367-2397) = calc_zoom + resume_lensmap_inverse
  * (2084-2124) or resume_lensmap_forward (2126-2217), run to completion on the GPU,
  * including the NULL/255 clears of F_RenderView (731-732).
- * display_out (nullable) receives globe.plates[i].display; scale_out lens.scale. */
+ * display_out (nullable) receives globe.plates[i].display; scale_out lens.scale.
+ * A callback that fails at run time (malformed result, arithmetic on nil, runaway loop) makes bk_build return
+ * BK_E_SCRIPT and leaves an EMPTY lensmap (the reference keeps the rows built before the failing pixel).
+ * Script globals that lens_inverse / lens_forward / globe_plate ASSIGN are per-pixel state on the GPU, initialised
+ * from their value after the chunk ran: fine for scratch variables and pure caches (all bundled scripts), but a
+ * script that accumulates state from one pixel to the next does not behave as in the reference's sequential scan. */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
 int bk_calc_zoom(bk_ctx *ctx, double *scale_out);                                   /* calc_zoom only */
+/* Exactness bookkeeping of the last bk_build.  The kernels evaluate the scripts' transcendentals with a portable
+ * libm; the reference's Lua VM calls the platform's.  Every value on the device carries a bound on that
+ * discrepancy, and each pixel / texel corner whose DISCRETE outcome (a float narrowing, a comparison, a floor)
+ * could depend on it is flagged, re-derived by the host interpreter on the platform libm - the evaluator
+ * bk_calc_zoom and bk_load_globe already use - and patched before bk_build returns.
+ * flagged = entries re-derived on the host, changed = entries whose value differed from the device's. */
+int bk_last_build_fixups(const bk_ctx *ctx, int *flagged, int *changed);
 /* direct access to the table (lens.pixels / lens.pixel_tints of the owned rows) */
 int bk_set_lensmap(bk_ctx *ctx, const uint32_t *offsets, const uint8_t *tints);
 int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints);

@@ -30,7 +30,12 @@ CONFIGS = [
     ("cube", "panini", "f_fov 120", 322, 203),    # odd sizes, W%4 != 0
     ("cube", "hammer", "f_cover", 500, 300),
     ("cube", "stereographic", "f_vfov 90", 300, 500),   # portrait: ps = W
+    ("cube", "hammer", None, 7680, 4320),         # BASELINE.json configs[4] (C5); its 64-frame batch below
 ]
+# configs whose record also carries `fnv_frames`: one hash per frame of a batch over the LCG globes 0..n-1
+# (SURVEY.md 8(d)).  Frame 0 comes from the unmodified reference; the others from the oracle's render_lensmap
+# restatement applied to the REFERENCE's lensmap (building the 8K map 64 times over would take ten minutes).
+BATCH = {("cube", "hammer", None, 7680, 4320): 64, ("cube", "panini", None, 3840, 2160): 16}
 
 
 def main():
@@ -40,6 +45,15 @@ def main():
         rec = dict(globe=globe, lens=lens, zoom=zoom, W=W, H=H, built=bool(lm.built), scale=repr(lm.scale),
                    display=lm.display, nonnull=lm.nonnull, fnv_offsets=O.fnv(lm.offsets),
                    fnv_tints=O.fnv(lm.tints), fnv_frame=O.fnv(frame))
+        nb = BATCH.get((globe, lens, zoom, W, H), 0)
+        if nb:
+            import numpy as np
+            hashes = []
+            for f in range(nb):
+                fr = O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, lm.numplates, f), np.zeros((H, W), np.uint8))
+                hashes.append(O.fnv(fr))
+            assert hashes[0] == rec["fnv_frame"]            # the restatement's frame 0 IS the reference's
+            rec["fnv_frames"] = hashes
         print(rec)
         out.append(rec)
     pal = O.ref_palettes()

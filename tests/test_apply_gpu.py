@@ -207,6 +207,38 @@ def test_apply_4k_frame_hash_equals_reference_golden(bk, key, variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("key", [k for k, r in GOLD.items() if "fnv_frames" in r], ids=lambda k: f"{k[0]}-{k[1]}-{k[3]}x{k[4]}")
+def test_batch_launch_equals_reference_golden_frames(bk, key):
+    """BASELINE.json configs[4] at full size (7680x4320 cube/hammer, 64 frames, 64 distinct resident globes) and the
+    bench workload (3840x2160 cube/panini, 16 frames): the GPU builds the lensmap from the Lua scripts, ONE
+    bk_apply_device launch warps the whole batch, and every frame's hash equals the golden (frame 0 recorded from
+    the unmodified reference, the others from the oracle's gather over the reference's lensmap)."""
+    import torch
+    import scripts as S
+    rec = GOLD[key]
+    globe, lens, zoom, W, H = key
+    F = len(rec["fnv_frames"])
+    ctx = bk.Context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_frames(F)
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    display, scale = ctx.build()
+    assert repr(scale) == rec["scale"] and display[: len(rec["display"])] == rec["display"]
+    off, tin = ctx.read_lensmap()
+    assert O.fnv(off) == rec["fnv_offsets"] and O.fnv(tin) == rec["fnv_tints"]
+    assert int((off != O.NULL).sum()) == rec["nonnull"]
+    del off, tin
+    for f in range(F):
+        for p in range(len(rec["display"])):
+            ctx.fill_plate_lcg(f, p, seed_frame=f)
+    out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
+    ctx.apply_device(out.data_ptr(), W, H * W, frame0=0, nframes=F)
+    torch.cuda.synchronize()
+    for f in range(F):
+        assert O.fnv(out[f].cpu().numpy()) == rec["fnv_frames"][f], f"frame {f}"
+    ctx.close()
+
+
 @pytest.mark.parametrize("lens", __import__("scripts").LENSES)
 def test_apply_on_every_shipped_lens(bk, lens):
     """build on the GPU, then warp two frames (rubix off / on) and compare with the oracle's render_lensmap over the

@@ -43,25 +43,11 @@ def test_build_equals_reference_golden(bk, rec):
     assert display[:nplates] == rec["display"]
     assert int((off != O.NULL).sum()) == rec["nonnull"]
     assert O.fnv(tin) == rec["fnv_tints"]
-    if O.fnv(off) != rec["fnv_offsets"]:
-        # The one accepted cause: pixels whose texel coordinate is an EXACT tie (u*ps integral because
-        # a libm result cancels to exactly 0 on the platform libm and to +-1 ulp on another correct
-        # libm).  Seen on 2 of 8 294 400 entries of cube/quincuncial 4K, nowhere else.  Such an entry
-        # must be the neighbouring texel of the same plate; everything else must be identical.
-        lm = O.lensmap(rec["globe"], rec["lens"], rec["zoom"], rec["W"], rec["H"])
-        assert O.fnv(lm.offsets) == rec["fnv_offsets"]
-        bad = np.nonzero(off != lm.offsets)[0]
-        assert 0 < len(bad) <= 4, f"{len(bad)} entries differ from the reference"
-        ps = min(rec["W"], rec["H"])
-        for i in bad:
-            a, b = int(off[i]), int(lm.offsets[i])
-            assert a != O.NULL and b != O.NULL and a // (ps * ps) == b // (ps * ps)
-            assert abs(a - b) in (1, ps), (i, a, b)
-        # and it is the libm, not the algorithm: the same oracle on the portable libm agrees exactly
-        lmp = O.lensmap(rec["globe"], rec["lens"], rec["zoom"], rec["W"], rec["H"], portable=True)
-        np.testing.assert_array_equal(off, lmp.offsets)
-        ctx.close()
-        return
+    assert O.fnv(off) == rec["fnv_offsets"]         # bit-exact, no exceptions
+    # the exactness bookkeeping: what the device could not decide on its own libm went through the host
+    # interpreter (platform libm); that must stay a vanishing fraction of the table
+    flagged, changed = ctx.last_build_fixups()
+    assert changed <= flagged <= max(64, off.size // 1000), (flagged, changed)
     # and the whole path: GPU-built map applied on the GPU to the LCG globe == the reference's frame
     for p in range(nplates):
         ctx.fill_plate_lcg(0, p, 0)
@@ -110,6 +96,27 @@ def test_gpu_equals_portable_libm_oracle_exactly(bk, cfg):
     assert scale == lm.scale and display[: lm.numplates] == lm.display
     np.testing.assert_array_equal(off, lm.offsets)
     np.testing.assert_array_equal(tin, lm.tints)
+    ctx.close()
+
+
+def test_exact_ties_are_resolved_on_the_platform_libm(bk):
+    """cube/quincuncial at 3840x2160 (BASELINE.json configs[2]): at a few pixels 2*atan2(r,1) - pi/2 cancels to
+    exactly 0 on glibc and to +-1 ulp on any other correct libm, which moves u*ps across an integer.  The device
+    flags those pixels, the host interpreter re-derives them on the platform libm, and the table equals the
+    unmodified reference's; with the host switched to the portable libm the same pixels are flagged and nothing
+    changes (the result is then a pure function of the scripts)."""
+    rec = next(r for r in GOLD if r["lens"] == "quincuncial" and r["W"] == 3840)
+    ctx, _, _, off, _ = build(bk, rec["globe"], rec["lens"], rec["zoom"], rec["W"], rec["H"])
+    flagged, changed = ctx.last_build_fixups()
+    assert O.fnv(off) == rec["fnv_offsets"]
+    assert changed >= 1 and flagged >= changed
+    ctx.close()
+    ctx = bk.Context()
+    ctx.set_host_math(True)
+    S.configure(ctx, rec["globe"], rec["lens"], rec["zoom"], (rec["W"], rec["H"]))
+    ctx.build()
+    flagged_p, changed_p = ctx.last_build_fixups()
+    assert flagged_p == flagged and changed_p == 0
     ctx.close()
 
 
@@ -171,8 +178,7 @@ def test_device_callbacks_bit_equal_host_interpreter(bk, lens):
 def test_every_shipped_lens_builds_the_oracle_table(bk, lens):
     """All 31 lens scripts (21 inverse, 10 forward-only), cube and trism globes, small frame: the GPU build
     against the oracle's fisheye.c restatement whose lens callbacks are evaluated by the host interpreter
-    on the platform libm (i.e. the way the reference's Lua VM would).  Exact-tie pixels aside (none at this
-    size), the tables must be identical."""
+    on the platform libm (i.e. the way the reference's Lua VM would).  The tables must be identical."""
     for globe, (W, H) in (("cube", (160, 120)), ("trism", (96, 128))):
         hostctx = bk.Context(bk.ffi.DEVICE_NONE)            # interpreter only, platform libm
         info = S.configure(hostctx, globe, lens, None, (W, H))
