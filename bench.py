@@ -5,19 +5,29 @@ Workload (BASELINE.json metric): 3840x2160 output, cube globe (6 faces of 2160x2
 lens, f_fov 180.  Synthetic data: LCG globe faces (SURVEY.md 8(d)) generated on the device;
 the lensmap is built on the device from the bundled Lua scripts before the timed region.
 
-A *step* = one pass of the hot path over one batch: `frames` frames (distinct resident globes,
-one shared lensmap) warped by one bk_apply_device launch; with N > 1 ranks each rank owns a
-stripe of output rows (it builds and keeps only that stripe of the lensmap, holds a full globe
-replica) and the step ends with the frames' reassembly: one grouped RCCL send/recv in which frame f's
-stripes travel to rank f % N (blinky_amd.multigpu.exchange_rotating), overlapped with the next batch's
-warp.  (All frames gathered onto rank 0 - the single-display case, bounded by one GPU's xGMI ingest -
-is timed too and reported as `assembled_on_rank0_mpx_s`.)
+A *step* = one pass of the hot path over one batch: `frames` frames warped by ONE bk_apply_device launch from
+`frames` consecutive globes of a resident ring of `ring` distinct globes (default 64 = 1.8 GB), into one of four
+rotating output buffers.  The ring advances every step, so a globe is re-read only after the whole ring - several
+times the 256 MiB Infinity Cache - has gone by: the timed region runs against HBM, not against the last-level
+cache (the figure for a ring that fits the cache is reported beside it as `roofline.warm_ring`).
+With N > 1 ranks each rank owns a stripe of output rows (it builds and keeps only that stripe of the lensmap, holds
+a full globe replica) and the step ends with the frames' reassembly: one grouped RCCL send/recv in which frame f's
+stripes travel to rank f % N (blinky_amd.multigpu.exchange_rotating), overlapped with the next batch's warp.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
+`python -m torch.distributed.run --nproc-per-node N`; a world size that differs from --gpus is an error.
+
+The timed region of K steps is repeated (--repeats, default 31 regions, each bracketed by barrier + synchronize,
+max over ranks); `value` is the MEDIAN region, min / max are printed beside it.
 Prints ONE JSON line (rank 0).  `value` = whole-job Mpixels/s = W*H*frames*steps / time.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,14 +35,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 W, H = 3840, 2160
 GLOBE, LENS, ZOOM = "cube", "panini", "f_fov 180"
 ALGO_BYTES_PER_PX = 6          # 4 B lensmap index + 1 B texel + 1 B store
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+KERNEL_SOURCES = ("blinky_amd/csrc/bk_apply_coop.hip", "blinky_amd/csrc/bk_apply.hip", "blinky_amd/csrc/bk_build_params.h")
+
+
+def kernel_source_hash():
+    """identifies the apply kernels a PMC traffic record was measured on (profiles/apply_traffic.json)"""
+    h = hashlib.sha1()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(frames_budget_s=6.0):
@@ -41,6 +56,7 @@ def cpu_baseline(frames_budget_s=6.0):
     otherwise the oracle's C restatement.  Bounded sample: the 4K lensmap build once plus
     ~frames_budget_s of render_lensmap() calls."""
     import ctypes as C
+    import numpy as np
     import oracle_ffi as O
     if O.have_ref():
         t0 = time.time()
@@ -78,29 +94,57 @@ def cpu_baseline(frames_budget_s=6.0):
             "build_ms": round(build_s * 1e3, 1)}
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` outside torchrun: one process per GPU, this node, RCCL"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a torchrun environment: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=16, help="frames per step (batch warped by one launch)")
+    ap.add_argument("--ring", type=int, default=64, help="distinct resident globes the steps cycle through")
+    ap.add_argument("--repeats", type=int, default=31, help="how many times the K-step timed region is measured (median reported)")
     ap.add_argument("--variant", type=int, default=-1, help="apply kernel variant (-1 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region, compare every reassembled frame this rank owns with a full-frame warp")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a "
+                 f"{world}-GPU number as a {args.gpus}-GPU one")
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # BLINKY_BENCH_BACKEND=gloo + BLINKY_BENCH_ONE_GPU=1: developer smoke of the N > 1 control flow on a
         # single-GPU box (all ranks on cuda:0, stripes exchanged through host memory); never a measurement
         dist.init_process_group(os.environ.get("BLINKY_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"[bench] process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     host_exchange = world > 1 and dist.get_backend() == "gloo"
     if os.environ.get("BLINKY_BENCH_ONE_GPU") == "1":
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        sys.exit(f"[bench] rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -108,11 +152,11 @@ def main():
     import scripts as S
     from blinky_amd import multigpu
 
-    F = args.frames
+    F, R = args.frames, max(args.ring, args.frames)
     ctx = blinky_amd.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    ctx.set_frames(F)
+    ctx.set_frames(R)
     S.configure(ctx, GLOBE, LENS, ZOOM, (W, H))
     bounds = multigpu.stripe_bounds(H, world)
     r0, r1 = bounds[rank], bounds[rank + 1]
@@ -122,13 +166,14 @@ def main():
 
     # ---- lensmap build (each rank: its own stripe; no exchange) ----------------------------------
     t0 = time.time()
-    ctx.build()                                   # includes hiprtc compilation of the lens
+    ctx.build()                                   # includes hiprtc compilation of the lens (or the module cache)
     build_first_wall_ms = (time.time() - t0) * 1e3
     t0 = time.time()
-    display, scale = ctx.build()                  # module cached: emit + launch only
+    display, scale = ctx.build()                  # module cached: emit + launch (+ host fix-up of flagged pixels) only
     display = multigpu.or_display(display, world, dev)   # which plates the whole frame reads
     build_wall_ms = (time.time() - t0) * 1e3
     build_kernel_ms = ctx.last_build_ms()
+    fix_flagged, fix_changed = ctx.last_build_fixups()
     t0 = time.time()
     tile_stats = ctx.tile_stats()                 # compiles the block map (chunk lists) of the lensmap for the apply kernel
     tilemap_first_wall_ms = (time.time() - t0) * 1e3      # includes the one-off buffer allocations
@@ -137,14 +182,17 @@ def main():
     t0 = time.time()
     tile_stats = ctx.tile_stats()
     tilemap_wall_ms = (time.time() - t0) * 1e3            # steady state: what a zoom / lens change costs on top of the build
-    for f in range(F):
+    model = ctx.traffic_model()
+    for f in range(R):
         for p in range(6):
             ctx.fill_plate_lcg(f, p, f)
     torch.cuda.synchronize()
 
     rows = r1 - r0
-    # Draw_TileClear stand-in: 0.  Two stripe buffers, so that batch i+1 is warped while batch i's stripes travel.
-    stripes = [torch.zeros((F, rows, W), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    # Draw_TileClear stand-in: 0.  N = 1: four rotating output buffers.  N > 1: two stripe buffers, so that batch i+1 is
+    # warped while batch i's stripes travel.
+    NB = 4 if world == 1 else 2
+    stripes = [torch.zeros((F, rows, W), dtype=torch.uint8, device=dev) for _ in range(NB)]
     stripe = stripes[0]
     nown = (F + world - 1) // world
     xdev = torch.device("cpu") if host_exchange else dev
@@ -160,14 +208,18 @@ def main():
         # a stripe buffer holds just those rows, so its frame origin lies r0 rows before it
         return t.data_ptr() - r0 * W
 
+    def first_globe(i):
+        return (i * F) % R                       # the ring advances by one batch every step
+
     def step(i):
-        # one batch: warp this rank's stripe of F frames, then reassemble frame f on rank f % world (one grouped
+        # one batch: warp this rank's stripe of F frames, then (N > 1) reassemble frame f on rank f % world (one grouped
         # RCCL send/recv per batch; buffers alternate, the exchange of batch i overlaps the warp of batch i+1)
-        b = i & 1 if world > 1 else 0
-        for w in pending[b]:
-            w.wait()
-        pending[b] = []
-        ctx.apply_device(origin(stripes[b]), W, rows * W, frame0=(i * F) % F, nframes=F)
+        b = i % NB
+        if world > 1:
+            for w in pending[b]:
+                w.wait()
+            pending[b] = []
+        ctx.apply_device(origin(stripes[b]), W, rows * W, frame0=first_globe(i), nframes=F)
         if world > 1:
             src = stripes[b].cpu() if host_exchange else stripes[b]
             pending[b] = multigpu.exchange_rotating(src, bounds, rank, world, frames_out[b], wait=False)
@@ -180,7 +232,7 @@ def main():
 
     def step_root(i):
         # the single-display variant: every frame of the batch gathered onto rank 0
-        ctx.apply_device(origin(stripe), W, rows * W, frame0=(i * F) % F, nframes=F)
+        ctx.apply_device(origin(stripe), W, rows * W, frame0=first_globe(i), nframes=F)
         multigpu.gather_stripes(stripe.cpu() if host_exchange else stripe, bounds, rank, world, 0,
                                 None if host_exchange else gather_list)
 
@@ -189,6 +241,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # Should the grouped send/recv not be usable on this node, fall back to the plain gather onto rank 0 (and say so)
     # rather than lose the measurement; every rank takes the same decision.
@@ -208,21 +267,24 @@ def main():
             exchange_mode = "root"
             pending[0], pending[1] = [], []
     run_step = step if exchange_mode == "rotating" else step_root
+
+    def timed_region(first):
+        """EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(first, first + args.steps):
+            run_step(i)
+        drain()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
     for i in range(args.warmup):
         run_step(i)
     drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(i)
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    regions = [timed_region(args.warmup + k * args.steps) for k in range(max(1, args.repeats))]
+    elapsed = statistics.median(regions)
     root_elapsed = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # extra (not `value`): all frames assembled on rank 0 - bounded by one GPU's xGMI ingest
         nroot = max(3, args.steps // 5)
         step_root(0)
@@ -231,34 +293,34 @@ def main():
         for i in range(nroot):
             step_root(i)
         barrier()
-        t = torch.tensor([(time.perf_counter() - t0) / nroot], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        root_elapsed = float(t.item())
+        root_elapsed = max_over_ranks((time.perf_counter() - t0) / nroot)
 
     # ---- the dominant kernel alone, HIP events on the launch stream (roofline) ------------------------
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    e0.record(stream)
-    for i in range(args.steps):
-        ctx.apply_device(origin(stripe), W, rows * W, frame0=0, nframes=F)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    kernel_ms = e0.elapsed_time(e1) / args.steps
-    stripe_mpx = W * rows * F / (kernel_ms * 1e-3) / 1e6
+
+    def kernel_ms(ring, nframes=F, launches=args.steps, repeats=max(1, min(args.repeats, 15))):
+        """median over `repeats` of: HIP events around `launches` back-to-back launches cycling a ring of `ring` globes"""
+        out = []
+        for k in range(repeats):
+            barrier()
+            e0.record(stream)
+            for i in range(launches):
+                ctx.apply_device(origin(stripes[i % NB]), W, rows * W, frame0=(i * nframes) % ring, nframes=nframes)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) / launches)
+        return statistics.median(out), min(out), max(out)
+
+    k_med, k_min, k_max = kernel_ms(R)
+    kw_med, _, _ = kernel_ms(F)                           # the ring that fits the Infinity Cache: the same F globes every launch
+    stripe_mpx = W * rows * F / (k_med * 1e-3) / 1e6
     if world > 1:
         t = torch.tensor([stripe_mpx], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         stripe_complete_mpx = float(t.item())
     else:
         stripe_complete_mpx = stripe_mpx
-    # single-frame launches (launch-latency sensitive)
-    barrier()
-    e0.record(stream)
-    for i in range(args.steps):
-        ctx.apply_device(origin(stripe), W, rows * W, frame0=i % F, nframes=1)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    single_ms = e0.elapsed_time(e1) / args.steps
+    single_ms, _, _ = kernel_ms(R, nframes=1)            # single-frame launches (what the engine drop-in issues), cold ring
 
     if args.check:
         # every frame this rank ends up holding == the same frame warped whole by a full-height context
@@ -267,20 +329,22 @@ def main():
         full_ctx.set_frames(F)
         S.configure(full_ctx, GLOBE, LENS, ZOOM, (W, H))
         full_ctx.build()
+        last_i = args.warmup + max(1, args.repeats) * args.steps - 1          # the last step of the last timed region
+        g0 = first_globe(last_i)
         for f in range(F):
             for p in range(6):
-                full_ctx.fill_plate_lcg(f, p, f)
+                full_ctx.fill_plate_lcg(f, p, (g0 + f) % R)
         full = torch.zeros((F, H, W), dtype=torch.uint8, device=dev)
         full_ctx.apply_device(full.data_ptr(), W, H * W, frame0=0, nframes=F)
         torch.cuda.synchronize()
         if world > 1:
             if exchange_mode == "rotating":
-                last = frames_out[(args.steps - 1) & 1]
+                last = frames_out[last_i % NB]
                 bad = [f for f in multigpu.owned_frames(F, rank, world) if not torch.equal(last[f // world].to(dev), full[f])]
             else:
                 bad = []
         else:
-            ctx.apply_device(origin(stripe), W, rows * W, frame0=0, nframes=F)
+            ctx.apply_device(origin(stripe), W, rows * W, frame0=g0, nframes=F)
             torch.cuda.synchronize()
             bad = [f for f in range(F) if not torch.equal(stripe[f], full[f])]
         print(f"[check] rank {rank}: {'OK' if not bad else 'MISMATCH in frames ' + str(bad)}", file=sys.stderr, flush=True)
@@ -291,31 +355,66 @@ def main():
         px_per_step = W * H * F
         value = px_per_step * args.steps / elapsed / 1e6
         algo_bytes = ALGO_BYTES_PER_PX * W * rows * F                      # per launch on this rank
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        achieved = algo_bytes / (k_med * 1e-3) / 1e9
+        # what the kernel has to move per launch: every mapped pixel stored once, every distinct globe line the lensmap
+        # touches read once per frame, the block map (headers + chunk lists + 16-bit pixel addresses) once per block visit
+        visits = -(-F // int(model["frames_per_visit"])) if F >= 8 else 1
+        if 8 <= F < 16:
+            visits = 2
+        compulsory = F * (model["mapped_pixels"] + 128 * model["unique_globe_lines"]) + visits * model["blockmap_bytes_per_visit"]
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "apply_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
                 rec = json.load(open(tpath))
-                if rec.get("workload") == f"{W}x{H} {GLOBE}/{LENS} x{F}" and world == 1:
+                want = f"{W}x{H} {GLOBE}/{LENS} x{F} ring{R}"
+                if rec.get("workload") == want and rec.get("kernel_source_sha1_16") == kernel_source_hash():
                     traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                    traffic_src = {k: rec.get(k) for k in ("profile", "commit", "kernel_source_sha1_16", "FETCH_SIZE_KiB_per_launch",
+                                                           "WRITE_SIZE_KiB_per_launch")}
+                else:
+                    traffic_src = {"stale": True, "why": f"profiles/apply_traffic.json was measured on workload {rec.get('workload')!r}, "
+                                   f"kernel sources {rec.get('kernel_source_sha1_16')}; this run is {want!r}, {kernel_source_hash()} - "
+                                   "rerun tools/profile_bench.sh"}
+            except Exception as e:      # noqa: BLE001
+                traffic_src = {"stale": True, "why": f"unreadable record: {e}"}
+        t_launch = k_med * 1e-3
         out = {
             "metric": "warped Mpixels/s (lensmap apply)", "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step (distinct resident globes, one lensmap)",
-                       "frames_per_step": F, "parallelism": f"row-stripes x{world}" + ("" if world == 1 else " + RCCL grouped send/recv: frame f reassembled on rank f%N"
+            "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step from a resident ring of {R} distinct globes "
+                                   f"({R * 6 * 2160 * 2176 / 1e9:.2f} GB, advanced every step), one lensmap",
+                       "frames_per_step": F, "ring_globes": R,
+                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else " + RCCL grouped send/recv: frame f reassembled on rank f%N"
                                                                      if exchange_mode == "rotating" else " + RCCL gather of every frame onto rank 0"),
                        "apply_variant": args.variant},
+            "timed_regions": {"count": len(regions), "steps_each": args.steps, "value_is": "median",
+                              "mpx_s_median": round(value, 1),
+                              "mpx_s_min": round(px_per_step * args.steps / max(regions) / 1e6, 1),
+                              "mpx_s_max": round(px_per_step * args.steps / min(regions) / 1e6, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms_per_launch": round(kernel_ms, 5), "algorithmic_bytes_per_launch": algo_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_is": "ALGORITHMIC bytes (6 B/px, SURVEY.md 8(d)) / kernel time / peak, as the bench contract defines it; the "
+                                    "kernel moves fewer bytes than that (2-byte LDS addresses read once per 8 frames instead of a 4-byte "
+                                    "index per pixel and frame), so this ratio can exceed 1 and is NOT a bandwidth utilisation - "
+                                    "frac_traffic and frac_compulsory are",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_traffic": round(traffic / t_launch / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                         "compulsory_bytes_per_launch": int(compulsory),
+                         "frac_compulsory": round(compulsory / t_launch / 1e9 / HBM_PEAK_GBS, 4),
+                         "kernel_ms_per_launch": round(k_med, 5), "kernel_ms_min": round(k_min, 5), "kernel_ms_max": round(k_max, 5),
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "ring_globes": R, "model": {k: int(v) for k, v in model.items()},
+                         "warm_ring": {"ring_globes": F, "kernel_ms_per_launch": round(kw_med, 5),
+                                       "achieved": round(algo_bytes / (kw_med * 1e-3) / 1e9, 1),
+                                       "frac_compulsory": round(compulsory / (kw_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "the same F globes every launch: touched set fits the 256 MiB Infinity Cache"}},
             "lensmap_build_ms": round(build_kernel_ms, 3),
             "lensmap_build_wall_ms": round(build_wall_ms, 2),
             "lensmap_build_first_wall_ms_incl_hiprtc": round(build_first_wall_ms, 1),
+            "lensmap_build_host_fixups": {"flagged": fix_flagged, "changed": fix_changed},
             "lensmap_blockmap_compile_wall_ms": round(tilemap_wall_ms, 3),
             "lensmap_blockmap_first_wall_ms_incl_alloc": round(tilemap_first_wall_ms, 3), "tile_stats": tile_stats,
             "stripe_complete_mpx_s": round(stripe_complete_mpx, 1),

@@ -265,6 +265,14 @@ extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
     return bk::coopmap_stats(ctx, out);
 }
 
+extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "no lensmap");
+    if (int r = ensure_device(ctx)) return r;
+    return bk::coopmap_traffic_model(ctx, out);
+}
+
 extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }
 
 // ---- lensmap table -------------------------------------------------------------------

@@ -706,6 +706,70 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     return BK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// compulsory-traffic model of the staged apply (bench.py's roofline; bk_debug_traffic_model)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mark_lines_kernel(const uint32_t *__restrict__ lmap, size_t npix, uint32_t *__restrict__ bitmap,
+                                                         unsigned long long *__restrict__ counts)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t o = i < npix ? lmap[i] : BK_NULL_OFFSET;
+    const bool mapped = o != BK_NULL_OFFSET;
+    if (mapped) {
+        const uint32_t line = o >> 7;
+        atomicOr(&bitmap[line >> 5], 1u << (line & 31u));
+    }
+    const uint64_t b = __ballot(mapped);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[0], (unsigned long long)__popcll(b));
+}
+__global__ __launch_bounds__(256) void count_bits_kernel(const uint32_t *__restrict__ bitmap, size_t nwords, unsigned long long *__restrict__ counts)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = i < nwords ? (uint32_t)__popc(bitmap[i]) : 0u;
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[1], (unsigned long long)c);
+}
+
+// out[0] distinct 128-byte globe lines the owned rows of the lensmap read (per frame: the compulsory globe traffic / 128)
+// out[1] 128-byte lines staged per frame by all blocks (each block counts its own distinct lines: L2 / Infinity Cache
+//        absorb what neighbouring blocks share)          out[2] 16-byte chunks staged per frame
+// out[3] bytes of block map read per block visit, summed over blocks: headers + chunk lists + 16-bit pixel addresses
+//        (a visit serves up to out[5] frames)            out[4] mapped pixels = bytes stored per frame
+// out[5] frames per block visit                          out[6] blocks        out[7] block height in pixels
+int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8])
+{
+    if (int r = ensure_coopmap(ctx)) return r;
+    CoopMap *cm = ctx->coopmap;
+    const size_t npix = (size_t)ctx->W * ctx->rows();
+    const size_t nlines = (ctx->globe_stride() + 127) / 128, nwords = (nlines + 31) / 32;
+    uint32_t *bitmap = nullptr;
+    unsigned long long *counts = nullptr, h[2] = {0, 0};
+    BK_HIP(ctx, hipMalloc((void **)&bitmap, nwords * 4));
+    hipError_t e = hipMalloc((void **)&counts, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(bitmap, 0, nwords * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(counts, 0, 16, ctx->stream);
+    if (e == hipSuccess && npix) {
+        hipLaunchKernelGGL(mark_lines_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_offsets, npix, bitmap, counts);
+        hipLaunchKernelGGL(count_bits_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, bitmap, nwords, counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(bitmap);
+    (void)hipFree(counts);
+    if (e != hipSuccess) return ctx->fail(BK_E_HIP, "traffic model: %s", hipGetErrorString(e));
+    const uint64_t nblocks = (uint64_t)cm->blocks_x * cm->blocks_y, live = nblocks - cm->stats[2];
+    out[0] = h[1];
+    out[1] = cm->stats[3];
+    out[2] = cm->stats[4];
+    out[3] = nblocks * sizeof(CoopHdr) + (uint64_t)cm->stats[4] * 4u + live * (uint64_t)(1024 * cm->rg) * 2u;
+    out[4] = h[0];
+    out[5] = 8;
+    out[6] = nblocks;
+    out[7] = (uint64_t)(8 * cm->rg);
+    return BK_OK;
+}
+
 int coopmap_stats(bk_ctx *ctx, int out[6])
 {
     if (int r = ensure_coopmap(ctx)) return r;

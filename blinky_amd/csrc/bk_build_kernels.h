@@ -156,8 +156,8 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
         const double fx = r[0].n / P.scale + (double)(P.W / 2), fy = -r[1].n / P.scale + (double)(P.H / 2);
         sx = bk_trunc_to_int(fx);                                            /* :2239 */
         sy = bk_trunc_to_int(fy);                                            /* :2240 */
-        bk_need_same_trunc(S, fx, bk_eop(fx, r[0].e / P.scale));
-        bk_need_same_trunc(S, fy, bk_eop(fy, r[1].e / P.scale));
+        bk_need_same_trunc(S, fx, bk_eop(S, fx, r[0].e / P.scale));
+        bk_need_same_trunc(S, fy, bk_eop(S, fy, r[1].e / P.scale));
         ok = 1;
     } else if (!(n == 1 && r[0].t == BK_TNIL)) {
         S.err |= BK_ERR_RESULT;

@@ -45,10 +45,22 @@ BK_DEV bool bk_tick(BkState &S) { if (++S.steps > BK_LOOP_BUDGET) { S.err |= BK_
 
 /* ---- error bookkeeping helpers ------------------------------------------------------------------ */
 BK_DEV double bk_abs(double x) { return __builtin_fabs(x); }
+/* A NaN or infinity that arises from exact arguments arises on every libm alike (domain errors, overflow, x/0) and then
+ * propagates by IEEE rules: it carries no bound.  One that arises from INEXACT arguments cannot be bounded: flagged. */
+BK_DEV bool bk_finite(double z) { return bk_abs(z) < BKM_INF; }
 /* bound after an IEEE operation whose inputs are inexact: propagated part + the two roundings */
-BK_DEV double bk_eop(double z, double eprop) { return eprop != 0.0 ? eprop + bk_abs(z) * BK_ROUND_REL : 0.0; }
+BK_DEV double bk_eop(BkState &S, double z, double eprop)
+{
+    if (eprop == 0.0) return 0.0;
+    if (!bk_finite(z) || !bk_finite(eprop)) { S.flag = 1; return 0.0; }
+    return eprop + bk_abs(z) * BK_ROUND_REL;
+}
 /* bound after a libm call: propagated part + the libm discrepancy itself (also for exact inputs) */
-BK_DEV double bk_elibm(double z, double eprop) { return eprop + bk_abs(z) * BK_LIBM_REL; }
+BK_DEV double bk_elibm(BkState &S, double z, double eprop)
+{
+    if (!bk_finite(z) || !bk_finite(eprop)) { if (eprop != 0.0) S.flag = 1; return 0.0; }
+    return eprop + bk_abs(z) * BK_LIBM_REL;
+}
 /* the decision "which integer is floor/trunc/rint of x" is stable over [x-e, x+e] */
 BK_DEV void bk_need_same_floor(BkState &S, double x, double e)
 {
@@ -70,24 +82,24 @@ BK_DEV float bk_narrow(BkState &S, double v, double e)
 BK_DEV bkv bk_add(BkState &S, bkv a, bkv b)
 {
     const double z = bk_tonum(S, a) + bk_tonum(S, b);
-    return bk_nume(z, bk_eop(z, a.e + b.e));
+    return bk_nume(z, bk_eop(S, z, a.e + b.e));
 }
 BK_DEV bkv bk_sub(BkState &S, bkv a, bkv b)
 {
     const double z = bk_tonum(S, a) - bk_tonum(S, b);
-    return bk_nume(z, bk_eop(z, a.e + b.e));
+    return bk_nume(z, bk_eop(S, z, a.e + b.e));
 }
 BK_DEV bkv bk_mul(BkState &S, bkv a, bkv b)
 {
     const double x = bk_tonum(S, a), y = bk_tonum(S, b), z = x * y;
     if (a.e == 0.0 && b.e == 0.0) return bk_num(z);
-    return bk_nume(z, bk_eop(z, bk_abs(x) * b.e + bk_abs(y) * a.e + a.e * b.e));
+    return bk_nume(z, bk_eop(S, z, bk_abs(x) * b.e + bk_abs(y) * a.e + a.e * b.e));
 }
 BK_DEV double bk_ediv(BkState &S, double x, double ex, double y, double ey, double z)
 {
     if (ex == 0.0 && ey == 0.0) return 0.0;
     if (!(bk_abs(y) > 2.0 * ey)) { S.flag = 1; return 0.0; }        /* the divisor's sign / magnitude is not determined */
-    return bk_eop(z, (ex + bk_abs(z) * ey) / (bk_abs(y) - ey));
+    return bk_eop(S, z, (ex + bk_abs(z) * ey) / (bk_abs(y) - ey));
 }
 BK_DEV bkv bk_div(BkState &S, bkv a, bkv b)
 {
@@ -100,19 +112,24 @@ BK_DEV bkv bk_mod(BkState &S, bkv a, bkv b)       /* luai_nummod: a - floor(a/b)
     const double q = x / y, fl = bkm_floor(q), z = x - fl * y;
     if (a.e == 0.0 && b.e == 0.0) return bk_num(z);
     bk_need_same_floor(S, q, bk_ediv(S, x, a.e, y, b.e, q));
-    return bk_nume(z, bk_eop(z, a.e + bk_abs(fl) * b.e) + bk_abs(fl * y) * BK_ROUND_REL);
+    return bk_nume(z, bk_eop(S, z, a.e + bk_abs(fl) * b.e) + bk_abs(fl * y) * BK_ROUND_REL);
 }
 /* z = x ^ y through bkm_pow (glibc's pow on the reference side) */
 BK_DEV bkv bk_powv(BkState &S, bkv a, bkv b)
 {
     const double x = bk_tonum(S, a), y = bk_tonum(S, b), z = bkm_pow(x, y);
     double ep = 0.0;
-    if (a.e != 0.0 || b.e != 0.0) {
+    if (b.e == 0.0 && a.e != 0.0 && y == bkm_trunc(y) && y >= 1.0 && y <= 64.0) {
+        /* an integer power is smooth through 0 and for negative bases: |d x^n| <= n (|x| + e)^(n-1) dx */
+        double m = 1.0;
+        for (int k = 1; k < (int)y; ++k) m *= bk_abs(x) + a.e;
+        ep = 2.0 * y * m * a.e;
+    } else if (a.e != 0.0 || b.e != 0.0) {
         /* d(x^y) = x^y (y dx/x + ln x dy); only for a base safely away from 0 and a finite result */
         if (!(x - 2.0 * a.e > 0.0) || !(bk_abs(z) < BKM_INF)) { S.flag = 1; return bk_num(z); }
         ep = 2.0 * bk_abs(z) * (bk_abs(y) * a.e / (x - a.e) + (bk_abs(bkm_log(x)) + 1.0) * b.e);
     }
-    return bk_nume(z, bk_elibm(z, ep));
+    return bk_nume(z, bk_elibm(S, z, ep));
 }
 BK_DEV bkv bk_pow(BkState &S, bkv a, bkv b) { return bk_powv(S, a, b); }
 BK_DEV bkv bk_unm(BkState &S, bkv a) { return bk_nume(-bk_tonum(S, a), a.e); }
@@ -160,10 +177,10 @@ BK_DEV void bk_aset(BkState &S, bkv *arr, int n, bkv idx, bkv v)
 }
 
 /* ---- the math library (lmathlib.c on the reference side), value + bound --------------------------- */
-BK_DEV bkv bk_f_sin(BkState &S, bkv a) { const double z = bkm_sin(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, a.e)); }
-BK_DEV bkv bk_f_cos(BkState &S, bkv a) { const double z = bkm_cos(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, a.e)); }
-BK_DEV bkv bk_f_atan(BkState &S, bkv a) { const double z = bkm_atan(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, a.e)); }
-BK_DEV bkv bk_f_tanh(BkState &S, bkv a) { const double z = bkm_tanh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, a.e)); }
+BK_DEV bkv bk_f_sin(BkState &S, bkv a) { const double z = bkm_sin(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
+BK_DEV bkv bk_f_cos(BkState &S, bkv a) { const double z = bkm_cos(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
+BK_DEV bkv bk_f_atan(BkState &S, bkv a) { const double z = bkm_atan(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
+BK_DEV bkv bk_f_tanh(BkState &S, bkv a) { const double z = bkm_tanh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
 BK_DEV bkv bk_f_tan(BkState &S, bkv a)
 {
     const double z = bkm_tan(bk_tonum(S, a));
@@ -172,7 +189,7 @@ BK_DEV bkv bk_f_tan(BkState &S, bkv a)
         ep = 2.0 * a.e * (1.0 + z * z);                                     /* sec^2, with slack for its change over the interval */
         if (!(ep < 0x1p-10 * (1.0 + bk_abs(z)))) { S.flag = 1; ep = 0.0; }
     }
-    return bk_nume(z, bk_elibm(z, ep));
+    return bk_nume(z, bk_elibm(S, z, ep));
 }
 BK_DEV double bk_e_asin(BkState &S, double x, double e)                   /* Lipschitz bound of asin / acos over [x-e, x+e] */
 {
@@ -184,12 +201,12 @@ BK_DEV double bk_e_asin(BkState &S, double x, double e)                   /* Lip
 BK_DEV bkv bk_f_asin(BkState &S, bkv a)
 {
     const double x = bk_tonum(S, a), z = bkm_asin(x);
-    return bk_nume(z, bk_elibm(z, bk_e_asin(S, x, a.e)));
+    return bk_nume(z, bk_elibm(S, z, bk_e_asin(S, x, a.e)));
 }
 BK_DEV bkv bk_f_acos(BkState &S, bkv a)
 {
     const double x = bk_tonum(S, a), z = bkm_acos(x);
-    return bk_nume(z, bk_elibm(z, bk_e_asin(S, x, a.e)));
+    return bk_nume(z, bk_elibm(S, z, bk_e_asin(S, x, a.e)));
 }
 BK_DEV double bk_e_grow(BkState &S, double z, double e)                    /* sinh / cosh / exp: |f'| <= 1 + |f| */
 {
@@ -197,23 +214,23 @@ BK_DEV double bk_e_grow(BkState &S, double z, double e)                    /* si
     if (!(e < 0x1p-10)) { S.flag = 1; return 0.0; }
     return 2.0 * e * (1.0 + bk_abs(z));
 }
-BK_DEV bkv bk_f_sinh(BkState &S, bkv a) { const double z = bkm_sinh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, bk_e_grow(S, z, a.e))); }
-BK_DEV bkv bk_f_cosh(BkState &S, bkv a) { const double z = bkm_cosh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, bk_e_grow(S, z, a.e))); }
-BK_DEV bkv bk_f_exp(BkState &S, bkv a) { const double z = bkm_exp(bk_tonum(S, a)); return bk_nume(z, bk_elibm(z, bk_e_grow(S, z, a.e))); }
+BK_DEV bkv bk_f_sinh(BkState &S, bkv a) { const double z = bkm_sinh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, bk_e_grow(S, z, a.e))); }
+BK_DEV bkv bk_f_cosh(BkState &S, bkv a) { const double z = bkm_cosh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, bk_e_grow(S, z, a.e))); }
+BK_DEV bkv bk_f_exp(BkState &S, bkv a) { const double z = bkm_exp(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, bk_e_grow(S, z, a.e))); }
 BK_DEV double bk_e_log(BkState &S, double x, double e)
 {
     if (e == 0.0) return 0.0;
     if (!(x - 2.0 * e > 0.0)) { S.flag = 1; return 0.0; }
     return e / (x - e);
 }
-BK_DEV bkv bk_f_log(BkState &S, bkv a) { const double x = bk_tonum(S, a), z = bkm_log(x); return bk_nume(z, bk_elibm(z, bk_e_log(S, x, a.e))); }
-BK_DEV bkv bk_f_log10(BkState &S, bkv a) { const double x = bk_tonum(S, a), z = bkm_log10(x); return bk_nume(z, bk_elibm(z, bk_e_log(S, x, a.e))); }
+BK_DEV bkv bk_f_log(BkState &S, bkv a) { const double x = bk_tonum(S, a), z = bkm_log(x); return bk_nume(z, bk_elibm(S, z, bk_e_log(S, x, a.e))); }
+BK_DEV bkv bk_f_log10(BkState &S, bkv a) { const double x = bk_tonum(S, a), z = bkm_log10(x); return bk_nume(z, bk_elibm(S, z, bk_e_log(S, x, a.e))); }
 BK_DEV bkv bk_f_sqrt(BkState &S, bkv a)                                    /* IEEE: exact on an exact argument */
 {
     const double x = bk_tonum(S, a), z = bkm_sqrt(x);
     if (a.e == 0.0) return bk_num(z);
     if (!(x - 2.0 * a.e > 0.0)) { S.flag = 1; return bk_num(z); }
-    return bk_nume(z, bk_eop(z, a.e / (2.0 * bkm_sqrt(x - a.e))));
+    return bk_nume(z, bk_eop(S, z, a.e / (2.0 * bkm_sqrt(x - a.e))));
 }
 BK_DEV bkv bk_f_abs(BkState &S, bkv a) { return bk_nume(bkm_fabs(bk_tonum(S, a)), a.e); }
 BK_DEV bkv bk_f_floor(BkState &S, bkv a) { const double x = bk_tonum(S, a); bk_need_same_floor(S, x, a.e); return bk_num(bkm_floor(x)); }
@@ -229,7 +246,9 @@ BK_DEV double bk_e_atan2(BkState &S, double y, double ey, double x, double ex)
 BK_DEV bkv bk_f_atan2(BkState &S, bkv a, bkv b)
 {
     const double y = bk_tonum(S, a), x = bk_tonum(S, b), z = bkm_atan2(y, x);
-    return bk_nume(z, bk_elibm(z, bk_e_atan2(S, y, a.e, x, b.e)));
+    /* on an axis (exact arguments) every libm returns the correctly rounded 0, +-pi/2 or +-pi (C99 F.9.1.4) */
+    if (a.e == 0.0 && b.e == 0.0 && (x == 0.0 || y == 0.0)) return bk_num(z);
+    return bk_nume(z, bk_elibm(S, z, bk_e_atan2(S, y, a.e, x, b.e)));
 }
 BK_DEV bkv bk_f_fmod(BkState &S, bkv a, bkv b)                             /* C fmod: exact, x - trunc(x/y)*y */
 {
@@ -237,12 +256,12 @@ BK_DEV bkv bk_f_fmod(BkState &S, bkv a, bkv b)                             /* C 
     if (a.e == 0.0 && b.e == 0.0) return bk_num(z);
     const double q = x / y;
     bk_need_same_trunc(S, q, bk_ediv(S, x, a.e, y, b.e, q));
-    return bk_nume(z, bk_eop(z, a.e + bk_abs(bkm_trunc(q)) * b.e));
+    return bk_nume(z, bk_eop(S, z, a.e + bk_abs(bkm_trunc(q)) * b.e));
 }
 BK_DEV bkv bk_f_scale(BkState &S, bkv a, double c, bool divide)            /* math.deg / math.rad */
 {
     const double x = bk_tonum(S, a), z = divide ? x / c : x * c;
-    return bk_nume(z, bk_eop(z, divide ? a.e / c : a.e * c));
+    return bk_nume(z, bk_eop(S, z, divide ? a.e / c : a.e * c));
 }
 BK_DEV bkv bk_f_logb(BkState &S, bkv a, bkv b)                             /* math.log(x [, base]), lmathlib.c */
 {
@@ -287,14 +306,14 @@ BK_DEV void bk_vector_normalize(float *v)                                       
 /* latlon_to_ray, fisheye.c:1184: double products narrowed into a vec3_t; `elat`/`elon` bound the arguments */
 BK_DEV void bk_latlon_to_ray(BkState &S, double lat, double elat, double lon, double elon, float *ray)
 {
-    const double clat = bkm_cos(lat), ec = bk_elibm(clat, elat);
-    const double slon = bkm_sin(lon), es = bk_elibm(slon, elon);
-    const double clon = bkm_cos(lon), ek = bk_elibm(clon, elon);
+    const double clat = bkm_cos(lat), ec = bk_elibm(S, clat, elat);
+    const double slon = bkm_sin(lon), es = bk_elibm(S, slon, elon);
+    const double clon = bkm_cos(lon), ek = bk_elibm(S, clon, elon);
     const double slat = bkm_sin(lat);
     const double p0 = slon * clat, p2 = clon * clat;
-    ray[0] = bk_narrow(S, p0, bk_eop(p0, bk_abs(slon) * ec + bk_abs(clat) * es + ec * es));
-    ray[1] = bk_narrow(S, slat, bk_elibm(slat, elat));
-    ray[2] = bk_narrow(S, p2, bk_eop(p2, bk_abs(clon) * ec + bk_abs(clat) * ek + ec * ek));
+    ray[0] = bk_narrow(S, p0, bk_eop(S, p0, bk_abs(slon) * ec + bk_abs(clat) * es + ec * es));
+    ray[1] = bk_narrow(S, slat, bk_elibm(S, slat, elat));
+    ray[2] = bk_narrow(S, p2, bk_eop(S, p2, bk_abs(clon) * ec + bk_abs(clat) * ek + ec * ek));
 }
 BK_DEV void bk_plate_uv_to_ray(const BkBuildParams &P, int plate, double u, double v, float *ray)    /* fisheye.c:1198 */
 {
@@ -328,7 +347,7 @@ BK_DEV int bk_host_ray_to_latlon(BkState &S, bkv x, bkv y, bkv z, bkv *r)      /
     const float ray[3] = {bk_narrow(S, bk_tonum(S, x), x.e), bk_narrow(S, bk_tonum(S, y), y.e), bk_narrow(S, bk_tonum(S, z), z.e)};
     const double lon = bkm_atan2((double)ray[0], (double)ray[2]);
     const double lat = bkm_atan2((double)ray[1], bkm_sqrt((double)(ray[0] * ray[0] + ray[2] * ray[2])));
-    r[0] = bk_nume(lat, bk_elibm(lat, 0.0)); r[1] = bk_nume(lon, bk_elibm(lon, 0.0));
+    r[0] = bk_nume(lat, bk_elibm(S, lat, 0.0)); r[1] = bk_nume(lon, bk_elibm(S, lon, 0.0));
     return 2;
 }
 BK_DEV int bk_host_plate_to_ray(BkState &S, bkv plate, bkv u, bkv v, bkv *r)

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <unistd.h>
 
 #include "bk_build_params.h"
@@ -599,12 +601,19 @@ int h_trunc_to_int(double v)                                                    
     return (int)v;
 }
 
+/* who evaluates: the context's interpreter, or a per-thread copy of it (Interp::clone) */
+struct HostEval {
+    Interp *I;
+    Value lens_inverse, lens_forward, globe_plate;
+    Values call(const Value &f, const Values &a) { I->steps = 0; return I->call(f, a); }
+};
+
 /* ray_to_plate_index, fisheye.c:2023-2050 (same out-of-range handling as the kernel's) */
-int h_ray_to_plate_index(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, const float *ray)
+int h_ray_to_plate_index(HostEval &E, const BkBuildParams &bp, const float *ray)
 {
-    if (P->globe_plate.is_function()) {
-        Values r = P->interp.call(P->globe_plate, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
-                                                         Value::number((double)ray[2])});
+    if (E.globe_plate.is_function()) {
+        Values r = E.call(E.globe_plate, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
+                                                Value::number((double)ray[2])});
         if (r.empty() || r.back().t != Value::NUM) return -1;
         const double d = r.back().n;
         if (!(d > -2147483648.0 && d < 2147483647.0)) return -1;
@@ -618,7 +627,6 @@ int h_ray_to_plate_index(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, c
         const double dp = (double)h_dot3(ray, bp.plates[i].forward);
         if (dp > max_dp) { max_dp = dp; plate_index = i; }
     }
-    (void)ctx;
     return plate_index;
 }
 
@@ -629,17 +637,17 @@ bool h_offgrid(const BkBuildParams &bp, int px, int py)                         
 }
 
 /* one pixel of resume_lensmap_inverse (fisheye.c:2084-2124, 1545-1588, 1995-2013); o = index inside the owned stripe */
-void h_inverse_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32_t o, uint32_t *off, uint8_t *tint,
+void h_inverse_entry(HostEval &E, const BkBuildParams &bp, uint32_t o, uint32_t *off, uint8_t *tint,
                      int *plate_shown, int *err)
 {
     *off = BK_NULL_OFFSET; *tint = 255; *plate_shown = -1;
     const int lyl = (int)(o / (uint32_t)bp.W), lx = (int)(o - (uint32_t)lyl * (uint32_t)bp.W), ly = bp.row0 + lyl;
     const double y = (double)(-(ly - bp.H / 2)) * bp.scale, x = (double)(lx - bp.W / 2) * bp.scale;
-    Values r = P->interp.call(P->lens_inverse, Values{Value::number(x), Value::number(y)});
+    Values r = E.call(E.lens_inverse, Values{Value::number(x), Value::number(y)});
     if (r.size() == 3 && r[0].t == Value::NUM && r[1].t == Value::NUM && r[2].t == Value::NUM) {
         float ray[3] = {(float)r[0].n, (float)r[1].n, (float)r[2].n};
         bk::h_vector_normalize(ray);
-        const int plate = h_ray_to_plate_index(ctx, P, bp, ray);
+        const int plate = h_ray_to_plate_index(E, bp, ray);
         if (plate < 0) return;
         const BkPlateDev &p = bp.plates[plate];
         const double px_ = (double)h_dot3(p.right, ray), py_ = (double)h_dot3(p.up, ray), pz_ = (double)h_dot3(p.forward, ray);
@@ -658,7 +666,7 @@ void h_inverse_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint3
 }
 
 /* one texel corner of the forward build: uv_to_screen, fisheye.c:2227-2243 */
-void h_corner_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32_t id, int *sx, int *sy, uint8_t *ok, int *err)
+void h_corner_entry(bk_ctx *ctx, HostEval &E, const BkBuildParams &bp, uint32_t id, int *sx, int *sy, uint8_t *ok, int *err)
 {
     const uint32_t n1 = (uint32_t)bp.ps + 1u;
     const uint32_t plate = id / (n1 * n1), rem = id - plate * n1 * n1, j = rem / n1, i = rem - j * n1;
@@ -666,8 +674,8 @@ void h_corner_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32
     float ray[3];
     bk::h_plate_uv_to_ray(ctx->plates[plate], u, v, ray);
     *sx = 0; *sy = 0; *ok = 0;
-    Values r = P->interp.call(P->lens_forward, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
-                                                      Value::number((double)ray[2])});
+    Values r = E.call(E.lens_forward, Values{Value::number((double)ray[0]), Value::number((double)ray[1]),
+                                              Value::number((double)ray[2])});
     if (r.size() == 2 && r[0].t == Value::NUM && r[1].t == Value::NUM) {
         *sx = h_trunc_to_int(r[0].n / bp.scale + (double)(bp.W / 2));
         *sy = h_trunc_to_int(-r[1].n / bp.scale + (double)(bp.H / 2));
@@ -678,12 +686,44 @@ void h_corner_entry(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32
 }
 
 /* forward build: does the ray through texel `id` select its own plate (fisheye.c:2193-2196) */
-bool h_texel_owns(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, uint32_t id)
+bool h_texel_owns(bk_ctx *ctx, HostEval &E, const BkBuildParams &bp, uint32_t id)
 {
     const uint32_t ps = (uint32_t)bp.ps, plate = id / (ps * ps), rem = id - plate * ps * ps, py = rem / ps, px = rem - py * ps;
     float ray[3];
     bk::h_plate_uv_to_ray(ctx->plates[plate], (double)px / bp.ps, (double)py / bp.ps, ray);
-    return (int)plate == h_ray_to_plate_index(ctx, P, bp, ray);
+    return (int)plate == h_ray_to_plate_index(E, bp, ray);
+}
+
+/* fn(E, i) for i in [0, n): on the context's interpreter when the list is short, otherwise on per-thread copies of it.
+ * The first script error any worker meets is rethrown here. */
+template <typename Fn>
+void for_each_flagged(LensProgram *P, size_t n, Fn fn)
+{
+    HostEval main_eval{&P->interp, P->lens_inverse, P->lens_forward, P->globe_plate};
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 64), n / 256);
+    if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) nthreads = (size_t)std::max(1, atoi(e));
+    if (nthreads <= 1 || n < 2) {
+        for (size_t i = 0; i < n; ++i) fn(main_eval, i);
+        return;
+    }
+    std::vector<std::unique_ptr<Interp>> interps(nthreads);
+    std::vector<HostEval> evals(nthreads);
+    for (size_t t = 0; t < nthreads; ++t) {
+        Values roots;
+        interps[t] = P->interp.clone(Values{P->lens_inverse, P->lens_forward, P->globe_plate}, &roots);
+        evals[t] = HostEval{interps[t].get(), roots[0], roots[1], roots[2]};
+    }
+    std::vector<std::string> errors(nthreads);
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t]() {
+            try {
+                for (size_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i) fn(evals[t], i);
+            } catch (const LuaError &e) { errors[t] = e.what(); }
+        });
+    for (std::thread &th : pool) th.join();
+    for (const std::string &e : errors) if (!e.empty()) throw LuaError(e);
 }
 
 }  // namespace
@@ -784,13 +824,23 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             // re-derive the flagged pixels on the host and patch the ones that differ
             std::vector<uint32_t> idx, voff;
             std::vector<uint8_t> vtint;
-            for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
-                uint32_t off; uint8_t tint; int shown;
-                h_inverse_entry(ctx, P, bp, flagged[k], &off, &tint, &shown, &host_err);
-                if (shown >= 0) host_display[shown] = 1;
-                if (off != flagged[k + 1] || tint != (uint8_t)flagged[k + 2]) { idx.push_back(flagged[k]); voff.push_back(off); vtint.push_back(tint); }
+            const size_t nfl = flagged.size() / 4;
+            {
+                std::vector<uint32_t> roff(nfl);
+                std::vector<uint8_t> rtint(nfl);
+                std::vector<int> rshown(nfl), rerr(nfl, 0);
+                for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
+                    h_inverse_entry(E, bp, flagged[4 * i], &roff[i], &rtint[i], &rshown[i], &rerr[i]);
+                });
+                for (size_t i = 0; i < nfl; ++i) {
+                    host_err |= rerr[i];
+                    if (rshown[i] >= 0) host_display[rshown[i]] = 1;
+                    if (roff[i] != flagged[4 * i + 1] || rtint[i] != (uint8_t)flagged[4 * i + 2]) {
+                        idx.push_back(flagged[4 * i]); voff.push_back(roff[i]); vtint.push_back(rtint[i]);
+                    }
+                }
             }
-            ctx->last_flagged = (int)(flagged.size() / 4);
+            ctx->last_flagged = (int)nfl;
             ctx->last_changed = (int)idx.size();
             BK_RC_C(bk::launch_scatter32(ctx, ctx->d_offsets, idx.data(), voff.data(), idx.size()));
             BK_RC_C(bk::launch_scatter8(ctx, ctx->d_tints, idx.data(), vtint.data(), idx.size()));
@@ -823,9 +873,17 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             {
                 std::vector<uint32_t> ixy, vxy, iok;
                 std::vector<uint8_t> vok;
-                for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
-                    int sx, sy; uint8_t ok;
-                    h_corner_entry(ctx, P, bp, flagged[k], &sx, &sy, &ok, &host_err);
+                const size_t nfl = flagged.size() / 4;
+                std::vector<int> rsx(nfl), rsy(nfl), rerr(nfl, 0);
+                std::vector<uint8_t> rok(nfl);
+                for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
+                    h_corner_entry(ctx, E, bp, flagged[4 * i], &rsx[i], &rsy[i], &rok[i], &rerr[i]);
+                });
+                for (size_t i = 0; i < nfl; ++i) {
+                    const size_t k = 4 * i;
+                    const int sx = rsx[i], sy = rsy[i];
+                    const uint8_t ok = rok[i];
+                    host_err |= rerr[i];
                     if ((uint32_t)sx != flagged[k + 1] || (uint32_t)sy != flagged[k + 2] || ok != (uint8_t)flagged[k + 3]) {
                         ixy.push_back(2 * flagged[k]); vxy.push_back((uint32_t)sx);
                         ixy.push_back(2 * flagged[k] + 1); vxy.push_back((uint32_t)sy);
@@ -856,8 +914,11 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 }
                 if (pass == 0 && !flagged.empty()) {
                     std::vector<std::pair<uint32_t, uint32_t>> ans;
+                    const size_t nfl = flagged.size() / 4;
+                    std::vector<uint8_t> rown(nfl);
+                    for_each_flagged(P, nfl, [&](HostEval &E, size_t i) { rown[i] = h_texel_owns(ctx, E, bp, flagged[4 * i]) ? 1 : 0; });
                     for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
-                        const bool own = h_texel_owns(ctx, P, bp, flagged[k]);
+                        const bool own = rown[k / 4] != 0;
                         if ((own ? 1u : 0u) != flagged[k + 1]) { again = true; ++ctx->last_changed; }
                         ans.push_back({flagged[k], own ? 1u : 0u});
                     }
@@ -902,6 +963,53 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
         return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
+    }
+    return BK_OK;
+}
+
+/* test hook: the kernel-argument block bk_build would launch with (calc_zoom done, device pointers as they are -
+ * null on a BK_DEVICE_NONE context).  tests/hostemu compiles the generated translation unit for the host and runs it
+ * on this block to inspect the device code's results and flags without a GPU. */
+extern "C" int bk_debug_build_params(bk_ctx *ctx, void *out, size_t cap, size_t *needed)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (needed) *needed = sizeof(BkBuildParams);
+    if (!out) return BK_OK;
+    if (cap < sizeof(BkBuildParams)) return ctx->fail(BK_E_INVALID, "bk_debug_build_params: buffer too small");
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");
+    if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
+    if (int r = bk_calc_zoom(ctx, nullptr)) return r;
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    memcpy(out, &bp, sizeof bp);
+    return BK_OK;
+}
+
+/* test hook: the host re-evaluation bk_build applies to flagged pixels, run over ANY pixel indices of the owned rows
+ * (works on a BK_DEVICE_NONE context).  offsets come back in the reference layout plate*ps*ps + py*ps + px. */
+extern "C" int bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n, uint32_t *offsets, uint8_t *tints)
+{
+    if (!ctx || !ids || !offsets || !tints) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid || !P->lens_inverse.is_function()) return ctx->fail(BK_E_STATE, "no lens_inverse");
+    if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
+    if (int r = bk_calc_zoom(ctx, nullptr)) return r;
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    for (size_t i = 0; i < n; ++i) if (ids[i] >= px) return ctx->fail(BK_E_INVALID, "bk_debug_host_entries: index out of range");
+    std::vector<int> shown(n), err(n, 0);
+    try {
+        for_each_flagged(P, n, [&](HostEval &E, size_t i) { h_inverse_entry(E, bp, ids[i], &offsets[i], &tints[i], &shown[i], &err[i]); });
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "%s", e.what());
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i] == BK_NULL_OFFSET) continue;
+        unsigned plate, x, y;
+        bk_texel_coords((unsigned)ctx->gp, (unsigned)ctx->ph, offsets[i], &plate, &x, &y);
+        offsets[i] = plate * (unsigned)(ctx->ps * ctx->ps) + y * (unsigned)ctx->ps + x;
     }
     return BK_OK;
 }

@@ -1148,6 +1148,75 @@ void Interp::register_builtin(const std::string &name, BuiltinFn fn)
     t.tab->shash[field] = v;
 }
 
+namespace {
+struct Cloner {
+    std::map<const Table *, std::shared_ptr<Table>> tabs;
+    std::map<const Closure *, std::shared_ptr<Closure>> fns;
+    std::map<const Value *, std::shared_ptr<Value>> cells;
+    std::map<const Builtin *, std::shared_ptr<Builtin>> bis;
+    Value value(const Value &v)
+    {
+        Value o = v;
+        if (v.t == Value::TABLE) o.tab = table(v.tab);
+        else if (v.t == Value::FUNC) o.fn = closure(v.fn);
+        else if (v.t == Value::BUILTIN && v.bi) {
+            // (immutable, but every evaluation of `sin` copies the Value: a private copy keeps the reference count -
+            // an atomic - out of the other threads' cache lines)
+            auto it = bis.find(v.bi.get());
+            if (it == bis.end()) it = bis.emplace(v.bi.get(), std::make_shared<Builtin>(*v.bi)).first;
+            o.bi = it->second;
+        } else if (v.t == Value::STR && v.s) o.s = std::make_shared<std::string>(*v.s);
+        return o;
+    }
+    std::shared_ptr<Table> table(const std::shared_ptr<Table> &t)
+    {
+        if (!t) return t;
+        auto it = tabs.find(t.get());
+        if (it != tabs.end()) return it->second;
+        auto n = std::make_shared<Table>();
+        tabs[t.get()] = n;                                   // (registered first: tables may refer to themselves)
+        for (const Value &x : t->arr) n->arr.push_back(value(x));
+        for (const auto &kv : t->nhash) n->nhash[kv.first] = value(kv.second);
+        for (const auto &kv : t->shash) n->shash[kv.first] = value(kv.second);
+        return n;
+    }
+    std::shared_ptr<Closure> closure(const std::shared_ptr<Closure> &c)
+    {
+        if (!c) return c;
+        auto it = fns.find(c.get());
+        if (it != fns.end()) return it->second;
+        auto n = std::make_shared<Closure>();
+        fns[c.get()] = n;
+        n->proto = c->proto;
+        n->chunk = c->chunk;
+        for (const std::shared_ptr<Value> &u : c->upvals) {
+            auto ci = cells.find(u.get());
+            if (ci != cells.end()) { n->upvals.push_back(ci->second); continue; }
+            auto cell = std::make_shared<Value>();
+            cells[u.get()] = cell;
+            n->upvals.push_back(cell);
+            if (u) *cell = value(*u);
+        }
+        return n;
+    }
+};
+}  // namespace
+
+std::unique_ptr<Interp> Interp::clone(const std::vector<Value> &roots, std::vector<Value> *roots_out) const
+{
+    std::unique_ptr<Interp> n(new Interp(*math));
+    Cloner c;
+    n->globals.clear();
+    for (const auto &kv : globals) n->globals[kv.first] = c.value(kv.second);
+    n->max_steps = max_steps;
+    n->print_sink = nullptr;
+    if (roots_out) {
+        roots_out->clear();
+        for (const Value &r : roots) roots_out->push_back(c.value(r));
+    }
+    return n;
+}
+
 std::string Interp::tostring(const Value &v) const
 {
     char buf[64];

@@ -155,6 +155,11 @@ struct Interp {
     // call any function value (lua_call with LUA_MULTRET)
     Values call(const Value &f, const Values &args);
     std::string tostring(const Value &v) const;
+    // An independent copy of this interpreter's state for another thread: globals, tables, closures and their
+    // upvalue cells are deep-copied (ASTs, strings and builtins are immutable and stay shared); `roots` are values
+    // of this interpreter (e.g. the lens callbacks) whose counterparts in the copy are returned in roots_out.
+    // print() in the copy is silent.
+    std::unique_ptr<Interp> clone(const std::vector<Value> &roots, std::vector<Value> *roots_out) const;
 };
 
 }  // namespace bklua

@@ -80,6 +80,9 @@ _SIGS = {
     "bk_download_plate": (_i, [_vp, _i, _i, _vp, _i]),
     "bk_save_plate": (_i, [_vp, _i, _i, _i, _vp, _i]),
     "bk_debug_tile_stats": (_i, [_vp, C.POINTER(_i)]),
+    "bk_debug_traffic_model": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "bk_debug_set_ablation": (_i, [_vp, _i]),
     "bk_debug_set_tile_shape": (_i, [_vp, _i]),
     "bk_debug_kernel_source": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), _i]),
@@ -249,6 +252,28 @@ class Context:
         out = (_i * 6)()
         self._chk(lib.bk_debug_tile_stats(self._h, out))
         return dict(tiles=out[0], slow=out[1], empty=out[2], lds_bytes_per_wave=out[3], tile_h=out[4], lines=out[5])
+
+    def build_params(self):
+        """raw BkBuildParams bytes (tests/hostemu)"""
+        need = _sz()
+        self._chk(lib.bk_debug_build_params(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        self._chk(lib.bk_debug_build_params(self._h, buf, need.value, None))
+        return buf
+
+    def host_entries(self, ids):
+        """the host fix-up's value for the given pixel indices: (offsets in the reference layout, tints)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        off = np.empty(len(ids), np.uint32)
+        tin = np.empty(len(ids), np.uint8)
+        self._chk(lib.bk_debug_host_entries(self._h, _ptr(ids), len(ids), _ptr(off), _ptr(tin)))
+        return off, tin
+
+    def traffic_model(self):
+        out = (C.c_uint64 * 8)()
+        self._chk(lib.bk_debug_traffic_model(self._h, out))
+        return dict(unique_globe_lines=out[0], staged_lines=out[1], staged_chunks=out[2], blockmap_bytes_per_visit=out[3],
+                    mapped_pixels=out[4], frames_per_visit=out[5], blocks=out[6], block_height=out[7])
 
     def set_tile_shape(self, lw):
         self._chk(lib.bk_debug_set_tile_shape(self._h, lw))

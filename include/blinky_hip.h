@@ -181,6 +181,11 @@ int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
 /* staged apply statistics of the current lensmap: out = {blocks, blocks on the direct-gather fallback,
  * empty blocks, bytes of one LDS staging buffer, 128000 + block height in pixels, 128-byte lines staged per frame} */
 int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
+/* What the staged apply has to move for the current lensmap (bench.py's compulsory-traffic roofline):
+ * out = {distinct 128-byte globe lines the owned rows read per frame, lines staged per frame summed over blocks,
+ * 16-byte chunks staged per frame, bytes of block map read per block visit summed over blocks, mapped pixels
+ * (= bytes stored per frame), frames served per block visit, blocks, block height in pixels} */
+int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8]);
 /* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
  * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
@@ -189,6 +194,12 @@ double      bk_last_build_ms(const bk_ctx *ctx);
 /* the HIP translation unit generated for the current lens + globe scripts (needed = strlen+1);
  * compile != 0 also runs it through hiprtc (works on a BK_DEVICE_NONE context) */
 int         bk_debug_kernel_source(bk_ctx *ctx, char *buf, size_t cap, size_t *needed, int compile);
+/* test hook: the kernel-argument block (BkBuildParams, blinky_amd/csrc/bk_build_params.h) bk_build would launch the
+ * current lens + globe with; works on a BK_DEVICE_NONE context (tests/hostemu runs the generated code on the host) */
+int         bk_debug_build_params(bk_ctx *ctx, void *out, size_t cap, size_t *needed);
+/* test hook: the host re-evaluation bk_build applies to the pixels it flags (bk_last_build_fixups), over any pixel
+ * indices (row-major inside the owned rows); offsets in the reference layout.  Works without a device. */
+int         bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n, uint32_t *offsets, uint8_t *tints);
 /* evaluate a callback with the HOST interpreter, for diagnosing a script: which 0 = lens_inverse(x,y),
  * 1 = lens_forward(x,y,z), 2 = globe_plate(x,y,z); *nout = number of results, -1 for a single nil */
 int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs, double out[8], int *nout);

@@ -1,0 +1,126 @@
+"""TEST INFRASTRUCTURE: compile the HIP translation unit libblinkyhip generates for a lens + globe as host C++
+(g++, -ffp-contract=off like the hiprtc build) and run the inverse build kernel serially.  Gives CPU tests and
+tools/flag_probe.py the device code's lensmap AND the list of pixels it flags for the host fix-up, without a GPU."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "blinky_amd", "csrc")
+_cache = {}
+
+
+def compile_source(src):
+    """generated source text -> loaded shared object"""
+    key = hashlib.sha1((src + open(os.path.join(CSRC, "bk_device_rt.h")).read() +
+                        open(os.path.join(CSRC, "bk_build_kernels.h")).read()).encode()).hexdigest()[:16]
+    if key in _cache:
+        return _cache[key]
+    d = os.path.join(tempfile.gettempdir(), "bk_hostemu")
+    os.makedirs(d, exist_ok=True)
+    cpp, so = os.path.join(d, key + ".cpp"), os.path.join(d, key + ".so")
+    if not os.path.exists(so):
+        with open(cpp, "w") as f:
+            f.write('#include "emu_prelude.h"\n' + src + "\n" + open(os.path.join(HERE, "emu_driver.inc")).read())
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
+                               "-I", HERE, "-I", CSRC, "-o", so + ".tmp", cpp])
+        os.replace(so + ".tmp", so)
+    lib = C.CDLL(so)
+    _cache[key] = lib
+    return lib
+
+
+def _field_offsets():
+    """byte offsets of the pointer / count fields of BkBuildParams (bk_build_params.h), found by compiling a probe"""
+    if "off" in _cache:
+        return _cache["off"]
+    d = os.path.join(tempfile.gettempdir(), "bk_hostemu")
+    os.makedirs(d, exist_ok=True)
+    src = os.path.join(d, "offs.c")
+    with open(src, "w") as f:
+        f.write('#include <stddef.h>\n#include <stdio.h>\n#include "bk_build_params.h"\nint main(){'
+                'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", offsetof(BkBuildParams, offsets), offsetof(BkBuildParams, tints),'
+                'offsetof(BkBuildParams, display), offsetof(BkBuildParams, err), offsetof(BkBuildParams, flag_list),'
+                'offsetof(BkBuildParams, flag_count), offsetof(BkBuildParams, flag_cap), sizeof(BkBuildParams), offsetof(BkBuildParams, corner_xy), offsetof(BkBuildParams, corner_ok));return 0;}')
+    exe = os.path.join(d, "offs")
+    subprocess.check_call(["gcc", "-I", CSRC, "-o", exe, src])
+    vals = [int(v) for v in subprocess.check_output([exe]).split()]
+    _cache["off"] = dict(zip(["offsets", "tints", "display", "err", "flag_list", "flag_count", "flag_cap", "size", "corner_xy", "corner_ok"], vals))
+    return _cache["off"]
+
+
+def build_inverse(ctx):
+    """ctx: a configured blinky_amd Context (BK_DEVICE_NONE is enough; bk_resize done).  Runs the generated
+    bk_build_inverse on the host.  Returns (offsets in DEVICE layout uint32 [rows*W], tints, flagged ids, err bits)."""
+    lib = compile_source(ctx.kernel_source())
+    fo = _field_offsets()
+    bp = ctx.build_params()
+    assert len(bp) == fo["size"] == lib.emu_sizeof_params()
+    W, H, ps, r0, r1 = ctx.size()
+    n = W * (r1 - r0)
+    off = np.full(n, 0xFFFFFFFF, np.uint32)
+    tin = np.full(n, 255, np.uint8)
+    misc = np.zeros(8, np.int32)                 # display[6], err, flag_count
+    cap = n
+    flags = np.zeros((cap, 4), np.uint32)
+
+    def put(name, addr):
+        C.memmove(C.addressof(bp) + fo[name], C.byref(C.c_uint64(addr)), 8)
+    put("offsets", off.ctypes.data)
+    put("tints", tin.ctypes.data)
+    put("display", misc.ctypes.data)
+    put("err", misc.ctypes.data + 24)
+    put("flag_count", misc.ctypes.data + 28)
+    put("flag_list", flags.ctypes.data)
+    C.memmove(C.addressof(bp) + fo["flag_cap"], C.byref(C.c_uint32(cap)), 4)
+    lib.emu_build_inverse(bp)
+    nf = int(misc[7])
+    return off, tin, flags[:nf, 0].copy(), int(misc[6])
+
+
+def device_to_reference_layout(off, ps):
+    """device (16x8-tile) offsets -> plate*ps*ps + py*ps + px (bk_texel_coords, bk_build_params.h)"""
+    gp, ph = (ps + 63) & ~63, (ps + 7) & ~7
+    out = np.full(off.shape, 0xFFFFFFFF, np.uint32)
+    m = off != 0xFFFFFFFF
+    o = off[m].astype(np.uint64)
+    p = o // (gp * ph)
+    rem = o - p * (gp * ph)
+    tile = rem >> 7
+    tpr = gp >> 4
+    ty, tx = tile // tpr, tile % tpr
+    px = tx * 16 + (rem & 15)
+    py = ty * 8 + ((rem >> 4) & 7)
+    out[m] = (p * ps * ps + py * ps + px).astype(np.uint32)
+    return out
+
+
+def forward_corners(ctx):
+    """the generated bk_forward_corners on the host: (corner_xy int32 [n,2], corner_ok uint8 [n], flagged ids, err)"""
+    lib = compile_source(ctx.kernel_source())
+    fo = _field_offsets()
+    bp = ctx.build_params()
+    W, H, ps, r0, r1 = ctx.size()
+    nplates = len(ctx.globe())
+    n = nplates * (ps + 1) * (ps + 1)
+    xy = np.zeros((n, 2), np.int32)
+    ok = np.zeros(n, np.uint8)
+    misc = np.zeros(8, np.int32)
+    flags = np.zeros((n, 4), np.uint32)
+
+    def put(name, addr):
+        C.memmove(C.addressof(bp) + fo[name], C.byref(C.c_uint64(addr)), 8)
+    put("corner_xy", xy.ctypes.data)
+    put("corner_ok", ok.ctypes.data)
+    put("display", misc.ctypes.data)
+    put("err", misc.ctypes.data + 24)
+    put("flag_count", misc.ctypes.data + 28)
+    put("flag_list", flags.ctypes.data)
+    C.memmove(C.addressof(bp) + fo["flag_cap"], C.byref(C.c_uint32(n)), 4)
+    lib.emu_forward_corners(bp)
+    return xy, ok, flags[: int(misc[7]), 0].copy(), int(misc[6])

@@ -22,7 +22,7 @@ def _free_port():
 
 
 def test_bench_line_and_check_single_gpu():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--check",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "3", "--check",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "[check] rank 0: OK" in r.stderr
@@ -33,16 +33,36 @@ def test_bench_line_and_check_single_gpu():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["dtype"] == "u8" and out["value"] > 0
-    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    rf = out["roofline"]
+    assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "compulsory_bytes_per_launch",
+                       "frac_compulsory", "ring_globes", "warm_ring"}
+    # the timed ring is larger than the 256 MiB Infinity Cache, and what the kernel must move cannot exceed the HBM peak
+    assert rf["ring_globes"] * 6 * 2160 * 2176 > 4 * 256 * 2 ** 20
+    assert 0 < rf["frac_compulsory"] <= 1.0
+    assert rf["traffic"] is None or rf["frac_traffic"] <= 1.0
+    assert out["timed_regions"]["count"] == 3
+    assert out["timed_regions"]["mpx_s_min"] <= out["value"] <= out["timed_regions"]["mpx_s_max"]
 
 
 def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():
     env = dict(os.environ, BLINKY_BENCH_BACKEND="gloo", BLINKY_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--frames", "5", "--check"]
+           "--frames", "5", "--ring", "10", "--repeats", "2", "--check"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "[check] rank 0: OK" in r.stderr and "[check] rank 1: OK" in r.stderr
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 5
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (the round-1 bench silently
+    measured one GPU); here both ranks share the one GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BLINKY_BENCH_BACKEND="gloo", BLINKY_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4",
+                        "--ring", "8", "--repeats", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2

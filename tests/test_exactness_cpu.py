@@ -1,0 +1,91 @@
+"""The exactness bookkeeping of the generated build code (blinky_amd/csrc/bk_device_rt.h), checked WITHOUT a GPU:
+tests/hostemu compiles the very translation unit hiprtc gets as host C++ and runs the inverse build kernel serially.
+
+What must hold: wherever the table built on the portable libm (what the device computes) differs from the table
+the reference computes on the platform libm, the device code has FLAGGED that pixel - so the host fix-up
+(bk_lens.cpp) re-derives it and the final table is the reference's.  And the flagged set stays small."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hostemu"))
+
+import emu              # noqa: E402
+import oracle_ffi as O  # noqa: E402
+import scripts as S     # noqa: E402
+
+
+def emu_build(globe, lens, zoom, W, H):
+    import blinky_amd
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    off, tin, flagged, err = emu.build_inverse(ctx)
+    ctx.close()
+    assert err == 0
+    return emu.device_to_reference_layout(off, min(W, H)), tin, flagged
+
+
+@pytest.mark.parametrize("cfg", [
+    ("cube", "quincuncial", None, 1920, 1080),     # the size at which one exact tie separates glibc from any other libm
+    ("cube", "quincuncial", None, 640, 480),
+    ("cube", "stereographic", None, 960, 540),
+    ("cube", "hammer", None, 960, 540),
+    ("trism", "panini", None, 640, 360),
+])
+def test_every_libm_dependent_pixel_is_flagged(cfg):
+    globe, lens, zoom, W, H = cfg
+    off, tin, flagged = emu_build(globe, lens, zoom, W, H)
+    portable = O.lensmap(globe, lens, zoom, W, H, portable=True)
+    platform = O.lensmap(globe, lens, zoom, W, H)
+    # the generated code IS the portable-libm oracle, entry for entry
+    np.testing.assert_array_equal(off, portable.offsets)
+    np.testing.assert_array_equal(tin, portable.tints)
+    # and every entry the platform libm decides differently has been flagged for the host
+    differs = np.nonzero((platform.offsets != off) | (platform.tints != tin))[0]
+    assert set(differs.tolist()) <= set(flagged.tolist()), f"{len(differs)} differing entries, not all flagged"
+    if (lens, W) == ("quincuncial", 1920):
+        assert len(differs) >= 1          # (the case DESIGN.md section 5 describes; it is why the fix-up exists)
+    assert len(flagged) <= max(64, 8 * (W + H)), len(flagged)     # lines of symmetry at most, never areas
+
+
+@pytest.mark.parametrize("lens", [l for l in S.LENSES if l not in ("eckert4",)])
+def test_flagged_set_is_small_for_every_inverse_lens(lens):
+    import blinky_amd
+    W, H = 320, 240
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    info = S.configure(ctx, "cube", lens, None, (W, H))
+    if not info.has_inverse or info.map_type != blinky_amd.ffi.MAP_INVERSE:
+        ctx.close()
+        pytest.skip("forward-map lens")
+    off, tin, flagged, err = emu.build_inverse(ctx)
+    ctx.close()
+    assert err == 0
+    assert len(flagged) <= 8 * (W + H), f"{lens}: {len(flagged)} of {W * H} pixels flagged"
+
+
+def test_platform_libm_is_within_the_assumed_bound_of_bkm():
+    """BK_LIBM_REL (2^-50): the bound the bookkeeping assumes between bkm.h and the platform libm, sampled."""
+    import ctypes as C
+    import math
+    lib = C.CDLL(os.path.join(os.path.dirname(HERE), "blinky_amd", "libbkm_host.so"))
+    rng = np.random.default_rng(11)
+    cases = {
+        "sin": (math.sin, rng.uniform(-20, 20, 20000)), "cos": (math.cos, rng.uniform(-20, 20, 20000)),
+        "tan": (math.tan, rng.uniform(-1.5, 1.5, 20000)), "asin": (math.asin, rng.uniform(-1, 1, 20000)),
+        "acos": (math.acos, rng.uniform(-1, 1, 20000)), "atan": (math.atan, rng.uniform(-50, 50, 20000)),
+        "exp": (math.exp, rng.uniform(-20, 20, 20000)), "log": (math.log, rng.uniform(1e-6, 1e3, 20000)),
+        "sinh": (math.sinh, rng.uniform(-10, 10, 20000)), "cosh": (math.cosh, rng.uniform(-10, 10, 20000)),
+        "tanh": (math.tanh, rng.uniform(-5, 5, 20000)),
+    }
+    for name, (ref, xs) in cases.items():
+        fn = getattr(lib, "bkmh_" + name)
+        fn.restype, fn.argtypes = C.c_double, [C.c_double]
+        worst = 0.0
+        for x in xs:
+            a, b = fn(float(x)), ref(float(x))
+            if b != 0:
+                worst = max(worst, abs(a - b) / abs(b))
+        assert worst <= 2.0 ** -50, (name, worst)

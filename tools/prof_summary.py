@@ -47,7 +47,66 @@ def pmc_sequence(path, like="%apply_%"):
         print(f"{d:5d} grid {gx}x{gy} {dur:9.2f} us  " + "  ".join(f"{k}={v:.0f}" for k, v in cs.items()))
 
 
+def traffic_record(out_json, profile_name, bench_log, kt_db, fetch_db, write_db, rdreq_db):
+    """profiles/apply_traffic.json: measured HBM bytes per launch of the bench's batch launches (the apply kernel with the
+    largest grid), per MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE from separate --pmc passes, in KiB;
+    on gfx950 FETCH_SIZE tallies the 128-byte TCC->EA read requests at 64 bytes, so reads are doubled - cross-checked here
+    against the request-size counters of a third pass."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def dominant(db, counter):
+        con = sqlite3.connect(db)
+        q = ("select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name = ? and "
+             "kernel_name like '%apply_%' group by kernel_name, grid_size order by grid_size desc")
+        rows = list(con.execute(q, (counter,)))
+        return rows[0] if rows else None
+    f, w = dominant(fetch_db, "FETCH_SIZE"), dominant(write_db, "WRITE_SIZE")
+    req = {c: dominant(rdreq_db, c) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")}
+    con = sqlite3.connect(kt_db)
+    krow = list(con.execute("select name, grid_x * grid_y, count(*), avg(duration)/1e3 from kernels where name like '%apply_%' "
+                            "group by name, grid_x, grid_y order by grid_x * grid_y desc"))[0]
+    bench = None
+    for line in open(bench_log):
+        if line.startswith("{") and '"metric"' in line:
+            bench = json.loads(line)
+    h = hashlib.sha1()
+    for rel in ("blinky_amd/csrc/bk_apply_coop.hip", "blinky_amd/csrc/bk_apply.hip", "blinky_amd/csrc/bk_build_params.h"):
+        h.update(open(os.path.join(root, rel), "rb").read())
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        commit = os.environ.get("BLINKY_COMMIT", "unknown (no .git on the GPU box; see the profile's commit in git log)")
+    F, R = bench["config"]["frames_per_step"], bench["config"]["ring_globes"]
+    rd128 = req["TCC_EA0_RDREQ_128B_sum"][3] if req["TCC_EA0_RDREQ_128B_sum"] else None
+    rd64 = req["TCC_EA0_RDREQ_64B_sum"][3] if req["TCC_EA0_RDREQ_64B_sum"] else 0
+    rd32 = req["TCC_EA0_RDREQ_32B_sum"][3] if req["TCC_EA0_RDREQ_32B_sum"] else 0
+    rdall = req["TCC_EA0_RDREQ_sum"][3] if req["TCC_EA0_RDREQ_sum"] else None
+    rec = {
+        "workload": f"3840x2160 cube/panini x{F} ring{R}",
+        "profile": profile_name, "commit": commit, "kernel_source_sha1_16": h.hexdigest()[:16],
+        "kernel": f"{f[0]} (grid {f[1]} work-items, {f[2]} launches profiled)",
+        "kernel_avg_us_in_kernel_trace": round(krow[3], 2),
+        "FETCH_SIZE_KiB_per_launch": round(f[3], 2), "WRITE_SIZE_KiB_per_launch": round(w[3], 2),
+        "hbm_bytes_per_launch": int(round((2 * f[3] + w[3]) * 1024)),
+        "read_requests_per_launch": {"all": rdall, "32B": rd32, "64B": rd64, "128B": rd128},
+        "read_bytes_by_request_size": int(round(rd128 * 128 + rd64 * 64 + rd32 * 32)) if rd128 is not None else None,
+        "correction": "MI355X_MICROARCH.md (HBM): FETCH_SIZE on gfx950 counts the 128-byte TCC->EA read requests as 64 bytes -> reads "
+                      "doubled (cross-check: read_bytes_by_request_size from the TCC_EA0_RDREQ_* pass); WRITE_SIZE as reported. "
+                      "Separate --pmc passes, each with --kernel-trace only.",
+        "algorithmic_bytes_per_launch": 6 * 3840 * 2160 * F,
+    }
+    json.dump(rec, open(out_json, "w"), indent=1)
+    print("== traffic record:", json.dumps(rec))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--traffic":
+        traffic_record(*sys.argv[2:9])
+        sys.exit(0)
     if sys.argv[1] == "--seq":
         for p in sys.argv[2:]:
             pmc_sequence(p)
