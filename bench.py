@@ -161,6 +161,12 @@ def main():
     bounds = multigpu.stripe_bounds(H, world)
     r0, r1 = bounds[rank], bounds[rank + 1]
     ctx.set_rows(r0, r1)
+    # the stripe exchange behind the C ABI: bk_comm = librccl called from libblinkyhip (grouped ncclSend / ncclRecv on the
+    # communicator's own stream); torch.distributed only ships the unique id.  The gloo developer smoke keeps host tensors.
+    comm = None
+    if world > 1 and not host_exchange:
+        comm = multigpu.rccl_comm(ctx, world, rank, dev)
+        assert comm.stripe(rank) == (r0, r1)
     if args.variant >= 0:
         ctx.set_apply_variant(args.variant)
 
@@ -170,7 +176,7 @@ def main():
     build_first_wall_ms = (time.time() - t0) * 1e3
     t0 = time.time()
     display, scale = ctx.build()                  # module cached: emit + launch (+ host fix-up of flagged pixels) only
-    display = multigpu.or_display(display, world, dev)   # which plates the whole frame reads
+    display = comm.or_display(display) if comm else multigpu.or_display(display, world, dev)   # which plates the whole frame reads
     build_wall_ms = (time.time() - t0) * 1e3
     build_kernel_ms = ctx.last_build_ms()
     fix_flagged, fix_changed = ctx.last_build_fixups()
@@ -198,10 +204,7 @@ def main():
     xdev = torch.device("cpu") if host_exchange else dev
     frames_out = [torch.zeros((nown, H, W), dtype=torch.uint8, device=xdev) for _ in range(2)] if world > 1 else None
     pending = [[], []]
-    gather_list = None
-    if world > 1 and rank == 0:
-        hmax = max(bounds[r + 1] - bounds[r] for r in range(world))
-        gather_list = [torch.empty((F, hmax, W), dtype=torch.uint8, device=dev) for r in range(world)]
+    root_frames = torch.zeros((F, H, W), dtype=torch.uint8, device=dev) if (comm and rank == 0) else None
 
     def origin(t):
         # bk_apply_device takes the address of the frame's pixel (0,0) and writes the owned rows [r0, r1) only;
@@ -215,16 +218,21 @@ def main():
         # one batch: warp this rank's stripe of F frames, then (N > 1) reassemble frame f on rank f % world (one grouped
         # RCCL send/recv per batch; buffers alternate, the exchange of batch i overlaps the warp of batch i+1)
         b = i % NB
-        if world > 1:
+        if comm:
+            comm.wait(b)                          # (device-side) the exchange that last used buffer pair b has finished
+        elif world > 1:
             for w in pending[b]:
                 w.wait()
             pending[b] = []
         ctx.apply_device(origin(stripes[b]), W, rows * W, frame0=first_globe(i), nframes=F)
-        if world > 1:
-            src = stripes[b].cpu() if host_exchange else stripes[b]
-            pending[b] = multigpu.exchange_rotating(src, bounds, rank, world, frames_out[b], wait=False)
+        if comm:
+            comm.exchange_rotating(stripes[b].data_ptr(), F, frames_out[b].data_ptr(), H * W, slot=b)
+        elif world > 1:
+            pending[b] = multigpu.exchange_rotating(stripes[b].cpu(), bounds, rank, world, frames_out[b], wait=False)
 
     def drain():
+        if comm:
+            comm.synchronize()
         for b in range(2):
             for w in pending[b]:
                 w.wait()
@@ -232,9 +240,13 @@ def main():
 
     def step_root(i):
         # the single-display variant: every frame of the batch gathered onto rank 0
+        if comm:
+            comm.wait(0)
+            ctx.apply_device(origin(stripe), W, rows * W, frame0=first_globe(i), nframes=F)
+            comm.gather(stripe.data_ptr(), F, 0, root_frames.data_ptr() if rank == 0 else None, H * W, slot=0)
+            return
         ctx.apply_device(origin(stripe), W, rows * W, frame0=first_globe(i), nframes=F)
-        multigpu.gather_stripes(stripe.cpu() if host_exchange else stripe, bounds, rank, world, 0,
-                                None if host_exchange else gather_list)
+        multigpu.gather_stripes(stripe.cpu(), bounds, rank, world, 0, None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -387,8 +399,8 @@ def main():
             "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step from a resident ring of {R} distinct globes "
                                    f"({R * 6 * 2160 * 2176 / 1e9:.2f} GB, advanced every step), one lensmap",
                        "frames_per_step": F, "ring_globes": R,
-                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else " + RCCL grouped send/recv: frame f reassembled on rank f%N"
-                                                                     if exchange_mode == "rotating" else " + RCCL gather of every frame onto rank 0"),
+                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else (" + bk_comm (librccl grouped ncclSend/ncclRecv behind the C ABI)" if comm else " + gloo host exchange (developer smoke)") +
+                                                                     (": frame f reassembled on rank f%N" if exchange_mode == "rotating" else ": every frame gathered onto rank 0")),
                        "apply_variant": args.variant},
             "timed_regions": {"count": len(regions), "steps_each": args.steps, "value_is": "median",
                               "mpx_s_median": round(value, 1),
@@ -432,6 +444,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
+    if comm:
+        comm.synchronize()
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -369,6 +369,30 @@ extern "C" int bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t see
     return bk::launch_fill_lcg(ctx, ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes(), seed);
 }
 
+// ---- plain device buffers for hosts that do not link HIP themselves (stripe / frame buffers of the multi-GPU exchange)
+extern "C" void *bk_dev_alloc(bk_ctx *ctx, size_t bytes)
+{
+    if (!ctx || !bytes || ensure_device(ctx) != BK_OK) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); ctx->fail(BK_E_NOMEM, "bk_dev_alloc: out of device memory (%zu bytes)", bytes); return nullptr; }
+    if (hipMemsetAsync(p, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    return p;
+}
+extern "C" void bk_dev_free(bk_ctx *ctx, void *p)
+{
+    if (!ctx || !p || ensure_device(ctx) != BK_OK) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(p);
+}
+extern "C" int bk_dev_read(bk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (!ctx || !dst_host || !src_dev) return BK_E_INVALID;
+    if (int r = ensure_device(ctx)) return r;
+    BK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
 // ---- apply ------------------------------------------------------------------------------
 
 static int upload_pal(bk_ctx *ctx, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256])

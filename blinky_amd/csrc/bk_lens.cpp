@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 
@@ -444,8 +446,16 @@ static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source
         arch = std::string("--offload-arch=") + prop.gcnArchName;
     std::vector<char> code;
     const std::string cpath = cache_path(source, arch);
-    P->module_from_cache = cache_load(cpath, &code);
-    if (!P->module_from_cache) {
+    // one compilation per (source, arch) and process: the stripe contexts of a bk_multi build the same lens side by side
+    static std::mutex rtc_mutex;
+    static std::map<uint64_t, std::shared_ptr<std::vector<char>>> rtc_cache;
+    std::lock_guard<std::mutex> rtc_lock(rtc_mutex);
+    const uint64_t mem_key = fnv1a64(arch.data(), arch.size(), fnv1a64(source.data(), source.size()));
+    auto hit = rtc_cache.find(mem_key);
+    const bool in_memory = hit != rtc_cache.end();
+    if (in_memory) code = *hit->second;
+    P->module_from_cache = !in_memory && cache_load(cpath, &code);
+    if (!in_memory && !P->module_from_cache) {
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, source.c_str(), "bk_lens_build.hip", (int)hnames.size(), htexts.data(), hnames.data()) != HIPRTC_SUCCESS)
             return ctx->fail(BK_E_HIP, "hiprtcCreateProgram failed");
@@ -465,6 +475,10 @@ static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source
         hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
         cache_store(cpath, code);
+    }
+    if (!in_memory) {
+        if (rtc_cache.size() >= 64) rtc_cache.clear();          // (a long session cycling through many lenses)
+        rtc_cache[mem_key] = std::make_shared<std::vector<char>>(code);
     }
     if (ctx->device < 0) {              // host-only context: compiling is all we can do
         P->module_source = source;

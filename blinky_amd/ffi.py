@@ -90,6 +90,45 @@ _SIGS = {
     "bk_script_console": (C.c_char_p, [_vp]),
     "bk_set_host_math": (_i, [_vp, _i]),
     "bk_debug_eval_device": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "bk_dev_alloc": (_vp, [_vp, _sz]),
+    "bk_dev_free": (None, [_vp, _vp]),
+    "bk_dev_read": (_i, [_vp, _vp, _vp, _sz]),
+    # multi-GPU (bk_comm.cpp)
+    "bk_comm_unique_id": (_i, [_vp]),
+    "bk_comm_create": (_vp, [_vp, _i, _i, _vp]),
+    "bk_comm_destroy": (None, [_vp]),
+    "bk_comm_last_error": (C.c_char_p, [_vp]),
+    "bk_comm_stripe": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "bk_comm_restripe": (_i, [_vp]),
+    "bk_comm_or_display": (_i, [_vp, C.POINTER(_i)]),
+    "bk_comm_gather": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i]),
+    "bk_comm_exchange_rotating": (_i, [_vp, _vp, _i, _vp, _sz, _i]),
+    "bk_comm_wait": (_i, [_vp, _i]),
+    "bk_comm_synchronize": (_i, [_vp]),
+    "bk_create_multi": (_vp, [_i, C.POINTER(_i)]),
+    "bk_destroy_multi": (None, [_vp]),
+    "bk_multi_last_error": (C.c_char_p, [_vp]),
+    "bk_multi_size": (_i, [_vp]),
+    "bk_multi_ctx": (_vp, [_vp, _i]),
+    "bk_multi_comm": (_vp, [_vp, _i]),
+    "bk_multi_uses_rccl": (_i, [_vp]),
+    "bk_multi_load_globe": (_i, [_vp, C.c_char_p, _sz, C.c_char_p]),
+    "bk_multi_load_lens": (_i, [_vp, C.c_char_p, _sz, C.c_char_p]),
+    "bk_multi_clear_lens": (_i, [_vp]),
+    "bk_multi_clear_globe": (_i, [_vp]),
+    "bk_multi_resize": (_i, [_vp, _i, _i]),
+    "bk_multi_set_frames": (_i, [_vp, _i]),
+    "bk_multi_set_zoom": (_i, [_vp, _i, _i]),
+    "bk_multi_set_rubixgrid": (_i, [_vp, _i, _d, _d]),
+    "bk_multi_upload_plate": (_i, [_vp, _i, _i, _vp, _i]),
+    "bk_multi_fill_plate_lcg": (_i, [_vp, _i, _i, C.c_uint32]),
+    "bk_multi_synchronize": (_i, [_vp]),
+    "bk_multi_build": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
+    "bk_multi_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "bk_multi_apply_stripes": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp]),
+    "bk_multi_wait": (_i, [_vp, _i]),
+    "bk_multi_gather": (_i, [_vp, C.POINTER(_vp), _i, _i, _vp, _sz, _i]),
+    "bk_multi_exchange_rotating": (_i, [_vp, C.POINTER(_vp), _i, C.POINTER(_vp), _sz, _i]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch
@@ -109,15 +148,16 @@ def _ptr(a):
 class Context:
     """Thin object wrapper over a ``bk_ctx*``."""
 
-    def __init__(self, device=-1):
-        self._h = lib.bk_create(device)
+    def __init__(self, device=-1, _borrowed=None):
+        self._owned = _borrowed is None
+        self._h = lib.bk_create(device) if _borrowed is None else _borrowed
         if not self._h:
             raise BlinkyError(lib.bk_last_error(None).decode())
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             lib.bk_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -345,8 +385,159 @@ class Context:
     def module_from_cache(self):
         return bool(lib.bk_debug_module_from_cache(self._h))
 
+    def dev_alloc(self, nbytes):
+        p = lib.bk_dev_alloc(self._h, nbytes)
+        if not p:
+            raise BlinkyError("bk_dev_alloc failed: " + lib.bk_last_error(self._h).decode())
+        return p
+
+    def dev_free(self, p):
+        lib.bk_dev_free(self._h, p)
+
+    def dev_read(self, p, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        self._chk(lib.bk_dev_read(self._h, _ptr(out), p, nbytes))
+        return out
+
     def set_apply_variant(self, v):
         self._chk(lib.bk_set_apply_variant(self._h, v))
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte id every rank passes to Comm (ncclGetUniqueId)"""
+    buf = (C.c_uint8 * 128)()
+    if lib.bk_comm_unique_id(buf) != OK:
+        raise BlinkyError(lib.bk_comm_last_error(None).decode())
+    return bytes(buf)
+
+
+class Comm:
+    """One rank of the stripe exchange (``bk_comm*``): RCCL send/recv on the context's stream."""
+
+    def __init__(self, ctx, nranks, rank, unique_id=None):
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        self._h = lib.bk_comm_create(ctx._h, nranks, rank, idbuf)
+        if not self._h:
+            raise BlinkyError(lib.bk_comm_last_error(None).decode())
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if self._h:
+            lib.bk_comm_destroy(self._h)
+            self._h = None
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise BlinkyError(f"[{rc}] {lib.bk_comm_last_error(self._h).decode()}")
+
+    def stripe(self, rank):
+        a, b = _i(), _i()
+        self._chk(lib.bk_comm_stripe(self._h, rank, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def or_display(self, display):
+        arr = (_i * MAX_PLATES)(*display)
+        self._chk(lib.bk_comm_or_display(self._h, arr))
+        return list(arr)
+
+    def gather(self, stripe_ptr, nframes, root, frames_ptr, frame_stride, slot=0):
+        self._chk(lib.bk_comm_gather(self._h, stripe_ptr, nframes, root, frames_ptr, frame_stride, slot))
+
+    def exchange_rotating(self, stripe_ptr, nframes, frames_ptr, frame_stride, slot=0):
+        self._chk(lib.bk_comm_exchange_rotating(self._h, stripe_ptr, nframes, frames_ptr, frame_stride, slot))
+
+    def wait(self, slot=0):
+        self._chk(lib.bk_comm_wait(self._h, slot))
+
+    def synchronize(self):
+        self._chk(lib.bk_comm_synchronize(self._h))
+
+
+class Multi:
+    """N stripe contexts + communicators driven by one host thread (``bk_multi*``)."""
+
+    def __init__(self, devices):
+        arr = (_i * len(devices))(*devices)
+        self._h = lib.bk_create_multi(len(devices), arr)
+        if not self._h:
+            raise BlinkyError(lib.bk_multi_last_error(None).decode())
+        self.n = len(devices)
+
+    def close(self):
+        if self._h:
+            lib.bk_destroy_multi(self._h)
+            self._h = None
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise BlinkyError(f"[{rc}] {lib.bk_multi_last_error(self._h).decode()}")
+
+    def ctx(self, i):
+        return Context(_borrowed=lib.bk_multi_ctx(self._h, i))
+
+    def uses_rccl(self):
+        return bool(lib.bk_multi_uses_rccl(self._h))
+
+    def load_globe(self, src, name="globe"):
+        b = src.encode()
+        self._chk(lib.bk_multi_load_globe(self._h, b, len(b), name.encode()))
+
+    def load_lens(self, src, name="lens"):
+        b = src.encode()
+        self._chk(lib.bk_multi_load_lens(self._h, b, len(b), name.encode()))
+
+    def resize(self, w, h):
+        self._chk(lib.bk_multi_resize(self._h, w, h))
+
+    def set_frames(self, n):
+        self._chk(lib.bk_multi_set_frames(self._h, n))
+
+    def set_zoom(self, ztype, fov=0):
+        self._chk(lib.bk_multi_set_zoom(self._h, ztype, fov))
+
+    def set_rubixgrid(self, numcells, cell, pad):
+        self._chk(lib.bk_multi_set_rubixgrid(self._h, numcells, cell, pad))
+
+    def upload_plate(self, frame, plate, src, pitch=None):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        self._chk(lib.bk_multi_upload_plate(self._h, frame, plate, _ptr(src), src.shape[-1] if pitch is None else pitch))
+
+    def fill_plate_lcg(self, frame, plate, seed_frame=None):
+        self._chk(lib.bk_multi_fill_plate_lcg(self._h, frame, plate, frame if seed_frame is None else seed_frame))
+
+    def synchronize(self):
+        self._chk(lib.bk_multi_synchronize(self._h))
+
+    def build(self):
+        disp = (_i * MAX_PLATES)()
+        scale = _d()
+        self._chk(lib.bk_multi_build(self._h, disp, C.byref(scale)))
+        return list(disp), scale.value
+
+    def apply(self, dst, frame=0, pitch=None, x0=0, y0=0, rubix_on=False, pal=None):
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        if pal is not None:
+            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        self._chk(lib.bk_multi_apply(self._h, frame, _ptr(dst), dst.shape[-1] if pitch is None else pitch, x0, y0, int(rubix_on), _ptr(pal)))
+        return dst
+
+    def apply_stripes(self, stripe_ptrs, frame0=0, nframes=1, rubix_on=False, pal=None):
+        arr = (_vp * self.n)(*stripe_ptrs)
+        if pal is not None:
+            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        self._chk(lib.bk_multi_apply_stripes(self._h, frame0, nframes, arr, int(rubix_on), _ptr(pal)))
+
+    def gather(self, stripe_ptrs, nframes, root, frames_ptr, frame_stride, slot=0):
+        arr = (_vp * self.n)(*stripe_ptrs)
+        self._chk(lib.bk_multi_gather(self._h, arr, nframes, root, frames_ptr, frame_stride, slot))
+
+    def exchange_rotating(self, stripe_ptrs, nframes, frames_ptrs, frame_stride, slot=0):
+        a = (_vp * self.n)(*stripe_ptrs)
+        b = (_vp * self.n)(*frames_ptrs)
+        self._chk(lib.bk_multi_exchange_rotating(self._h, a, nframes, b, frame_stride, slot))
+
+    def wait(self, slot=0):
+        self._chk(lib.bk_multi_wait(self._h, slot))
 
 
 def create_palmap(basepal):

@@ -12,9 +12,26 @@ gloo in the CPU tests):
                          every GPU ends up holding whole frames (1/N of the batch each).
 
 The only other exchange is a 6-int OR of the display[] flags after a build, so every rank knows
-which plates the whole frame reads."""
+which plates the whole frame reads.
+
+On GPUs the exchange itself lives behind the C ABI (include/blinky_hip.h, bk_comm_*: librccl called directly -
+ncclCommInitRank, grouped ncclSend / ncclRecv, ncclAllReduce); `rccl_comm` below only ships the communicator's
+unique id to the ranks through the process group the launcher set up.  The torch.distributed functions in this module
+are the same schedule for host tensors (gloo), which is what the CPU tests and the one-GPU developer smoke use."""
 import torch
 import torch.distributed as dist
+
+
+def rccl_comm(ctx, world, rank, device):
+    """bk_comm for this rank: rank 0 draws the RCCL unique id, the process group broadcasts it, every rank joins
+    (ncclCommInitRank inside libblinkyhip).  Also restricts `ctx` to this rank's stripe."""
+    from . import ffi
+    t = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        t.copy_(torch.frombuffer(bytearray(ffi.comm_unique_id()), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(t, src=0)
+    return ffi.Comm(ctx, world, rank, bytes(t.cpu().numpy().tobytes()))
 
 
 def stripe_bounds(height, world):

@@ -162,6 +162,82 @@ int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst
                     size_t frame_stride, int x0, int y0, int rubix_on,
                     const uint8_t pal[BK_MAX_PLATES][256]);
 
+/* ---- multi-GPU: row stripes + RCCL over xGMI ---------------------------------------------------------------
+ * No counterpart in the reference (fisheye.c is single-threaded CPU code).  Every output pixel is independent, so
+ * GPU r of N owns rows [H*r/N, H*(r+1)/N): it builds and keeps only that stripe of the lensmap (no exchange, ever),
+ * holds a full replica of the globe, warps its stripe; ONE exchange step reassembles frames.  Stripe buffers are
+ * tight: [nframes][rows_r][W] bytes; frame buffers are tight [slots][H][W] with `frame_stride` bytes between slots.
+ * An exchange is asynchronous: it starts once the work queued on the context's stream so far (the warp of the stripe)
+ * has finished and runs on the communicator's own stream, so that the NEXT batch's warp overlaps the stripes' travel;
+ * `slot` (0..BK_COMM_SLOTS-1) names it for bk_comm_wait.  librccl is loaded on first use.
+ *
+ * bk_comm: ONE rank.  Ranks may be processes (one per GPU, e.g. under torchrun / mpirun: rank 0 calls
+ * bk_comm_unique_id and ships the 128 bytes to the others by any means) or several contexts of one process. */
+#define BK_COMM_ID_BYTES 128
+#define BK_COMM_SLOTS 4     /* exchanges in flight that a caller can tell apart (double / quadruple buffering) */
+typedef struct bk_comm bk_comm;
+int         bk_comm_unique_id(uint8_t id[BK_COMM_ID_BYTES]);                      /* ncclGetUniqueId */
+/* joins the communicator (ncclCommInitRank on the context's device; blocks until all nranks joined) and restricts the
+ * context to this rank's stripe (bk_set_rows); needs bk_resize first.  nranks == 1 needs no id. */
+bk_comm    *bk_comm_create(bk_ctx *ctx, int nranks, int rank, const uint8_t id[BK_COMM_ID_BYTES]);
+void        bk_comm_destroy(bk_comm *c);
+const char *bk_comm_last_error(const bk_comm *c);                                  /* c may be NULL: last failed create */
+int         bk_comm_stripe(const bk_comm *c, int rank, int *row0, int *row1);      /* any rank's rows */
+int         bk_comm_restripe(bk_comm *c);                                          /* after a later bk_resize */
+/* display[] |= every other rank's (which plates the WHOLE frame reads, fisheye.c:1976): ncclAllReduce(MAX); synchronous */
+int         bk_comm_or_display(bk_comm *c, int display[BK_MAX_PLATES]);
+/* every frame of the batch onto `root` (what a single display needs): grouped ncclSend / ncclRecv; frames_dev is
+ * used on the root only and receives frame f at slot f */
+int         bk_comm_gather(bk_comm *c, const void *stripe_dev, int nframes, int root, void *frames_dev, size_t frame_stride, int slot);
+/* batches: frame f is reassembled on rank f % N at slot f / N (a gather whose root rotates): all N*(N-1) xGMI links
+ * carry stripes at once and every GPU ends up with 1/N of the batch as whole frames */
+int         bk_comm_exchange_rotating(bk_comm *c, const void *stripe_dev, int nframes, void *frames_dev, size_t frame_stride, int slot);
+/* the context's stream waits - on the device, the host does not block - for the exchange last posted with `slot`:
+ * call before warping into the stripe buffer, or reading the frames, that exchange used */
+int         bk_comm_wait(bk_comm *c, int slot);
+int         bk_comm_synchronize(bk_comm *c);         /* host waits for the context's stream and every posted exchange */
+
+/* bk_multi: N stripe contexts + their communicators driven by ONE host thread - what a single-process C host
+ * (blinky_amd/host/fisheye_hip.c) uses to spread F_RenderView's warp over the node's GPUs.  ncclCommInitAll; every
+ * exchange is posted for all ranks inside one ncclGroup.  A device named twice (one-GPU box; RCCL refuses duplicates)
+ * or BLINKY_HIP_COMM=copy selects device-to-device copies over the same schedule instead. */
+typedef struct bk_multi bk_multi;
+bk_multi   *bk_create_multi(int ndev, const int *devices);
+void        bk_destroy_multi(bk_multi *m);
+const char *bk_multi_last_error(const bk_multi *m);
+int         bk_multi_size(const bk_multi *m);
+bk_ctx     *bk_multi_ctx(bk_multi *m, int i);        /* stripe context i (introspection, per-context calls) */
+bk_comm    *bk_multi_comm(bk_multi *m, int i);       /* after bk_multi_resize */
+int         bk_multi_uses_rccl(const bk_multi *m);
+/* the per-context calls applied to every stripe context (same meaning as their bk_* namesakes) */
+int bk_multi_load_globe(bk_multi *m, const char *src, size_t len, const char *chunkname);
+int bk_multi_load_lens(bk_multi *m, const char *src, size_t len, const char *chunkname);
+int bk_multi_clear_lens(bk_multi *m);
+int bk_multi_clear_globe(bk_multi *m);
+int bk_multi_resize(bk_multi *m, int width, int height);          /* + stripes: context i owns rows [H*i/N, H*(i+1)/N) */
+int bk_multi_set_frames(bk_multi *m, int nframes);
+int bk_multi_set_zoom(bk_multi *m, int zoom_type, int fov_degrees);
+int bk_multi_set_rubixgrid(bk_multi *m, int numcells, double cell_size, double pad_size);
+int bk_multi_upload_plate(bk_multi *m, int frame, int plate, const uint8_t *src, int src_pitch);   /* replica on every GPU */
+int bk_multi_fill_plate_lcg(bk_multi *m, int frame, int plate, uint32_t seed_frame);
+int bk_multi_synchronize(bk_multi *m);       /* host waits for every stream of every rank */
+int bk_multi_wait(bk_multi *m, int slot);    /* bk_comm_wait on every rank */
+/* all stripes built concurrently (one host thread per device); display_out = OR over the stripes */
+int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], double *scale_out);
+/* host frame: every device warps its stripe and copies it straight into dst (N PCIe links side by side) */
+int bk_multi_apply(bk_multi *m, int frame, uint8_t *dst, int dst_pitch, int x0, int y0, int rubix_on,
+                   const uint8_t pal[BK_MAX_PLATES][256]);
+/* device frames: warp into per-device stripe buffers, then gather / rotating exchange as bk_comm_* */
+int bk_multi_apply_stripes(bk_multi *m, int frame0, int nframes, void *const *stripes_dev, int rubix_on,
+                           const uint8_t pal[BK_MAX_PLATES][256]);
+int bk_multi_gather(bk_multi *m, void *const *stripes_dev, int nframes, int root, void *frames_dev, size_t frame_stride, int slot);
+int bk_multi_exchange_rotating(bk_multi *m, void *const *stripes_dev, int nframes, void *const *frames_dev, size_t frame_stride, int slot);
+
+/* plain device buffers for hosts that do not link HIP themselves (zero-filled; ordered on the context's stream) */
+void *bk_dev_alloc(bk_ctx *ctx, size_t bytes);
+void  bk_dev_free(bk_ctx *ctx, void *dev_ptr);
+int   bk_dev_read(bk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* synchronous */
+
 /* rubix palettes: create_palmap / find_closest_pal_index (fisheye.c:835-908); basepal = 768 bytes */
 void bk_create_palmap(const uint8_t *basepal, uint8_t pal_out[BK_MAX_PLATES][256]);
 

@@ -1,0 +1,119 @@
+"""Multi-GPU behind the C ABI (include/blinky_hip.h: bk_comm_*, bk_multi_*), on the one GPU the test box has.
+
+RCCL refuses the same device twice in one communicator, so a one-GPU box cannot run two RCCL ranks; what runs here:
+  * the schedule (who sends which rows where, uneven stripes, rotating roots, slots) over bk_multi's copy transport with
+    two and three "devices" that are all GPU 0 - from a plain C host (tests/host/multi_test.c) and from Python;
+  * librccl itself being found and answering (bk_comm_unique_id), and the single-rank communicator.
+The N > 1 RCCL transport posts exactly the same per-rank op lists (bk_comm.cpp: ops_gather / ops_rotating -> post_rccl);
+bench.py runs it when the driver launches N ranks."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scripts as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import blinky_amd
+    return blinky_amd
+
+
+def oracle_frames(globe, lens, W, H, F):
+    lm = O.lensmap(globe, lens, None, W, H)
+    return lm, [O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, f), np.zeros((H, W), np.uint8)) for f in range(F)]
+
+
+@pytest.mark.parametrize("devs", ["0,0", "0,0,0"])
+def test_c_host_spreads_the_warp_over_several_ranks(tmp_path, devs):
+    """tests/host/multi_test.c: bk_create_multi -> stripe-wise build -> host frame, gather onto rank 0, rotating exchange"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host"), "multi_test"], stdout=subprocess.DEVNULL)
+    globe, lens, W, H, F = "cube", "hammer", 322, 203, 5           # W % 4 != 0, H % N != 0: uneven stripes
+    (tmp_path / "g.lua").write_text(S.script("globes", globe))
+    (tmp_path / "l.lua").write_text(S.script("lenses", lens))
+    out = tmp_path / "frames.bin"
+    r = subprocess.run([os.path.join(ROOT, "tests", "host", "multi_test"), str(tmp_path / "g.lua"), str(tmp_path / "l.lua"),
+                        str(W), str(H), str(F), devs, str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lm, want = oracle_frames(globe, lens, W, H, F)
+    head = r.stdout.splitlines()[0].split()
+    assert head[1] == str(len(devs.split(","))) and head[3] == "0"            # ranks, copy transport
+    assert float(head[5]) == lm.scale and head[7] == "".join(str(d) for d in lm.display + [0] * (6 - len(lm.display)))
+    got = np.fromfile(out, np.uint8).reshape(1 + 2 * F, H, W)
+    np.testing.assert_array_equal(got[0], want[0], err_msg="bk_multi_apply (host frame)")
+    for f in range(F):
+        np.testing.assert_array_equal(got[1 + f], want[f], err_msg=f"gather, frame {f}")
+        np.testing.assert_array_equal(got[1 + F + f], want[f], err_msg=f"rotating exchange, frame {f}")
+
+
+def test_multi_from_python_with_rubix_and_double_buffering(bk):
+    import torch
+    globe, lens, W, H, F, N = "trism", "panini", 480, 270, 6, 3
+    m = bk.Multi([0] * N)
+    assert not m.uses_rccl()
+    m.set_frames(F)
+    m.load_globe(S.script("globes", globe), globe)
+    m.load_lens(S.script("lenses", lens), lens)
+    m.set_zoom(bk.ffi.ZOOM_FOV, 180)
+    m.resize(W, H)
+    display, scale = m.build()
+    lm = O.lensmap(globe, lens, None, W, H)
+    assert scale == lm.scale and display[: lm.numplates] == lm.display
+    # every stripe context holds exactly its rows of the oracle's table
+    bounds = [H * r // N for r in range(N + 1)]
+    for r in range(N):
+        off, tin = m.ctx(r).read_lensmap()
+        np.testing.assert_array_equal(off, lm.offsets.reshape(H, W)[bounds[r]:bounds[r + 1]].ravel())
+    for f in range(F):
+        for p in range(6):
+            m.fill_plate_lcg(f, p, f)
+    pal = O.palmap(O.synthetic_basepal())
+    want = [O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, f), np.zeros((H, W), np.uint8), rubix_on=True, pal=pal) for f in range(F)]
+    np.testing.assert_array_equal(m.apply(np.zeros((H, W), np.uint8), frame=2, rubix_on=True, pal=pal), want[2])
+    # two buffer pairs in flight (slots 0 and 1), as bench.py's steps use them
+    stripes = [[torch.zeros((F, bounds[r + 1] - bounds[r], W), dtype=torch.uint8, device="cuda") for r in range(N)] for _ in range(2)]
+    frames = [[torch.zeros(((F + N - 1) // N, H, W), dtype=torch.uint8, device="cuda") for r in range(N)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for step in range(4):
+        b = step & 1
+        m.wait(b)
+        m.apply_stripes([t.data_ptr() for t in stripes[b]], frame0=0, nframes=F, rubix_on=True, pal=pal)
+        m.exchange_rotating([t.data_ptr() for t in stripes[b]], F, [t.data_ptr() for t in frames[b]], H * W, slot=b)
+    m.synchronize()
+    for b in range(2):
+        for f in range(F):
+            np.testing.assert_array_equal(frames[b][f % N][f // N].cpu().numpy(), want[f], err_msg=f"buffer {b} frame {f}")
+    m.close()
+
+
+def test_rccl_is_reachable_and_a_single_rank_communicator_works(bk):
+    import torch
+    uid = bk.ffi.comm_unique_id()                    # dlopen(librccl) + ncclGetUniqueId
+    assert len(uid) == 128 and any(uid)
+    lm, want = oracle_frames("cube", "panini", 320, 240, 3)
+    ctx = bk.Context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_frames(3)
+    S.configure(ctx, "cube", "panini", None, (320, 240))
+    comm = bk.Comm(ctx, 1, 0)
+    assert comm.stripe(0) == (0, 240)
+    display, _ = ctx.build()
+    assert comm.or_display(display) == display
+    for f in range(3):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, f)
+    stripe = torch.zeros((3, 240, 320), dtype=torch.uint8, device="cuda")
+    frames = torch.zeros((3, 240, 320), dtype=torch.uint8, device="cuda")
+    ctx.apply_device(stripe.data_ptr(), 320, 240 * 320, frame0=0, nframes=3)
+    comm.exchange_rotating(stripe.data_ptr(), 3, frames.data_ptr(), 240 * 320, slot=2)
+    comm.synchronize()
+    for f in range(3):
+        np.testing.assert_array_equal(frames[f].cpu().numpy(), want[f])
+    comm.close()
+    ctx.close()
