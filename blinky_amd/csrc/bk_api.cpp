@@ -53,6 +53,16 @@ extern "C" bk_ctx *bk_create(int device)
     return ctx;
 }
 
+static void free_plate_slots(bk_ctx *ctx)
+{
+    for (int i = 0; i < bk_ctx::kPlateSlots; ++i) {
+        if (ctx->plate_ev[i]) { (void)hipEventSynchronize(ctx->plate_ev[i]); (void)hipEventDestroy(ctx->plate_ev[i]); ctx->plate_ev[i] = nullptr; }
+        if (ctx->h_plate[i]) { (void)hipHostFree(ctx->h_plate[i]); ctx->h_plate[i] = nullptr; }
+        if (ctx->d_plate_slot[i]) { (void)hipFree(ctx->d_plate_slot[i]); ctx->d_plate_slot[i] = nullptr; }
+    }
+    ctx->plate_slot_bytes = 0;
+}
+
 static void free_maps(bk_ctx *ctx)
 {
     hipFree(ctx->d_offsets); ctx->d_offsets = nullptr;
@@ -76,6 +86,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     free_maps(ctx);
+    free_plate_slots(ctx);
     hipFree(ctx->d_globe);
     hipFree(ctx->d_plate_stage);
     hipFree(ctx->d_pal);
@@ -174,6 +185,7 @@ extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_empty(ctx->fail(BK_E_HIP, "bk_resize: hipStreamSynchronize failed"));
     (void)hipFree(ctx->d_plate_stage);
     ctx->d_plate_stage = nullptr;
+    free_plate_slots(ctx);                                  // (sized for the old platesize; re-created on the next async upload)
     if (hipMalloc((void **)&ctx->d_plate_stage, (size_t)gp * ps) != hipSuccess) {
         (void)hipGetLastError();
         return fail_empty(ctx->fail(BK_E_NOMEM, "bk_resize: out of device memory (plate staging, %dx%d)", width, height));
@@ -343,6 +355,39 @@ extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t 
     return BK_OK;
 }
 
+// render_plate's memcpy (fisheye.c:2441-2449) lands in a pinned buffer and the DMA + retile are only ENQUEUED: the
+// engine goes on to render the next plate while this one travels.  Three slots; the call blocks only if the slot it is
+// about to reuse (three uploads ago) is still in flight.  Ordered with everything else on the context's stream.
+extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch)
+{
+    if (!ctx || !src) return BK_E_INVALID;
+    if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate_async: call bk_resize first");
+    if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
+        return ctx->fail(BK_E_INVALID, "bk_upload_plate_async: bad frame/plate/pitch");
+    if (int r = ensure_device(ctx)) return r;
+    const size_t ps = ctx->ps, gp = ctx->gp, bytes = gp * ps;
+    if (ctx->plate_slot_bytes != bytes) {
+        free_plate_slots(ctx);
+        for (int i = 0; i < bk_ctx::kPlateSlots; ++i) {
+            BK_HIP(ctx, hipHostMalloc((void **)&ctx->h_plate[i], bytes, hipHostMallocDefault));
+            BK_HIP(ctx, hipMalloc((void **)&ctx->d_plate_slot[i], bytes));
+            BK_HIP(ctx, hipEventCreateWithFlags(&ctx->plate_ev[i], hipEventDisableTiming));
+        }
+        ctx->plate_slot_bytes = bytes;
+        ctx->plate_next = 0;
+    }
+    const int slot = ctx->plate_next;
+    ctx->plate_next = (slot + 1) % bk_ctx::kPlateSlots;
+    BK_HIP(ctx, hipEventSynchronize(ctx->plate_ev[slot]));               // (a never-recorded event is complete)
+    uint8_t *h = ctx->h_plate[slot];
+    for (size_t y = 0; y < ps; ++y) memcpy(h + y * gp, src + y * (size_t)src_pitch, ps);      // rows gp apart, as the staging twin expects
+    uint8_t *dst = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_plate_slot[slot], h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int r = bk::launch_plate_retile(ctx, dst, 1, ctx->d_plate_slot[slot])) return r;
+    BK_HIP(ctx, hipEventRecord(ctx->plate_ev[slot], ctx->stream));
+    return BK_OK;
+}
+
 extern "C" int bk_download_plate(bk_ctx *ctx, int frame, int plate, uint8_t *dst_host, int dst_pitch)
 {
     if (!ctx || !dst_host) return BK_E_INVALID;
@@ -440,6 +485,9 @@ static int ensure_spans(bk_ctx *ctx)
         }
     }
     ctx->spans_valid = true;
+    // every pixel of the owned rows mapped (panini, stereographic, ...): no merge needed, the frame can be copied whole
+    ctx->fully_mapped = ctx->spans.size() == (size_t)ctx->rows();
+    for (const bk::Span &s : ctx->spans) if (s.x0 != 0 || s.x1 != ctx->W) { ctx->fully_mapped = false; break; }
     return BK_OK;
 }
 
@@ -456,6 +504,13 @@ extern "C" int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int
     // into the caller's buffer (VBUFFER(x+scr_vrect.x, y+scr_vrect.y), fisheye.c:2414-2421)
     const int rows = ctx->rows();
     if (int r = bk::launch_apply(ctx, frame, 1, ctx->d_frame, ctx->W, 0, rubix_on)) return r;
+    if (ctx->fully_mapped) {
+        // nothing to preserve between the mapped pixels: one 2-D copy straight into the caller's buffer, no host merge
+        BK_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)(y0 + ctx->row0) * dst_pitch + x0, (size_t)dst_pitch, ctx->d_frame, (size_t)ctx->W,
+                                     (size_t)ctx->W, (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return BK_OK;
+    }
     BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (const bk::Span &s : ctx->spans)

@@ -256,11 +256,11 @@ int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_device)
     return BK_OK;
 }
 
-int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled)
+int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled, uint8_t *rowmajor)
 {
     const int threads = (ctx->gp >> 4) * ctx->ps;
     hipLaunchKernelGGL(plate_retile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                       plate_tiled, ctx->d_plate_stage, ctx->ps, ctx->gp, ctx->ph, to_tiled);
+                       plate_tiled, rowmajor ? rowmajor : ctx->d_plate_stage, ctx->ps, ctx->gp, ctx->ph, to_tiled);
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;
 }

@@ -400,7 +400,7 @@ extern "C" int bk_multi_clear_globe(bk_multi *m) { if (!m) return BK_E_INVALID; 
 extern "C" int bk_multi_set_frames(bk_multi *m, int nframes) { if (!m) return BK_E_INVALID; BK_EACH(m, bk_set_frames(c, nframes)); return BK_OK; }
 extern "C" int bk_multi_set_zoom(bk_multi *m, int zoom_type, int fov) { if (!m) return BK_E_INVALID; BK_EACH(m, bk_set_zoom(c, zoom_type, fov)); return BK_OK; }
 extern "C" int bk_multi_set_rubixgrid(bk_multi *m, int n, double cell, double pad) { if (!m) return BK_E_INVALID; BK_EACH(m, bk_set_rubixgrid(c, n, cell, pad)); return BK_OK; }
-extern "C" int bk_multi_upload_plate(bk_multi *m, int frame, int plate, const uint8_t *src, int pitch) { if (!m) return BK_E_INVALID; BK_EACH(m, bk_upload_plate(c, frame, plate, src, pitch)); return BK_OK; }
+extern "C" int bk_multi_upload_plate(bk_multi *m, int frame, int plate, const uint8_t *src, int pitch) { if (!m) return BK_E_INVALID; BK_EACH(m, bk_upload_plate_async(c, frame, plate, src, pitch)); return BK_OK; }   /* N DMAs side by side */
 extern "C" int bk_multi_fill_plate_lcg(bk_multi *m, int frame, int plate, uint32_t seed_frame) { if (!m) return BK_E_INVALID; BK_EACH(m, bk_fill_plate_lcg(c, frame, plate, seed_frame)); return BK_OK; }
 extern "C" int bk_multi_synchronize(bk_multi *m)
 {

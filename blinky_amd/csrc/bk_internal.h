@@ -50,6 +50,15 @@ struct bk_ctx {
     // device memory
     uint8_t *d_globe = nullptr;      // [nframes][6][ph/8][gp/16] tiles of 16x8 texels (bk_texel_offset, bk_build_params.h)
     uint8_t *d_plate_stage = nullptr;  // [ps][gp] row-major staging of one plate for bk_upload_plate / bk_download_plate
+    // bk_upload_plate_async: pinned host buffers the caller's rows are copied into, their device-side staging twins and
+    // the event that says "this slot's DMA + retile are done" - three slots, so that the DMA of plate k overlaps the
+    // engine's render of plate k+1
+    static constexpr int kPlateSlots = 3;
+    uint8_t *h_plate[kPlateSlots] = {};
+    uint8_t *d_plate_slot[kPlateSlots] = {};
+    hipEvent_t plate_ev[kPlateSlots] = {};
+    size_t plate_slot_bytes = 0;
+    int plate_next = 0;
     uint32_t *d_offsets = nullptr;   // [row1-row0][W]  offsets into the PADDED globe layout
     uint32_t *d_convert = nullptr;   // [row1-row0][W]  scratch for layout conversion at the ABI boundary
     uint8_t *d_tints = nullptr;      // [row1-row0][W]
@@ -68,6 +77,7 @@ struct bk_ctx {
     bool lensmap_valid = false;
     std::vector<bk::Span> spans;     // mapped spans of the owned rows
     bool spans_valid = false;
+    bool fully_mapped = false;       // every pixel of the owned rows is mapped: bk_apply copies the frame whole
 
     int apply_variant = -1;          // -1 auto (= 2); 0 direct gather, 2 workgroup-cooperative LDS blocks
     int num_cus = 256;               // multiProcessorCount of the device
@@ -79,6 +89,7 @@ struct bk_ctx {
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
+    bool async_compile = false;      // bk_set_async_compile: bk_build returns BK_PENDING instead of waiting for hiprtc
 
     int fail(int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)))
     {
@@ -110,7 +121,7 @@ int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_
 int launch_mask(bk_ctx *ctx);                 // d_offsets -> d_mask
 int launch_fill_lcg(bk_ctx *ctx, uint8_t *plate_dst, uint32_t seed);   // one plate, padded rows
 int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_device);   // reference <-> device (tiled) layout
-int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled);          // d_plate_stage (row-major) <-> a plate of the globe
+int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled, uint8_t *rowmajor = nullptr);   // row-major staging (default d_plate_stage) <-> a plate of the globe
 int launch_scatter32(bk_ctx *ctx, uint32_t *dst, const uint32_t *h_idx, const uint32_t *h_val, size_t n);   // dst[idx[i]] = val[i]; synchronous
 int launch_scatter8(bk_ctx *ctx, uint8_t *dst, const uint32_t *h_idx, const uint8_t *h_val, size_t n);
 // bk_apply_coop.hip

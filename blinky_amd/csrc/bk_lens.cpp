@@ -5,10 +5,13 @@
 
 #include <algorithm>
 #include <cstring>
+#include <chrono>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "bk_build_params.h"
@@ -18,6 +21,14 @@
 #include "bkm.h"
 
 using namespace bklua;
+
+// a compiled lens module (or why there is none): what the memory cache, the disk cache or hiprtc hands back
+struct CodeResult {
+    int rc = BK_OK;
+    std::string log;
+    std::shared_ptr<std::vector<char>> code;
+    bool from_disk = false;
+};
 
 namespace bk {
 
@@ -32,6 +43,8 @@ struct LensProgram {
     hipModule_t module = nullptr;
     bool module_from_cache = false;      // the last compile_module() loaded its code object from BLINKY_HIP_CACHE
     hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr;
+    std::shared_future<::CodeResult> pending;     // bk_set_async_compile: hiprtc running on another thread ...
+    std::string pending_source;                      // ... for this generated source
     std::string last_source;      // for bk_debug_kernel_source
     std::string console;          // print() output of the scripts
 
@@ -393,10 +406,36 @@ static uint64_t fnv1a64(const void *data, size_t n, uint64_t h = 146959810393466
     for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
     return h;
 }
+// Where compiled lens modules are kept: bk_set_cache_dir() if the host called it, else $BLINKY_HIP_CACHE ("" or "off"
+// disables the disk cache), else $XDG_CACHE_HOME/blinky_hip, else $HOME/.cache/blinky_hip.
+static std::mutex g_cache_dir_mutex;
+static std::string g_cache_dir;
+static bool g_cache_dir_set = false;
+
+extern "C" int bk_set_cache_dir(const char *dir)
+{
+    std::lock_guard<std::mutex> lock(g_cache_dir_mutex);
+    g_cache_dir = dir ? dir : "";
+    g_cache_dir_set = true;
+    return BK_OK;
+}
+
+static std::string cache_dir()
+{
+    {
+        std::lock_guard<std::mutex> lock(g_cache_dir_mutex);
+        if (g_cache_dir_set) return g_cache_dir;
+    }
+    if (const char *e = getenv("BLINKY_HIP_CACHE")) return (!*e || !strcmp(e, "off")) ? std::string() : std::string(e);
+    if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/blinky_hip";
+    if (const char *h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/blinky_hip";
+    return std::string();
+}
+
 static std::string cache_path(const std::string &source, const std::string &arch)
 {
-    const char *dir = getenv("BLINKY_HIP_CACHE");
-    if (!dir || !*dir) return std::string();
+    const std::string dir = cache_dir();
+    if (dir.empty()) return std::string();
     uint64_t h = fnv1a64(source.data(), source.size());
     for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) h = fnv1a64(bk::kEmbeddedHeaders[i].text, strlen(bk::kEmbeddedHeaders[i].text), h);
     h = fnv1a64(arch.data(), arch.size(), h);
@@ -404,7 +443,7 @@ static std::string cache_path(const std::string &source, const std::string &arch
     h = fnv1a64(ver, strlen(ver), h);
     char name[64];
     snprintf(name, sizeof name, "/bk_lens_%016llx.hsaco", (unsigned long long)h);
-    return std::string(dir) + name;
+    return dir + name;
 }
 static bool cache_load(const std::string &path, std::vector<char> *code)
 {
@@ -419,9 +458,15 @@ static bool cache_load(const std::string &path, std::vector<char> *code)
     fclose(f);
     return ok;
 }
+static void make_dirs(const std::string &dir)
+{
+    for (size_t i = 1; i <= dir.size(); ++i)
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+}
 static void cache_store(const std::string &path, const std::vector<char> &code)
 {
     if (path.empty()) return;
+    make_dirs(path.substr(0, path.rfind('/')));
     const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;                                     // a cache that cannot be written is simply not used
@@ -430,67 +475,129 @@ static void cache_store(const std::string &path, const std::vector<char> &code)
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
 }
 
-static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source)
+// ---- code objects: memory cache -> disk cache -> hiprtc ------------------------------------------------------------
+static std::mutex g_rtc_mutex;                                   // hiprtc + the memory cache
+static std::map<uint64_t, std::shared_ptr<std::vector<char>>> g_rtc_cache;
+
+static uint64_t code_key(const std::string &source, const std::string &arch)
 {
-    if (P->module && source == P->module_source) return BK_OK;
-    if (P->module) { (void)hipModuleUnload(P->module); P->module = nullptr; }
-    P->k_inverse = P->k_corners = P->k_quads = P->k_resolve = nullptr;
+    return fnv1a64(arch.data(), arch.size(), fnv1a64(source.data(), source.size()));
+}
+
+// memory / disk lookups only (cheap); empty result when the source still has to be compiled
+static CodeResult cached_code(const std::string &source, const std::string &arch)
+{
+    CodeResult r;
+    std::lock_guard<std::mutex> lock(g_rtc_mutex);
+    const bool use_mem = !getenv("BLINKY_HIP_NO_MEMCACHE");         // (tests of the disk cache switch the memory cache off)
+    auto hit = g_rtc_cache.find(code_key(source, arch));
+    if (use_mem && hit != g_rtc_cache.end()) { r.code = hit->second; return r; }
+    std::vector<char> code;
+    if (cache_load(cache_path(source, arch), &code)) {
+        r.code = std::make_shared<std::vector<char>>(std::move(code));
+        r.from_disk = true;
+        if (g_rtc_cache.size() >= 64) g_rtc_cache.clear();          // (a long session cycling through many lenses)
+        g_rtc_cache[code_key(source, arch)] = r.code;
+    }
+    return r;
+}
+
+// one compilation per (source, arch) and process: the stripe contexts of a bk_multi build the same lens side by side
+static CodeResult compile_code(const std::string &source, const std::string &arch)
+{
+    CodeResult r = cached_code(source, arch);
+    if (r.code) return r;
+    std::lock_guard<std::mutex> lock(g_rtc_mutex);
+    auto hit = g_rtc_cache.find(code_key(source, arch));
+    if (hit != g_rtc_cache.end() && !getenv("BLINKY_HIP_NO_MEMCACHE")) { r.code = hit->second; return r; }   // another thread was faster
     std::vector<const char *> hnames, htexts;
     for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) {
         hnames.push_back(bk::kEmbeddedHeaders[i].name);
         htexts.push_back(bk::kEmbeddedHeaders[i].text);
     }
-    hipDeviceProp_t prop;
-    std::string arch = "--offload-arch=gfx950";
-    if (ctx->device >= 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.gcnArchName[0])
-        arch = std::string("--offload-arch=") + prop.gcnArchName;
-    std::vector<char> code;
-    const std::string cpath = cache_path(source, arch);
-    // one compilation per (source, arch) and process: the stripe contexts of a bk_multi build the same lens side by side
-    static std::mutex rtc_mutex;
-    static std::map<uint64_t, std::shared_ptr<std::vector<char>>> rtc_cache;
-    std::lock_guard<std::mutex> rtc_lock(rtc_mutex);
-    const uint64_t mem_key = fnv1a64(arch.data(), arch.size(), fnv1a64(source.data(), source.size()));
-    auto hit = rtc_cache.find(mem_key);
-    const bool in_memory = hit != rtc_cache.end();
-    if (in_memory) code = *hit->second;
-    P->module_from_cache = !in_memory && cache_load(cpath, &code);
-    if (!in_memory && !P->module_from_cache) {
-        hiprtcProgram prog;
-        if (hiprtcCreateProgram(&prog, source.c_str(), "bk_lens_build.hip", (int)hnames.size(), htexts.data(), hnames.data()) != HIPRTC_SUCCESS)
-            return ctx->fail(BK_E_HIP, "hiprtcCreateProgram failed");
-        const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
-        hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
-        if (rc != HIPRTC_SUCCESS) {
-            size_t n = 0;
-            hiprtcGetProgramLogSize(prog, &n);
-            std::string log(n, 0);
-            if (n) hiprtcGetProgramLog(prog, &log[0]);
-            hiprtcDestroyProgram(&prog);
-            return ctx->fail(BK_E_HIP, "hiprtc failed to compile the lens kernels: %s", log.c_str());
-        }
-        size_t cs = 0;
-        hiprtcGetCodeSize(prog, &cs);
-        code.resize(cs);
-        hiprtcGetCode(prog, code.data());
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "bk_lens_build.hip", (int)hnames.size(), htexts.data(), hnames.data()) != HIPRTC_SUCCESS) {
+        r.rc = BK_E_HIP; r.log = "hiprtcCreateProgram failed";
+        return r;
+    }
+    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+    if (hiprtcCompileProgram(prog, 4, opts) != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, 0);
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
         hiprtcDestroyProgram(&prog);
-        cache_store(cpath, code);
+        r.rc = BK_E_HIP; r.log = "hiprtc failed to compile the lens kernels: " + log;
+        return r;
     }
-    if (!in_memory) {
-        if (rtc_cache.size() >= 64) rtc_cache.clear();          // (a long session cycling through many lenses)
-        rtc_cache[mem_key] = std::make_shared<std::vector<char>>(code);
-    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    r.code = std::make_shared<std::vector<char>>(cs);
+    hiprtcGetCode(prog, r.code->data());
+    hiprtcDestroyProgram(&prog);
+    cache_store(cache_path(source, arch), *r.code);
+    if (g_rtc_cache.size() >= 64) g_rtc_cache.clear();
+    g_rtc_cache[code_key(source, arch)] = r.code;
+    return r;
+}
+
+static std::string target_arch(bk_ctx *ctx)
+{
+    hipDeviceProp_t prop;
+    if (ctx->device >= 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.gcnArchName[0])
+        return std::string("--offload-arch=") + prop.gcnArchName;
+    return "--offload-arch=gfx950";
+}
+
+static int load_module(bk_ctx *ctx, LensProgram *P, const std::string &source, const CodeResult &cr)
+{
+    if (cr.rc != BK_OK) return ctx->fail(cr.rc, "%s", cr.log.c_str());
+    if (P->module) { (void)hipModuleUnload(P->module); P->module = nullptr; }
+    P->k_inverse = P->k_corners = P->k_quads = P->k_resolve = nullptr;
+    P->module_from_cache = cr.from_disk;
     if (ctx->device < 0) {              // host-only context: compiling is all we can do
         P->module_source = source;
         return BK_OK;
     }
-    BK_HIP(ctx, hipModuleLoadData(&P->module, code.data()));
+    BK_HIP(ctx, hipModuleLoadData(&P->module, cr.code->data()));
     (void)hipModuleGetFunction(&P->k_inverse, P->module, "bk_build_inverse");
     (void)hipModuleGetFunction(&P->k_corners, P->module, "bk_forward_corners");
     (void)hipModuleGetFunction(&P->k_quads, P->module, "bk_forward_quads");
     (void)hipModuleGetFunction(&P->k_resolve, P->module, "bk_forward_resolve");
     (void)hipGetLastError();
     P->module_source = source;
+    return BK_OK;
+}
+
+static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source)
+{
+    if (P->module_source == source && (P->module || ctx->device < 0)) return BK_OK;
+    return load_module(ctx, P, source, compile_code(source, target_arch(ctx)));
+}
+
+// bk_build with asynchronous compilation (bk_set_async_compile): BK_PENDING while hiprtc works on another thread
+static int compile_module_async(bk_ctx *ctx, LensProgram *P, const std::string &source)
+{
+    if (P->module_source == source && P->module) return BK_OK;
+    const std::string arch = target_arch(ctx);
+    if (P->pending.valid() && P->pending_source == source) {
+        if (P->pending.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return BK_PENDING;
+        CodeResult cr = P->pending.get();
+        P->pending_source.clear();
+        return load_module(ctx, P, source, cr);
+    }
+    CodeResult cr = cached_code(source, arch);                      // memory / disk: no reason to wait a frame
+    if (cr.code) return load_module(ctx, P, source, cr);
+    // (a compilation still running for an older source finishes on its own thread and lands in the caches)
+    P->pending_source = source;
+    P->pending = std::async(std::launch::async, [source, arch]() { return compile_code(source, arch); }).share();
+    return BK_PENDING;
+}
+
+extern "C" int bk_set_async_compile(bk_ctx *ctx, int on)
+{
+    if (!ctx) return BK_E_INVALID;
+    ctx->async_compile = on != 0;
     return BK_OK;
 }
 
@@ -770,6 +877,17 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_build: this context has no device");
     if (!ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_build: call bk_resize first");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    LensProgram *P = ctx->prog;
+    if (ctx->async_compile && P && P->lens_valid && ctx->globe_valid && P->info.map_type != BK_MAP_NONE) {
+        // a lens that still has to go through hiprtc (0.2-1.1 s): compile on another thread and leave the previous
+        // lensmap untouched until the module is there - the caller keeps drawing with it and calls bk_build again
+        std::string psrc;
+        bk::EmitRequest rq;
+        rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
+        bool emitted = true;
+        try { psrc = bk::emit_build_source(rq); } catch (const LuaError &) { emitted = false; }      // (reported by the normal path below)
+        if (emitted && compile_module_async(ctx, P, psrc) == BK_PENDING) return BK_PENDING;
+    }
     const size_t px = (size_t)ctx->W * ctx->rows();
     // F_RenderView clears the maps before (re)building, fisheye.c:731-732; whatever fails below,
     // the lensmap stays valid-and-empty so that bk_apply draws nothing, as the reference does.
@@ -783,7 +901,6 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     ctx->last_build_ms = 0;
     ctx->last_flagged = ctx->last_changed = 0;
 
-    LensProgram *P = ctx->prog;
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
     if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
     if (int r = bk_calc_zoom(ctx, scale_out)) return r;                                        /* :2376 */

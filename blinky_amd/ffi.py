@@ -24,6 +24,7 @@ MAX_PLATES = 6
 NULL_OFFSET = 0xFFFFFFFF
 DEVICE_NONE = -2
 OK = 0
+PENDING = 1
 MAP_NONE, MAP_INVERSE, MAP_FORWARD = 0, 1, 2
 ZOOM_NONE, ZOOM_FOV, ZOOM_VFOV, ZOOM_COVER, ZOOM_CONTAIN = range(5)
 
@@ -61,9 +62,12 @@ _SIGS = {
     "bk_build": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
     "bk_calc_zoom": (_i, [_vp, C.POINTER(_d)]),
     "bk_last_build_fixups": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "bk_set_cache_dir": (_i, [C.c_char_p]),
+    "bk_set_async_compile": (_i, [_vp, _i]),
     "bk_set_lensmap": (_i, [_vp, _vp, _vp]),
     "bk_read_lensmap": (_i, [_vp, _vp, _vp]),
     "bk_upload_plate": (_i, [_vp, _i, _i, _vp, _i]),
+    "bk_upload_plate_async": (_i, [_vp, _i, _i, _vp, _i]),
     "bk_globe_device_ptr": (_vp, [_vp, _i]),
     "bk_fill_plate_lcg": (_i, [_vp, _i, _i, C.c_uint32]),
     "bk_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
@@ -228,6 +232,19 @@ class Context:
         self._chk(lib.bk_build(self._h, disp, C.byref(scale)))
         return list(disp), scale.value
 
+    def set_async_compile(self, on):
+        self._chk(lib.bk_set_async_compile(self._h, int(on)))
+
+    def build_nowait(self):
+        """bk_build under bk_set_async_compile: None while the lens is still compiling, else (display, scale)"""
+        disp = (_i * MAX_PLATES)()
+        scale = _d()
+        rc = lib.bk_build(self._h, disp, C.byref(scale))
+        if rc == PENDING:
+            return None
+        self._chk(rc)
+        return list(disp), scale.value
+
     def calc_zoom(self):
         scale = _d()
         self._chk(lib.bk_calc_zoom(self._h, C.byref(scale)))
@@ -261,6 +278,10 @@ class Context:
         if pitch is None:
             pitch = src.shape[-1]
         self._chk(lib.bk_upload_plate(self._h, frame, plate, _ptr(src), pitch))
+
+    def upload_plate_async(self, frame, plate, src, pitch=None):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        self._chk(lib.bk_upload_plate_async(self._h, frame, plate, _ptr(src), src.shape[-1] if pitch is None else pitch))
 
     def globe_device_ptr(self, frame=0):
         return lib.bk_globe_device_ptr(self._h, frame)

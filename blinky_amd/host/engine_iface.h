@@ -51,7 +51,16 @@ typedef struct {                                /* include/render.h:125-141 (fie
 
 typedef void (*xcommand_t)(void);               /* include/cmd.h:76 */
 typedef enum { src_client, src_command } cmd_source_t;   /* include/cmd.h:90-95 */
-struct stree_root;
+struct rb_root { struct rb_node *rb_node; };              /* include/rb_tree.h:50-54 */
+#define QRB_ROOT (struct rb_root) { NULL, }
+struct stree_root {                                       /* include/shell.h:50-58 */
+    unsigned int entries;
+    unsigned int maxlen;
+    unsigned int minlen;
+    struct rb_root root;
+    struct stree_stack *stack;
+};
+#define STREE_ROOT (struct stree_root) { 0, 0, -1, QRB_ROOT, NULL }
 typedef struct stree_root *(*cmd_arg_f)(const char *);   /* include/cmd.h:84 */
 
 extern viddef_t vid;                            /* include/vid.h:59 */
@@ -77,6 +86,9 @@ void R_ViewChanged(vrect_t *pvrect, int lineadj, float aspect);      /* include/
 void R_SetVrect(const vrect_t *pvrectin, vrect_t *pvrect, int lineadj);   /* include/render.h:211 */
 void Draw_TileClear(int x, int y, int w, int h);                     /* include/draw.h:42 */
 void *Hunk_TempAlloc(int size);                                      /* include/zone.h:112 */
+void *Z_Malloc(int size);                                            /* include/zone.h:96 (zero-filled) */
+void STree_AllocInit(void);                                          /* include/shell.h:68 */
+void COM_ScanDir(struct stree_root *root, const char *path, const char *pfx, const char *ext, qboolean stripext);   /* include/common.h:206 */
 void COM_WriteFile(const char *filename, const void *data, int len); /* include/common.h:204 */
 void D_EnableBackBufferAccess(void);                                 /* include/d_iface.h:140 */
 void D_DisableBackBufferAccess(void);

@@ -22,7 +22,15 @@ qboolean shortcutkeys_enabled;
 double fisheye_plate_fov;
 
 /* ---- state (fisheye.c:334-528, without the buffers: those live in HBM) --------------------------- */
+/* The device side is ONE context, or - BLINKY_HIP_DEVICES="0,1,2,3" - a bk_multi that spreads the warp over several GPUs
+ * in row stripes (each GPU builds and keeps its stripe of the lensmap, holds a replica of the globe, and copies its
+ * rows of the frame straight into vid.buffer).  `bk` is the context scripts / plates are read back from: the single
+ * context, or stripe context 0. */
 static bk_ctx *bk;
+static bk_multi *mg;
+#define DEV(single, multi) (mg ? (multi) : (single))
+static const char *dev_error(void) { return mg ? bk_multi_last_error(mg) : bk_last_error(bk); }
+static int build_pending;                      /* bk_build answered BK_PENDING: the lens is compiling on another thread */
 static struct { char name[50]; qboolean valid, changed; } globe, lens;
 static struct { qboolean changed; int type, fov; } zoom;
 static struct { qboolean enabled; int numcells; double cell_size, pad_size; } rubix;
@@ -65,11 +73,11 @@ static qboolean load_lens(void)
     int rc;
     if (!bk) return false;
     src = read_script("lenses", lens.name, &len);
-    if (!src) { bk_clear_lens(bk); return false; }
+    if (!src) { DEV(bk_clear_lens(bk), bk_multi_clear_lens(mg)); return false; }
     snprintf(chunk, sizeof chunk, "%s.lua", lens.name);
-    rc = bk_load_lens(bk, src, len, chunk);
+    rc = DEV(bk_load_lens(bk, src, len, chunk), bk_multi_load_lens(mg, src, len, chunk));
     free(src);
-    if (rc != BK_OK) { Con_Printf("%s\n", bk_last_error(bk)); return false; }
+    if (rc != BK_OK) { Con_Printf("%s\n", dev_error()); return false; }
     return true;
 }
 
@@ -82,11 +90,11 @@ static qboolean load_globe(void)
     numplates = 0;
     if (!bk) return false;
     src = read_script("globes", globe.name, &len);
-    if (!src) { bk_clear_globe(bk); return false; }
+    if (!src) { DEV(bk_clear_globe(bk), bk_multi_clear_globe(mg)); return false; }
     snprintf(chunk, sizeof chunk, "%s.lua", globe.name);
-    rc = bk_load_globe(bk, src, len, chunk);
+    rc = DEV(bk_load_globe(bk, src, len, chunk), bk_multi_load_globe(mg, src, len, chunk));
     free(src);
-    if (rc != BK_OK) { Con_Printf("%s\n", bk_last_error(bk)); return false; }
+    if (rc != BK_OK) { Con_Printf("%s\n", dev_error()); return false; }
     bk_get_globe(bk, plates, &numplates);
     return true;
 }
@@ -347,15 +355,49 @@ static void cmd_globe(void)                         /* fisheye.c:1138-1161 */
     }
 }
 
+/* autocompletion for lens / globe names (fisheye.c:1105-1117, 1163-1175): the .lua files of the script directories */
+static struct stree_root *cmdarg_scripts(const char *dir, const char *arg)
+{
+    struct stree_root *root = (struct stree_root *)Z_Malloc(sizeof(struct stree_root));
+    if (root) {
+        *root = STREE_ROOT;
+        STree_AllocInit();
+        COM_ScanDir(root, dir, arg, ".lua", true);
+    }
+    return root;
+}
+static struct stree_root *cmdarg_lens(const char *arg) { return cmdarg_scripts("../lua-scripts/lenses", arg); }
+static struct stree_root *cmdarg_globe(const char *arg) { return cmdarg_scripts("../lua-scripts/globes", arg); }
+
 /* ---- public functions (engine/include/fisheye.h) ----------------------------------------------------- */
 
 void F_Init(void)                                   /* fisheye.c:642-676 */
 {
-    const char *dev = getenv("BLINKY_HIP_DEVICE");
+    const char *dev = getenv("BLINKY_HIP_DEVICE"), *devs = getenv("BLINKY_HIP_DEVICES");
+    char cache[1100];
     rubix.enabled = false;
+    /* compiled lens modules are kept next to the game data, so that only the first run of a lens waits for hiprtc */
+    if (!getenv("BLINKY_HIP_CACHE")) { snprintf(cache, sizeof cache, "%s/hipcache", com_basedir); bk_set_cache_dir(cache); }
     /* init_lua's counterpart: the script interpreter lives inside the context */
-    bk = bk_create(dev && !strcmp(dev, "none") ? BK_DEVICE_NONE : (dev ? atoi(dev) : -1));
-    if (!bk) Con_Printf("fisheye: %s\n", bk_last_error(NULL));
+    if (devs && strchr(devs, ',')) {
+        int list[16], n = 0;
+        char buf[128], *tok;
+        snprintf(buf, sizeof buf, "%s", devs);
+        for (tok = strtok(buf, ","); tok && n < 16; tok = strtok(NULL, ",")) list[n++] = atoi(tok);
+        mg = bk_create_multi(n, list);
+        if (!mg) Con_Printf("fisheye: %s\n", bk_multi_last_error(NULL));
+        else bk = bk_multi_ctx(mg, 0);
+    } else {
+        bk = bk_create(dev && !strcmp(dev, "none") ? BK_DEVICE_NONE : (dev ? atoi(dev) : (devs ? atoi(devs) : -1)));
+        if (!bk) Con_Printf("fisheye: %s\n", bk_last_error(NULL));
+    }
+    /* the first use of a lens compiles it (hiprtc, 0.2-1.1 s): do that off the render thread and keep drawing with the
+     * previous lensmap meanwhile - the reference's time-sliced builder never stalls a frame either (fisheye.c:2084-2217) */
+    if (bk && !getenv("BLINKY_HIP_SYNC_COMPILE")) {
+        int i;
+        if (mg) for (i = 0; i < bk_multi_size(mg); ++i) bk_set_async_compile(bk_multi_ctx(mg, i), 1);
+        else bk_set_async_compile(bk, 1);
+    }
 
     Cmd_AddCommand("fisheye", cmd_fisheye);
     Cmd_AddCommand("f_help", cmd_help);
@@ -367,7 +409,9 @@ void F_Init(void)                                   /* fisheye.c:642-676 */
     Cmd_AddCommand("f_fov", cmd_fov);
     Cmd_AddCommand("f_vfov", cmd_vfov);
     Cmd_AddCommand("f_lens", cmd_lens);
+    Cmd_SetCompletion("f_lens", cmdarg_lens);                        /* fisheye.c:661 */
     Cmd_AddCommand("f_globe", cmd_globe);
+    Cmd_SetCompletion("f_globe", cmdarg_globe);                      /* fisheye.c:663 */
     Cmd_AddCommand("f_saveglobe", cmd_saveglobe);
     Cmd_AddCommand("f_shortcutkeys", cmd_shortcutkeys);
 
@@ -384,7 +428,8 @@ void F_Init(void)                                   /* fisheye.c:642-676 */
 
 void F_Shutdown(void)                               /* fisheye.c:678-681 */
 {
-    bk_destroy(bk);
+    if (mg) bk_destroy_multi(mg); else bk_destroy(bk);
+    mg = NULL;
     bk = NULL;
 }
 
@@ -411,8 +456,10 @@ static void render_plate(int plate_index, vec3_t forward, vec3_t right, vec3_t u
     VectorCopy(up, r_refdef.up);
     R_PushDlights();
     R_RenderView();
-    if (bk_upload_plate(bk, 0, plate_index, VBUFFER(scr_vrect.x, scr_vrect.y), vid.rowbytes) != BK_OK)
-        Con_Printf("fisheye: %s\n", bk_last_error(bk));
+    /* pipelined: the rows go to a pinned buffer and the DMA runs while the engine renders the next plate */
+    if (DEV(bk_upload_plate_async(bk, 0, plate_index, VBUFFER(scr_vrect.x, scr_vrect.y), vid.rowbytes),
+            bk_multi_upload_plate(mg, 0, plate_index, VBUFFER(scr_vrect.x, scr_vrect.y), vid.rowbytes)) != BK_OK)
+        Con_Printf("fisheye: %s\n", dev_error());
 }
 
 void F_RenderView(void)                             /* fisheye.c:698-811 */
@@ -425,25 +472,32 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
     int i;
 
     if (!bk) return;
-    if (sizechange && bk_resize(bk, width_px, height_px) != BK_OK) {        /* fisheye.c:712-727; no exit(1) */
-        Con_Printf("Quake-Lenses: %s\n", bk_last_error(bk));
+    if (sizechange && DEV(bk_resize(bk, width_px, height_px), bk_multi_resize(mg, width_px, height_px)) != BK_OK) {   /* fisheye.c:712-727; no exit(1) */
+        Con_Printf("Quake-Lenses: %s\n", dev_error());
         return;
     }
-    if (sizechange || zoom.changed || lens.changed || globe.changed) {      /* fisheye.c:730-743 */
-        int rc;
-        /* the lens is loaded again so that variables depending on the globe (numplates) are fresh */
-        lens.valid = lens.name[0] ? load_lens() : false;
-        if (!lens.name[0]) bk_clear_lens(bk);
-        if (!lens.valid) {
-            strcpy(lens.name, "");
-            Con_Printf("not a valid lens\n");
+    if (sizechange || zoom.changed || lens.changed || globe.changed || build_pending) {      /* fisheye.c:730-743 */
+        int rc, newdisplay[BK_MAX_PLATES];
+        if (!build_pending || sizechange || zoom.changed || lens.changed || globe.changed) {
+            /* the lens is loaded again so that variables depending on the globe (numplates) are fresh */
+            lens.valid = lens.name[0] ? load_lens() : false;
+            if (!lens.name[0]) DEV(bk_clear_lens(bk), bk_multi_clear_lens(mg));
+            if (!lens.valid) {
+                strcpy(lens.name, "");
+                Con_Printf("not a valid lens\n");
+            }
+            DEV(bk_set_zoom(bk, zoom.type, zoom.fov), bk_multi_set_zoom(mg, zoom.type, zoom.fov));
+            DEV(bk_set_rubixgrid(bk, rubix.numcells, rubix.cell_size, rubix.pad_size),
+                bk_multi_set_rubixgrid(mg, rubix.numcells, rubix.cell_size, rubix.pad_size));
         }
-        bk_set_zoom(bk, zoom.type, zoom.fov);
-        bk_set_rubixgrid(bk, rubix.numcells, rubix.cell_size, rubix.pad_size);
-        for (i = 0; i < BK_MAX_PLATES; ++i) display[i] = 0;
-        rc = bk_build(bk, display, NULL);                                   /* create_lensmap, fisheye.c:2367-2397 */
-        lensmap_ok = rc == BK_OK;
-        if (rc != BK_OK && lens.valid && globe.valid) Con_Printf("%s\n", bk_last_error(bk));
+        for (i = 0; i < BK_MAX_PLATES; ++i) newdisplay[i] = 0;
+        rc = DEV(bk_build(bk, newdisplay, NULL), bk_multi_build(mg, newdisplay, NULL));      /* create_lensmap, fisheye.c:2367-2397 */
+        build_pending = rc == BK_PENDING;
+        if (!build_pending) {                    /* (while the new lens compiles the previous lensmap and its plates stay) */
+            for (i = 0; i < BK_MAX_PLATES; ++i) display[i] = newdisplay[i];
+            lensmap_ok = rc == BK_OK;
+            if (rc != BK_OK && lens.valid && globe.valid) Con_Printf("%s\n", dev_error());
+        }
     }
 
     AngleVectors(r_refdef.viewangles, forward, right, up);                  /* fisheye.c:750 */
@@ -476,8 +530,9 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
 
     Draw_TileClear(0, 0, vid.width, vid.height);                             /* fisheye.c:802 */
     /* render_lensmap, fisheye.c:2406-2424 */
-    if (bk_apply(bk, 0, vid.buffer, vid.rowbytes, scr_vrect.x, scr_vrect.y, rubix.enabled, palettes) != BK_OK && lensmap_ok)
-        Con_Printf("fisheye: %s\n", bk_last_error(bk));
+    if (DEV(bk_apply(bk, 0, vid.buffer, vid.rowbytes, scr_vrect.x, scr_vrect.y, rubix.enabled, palettes),
+            bk_multi_apply(mg, 0, vid.buffer, vid.rowbytes, scr_vrect.x, scr_vrect.y, rubix.enabled, palettes)) != BK_OK && lensmap_ok)
+        Con_Printf("fisheye: %s\n", dev_error());
 
     pwidth = width_px;
     pheight = height_px;

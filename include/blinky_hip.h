@@ -35,6 +35,7 @@ extern "C" {
 #define BK_DEVICE_NONE  (-2)          /* bk_create: host-only context (scripts, zoom, code generation) */
 
 enum {
+    BK_PENDING = 1,        /* bk_build with bk_set_async_compile: the lens is still compiling, call again later */
     BK_OK = 0,
     BK_E_INVALID = -1,     /* bad argument / call order */
     BK_E_HIP = -2,         /* HIP runtime or hiprtc failure (message has the detail) */
@@ -112,6 +113,15 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * script that accumulates state from one pixel to the next does not behave as in the reference's sequential scan. */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
 int bk_calc_zoom(bk_ctx *ctx, double *scale_out);                                   /* calc_zoom only */
+/* Lens modules are compiled with hiprtc on first use (0.2-1.1 s per lens) and kept (a) in the process and (b) on disk:
+ * bk_set_cache_dir(dir) / $BLINKY_HIP_CACHE / $XDG_CACHE_HOME/blinky_hip / $HOME/.cache/blinky_hip, in that order
+ * ("" or "off" disables the disk cache); a code object is keyed by generated source, embedded headers, GPU arch and
+ * library version.  With bk_set_async_compile(ctx, 1) a bk_build that would have to wait for hiprtc starts the
+ * compilation on another thread, returns BK_PENDING and leaves the previous lensmap (and display flags) in place,
+ * so a render loop keeps drawing - the reference's time-sliced builder never stalls the game either
+ * (fisheye.c:2084-2217) - and calls bk_build again on a later frame. */
+int bk_set_cache_dir(const char *dir);
+int bk_set_async_compile(bk_ctx *ctx, int on);
 /* Exactness bookkeeping of the last bk_build.  The kernels evaluate the scripts' transcendentals with a portable
  * libm; the reference's Lua VM calls the platform's.  Every value on the device carries a bound on that
  * discrepancy, and each pixel / texel corner whose DISCRETE outcome (a float narrowing, a comparison, a floor)
@@ -127,6 +137,10 @@ int bk_read_lensmap(bk_ctx *ctx, uint32_t *offsets, uint8_t *tints);
  * bk_upload_plate replaces render_plate's row memcpy loop (fisheye.c:2441-2449):
  * ps rows of ps bytes from src (pitch src_pitch) into plate `plate` of globe `frame`. */
 int   bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch);
+/* the same, pipelined: the rows are copied into a pinned staging buffer (render_plate's memcpy) and the DMA and the
+ * re-tiling are only enqueued on the context's stream, so that the caller renders the next plate meanwhile; src may be
+ * reused as soon as the call returns.  Three staging slots: the call waits only for the upload three calls ago. */
+int   bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const uint8_t *src, int src_pitch);
 /* the way back (the plate copy cmd_saveglobe reads, fisheye.c:1396-1465): ps rows of ps bytes to dst_host */
 int   bk_download_plate(bk_ctx *ctx, int frame, int plate, uint8_t *dst_host, int dst_pitch);
 /* the plate image f_saveglobe encodes (WritePCXplate's pixel loop, fisheye.c:1438-1456): texel, or 0xFE where
@@ -246,10 +260,8 @@ int         bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesi
 const char *bk_version(void);
 /* selects the apply kernel: 0 = direct gather, 2 = workgroup-cooperative LDS staging (default) */
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
-/* Lens modules are compiled with hiprtc on first use (0.2-1.1 s per lens).  Setting the environment variable
- * BLINKY_HIP_CACHE=<directory> keeps the compiled code objects there (keyed by generated source, embedded
- * headers, GPU arch and library version) so that later runs load them in milliseconds.
- * bk_debug_module_from_cache: 1 if the current module was loaded from that cache (test hook). */
+/* bk_debug_module_from_cache: 1 if the current module was loaded from the disk cache (test hook; BLINKY_HIP_NO_MEMCACHE
+ * in the environment bypasses the in-process cache so that the disk path can be observed). */
 int         bk_debug_module_from_cache(const bk_ctx *ctx);
 /* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
  * pipelining); results are wrong while bits 2/4 are set.  0 restores normal operation. */

@@ -49,7 +49,62 @@ static struct { const char *name; xcommand_t fn; } cmds[MAX_CMDS];
 static int ncmds, argc_;
 static char argbuf[1024], *argv_[16];
 void Cmd_AddCommand(const char *cmd_name, xcommand_t function) { cmds[ncmds].name = cmd_name; cmds[ncmds].fn = function; ncmds++; }
-void Cmd_SetCompletion(const char *cmd_name, cmd_arg_f completion) { (void)cmd_name; (void)completion; }
+/* tab completion: the registered callbacks are kept and can be invoked by the tests; COM_ScanDir lists <basedir>/<path
+ * without the leading "../"> like the engine's (which scans relative to the game directory, a child of the base dir) */
+static struct { const char *name; cmd_arg_f fn; } completions[8];
+static int ncompletions;
+static char scan_result[4096];
+void Cmd_SetCompletion(const char *cmd_name, cmd_arg_f completion)
+{
+    if (ncompletions < 8) { completions[ncompletions].name = cmd_name; completions[ncompletions].fn = completion; ncompletions++; }
+}
+void *Z_Malloc(int size) { return calloc(1, (size_t)size); }
+void STree_AllocInit(void) {}
+#include <dirent.h>
+static int cmp_str(const void *a, const void *b) { return strcmp(*(const char *const *)a, *(const char *const *)b); }
+void COM_ScanDir(struct stree_root *root, const char *path, const char *pfx, const char *ext, qboolean stripext)
+{
+    char dirpath[1200], *names[256];
+    DIR *d;
+    struct dirent *e;
+    int n = 0, i;
+    size_t el = strlen(ext), pl = pfx ? strlen(pfx) : 0;
+    snprintf(dirpath, sizeof dirpath, "%s/%s", com_basedir, strncmp(path, "../", 3) ? path : path + 3);
+    scan_result[0] = 0;
+    d = opendir(dirpath);
+    if (!d) return;
+    while ((e = readdir(d)) && n < 256) {
+        size_t l = strlen(e->d_name);
+        if (l <= el || strcmp(e->d_name + l - el, ext)) continue;
+        if (pl && strncmp(e->d_name, pfx, pl)) continue;
+        names[n] = strdup(e->d_name);
+        if (stripext) names[n][l - el] = 0;
+        n++;
+    }
+    closedir(d);
+    qsort(names, (size_t)n, sizeof names[0], cmp_str);
+    for (i = 0; i < n; ++i) {
+        strncat(scan_result, names[i], sizeof scan_result - strlen(scan_result) - 2);
+        strcat(scan_result, " ");
+        if (strlen(names[i]) > root->maxlen) root->maxlen = (unsigned)strlen(names[i]);
+        root->entries++;
+        free(names[i]);
+    }
+}
+/* the completions of `cmd <arg>`: space-separated names, -1 if the command has no completion callback */
+int hosttest_complete(const char *cmd, const char *arg, char *out, int cap)
+{
+    int i;
+    for (i = 0; i < ncompletions; ++i)
+        if (!strcmp(completions[i].name, cmd)) {
+            struct stree_root *r = completions[i].fn(arg);
+            int n = r ? (int)r->entries : -1;
+            snprintf(out, (size_t)cap, "%s", scan_result);
+            free(r);
+            return n;
+        }
+    return -1;
+}
 int Cmd_Argc(void) { return argc_; }
 const char *Cmd_Argv(int arg) { return arg < argc_ ? argv_[arg] : ""; }
 void Cmd_ExecuteString(const char *text, cmd_source_t src)

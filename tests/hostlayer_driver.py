@@ -1,0 +1,146 @@
+"""Scenarios for tests/test_host_layer.py, each run in a process of its own (the C host layer, like fisheye.c, keeps its
+state in file-scope statics):   python tests/hostlayer_driver.py <scenario> <basedir>
+frames   - whole F_RenderView frames through libhosttest.so compared byte for byte with the oracle (single context, or
+           several stripe contexts when BLINKY_HIP_DEVICES lists more than one device)
+async    - with asynchronous lens compilation (the default) no frame waits for hiprtc: the previous lensmap keeps being
+           drawn until the new module is ready
+complete - tab completion of f_lens / f_globe"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [ROOT, HERE]
+HOSTLIB = os.path.join(HERE, "host", "libhosttest.so")
+
+
+def load():
+    h = C.CDLL(HOSTLIB)
+    h.hosttest_console.restype = C.c_char_p
+    h.hosttest_plate_fov.restype = C.c_double
+    return h
+
+
+def render(h, O, globe, lens, zoom, W, H, x0, y0, extra, rubix=False, bg=7, fidx=2, pal=None, order_of=None):
+    """one F_RenderView; returns (frame as rendered, the oracle's frame, plates the host rendered, seconds)"""
+    lm = O.lensmap(globe, lens, zoom, W, H)
+    olm = O.lensmap(*order_of) if order_of else lm               # whose display[] decides which plates get painted
+    h.hosttest_resize(W, H, x0, y0, extra)
+    order = [i for i, d in enumerate(olm.display) if d]
+    arr = (C.c_int * len(order))(*order)
+    pitch, vh = h.hosttest_rowbytes(), h.hosttest_vidheight()
+    out = np.zeros((vh, pitch), np.uint8)
+    t0 = time.perf_counter()
+    n = h.hosttest_frame(arr, len(order), fidx, bg, out.ctypes.data_as(C.c_void_p))
+    dt = time.perf_counter() - t0
+    want = np.full((vh, pitch), bg, np.uint8)
+    # Draw_TileClear repaints [0,vid.width) x [0,vid.height); the plate renders are overwritten by it
+    O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, lm.numplates, fidx), want, pitch, x0, y0, rubix, pal)
+    return out[:, : pitch - extra], want[:, : pitch - extra], n, len(order), dt, lm
+
+
+def scenario_frames(base):
+    import blinky_amd  # noqa: F401  (loads torch's HIP runtime before libblinkyhip, see blinky_amd/ffi.py)
+    import oracle_ffi as O
+    os.environ["BLINKY_HIP_SYNC_COMPILE"] = "1"
+    h = load()
+    assert h.hosttest_init(base.encode()) == 1, h.hosttest_console().decode()
+    pal = O.palmap(O.synthetic_basepal())
+
+    def frame(*a, **kw):
+        got, want, n, nwant, _, lm = render(h, O, *a, pal=pal, **kw)
+        assert n == nwant, "the host must render exactly the plates the lensmap uses (display[])"
+        np.testing.assert_array_equal(got, want)
+        return lm
+
+    # defaults of F_Init: cube / panini / f_fov 180
+    frame("cube", "panini", None, 320, 200, 8, 4, 16)
+    assert abs(h.hosttest_plate_fov(0) - float(O.globe_plates("cube")[0][9])) == 0     # fisheye_plate_fov = plate fov
+    h.hosttest_cmd(b"f_rubix")                  # same lens, rubix overlay on
+    frame("cube", "panini", None, 320, 200, 8, 4, 16, rubix=True)
+    h.hosttest_cmd(b"f_rubix")
+    # a lens whose onload changes the zoom, another globe, a resize, an odd origin
+    h.hosttest_cmd(b"f_globe trism")
+    h.hosttest_cmd(b"f_lens hammer")
+    frame("trism", "hammer", None, 322, 203, 3, 1, 5)
+    h.hosttest_cmd(b"f_fov 150")
+    frame("trism", "hammer", "f_fov 150", 322, 203, 3, 1, 5)
+    h.hosttest_cmd(b"f_globe cube")             # forward-only lens
+    h.hosttest_cmd(b"f_lens eckert5")
+    frame("cube", "eckert5", None, 200, 120, 0, 0, 0)
+    # an invalid lens blanks the view (fisheye.c:737-741, 2372): only the cleared background remains
+    h.hosttest_console_clear()
+    h.hosttest_cmd(b"f_lens doesnotexist")
+    h.hosttest_resize(200, 120, 0, 0, 0)
+    out = np.zeros((h.hosttest_vidheight(), h.hosttest_rowbytes()), np.uint8)
+    h.hosttest_frame((C.c_int * 1)(0), 0, 0, 9, out.ctypes.data_as(C.c_void_p))
+    assert (out == 9).all()
+    assert "not a valid lens" in h.hosttest_console().decode()
+    h.hosttest_shutdown()
+    print("frames ok")
+
+
+def scenario_async(base):
+    import blinky_amd  # noqa: F401
+    import oracle_ffi as O
+    os.environ.pop("BLINKY_HIP_SYNC_COMPILE", None)
+    os.environ["BLINKY_HIP_CACHE"] = os.path.join(base, "fresh-cache")     # nothing compiled yet
+    h = load()
+    assert h.hosttest_init(base.encode()) == 1, h.hosttest_console().decode()
+    W, H = 2040, 1200                          # the engine's largest mode (MAXWIDTH x MAXHEIGHT)
+    worst, pending_frames = 0.0, 0
+    # panini compiles in the background: until it is ready nothing is drawn (there is no previous lensmap), then it appears
+    t0 = time.perf_counter()
+    while True:
+        got, want, n, nwant, dt, _ = render(h, O, "cube", "panini", None, W, H, 0, 0, 0)
+        worst = max(worst, dt)
+        if np.array_equal(got, want):
+            break
+        assert (got == 7).all(), "while the first lens compiles only the cleared background may be shown"
+        pending_frames += 1
+        assert time.perf_counter() - t0 < 120
+    first_ready = time.perf_counter() - t0
+    # now switch lens: the frames in between keep showing panini, then hammer takes over
+    h.hosttest_cmd(b"f_lens hammer")
+    shown_old = 0
+    t0 = time.perf_counter()
+    while True:
+        got, want_old, _, _, dt, _ = render(h, O, "cube", "panini", None, W, H, 0, 0, 0)
+        worst = max(worst, dt)
+        if np.array_equal(got, want_old):
+            shown_old += 1
+            assert time.perf_counter() - t0 < 120
+            continue
+        got, want_new, n, nwant, dt, _ = render(h, O, "cube", "hammer", None, W, H, 0, 0, 0)
+        worst = max(worst, dt)
+        np.testing.assert_array_equal(got, want_new)
+        assert n == nwant
+        break
+    h.hosttest_shutdown()
+    print(f"async ok: {pending_frames} blank frames while panini compiled ({first_ready * 1e3:.0f} ms), {shown_old} panini frames while "
+          f"hammer compiled, slowest F_RenderView {worst * 1e3:.1f} ms")
+    assert pending_frames >= 1 and shown_old >= 1, "hiprtc was expected to take longer than one frame"
+    assert worst < 0.25, f"a frame stalled for {worst * 1e3:.0f} ms"
+
+
+def scenario_complete(base):
+    os.environ["BLINKY_HIP_DEVICE"] = "none"
+    h = load()
+    h.hosttest_init(base.encode())
+    buf = C.create_string_buffer(4096)
+    n = h.hosttest_complete(b"f_lens", b"pa", buf, 4096)
+    assert (n, buf.value.decode().split()) == (1, ["panini"]), (n, buf.value)
+    n = h.hosttest_complete(b"f_lens", b"e", buf, 4096)
+    assert buf.value.decode().split() == ["eckert1", "eckert4", "eckert5", "equirect"]
+    n = h.hosttest_complete(b"f_globe", b"", buf, 4096)
+    assert (n, buf.value.decode().split()) == (6, ["cube", "cube_corner", "cube_edge", "fast", "tetra", "trism"]), buf.value
+    assert h.hosttest_complete(b"f_fov", b"", buf, 4096) == -1       # no completion registered for other commands
+    print("complete ok")
+
+
+if __name__ == "__main__":
+    {"frames": scenario_frames, "async": scenario_async, "complete": scenario_complete}[sys.argv[1]](sys.argv[2])

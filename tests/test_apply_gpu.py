@@ -123,6 +123,27 @@ def test_upload_download_plate_round_trip(bk):
     ctx.close()
 
 
+def test_pipelined_plate_uploads_equal_the_blocking_ones(bk):
+    """bk_upload_plate_async: the caller's buffer is free again when the call returns (the engine renders the next plate
+    into the same vid.buffer), three staging slots rotate, and the globe ends up byte-identical"""
+    ps, pitch = 200, 264
+    ctx = bk.Context()
+    ctx.set_frames(2)
+    ctx.resize(320, ps)
+    rng = np.random.default_rng(12)
+    plates = rng.integers(0, 256, (2, 6, ps, pitch), dtype=np.uint8)
+    scratch = np.empty((ps, pitch), np.uint8)                   # one buffer reused for every upload, like vid.buffer
+    for f in range(2):
+        for p in range(6):
+            scratch[:] = plates[f, p]
+            ctx.upload_plate_async(f, p, scratch, pitch)
+            scratch[:] = 0xEE                                   # overwritten right away
+    for f in range(2):
+        for p in range(6):
+            np.testing.assert_array_equal(ctx.download_plate(f, p), plates[f, p, :, :ps])
+    ctx.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_apply_device_batch_distinct_globes(bk, variant):
     """One launch warps a batch of frames, frame f from resident globe (frame0+f) % nframes."""

@@ -225,6 +225,7 @@ def test_globe_plate_override_fast_globe(bk):
 def test_module_cache_round_trip_builds_the_same_table(bk, tmp_path, monkeypatch):
     """a lens module loaded back from BLINKY_HIP_CACHE builds the identical lensmap"""
     monkeypatch.setenv("BLINKY_HIP_CACHE", str(tmp_path))
+    monkeypatch.setenv("BLINKY_HIP_NO_MEMCACHE", "1")          # (otherwise the second context is served from the process' own cache)
     tables = []
     for i in range(2):
         ctx = bk.Context()
@@ -235,6 +236,35 @@ def test_module_cache_round_trip_builds_the_same_table(bk, tmp_path, monkeypatch
         ctx.close()
     np.testing.assert_array_equal(tables[0][0], tables[1][0])
     np.testing.assert_array_equal(tables[0][1], tables[1][1])
+
+
+def test_async_compile_answers_pending_and_keeps_the_previous_lensmap(bk, tmp_path, monkeypatch):
+    """bk_set_async_compile: a lens that still has to go through hiprtc makes bk_build return BK_PENDING at once and leaves
+    the previous lensmap in place; a later call finds the module and builds."""
+    import time
+    monkeypatch.setenv("BLINKY_HIP_CACHE", str(tmp_path))
+    ctx = bk.Context()
+    S.configure(ctx, "cube", "panini", None, (320, 240))
+    ctx.build()
+    before = ctx.read_lensmap()[0].copy()
+    ctx.set_async_compile(True)
+    # a lens nobody has compiled yet in this process or on disk: the constant below ends up in the generated kernel
+    unique = 1.0 + (int(time.time() * 1e6) % 100000) * 1e-9
+    ctx.load_lens(f"lens_width = 4 lens_height = 3 function lens_inverse(x,y) local k = {unique!r} "
+                  "return latlon_to_ray(y * k * 0.5, x * k * 0.5) end", "unique.lua")
+    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN)
+    t0 = time.perf_counter()
+    assert ctx.build_nowait() is None
+    assert time.perf_counter() - t0 < 0.1                       # it did not wait for hiprtc
+    np.testing.assert_array_equal(ctx.read_lensmap()[0], before)    # the old table is still what bk_apply would use
+    deadline = time.time() + 120
+    while (res := ctx.build_nowait()) is None:
+        assert time.time() < deadline
+        time.sleep(0.01)
+    display, scale = res
+    assert scale == 4 / 320
+    assert not np.array_equal(ctx.read_lensmap()[0], before)
+    ctx.close()
 
 
 def test_script_runtime_errors_surface_as_errors(bk):

@@ -72,56 +72,35 @@ def test_console_commands_and_config_without_gpu(tmp_path):
     assert '[engine] bind 1 "f_lens panini"' in con and '[engine] bind p "f_globe fast"' in con
 
 
-@pytest.mark.gpu
-def test_full_frames_through_the_c_host_layer(tmp_path):
-    import blinky_amd  # noqa: F401  (loads torch's HIP runtime before libblinkyhip, see blinky_amd/ffi.py)
-    import oracle_ffi as O
+def run_scenario(name, tmp_path, env=None, timeout=900):
     build_hostlib()
     base = game_dir(tmp_path)
-    h = C.CDLL(HOSTLIB)
-    h.hosttest_console.restype = C.c_char_p
-    h.hosttest_plate_fov.restype = C.c_double
-    assert h.hosttest_init(base.encode()) == 1, h.hosttest_console().decode()
-    pal = O.palmap(O.synthetic_basepal())
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostlayer_driver.py"), name, base], env=e,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
 
-    def frame(globe, lens, zoom, W, H, x0, y0, extra, rubix=False, bg=7, fidx=2):
-        lm = O.lensmap(globe, lens, zoom, W, H)
-        h.hosttest_resize(W, H, x0, y0, extra)
-        order = [i for i, d in enumerate(lm.display) if d]
-        arr = (C.c_int * len(order))(*order)
-        pitch, vh = h.hosttest_rowbytes(), h.hosttest_vidheight()
-        out = np.zeros((vh, pitch), np.uint8)
-        n = h.hosttest_frame(arr, len(order), fidx, bg, out.ctypes.data_as(C.c_void_p))
-        assert n == len(order), "the host must render exactly the plates the lensmap uses (display[])"
-        want = np.full((vh, pitch), bg, np.uint8)
-        # Draw_TileClear repaints [0,vid.width) x [0,vid.height); the plate renders are overwritten by it
-        O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, lm.numplates, fidx), want, pitch, x0, y0, rubix, pal)
-        np.testing.assert_array_equal(out[:, : pitch - extra], want[:, : pitch - extra])
-        return lm
 
-    # defaults of F_Init: cube / panini / f_fov 180
-    lm = frame("cube", "panini", None, 320, 200, 8, 4, 16)
-    assert abs(h.hosttest_plate_fov(0) - float(O.globe_plates("cube")[0][9])) == 0     # fisheye_plate_fov = plate fov
-    # same lens, rubix overlay on
-    h.hosttest_cmd(b"f_rubix")
-    frame("cube", "panini", None, 320, 200, 8, 4, 16, rubix=True)
-    h.hosttest_cmd(b"f_rubix")
-    # a lens whose onload changes the zoom, another globe, a resize, an odd origin
-    h.hosttest_cmd(b"f_globe trism")
-    h.hosttest_cmd(b"f_lens hammer")
-    frame("trism", "hammer", None, 322, 203, 3, 1, 5)
-    h.hosttest_cmd(b"f_fov 150")
-    frame("trism", "hammer", "f_fov 150", 322, 203, 3, 1, 5)
-    # forward-only lens
-    h.hosttest_cmd(b"f_globe cube")
-    h.hosttest_cmd(b"f_lens eckert5")
-    frame("cube", "eckert5", None, 200, 120, 0, 0, 0)
-    # an invalid lens blanks the view (fisheye.c:737-741, 2372): only the cleared background remains
-    h.hosttest_console_clear()
-    h.hosttest_cmd(b"f_lens doesnotexist")
-    h.hosttest_resize(200, 120, 0, 0, 0)
-    out = np.zeros((h.hosttest_vidheight(), h.hosttest_rowbytes()), np.uint8)
-    h.hosttest_frame((C.c_int * 1)(0), 0, 0, 9, out.ctypes.data_as(C.c_void_p))
-    assert (out == 9).all()
-    assert "not a valid lens" in h.hosttest_console().decode()
-    h.hosttest_shutdown()
+def test_tab_completion_of_lens_and_globe_names(tmp_path):
+    """Cmd_SetCompletion("f_lens" / "f_globe", ...) (fisheye.c:661-663, 1105-1117, 1163-1175)"""
+    assert "complete ok" in run_scenario("complete", tmp_path)
+
+
+@pytest.mark.gpu
+def test_full_frames_through_the_c_host_layer(tmp_path):
+    assert "frames ok" in run_scenario("frames", tmp_path)
+
+
+@pytest.mark.gpu
+def test_full_frames_with_the_warp_spread_over_three_stripe_contexts(tmp_path):
+    """BLINKY_HIP_DEVICES=0,0,0: F_RenderView through bk_multi (three stripe contexts on the one GPU)"""
+    assert "frames ok" in run_scenario("frames", tmp_path, {"BLINKY_HIP_DEVICES": "0,0,0"})
+
+
+@pytest.mark.gpu
+def test_no_frame_waits_for_hiprtc(tmp_path):
+    """asynchronous lens compilation (default in the host layer): the render loop never stalls on `f_lens`"""
+    out = run_scenario("async", tmp_path)
+    assert "async ok" in out
