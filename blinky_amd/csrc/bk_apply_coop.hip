@@ -38,6 +38,10 @@ constexpr int BK_COOP_LDS_CAP = 65536;                 // max bytes of the stagi
 constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
 constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's rows of the block fully mapped / empty
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
+// how the block's per-pixel LDS addresses are stored (coop_compile_kernel picks the most compact form that can hold them):
+// raw = one u16 per pixel; LANE8 = one u16 base per lane (its 4*RG consecutive pixels) + one u8 offset per pixel;
+// GROUP8 = one u16 base per 4 pixels + one u8 offset per pixel.  Offset 255 = unmapped.  1.125 / 1.5 instead of 2 B/px.
+constexpr uint32_t CF_FMT_LANE8 = 0x400, CF_FMT_GROUP8 = 0x800;
 constexpr uint32_t BK_COOP_BINS = 65;                  // LDS-need histogram: 1 KiB bins, 0..64 KiB
 constexpr int BK_COOP_STATS = 208;                     // words per stats replica
 
@@ -49,10 +53,11 @@ struct CoopHdr {              // 8 bytes per block
 struct CoopMap {
     CoopHdr *d_hdr = nullptr;
     uint32_t *d_list = nullptr;     // [nblocks][256*4*RG] byte offsets (16-byte aligned) into a globe frame, ascending
-    uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][64 lanes][4] LDS addresses, 0xFFFF = unmapped
+    uint16_t *d_idx = nullptr;      // [nblocks][1024*RG u16]: per block the LDS addresses in one of three forms (CF_FMT_*), 0xFFFF = unmapped
     uint8_t *d_tint = nullptr;      // same order (rubix)
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
-                                    // [3] 128-B lines staged, [4] chunks staged, [8..73) blocks by LDS need (1 KiB bins),
+                                    // [3] 128-B lines staged, [4] chunks staged, [5] bytes of pixel addresses as stored, [6] LANE8 blocks,
+                                    // [7] GROUP8 blocks, [8..73) blocks by LDS need (1 KiB bins),
                                     // [73..138) 128-B lines of those blocks, [138..203) chunks of those blocks
     int blocks_x = 0, blocks_y = 0;
     int rg = 4;
@@ -160,15 +165,18 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     __syncthreads();
 
     // every pixel: slot of its chunk (binary search in the unique list) -> 16-bit LDS address
+    uint32_t a[RG][4];
+    uint32_t lmin = 0xFFFFu, lmax = 0u;                 // over this lane's mapped pixels
+    bool groups_fit = true;
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
-        uint32_t a[4], tw = 0;
+        uint32_t gmin = 0xFFFFu, gmax = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = r * 4 + k;
-            a[k] = 0xFFFFu;
+            a[r][k] = 0xFFFFu;
             if (o[i] != BK_NULL_OFFSET) {
-                a[k] = 0;
+                a[r][k] = 0;
                 if (!slow) {
                     const uint32_t c = o[i] >> 4;
                     uint32_t lo = 0, hi = nchunks;              // first slot with uniq[slot] >= c
@@ -176,21 +184,62 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
                         const uint32_t mid = (lo + hi) >> 1;
                         if (uniq[mid] < c) lo = mid + 1; else hi = mid;
                     }
-                    a[k] = lo * 16u + (o[i] & 15u);
+                    a[r][k] = lo * 16u + (o[i] & 15u);
                 }
+                gmin = min(gmin, a[r][k]); gmax = max(gmax, a[r][k]);
             }
-            tw |= (uint32_t)tn[i] << (8 * k);
         }
-        const size_t slab = (((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4;
-        *reinterpret_cast<uint2 *>(idx + slab) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
-        *reinterpret_cast<uint32_t *>(tint_t + slab) = tw;
+        groups_fit = groups_fit && (gmax <= gmin || gmax - gmin <= 254u);
+        lmin = min(lmin, gmin); lmax = max(lmax, gmax);
+    }
+    const bool lane_fits = lmax <= lmin || lmax - lmin <= 254u;
+    const bool all_lanes = __syncthreads_and(lane_fits) != 0, all_groups = __syncthreads_and(groups_fit) != 0;
+    const uint32_t fmt = slow ? 0u : all_lanes ? CF_FMT_LANE8 : all_groups ? CF_FMT_GROUP8 : 0u;
+    {
+        uint16_t *ib = idx + (size_t)blk * N;
+        uint8_t *ob = reinterpret_cast<uint8_t *>(ib);
+        if (fmt == CF_FMT_LANE8) {
+            const uint32_t base = lmin == 0xFFFFu ? 0u : lmin;
+            ib[wave * 64 + lane] = (uint16_t)base;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w |= (a[r][k] == 0xFFFFu ? 255u : a[r][k] - base) << (8 * k);
+                *reinterpret_cast<uint32_t *>(ob + 512 + (size_t)((wave * RG + r) * 64 + lane) * 4) = w;
+            }
+        } else if (fmt == CF_FMT_GROUP8) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                uint32_t base = 0xFFFFu, w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) base = min(base, a[r][k]);
+                if (base == 0xFFFFu) base = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w |= (a[r][k] == 0xFFFFu ? 255u : a[r][k] - base) << (8 * k);
+                ib[(wave * RG + r) * 64 + lane] = (uint16_t)base;
+                *reinterpret_cast<uint32_t *>(ob + N / 2 + (size_t)((wave * RG + r) * 64 + lane) * 4) = w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                *reinterpret_cast<uint2 *>(ib + ((size_t)(wave * RG + r) * 256 + (size_t)lane * 4)) =
+                    make_uint2(a[r][0] | (a[r][1] << 16), a[r][2] | (a[r][3] << 16));
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            uint32_t tw = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tw |= (uint32_t)tn[r * 4 + k] << (8 * k);
+            *reinterpret_cast<uint32_t *>(tint_t + ((((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4)) = tw;
+        }
     }
     if (threadIdx.x == 0) {
         const uint32_t wflags = s_flags;
         const bool any_blk = nchunks != 0;
         CoopHdr h;
         h.nchunks = slow ? 0u : nchunks;
-        h.flags = wflags | (slow ? CF_SLOW : 0u) | (any_blk ? 0u : CF_EMPTY);
+        h.flags = wflags | (slow ? CF_SLOW : 0u) | (any_blk ? 0u : CF_EMPTY) | fmt;
         hdr[blk] = h;
         uint32_t *st = stats + (blk & 63) * BK_COOP_STATS;
         if (!slow && any_blk) {
@@ -201,6 +250,11 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
             atomicAdd(&st[8 + 2 * BK_COOP_BINS + bin], nchunks);
             atomicAdd(&st[3], lines);
             atomicAdd(&st[4], nchunks);
+        }
+        if (any_blk) {
+            atomicAdd(&st[5], fmt == CF_FMT_LANE8 ? 512u + N : fmt == CF_FMT_GROUP8 ? N / 2u + N : 2u * N);      // bytes
+            if (fmt == CF_FMT_LANE8) atomicAdd(&st[6], 1u);
+            if (fmt == CF_FMT_GROUP8) atomicAdd(&st[7], 1u);
         }
         if (slow) atomicAdd(&st[1], 1u);
         if (!any_blk) atomicAdd(&st[2], 1u);
@@ -216,18 +270,33 @@ struct CoopIdx {              // a lane's LDS addresses (two 16-bit per dword) a
     uint32_t t4[RG];
 };
 // What a thread fetches ahead for its workgroup's NEXT block: the header (a vector load, so that it
-// is tracked by vmcnt like everything else), its first four chunk-list entries, its LDS indices.
+// is tracked by vmcnt like everything else) and its first four chunk-list entries.  The per-pixel LDS addresses are
+// loaded by coop_block once the header says which form they are stored in; they are not needed before the first
+// gather, so that load rides behind the globe loads instead of in front of them.
 template <int RG>
 struct CoopPrefetch {
     uint2 h;
     uint32_t c[4];
-    CoopIdx<RG> ix;
 };
 
+// Launch order of the blocks: position l of the walk -> block number (row-major by * blocks_x + bx, which is how the
+// block map is stored).  Patches of 8 block rows are walked column by column, so that the workgroups in flight at any
+// moment - consecutive positions - cover a compact 2-D region of the screen: the globe lines that vertically
+// neighbouring blocks share (1.3-1.4x of the distinct lines are staged, summed over blocks) are then requested close
+// together in time and meet in L2 instead of going to HBM twice.  Ablation bit 16 restores the row-major walk.
+__device__ __forceinline__ int bk_block_at(int l, int blocks_x, int nblocks, int kflags)
+{
+    if (kflags & 16) return l;
+    constexpr int PH = 8;
+    const int blocks_y = nblocks / blocks_x, per_patch = PH * blocks_x;
+    const int srow = l / per_patch, rem = l - srow * per_patch;
+    const int tall = min(PH, blocks_y - srow * PH);
+    const int col = rem / tall, row = rem - col * tall;
+    return (srow * PH + row) * blocks_x + col;
+}
+
 template <bool RUBIX, int RG>
-__device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list,
-                                                      const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
-                                                      int blk, int wave, int lane)
+__device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list, int blk)
 {
     constexpr int N = 1024 * RG;
     CoopPrefetch<RG> p;
@@ -237,15 +306,50 @@ __device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict
     const uint32_t *lp = list + (size_t)blk * N + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) p.c[j] = 256 * j < N ? lp[256 * j] : 0u;
+    return p;
+}
+
+// the block's per-pixel LDS addresses (and tints), expanded from whichever form they are stored in
+template <bool RUBIX, int RG>
+__device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t, int blk,
+                                                     uint32_t flags, int wave, int lane)
+{
+    constexpr int N = 1024 * RG;
+    CoopIdx<RG> ix;
+    const uint16_t *ib = idx + (size_t)blk * N;
+    const uint8_t *ob = reinterpret_cast<const uint8_t *>(ib);
     // (non-temporal loads of the list / indices were measured: slower, single frames by 25 % - between launches
     // they are served from L2 / Infinity Cache)
+    auto expand = [](uint32_t base, uint32_t w) {
+        const uint32_t o0 = w & 0xFFu, o1 = (w >> 8) & 0xFFu, o2 = (w >> 16) & 0xFFu, o3 = w >> 24;
+        const uint32_t a0 = o0 == 255u ? 0xFFFFu : base + o0, a1 = o1 == 255u ? 0xFFFFu : base + o1;
+        const uint32_t a2 = o2 == 255u ? 0xFFFFu : base + o2, a3 = o3 == 255u ? 0xFFFFu : base + o3;
+        return make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+    };
+    if (flags & CF_FMT_LANE8) {
+        const uint32_t base = ib[wave * 64 + lane];
+        uint32_t w[RG];
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-        const size_t slab = (((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4;
-        p.ix.iw[r] = *reinterpret_cast<const uint2 *>(idx + slab);
-        p.ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + slab) : 0xFFFFFFFFu;
+        for (int r = 0; r < RG; ++r) w[r] = *reinterpret_cast<const uint32_t *>(ob + 512 + (size_t)((wave * RG + r) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) ix.iw[r] = expand(base, w[r]);
+    } else if (flags & CF_FMT_GROUP8) {
+        uint32_t base[RG], w[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            base[r] = ib[(wave * RG + r) * 64 + lane];
+            w[r] = *reinterpret_cast<const uint32_t *>(ob + N / 2 + (size_t)((wave * RG + r) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) ix.iw[r] = expand(base[r], w[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) ix.iw[r] = *reinterpret_cast<const uint2 *>(ib + ((size_t)(wave * RG + r) * 256 + (size_t)lane * 4));
     }
-    return p;
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+        ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + ((((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4)) : 0xFFFFFFFFu;
+    return ix;
 }
 
 // Frames of one staged block.  A thread's first four chunks (16 KiB per block) are in registers;
@@ -447,9 +551,12 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
     }
 }
 
-// everything a workgroup does for one block: `cur` holds the block's header, list head and indices
+__device__ __forceinline__ int lane_of() { return (int)(threadIdx.x & 63u); }
+
+// everything a workgroup does for one block: `cur` holds the block's header and list head
 template <bool RUBIX, int RG>
 __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, const uint32_t *__restrict__ list,
+                                           const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
                                            const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
                                            int globe_frames, int frame0, int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch,
                                            size_t frame_stride, int W, int rows, int blocks_x, uint8_t *smem, int lds_buf,
@@ -462,14 +569,16 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     const int by = l / blocks_x, bx = l - by * blocks_x;
     const int row0 = by * 8 * RG + ry, x = bx * 128 + cx * 4 * RG;
     const bool tile_all = (flags >> wave) & 1u, tile_empty = (flags >> (4 + wave)) & 1u;
+    // the pixel addresses, in the form the header names: issued here, consumed at the first gather
+    const CoopIdx<RG> ix = coop_load_idx<RUBIX, RG>(idx, tint_t, l, flags, wave, lane_of());
     if (flags & CF_SLOW) {
         if (!tile_empty)
             coop_slow_frames<RUBIX, RG>(lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch,
-                                        frame_stride, W, rows, cur.ix, pal_s, row0, x);
+                                        frame_stride, W, rows, ix, pal_s, row0, x);
     } else if ((int)(nchunks * 16u) > lds_buf) {
         // a chunk list larger than this launch's staging buffer goes through it in passes
         coop_frames_multipass<RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
-                                         smem, (uint32_t)lds_buf, list + (size_t)l * N, nchunks, cur.ix, tile_all && aligned,
+                                         smem, (uint32_t)lds_buf, list + (size_t)l * N, nchunks, ix, tile_all && aligned,
                                          tile_empty, pal_s, row0, x);
     } else {
         const bool k0 = threadIdx.x < nchunks, k1 = threadIdx.x + 256u < nchunks, k2 = threadIdx.x + 512u < nchunks,
@@ -479,7 +588,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
         const uint32_t nq = (nchunks + 255u) >> 8;
 #define BK_COOP(NQ_) coop_frames<NQ_, RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, smem, \
                                                 list + (size_t)l * N, nchunks, s0, s1, s2, s3, k0, k1, k2, k3,                    \
-                                                cur.ix, fast_store, tile_empty, pal_s, row0, x, kflags)
+                                                ix, fast_store, tile_empty, pal_s, row0, x, kflags)
         if (nq <= 1) BK_COOP(1);
         else if (nq == 2) BK_COOP(2);
         else if (nq == 3) BK_COOP(3);
@@ -520,14 +629,14 @@ template <bool RUBIX, int RG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
-    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l, wave, lane);
+    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l, blocks_x, nblocks, kflags));
     for (;;) {
         const int l_next = l + wgs_per_band;
         const bool has_next = l_next < l_end;
         CoopPrefetch<RG> nxt = cur;
-        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l_next, wave, lane);
-        coop_block<RUBIX, RG>(cur, l, list, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
-                              W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
+        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l_next, blocks_x, nblocks, kflags));
+        coop_block<RUBIX, RG>(cur, bk_block_at(l, blocks_x, nblocks, kflags), list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
+                              dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
         if (!has_next) break;
         l = l_next;
         cur = nxt;
@@ -541,9 +650,9 @@ __global__ __launch_bounds__(256) void apply_coop_once_kernel(BK_COOP_KERNEL_ARG
 {
     BK_COOP_PROLOGUE;
     (void)wgs_per_band;
-    const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, idx, tint_t, l, wave, lane);
-    coop_block<RUBIX, RG>(cur, l, list, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
-                          W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
+    const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l, blocks_x, nblocks, kflags));
+    coop_block<RUBIX, RG>(cur, bk_block_at(l, blocks_x, nblocks, kflags), list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
+                          dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -736,7 +845,8 @@ __global__ __launch_bounds__(256) void count_bits_kernel(const uint32_t *__restr
 // out[3] bytes of block map read per block visit, summed over blocks: headers + chunk lists + 16-bit pixel addresses
 //        (a visit serves up to out[5] frames)            out[4] mapped pixels = bytes stored per frame
 // out[5] frames per block visit                          out[6] blocks        out[7] block height in pixels
-int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8])
+// out[8] / out[9] blocks stored in the LANE8 / GROUP8 address form
+int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[10])
 {
     if (int r = ensure_coopmap(ctx)) return r;
     CoopMap *cm = ctx->coopmap;
@@ -762,11 +872,14 @@ int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8])
     out[0] = h[1];
     out[1] = cm->stats[3];
     out[2] = cm->stats[4];
-    out[3] = nblocks * sizeof(CoopHdr) + (uint64_t)cm->stats[4] * 4u + live * (uint64_t)(1024 * cm->rg) * 2u;
+    (void)live;
+    out[3] = nblocks * sizeof(CoopHdr) + (uint64_t)cm->stats[4] * 4u + (uint64_t)cm->stats[5];
     out[4] = h[0];
     out[5] = 8;
     out[6] = nblocks;
     out[7] = (uint64_t)(8 * cm->rg);
+    out[8] = cm->stats[6];                      // blocks whose pixel addresses are stored as lane base + byte offsets
+    out[9] = cm->stats[7];                      // ... as 4-pixel group base + byte offsets (the rest: raw 16-bit)
     return BK_OK;
 }
 

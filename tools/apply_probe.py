@@ -51,6 +51,10 @@ for v, abl, shp, wg, fc, kb in [(v, a, sh, wg, fc, kb) for v in variants for sh 
         ctx.set_tile_shape(300 + fc)
         ctx.set_tile_shape(400 + kb)
         print(f"shape {shp} ablation {abl} wgs/cu {wg} fchunk {fc} ldskb {kb}; tile stats:", ctx.tile_stats(), flush=True)
+        if os.environ.get("BK_MODEL"):
+            m = ctx.traffic_model()
+            print(f"   model: unique lines {m['unique_globe_lines']} ({m['unique_globe_lines'] * 128 / 1e6:.1f} MB/frame), staged lines {m['staged_lines']} "
+                  f"(x{m['staged_lines'] / max(1, m['unique_globe_lines']):.2f}), mapped px {m['mapped_pixels']}, block map {m['blockmap_bytes_per_visit'] / 1e6:.1f} MB/visit", flush=True)
     for nf in sorted(set([1, F])):
         for _ in range(3):
             ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)
@@ -59,7 +63,7 @@ for v, abl, shp, wg, fc, kb in [(v, a, sh, wg, fc, kb) for v in variants for sh 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for r in range(reps):
-            ctx.apply_device(out.data_ptr(), W, 0 if SAMEOUT else H * W, (r * nf) % F, nf)
+            ctx.apply_device(out.data_ptr(), W, 0 if SAMEOUT else H * W, (r * nf) % RING, nf)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
