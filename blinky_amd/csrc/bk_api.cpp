@@ -277,7 +277,7 @@ extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
     return bk::coopmap_stats(ctx, out);
 }
 
-extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[10])
+extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8])
 {
     if (!ctx || !out) return BK_E_INVALID;
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "no lensmap");

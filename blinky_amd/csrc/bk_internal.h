@@ -129,7 +129,7 @@ void coopmap_invalidate(bk_ctx *ctx);
 int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,
                       size_t frame_stride, int rubix_on);
 int coopmap_stats(bk_ctx *ctx, int out[6]);   // blocks, direct-gather blocks, empty blocks, LDS bytes per buffer
-int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[10]);
+int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8]);
 void coopmap_free(CoopMap *);
 
 // bk_lens.cpp

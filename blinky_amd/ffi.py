@@ -331,11 +331,10 @@ class Context:
         return off, tin
 
     def traffic_model(self):
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 8)()
         self._chk(lib.bk_debug_traffic_model(self._h, out))
         return dict(unique_globe_lines=out[0], staged_lines=out[1], staged_chunks=out[2], blockmap_bytes_per_visit=out[3],
-                    mapped_pixels=out[4], frames_per_visit=out[5], blocks=out[6], block_height=out[7],
-                    blocks_lane8=out[8], blocks_group8=out[9])
+                    mapped_pixels=out[4], frames_per_visit=out[5], blocks=out[6], block_height=out[7])
 
     def set_tile_shape(self, lw):
         self._chk(lib.bk_debug_set_tile_shape(self._h, lw))

@@ -272,9 +272,8 @@ int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
 /* What the staged apply has to move for the current lensmap (bench.py's compulsory-traffic roofline):
  * out = {distinct 128-byte globe lines the owned rows read per frame, lines staged per frame summed over blocks,
  * 16-byte chunks staged per frame, bytes of block map read per block visit summed over blocks, mapped pixels
- * (= bytes stored per frame), frames served per block visit, blocks, block height in pixels, blocks whose pixel
- * addresses are stored as u16 lane base + u8 offsets, blocks stored as u16 base per 4 pixels + u8 offsets} */
-int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[10]);
+ * (= bytes stored per frame), frames served per block visit, blocks, block height in pixels} */
+int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8]);
 /* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
  * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);

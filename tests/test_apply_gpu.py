@@ -123,30 +123,6 @@ def test_upload_download_plate_round_trip(bk):
     ctx.close()
 
 
-def test_block_map_uses_the_compact_address_forms(bk):
-    """coop_compile_kernel stores a block's per-pixel LDS addresses in the most compact form that holds them: a magnifying
-    lens (panini) fits one u16 base per lane + byte offsets, a minifying one (hammer) mostly one base per 4 pixels, and an
-    arbitrary table falls back to raw 16-bit addresses - all three byte-exact (the parity tests above run on them)."""
-    import scripts as S
-    want = {"panini": "blocks_lane8", "hammer": "blocks_group8"}
-    for lens, key in want.items():
-        ctx = bk.Context()
-        S.configure(ctx, "cube", lens, None, (1920, 1080))
-        ctx.build()
-        m = ctx.traffic_model()
-        live = m["blocks"] - ctx.tile_stats()["empty"]
-        assert m[key] + (m["blocks_lane8"] if key == "blocks_group8" else 0) >= 0.9 * live, (lens, m)
-        assert m["blockmap_bytes_per_visit"] < 1.8 * m["mapped_pixels"] + 4 * m["staged_chunks"] + 8 * m["blocks"]
-        ctx.close()
-    lm = O.lensmap("cube", "panini", None, 640, 480)
-    rng = np.random.default_rng(3)
-    ctx = make_ctx(bk, lm)
-    ctx.set_lensmap(rng.permutation(lm.offsets), lm.tints)          # scrambled: addresses all over every block
-    m = ctx.traffic_model()
-    assert m["blocks_lane8"] == 0 and m["blocks_group8"] == 0
-    ctx.close()
-
-
 def test_pipelined_plate_uploads_equal_the_blocking_ones(bk):
     """bk_upload_plate_async: the caller's buffer is free again when the call returns (the engine renders the next plate
     into the same vid.buffer), three staging slots rotate, and the globe ends up byte-identical"""
