@@ -416,7 +416,7 @@ extern "C" int bk_set_cache_dir(const char *dir)
 {
     std::lock_guard<std::mutex> lock(g_cache_dir_mutex);
     g_cache_dir = dir ? dir : "";
-    g_cache_dir_set = true;
+    g_cache_dir_set = dir != nullptr;              // NULL: back to the environment / default location
     return BK_OK;
 }
 

@@ -120,7 +120,7 @@ int bk_calc_zoom(bk_ctx *ctx, double *scale_out);                               
  * compilation on another thread, returns BK_PENDING and leaves the previous lensmap (and display flags) in place,
  * so a render loop keeps drawing - the reference's time-sliced builder never stalls the game either
  * (fisheye.c:2084-2217) - and calls bk_build again on a later frame. */
-int bk_set_cache_dir(const char *dir);
+int bk_set_cache_dir(const char *dir);        /* process-wide; NULL returns to the environment / default location */
 int bk_set_async_compile(bk_ctx *ctx, int on);
 /* Exactness bookkeeping of the last bk_build.  The kernels evaluate the scripts' transcendentals with a portable
  * libm; the reference's Lua VM calls the platform's.  Every value on the device carries a bound on that

@@ -137,7 +137,10 @@ typedef struct {
 typedef struct {
     int numplates;
     double forward[OK_MAX_PLATES][3], up[OK_MAX_PLATES][3], fov_deg[OK_MAX_PLATES];
+    ok_globe_plate_fn globe_plate;       /* NULL unless the globe script defines globe_plate (globes/fast.lua) */
 } ok_globe_def;
+/* what a script's chunk can see while it runs: the registered C functions and `numplates` (fisheye.c:1670-1671) */
+void ok_set_script_env(const ok_host *host, int numplates);
 int  ok_find_lens(const char *name, ok_lens_def *d);
 int  ok_find_globe(const char *name, ok_globe_def *g);
 /* Returns 1 if known. */

@@ -33,6 +33,7 @@
 #define cosh bkm_cosh
 #define tanh bkm_tanh
 #define exp bkm_exp
+#define log bkm_log
 #endif
 static double (*volatile lua_pow)(double, double) = pow;
 static double (*volatile lua_sqrt)(double) = sqrt;
@@ -52,6 +53,8 @@ static double (*volatile lua_sinh)(double) = sinh;
 static double (*volatile lua_cosh)(double) = cosh;
 static double (*volatile lua_tanh)(double) = tanh;
 static double (*volatile lua_exp)(double) = exp;
+static double (*volatile lua_log)(double) = log;
+#undef log
 #undef sin
 #undef cos
 #undef tan
@@ -77,6 +80,7 @@ static double (*volatile lua_exp)(double) = exp;
 #define cosh lua_cosh
 #define tanh lua_tanh
 #define exp lua_exp
+#define log lua_log
 #define sqrt lua_sqrt
 
 /* The three C functions a script may call (fisheye.c:1257-1264) are reached
@@ -299,6 +303,316 @@ static int quincuncial_inverse(void *ud, double x, double y, double ray[3])     
     return q_inverse_intermediate(ud, x0, y0, ray);
 }
 
+
+/* =====================================================================================================
+ * Further scripts, transliterated the same way (Lua 5.2 evaluation order, one libm call per math.xxx).
+ * Together with the five above they pin 16 lenses and 4 globes against the unmodified reference
+ * independently of the product's Lua front-end.
+ * ===================================================================================================== */
+#define H_PLATE_TO_RAY(ud, plate, u, v, out) ((const ok_host *)(ud))->plate_to_ray(((const ok_host *)(ud))->ctx, plate, u, v, out)
+
+/* the host a script's CHUNK sees while it runs (lens_width = 2*lens_forward(latlon_to_ray(...)) in winkeltripel.lua):
+ * set by whoever "runs" the script (ok_use_lens, oracle/ref/ref_scripts.c) before ok_find_lens */
+static const ok_host *load_host;
+static int load_numplates;
+void ok_set_script_env(const ok_host *host, int numplates) { load_host = host; load_numplates = numplates; }
+
+/* ---- rectilinear.lua ---------------------------------------------------------------------------------- */
+static int rectilinear_inverse(void *ud, double x, double y, double ray[3])
+{
+    double r = sqrt(x * x + y * y);                         /* :8 */
+    double theta = atan(r);                                 /* :10 */
+    double s = sin(theta);                                  /* :12 */
+    (void)ud;
+    ray[0] = x / r * s; ray[1] = y / r * s; ray[2] = cos(theta);   /* :13 */
+    return 1;
+}
+static int rectilinear_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double theta = acos(z);                                 /* :17 */
+    double r = tan(theta);                                  /* :19 */
+    double c = r / sqrt(x * x + y * y);                     /* :21 */
+    (void)ud;
+    *ox = x * c; *oy = y * c;                               /* :22 */
+    return 1;
+}
+
+/* ---- equirect.lua --------------------------------------------------------------------------------------- */
+static int equirect_inverse(void *ud, double x, double y, double ray[3])
+{
+    if (fabs(y) > LUA_PI / 2 || fabs(x) > LUA_PI) return 0;     /* :10-12 */
+    H_LATLON_TO_RAY(ud, y, x, ray);                         /* :13-15 */
+    return 1;
+}
+static int equirect_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);               /* :19 */
+    *ox = lon; *oy = lat;                                   /* :20-22 */
+    return 1;
+}
+
+/* ---- mercator.lua ----------------------------------------------------------------------------------------- */
+static int mercator_inverse(void *ud, double x, double y, double ray[3])
+{
+    double lon, lat;
+    if (fabs(x) > LUA_PI) return 0;                         /* :13-15 */
+    lon = x;
+    lat = atan(sinh(y));                                    /* :17 */
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+static int mercator_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon;
+    *oy = log(tan(LUA_PI * 0.25 + lat * 0.5));              /* :25 */
+    return 1;
+}
+
+/* ---- cylinder.lua ------------------------------------------------------------------------------------------- */
+static int cylinder_inverse(void *ud, double x, double y, double ray[3])
+{
+    if (fabs(x) > LUA_PI) return 0;                         /* :9-11 */
+    H_LATLON_TO_RAY(ud, atan(y), x, ray);                   /* :12-14 */
+    return 1;
+}
+static int cylinder_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon; *oy = tan(lat);                              /* :19-21 */
+    return 1;
+}
+
+/* ---- miller.lua ----------------------------------------------------------------------------------------------- */
+static double miller_maxy;
+static int miller_inverse(void *ud, double x, double y, double ray[3])
+{
+    double lat;
+    if (fabs(y) > miller_maxy || fabs(x) > LUA_PI) return 0;    /* :12-14 */
+    lat = 5.0 / 4 * atan(sinh(4.0 / 5 * y));                /* :16 */
+    H_LATLON_TO_RAY(ud, lat, x, ray);
+    return 1;
+}
+static int miller_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon;
+    *oy = 1.25 * log(tan(0.25 * LUA_PI + 0.4 * lat));       /* :23 */
+    return 1;
+}
+
+/* ---- fisheye1.lua ------------------------------------------------------------------------------------------------ */
+static int fisheye1_inverse(void *ud, double x, double y, double ray[3])
+{
+    double r = sqrt(x * x + y * y), theta, s;               /* :10 */
+    (void)ud;
+    if (r > LUA_PI) return 0;                               /* :12-14 */
+    theta = r;
+    s = sin(theta);                                         /* :17 */
+    ray[0] = x / r * s; ray[1] = y / r * s; ray[2] = cos(theta);   /* :18 */
+    return 1;
+}
+static int fisheye1_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double theta = acos(z), r = theta, c = r / sqrt(x * x + y * y);   /* :22-26 */
+    (void)ud;
+    *ox = x * c; *oy = y * c;
+    return 1;
+}
+
+/* ---- cubestereo.lua ------------------------------------------------------------------------------------------------- */
+static int cubestereo_inverse(void *ud, double x, double y, double ray[3])
+{
+    double rx, ry, rz, magx = fabs(x), magy = fabs(y), z = 2, len;      /* :27-31 */
+    (void)ud;
+    if (magx <= 1 && magy <= 1) { rx = x; ry = y; rz = z - 1; }           /* :33-36 */
+    else if (magx > magy) { rx = x / magx; ry = y / magx; rz = z / magx - 1; }   /* :37-40 */
+    else { rx = x / magy; ry = y / magy; rz = z / magy - 1; }             /* :41-45 */
+    len = sqrt(rx * rx + ry * ry + rz * rz);                            /* :47 */
+    ray[0] = rx / len; ray[1] = ry / len; ray[2] = rz / len;            /* :48 */
+    return 1;
+}
+static int cubestereo_forward(void *ud, double rx, double ry, double rz, double *ox, double *oy)
+{
+    double magx = fabs(rx), magy = fabs(ry), magz = fabs(rz), mag = magz, x, y, z;   /* projectcube :7-19 */
+    (void)ud;
+    if (magx >= magy && magx >= magz) mag = magx;
+    else if (magy >= magx && magy >= magz) mag = magy;
+    x = rx / mag; y = ry / mag; z = rz / mag;
+    *ox = x / (z + 1) * 2; *oy = y / (z + 1) * 2;                       /* :23 */
+    return 1;
+}
+
+/* ---- mollweide.lua ---------------------------------------------------------------------------------------------------- */
+static double moll_root2;
+static int mollweide_inverse(void *ud, double x, double y, double ray[3])
+{
+    double t, lon, lat;
+    if (x * x / 8 + y * y / 2 > 1) return 0;                /* :22-24 */
+    t = asin(y / moll_root2);                               /* :25 */
+    lon = LUA_PI * x / (2 * moll_root2 * cos(t));           /* :26 */
+    lat = asin((2 * t + sin(2 * t)) / LUA_PI);              /* :27 */
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+static double moll_solveTheta(double lat)                   /* :11-19 */
+{
+    double t = lat, dt;
+    long guard = 0;
+    do {
+        dt = -(t + sin(t) - LUA_PI * sin(lat)) / (1 + cos(t));
+        t = t + dt;
+    } while (!(dt < 0.001) && ++guard < 100000000L);
+    return t / 2;
+}
+static int mollweide_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon, t;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    t = moll_solveTheta(lat);                               /* :33 */
+    *ox = 2 * sqrt(2) / LUA_PI * lon * cos(t);              /* :34 */
+    *oy = sqrt(2) * sin(t);                                 /* :35 */
+    return 1;
+}
+
+/* ---- eckert4.lua: lens_inverse keeps a per-row cache in script globals (lasty, maxx), carried from pixel to pixel ---- */
+static double eck4_maxy, eck4_maxx, eck4_lasty;
+static int eck4_lasty_set;
+static double eck4_solveTheta(double lat)                   /* :2-12 */
+{
+    double t = lat / 2, dt = 0;
+    int i;
+    for (i = 1; i <= 20; ++i) {
+        dt = -(t + sin(t) * cos(t) + 2 * sin(t) - (2 + LUA_PI * 0.5) * sin(lat)) / (2 * cos(t) * (1 + cos(t)));
+        t = t + dt;
+    }
+    return t;
+}
+static double eck4_get_max_x(double y, double lat)          /* :14-21 */
+{
+    if (!eck4_lasty_set || y != eck4_lasty) {
+        double t = eck4_solveTheta(fabs(lat));
+        eck4_maxx = 2 / sqrt(LUA_PI * (4 + LUA_PI)) * LUA_PI * (1 + cos(t));
+        eck4_lasty = y;
+        eck4_lasty_set = 1;
+    }
+    return eck4_maxx;
+}
+static int eckert4_inverse(void *ud, double x, double y, double ray[3])
+{
+    double t = asin(y / 2 * sqrt((4 + LUA_PI) / LUA_PI));                                /* :24 */
+    double lat = asin((t + sin(t) * cos(t) + 2 * sin(t)) / (2 + LUA_PI * 0.5));          /* :25 */
+    double lon = sqrt(LUA_PI * (4 + LUA_PI)) * x / (2 * (1 + cos(t)));                   /* :26 */
+    if (fabs(y) > eck4_maxy || fabs(x) > eck4_get_max_x(y, lat)) return 0;               /* :28-30 (`or` short-circuits) */
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+static int eckert4_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon, t;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    t = eck4_solveTheta(lat);                                                            /* :36 */
+    *ox = 2 / sqrt(LUA_PI * (4 + LUA_PI)) * lon * (1 + cos(t));                          /* :37 */
+    *oy = 2 * sqrt(LUA_PI / (4 + LUA_PI)) * sin(t);                                      /* :38 */
+    return 1;
+}
+
+/* ---- winkeltripel.lua --------------------------------------------------------------------------------------------------- */
+static double wt_clat0, wt_lens_height, wt_artifact_x, wt_artifact_y;
+static int winkeltripel_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon, clat, temp, D, C;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);               /* :10 */
+    clat = cos(lat);                                        /* :11 */
+    temp = clat * cos(lon * 0.5);                           /* :12 */
+    D = acos(temp);                                         /* :13 */
+    C = 1 - temp * temp;                                    /* :14 */
+    temp = D / sqrt(C);                                     /* :15 */
+    *ox = 0.5 * (2 * temp * clat * sin(lon * 0.5) + lon * wt_clat0);   /* :17 */
+    *oy = 0.5 * (temp * sin(lat) + lat);                    /* :18 */
+    return 1;
+}
+static int winkeltripel_inverse(void *ud, double x, double y, double ray[3])
+{
+    double lambda, phi, eps, halfpi, edge[3], x0, y0;
+    int iter;
+    if (fabs(y) >= wt_lens_height / 2) return 0;            /* :27-29 */
+    if (fabs(x) > wt_artifact_x && fabs(y) > wt_artifact_y) return 0;   /* :30-32, 97-99 */
+    lambda = x; phi = y;
+    eps = 0.0001;                                           /* :36 */
+    halfpi = LUA_PI / 2;                                    /* :37 */
+    for (iter = 1; iter <= 25; ++iter) {                    /* :39-74 */
+        double cosphi = cos(phi), sinphi = sin(phi), sin_2phi = sin(2 * phi);
+        double sin2phi = sinphi * sinphi, cos2phi = cosphi * cosphi;
+        double sinlambda = sin(lambda), coslambda_2 = cos(lambda / 2), sinlambda_2 = sin(lambda / 2);
+        double sin2lambda_2 = sinlambda_2 * sinlambda_2;
+        double C = 1 - cos2phi * coslambda_2 * coslambda_2;
+        double E, F, fx, fy, sigxsiglambda, sigxsigphi, sigysiglambda, sigysigphi, denominator, siglambda, sigphi;
+        if (C != 0) {
+            F = 1 / C;
+            E = acos(cosphi * coslambda_2) * sqrt(F);
+        } else {
+            E = 0;
+            F = 0;
+        }
+        fx = .5 * (2 * E * cosphi * sinlambda_2 + lambda / halfpi) - x;
+        fy = .5 * (E * sinphi + phi) - y;
+        sigxsiglambda = .5 * F * (cos2phi * sin2lambda_2 + E * cosphi * coslambda_2 * sin2phi) + .5 / halfpi;
+        sigxsigphi = F * (sinlambda * sin_2phi / 4 - E * sinphi * sinlambda_2);
+        sigysiglambda = .125 * F * (sin_2phi * sinlambda_2 - E * sinphi * cos2phi * sinlambda);
+        sigysigphi = .5 * F * (sin2phi * coslambda_2 + E * sin2lambda_2 * cosphi) + .5;
+        denominator = sigxsigphi * sigysiglambda - sigysigphi * sigxsiglambda;
+        siglambda = (fy * sigxsigphi - fx * sigysigphi) / denominator;
+        sigphi = (fx * sigysiglambda - fy * sigxsiglambda) / denominator;
+        lambda = lambda - siglambda;
+        phi = phi - sigphi;
+        if (fabs(siglambda) < eps && fabs(sigphi) < eps) break;
+    }
+    H_LATLON_TO_RAY(ud, phi, LUA_PI, edge);                 /* :77: x0,y0 = lens_forward(latlon_to_ray(lat, pi)) */
+    winkeltripel_forward(ud, edge[0], edge[1], edge[2], &x0, &y0);
+    if (fabs(x) < fabs(x0)) {                               /* :78-80 */
+        H_LATLON_TO_RAY(ud, phi, lambda, ray);
+        return 1;
+    }
+    return 0;
+}
+
+/* ---- debug.lua: one cell per plate, through plate_to_ray ------------------------------------------------------------------ */
+static int dbg_rows, dbg_cols[2];
+static int debug_inverse(void *ud, double x, double y, double ray[3])
+{
+    double ny = -y + dbg_rows / 2.0, r, v, nx, c, u, plate, rowcols;      /* row(y) :31-38 */
+    int i;
+    v = modf(ny, &r);
+    if (ny < 0 || ny >= dbg_rows) return 0;                 /* r == nil -> return nil :41-44 */
+    rowcols = dbg_cols[(int)r];                             /* cols[r+1] */
+    nx = x + rowcols / 2;                                   /* col(rowcols, x) :22-29 */
+    u = modf(nx, &c);
+    if (nx < 0 || nx >= rowcols) return 0;
+    plate = c;
+    for (i = 0; i < r; ++i) plate = plate + dbg_cols[i];    /* :50-54 */
+    return H_PLATE_TO_RAY(ud, plate, u, v, ray) ? 1 : 0;    /* plate_to_ray returns nil for a plate out of range */
+}
+
+/* ---- globes/fast.lua: globe_plate override ----------------------------------------------------------------------------------- */
+static int fast_globe_plate(void *ud, double x, double y, double z, int *plate)
+{
+    const double big_fov = 160;
+    double dist, size, u, v;
+    (void)ud;
+    if (z <= 0) return 0;                                   /* :11-13 */
+    dist = 0.5 / tan(big_fov * LUA_PI / 180 / 2);           /* :15 */
+    size = 2 * dist * tan(LUA_PI / 4);                      /* :16 */
+    u = x / z * dist;                                       /* :18 */
+    v = y / z * dist;                                       /* :19 */
+    *plate = (fabs(u) < size / 2 && fabs(v) < size / 2) ? 0 : 1;   /* :22-26 small / big */
+    return 1;
+}
+
 /* ---- registry ---------------------------------------------------------------- */
 
 static void lens_globals(const char *name, ok_lens_def *d)
@@ -327,6 +641,72 @@ static void lens_globals(const char *name, ok_lens_def *d)
         d->max_fov = 360; d->max_vfov = 180;
         d->width = LUA_PI * 2;                              /* eckert5.lua:5-6 */
         d->height = LUA_PI;
+    } else if (!strcmp(name, "rectilinear")) {
+        d->inverse = rectilinear_inverse; d->forward = rectilinear_forward;
+        d->max_fov = 180; d->max_vfov = 180; d->onload = "f_fov 110";
+    } else if (!strcmp(name, "equirect")) {
+        d->inverse = equirect_inverse; d->forward = equirect_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 2 * LUA_PI; d->height = LUA_PI;
+    } else if (!strcmp(name, "mercator")) {
+        d->inverse = mercator_inverse; d->forward = mercator_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_cover";
+        d->width = 2 * LUA_PI;
+    } else if (!strcmp(name, "cylinder")) {
+        d->inverse = cylinder_inverse; d->forward = cylinder_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_cover";
+        d->width = 2 * LUA_PI;
+    } else if (!strcmp(name, "miller")) {
+        miller_maxy = 1.25 * log(tan(0.25 * LUA_PI + 0.4 * LUA_PI * 0.5));      /* miller.lua:1 */
+        d->inverse = miller_inverse; d->forward = miller_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 2 * LUA_PI; d->height = miller_maxy * 2;
+    } else if (!strcmp(name, "fisheye1")) {
+        d->inverse = fisheye1_inverse; d->forward = fisheye1_forward;
+        d->max_fov = 360; d->max_vfov = 360; d->onload = "f_contain";
+        d->width = 2 * LUA_PI; d->height = 2 * LUA_PI;
+    } else if (!strcmp(name, "cubestereo")) {
+        d->inverse = cubestereo_inverse; d->forward = cubestereo_forward;
+        d->max_fov = 270; d->max_vfov = 270; d->onload = "f_fov 180";
+    } else if (!strcmp(name, "mollweide")) {
+        moll_root2 = lua_sqrt(2);                           /* mollweide.lua:1 */
+        d->inverse = mollweide_inverse; d->forward = mollweide_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 2 * lua_sqrt(2) * 2; d->height = lua_sqrt(2) * 2;            /* :6-7 */
+    } else if (!strcmp(name, "eckert4")) {
+        double t = eck4_solveTheta(LUA_PI * 0.5);           /* eckert4.lua:41-42 */
+        eck4_maxy = 2 * sqrt(LUA_PI / (4 + LUA_PI)) * sin(t);
+        eck4_lasty_set = 0;                                 /* (lasty, maxx: nil until the first pixel) */
+        t = eck4_solveTheta(0);                             /* :47 */
+        d->inverse = eckert4_inverse; d->forward = eckert4_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 2 / sqrt(LUA_PI * (4 + LUA_PI)) * LUA_PI * (1 + cos(t)) * 2;  /* :48 */
+        d->height = 2 * eck4_maxy;                          /* :49 */
+    } else if (!strcmp(name, "winkeltripel")) {
+        double r3[3], fx = 0, fy = 0;
+        wt_clat0 = 2 / LUA_PI;                              /* winkeltripel.lua:2 */
+        d->inverse = winkeltripel_inverse; d->forward = winkeltripel_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        if (load_host) {                                    /* :84-88: the chunk calls lens_forward(latlon_to_ray(...)) */
+            load_host->latlon_to_ray(load_host->ctx, LUA_PI / 2, 0, r3);
+            winkeltripel_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+            d->height = 2 * fy;
+            load_host->latlon_to_ray(load_host->ctx, 0, LUA_PI, r3);
+            winkeltripel_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+            d->width = 2 * fx;
+        }
+        wt_lens_height = d->height;
+        wt_artifact_x = d->width / 2 * 0.71;                /* :93-94 */
+        wt_artifact_y = d->height / 2 * 0.81;
+    } else if (!strcmp(name, "debug")) {
+        int n = load_numplates, maxcols;                    /* debug.lua:1-15 */
+        if (n == 4) { dbg_rows = 2; dbg_cols[0] = 2; dbg_cols[1] = 2; }
+        else if (n == 5) { dbg_rows = 2; dbg_cols[0] = 3; dbg_cols[1] = 2; }
+        else if (n == 6) { dbg_rows = 2; dbg_cols[0] = 3; dbg_cols[1] = 3; }
+        else { dbg_rows = 1; dbg_cols[0] = n; dbg_cols[1] = 0; }
+        maxcols = dbg_cols[0] > dbg_cols[1] || dbg_rows == 1 ? dbg_cols[0] : dbg_cols[1];
+        d->inverse = debug_inverse; d->onload = "f_contain";
+        d->width = maxcols; d->height = dbg_rows;           /* :17-18 */
     } else {
         d->name = NULL;
     }
@@ -368,6 +748,39 @@ int ok_find_globe(const char *name, ok_globe_def *g)
         g->numplates = 5;
         return 1;
     }
+    if (!strcmp(name, "tetra")) {                           /* globes/tetra.lua */
+        const double tau = LUA_PI * 2;                      /* init_lua alias, fisheye.c:1248 */
+        double d120 = tau / 3, d60 = d120 / 2;
+        double r = 1, s_ = 2 * r * sin(d60), h = sqrt(s_ * s_ - r * r), theta = acos(r / s_);
+        double c = s_ / 2 / sin(theta), e = r * cos(d60), f = h - c;
+        double fovr = 2 * atan(r / f), fovd = fovr * 180 / LUA_PI + 1;
+        double y = e - e * e / (r + e), z = -f + h * e / (r + e);
+        double fw[4][3] = {{0, -y / f, z / f},
+                           {y / f * sin(d120), -y / f * cos(d120), z / f},
+                           {y / f * sin(-d120), -y / f * cos(-d120), z / f},
+                           {0, 0, -1}};
+        double up[4][3] = {{0, -(e - y) / e, (-f - z) / e},
+                           {(e - y) / e * sin(d120), -(e - y) / e * cos(d120), (-f - z) / e},
+                           {(e - y) / e * sin(-d120), -(e - y) / e * cos(-d120), (-f - z) / e},
+                           {0, -1, 0}};
+        int i;
+        for (i = 0; i < 4; ++i) {
+            memcpy(g->forward[i], fw[i], sizeof fw[i]);
+            memcpy(g->up[i], up[i], sizeof up[i]);
+            g->fov_deg[i] = fovd;
+        }
+        g->numplates = 4;
+        return 1;
+    }
+    if (!strcmp(name, "fast")) {                            /* globes/fast.lua:5-8 */
+        static const double f[2][3] = {{0,0,1},{0,0,1}}, u[2][3] = {{0,1,0},{0,1,0}};
+        memcpy(g->forward, f, sizeof f);
+        memcpy(g->up, u, sizeof u);
+        g->fov_deg[0] = 90; g->fov_deg[1] = 160;
+        g->numplates = 2;
+        g->globe_plate = fast_globe_plate;
+        return 1;
+    }
     return 0;
 }
 
@@ -375,6 +788,7 @@ int ok_find_globe(const char *name, ok_globe_def *g)
 int ok_use_lens(ok_state *s, const char *name)
 {
     ok_lens_def d;
+    ok_set_script_env(&s->host, s->numplates);              /* LUA_load_lens publishes numplates (fisheye.c:1670-1671) */
     if (!ok_find_lens(name, &d)) return 0;
     s->inverse = d.inverse; s->forward = d.forward; s->ud = &s->host;
     s->width = d.width; s->height = d.height;               /* :1741-1747 */
@@ -402,6 +816,7 @@ int ok_use_globe(ok_state *s, const char *name)
     for (i = 0; i < g.numplates; ++i)
         if (!ok_set_plate(s, i, g.forward[i], g.up[i], g.fov_deg[i])) return 0;
     s->numplates = g.numplates;
+    s->globe_plate = g.globe_plate;                         /* fisheye.c:1778-1782 */
     return 1;
 }
 

@@ -154,6 +154,7 @@ int okpy_eval(const char *lens, int which, double x, double y, double z, double 
     ok_lens_def d;
     memset(&s, 0, sizeof s);
     ok_default_host(&s);
+    ok_set_script_env(&s.host, 6);
     if (!ok_find_lens(lens, &d)) return -1;
     if (which == 0) { if (!d.inverse) return -1; return d.inverse(&s.host, x, y, out); }
     if (!d.forward) return -1;
@@ -164,6 +165,10 @@ int okpy_lens_def(const char *lens, int *has_inverse, int *has_forward, int *max
                   double *width, double *height, char *onload, int cap)
 {
     ok_lens_def d;
+    ok_state s;
+    memset(&s, 0, sizeof s);
+    ok_default_host(&s);
+    ok_set_script_env(&s.host, 6);
     if (!ok_find_lens(lens, &d)) return 0;
     *has_inverse = d.inverse != NULL; *has_forward = d.forward != NULL;
     *max_fov = d.max_fov; *max_vfov = d.max_vfov; *width = d.width; *height = d.height;

@@ -73,6 +73,15 @@ static int L_lens_forward(lua_State *L)
     return 1;
 }
 
+static ok_globe_plate_fn cur_globe_plate;
+static int L_globe_plate(lua_State *L)
+{
+    int plate = 0;
+    if (cur_globe_plate(&ref_host, lua_tonumber(L, 1), lua_tonumber(L, 2), lua_tonumber(L, 3), &plate)) { lua_pushnumber(L, plate); return 1; }
+    lua_pushnil(L);
+    return 1;
+}
+
 /* ---- path -> (kind, name) ------------------------------------------------------ */
 static int split(const char *path, char *kind, char *name)
 {
@@ -112,6 +121,11 @@ void ref_script_run(lua_State *L, const char *path)
     ref_host.plate_to_ray = h_plate_to_ray;
     ref_host.ctx = L;
     if (!strcmp(kind, "lenses")) {
+        int np = 0;
+        lua_getglobal(L, "numplates");                       /* published by LUA_load_lens before the chunk runs */
+        np = (int)lua_tonumber(L, -1);
+        lua_pop(L, 1);
+        ok_set_script_env(&ref_host, np);
         if (!ok_find_lens(name, &cur_lens)) return;
         if (cur_lens.max_fov) setnum(L, "max_fov", cur_lens.max_fov);
         if (cur_lens.max_vfov) setnum(L, "max_vfov", cur_lens.max_vfov);
@@ -138,5 +152,7 @@ void ref_script_run(lua_State *L, const char *path)
             lua_rawseti(L, -2, i + 1);
         }
         lua_setglobal(L, "plates");
+        cur_globe_plate = g.globe_plate;
+        if (g.globe_plate) { lua_pushcfunction(L, L_globe_plate); lua_setglobal(L, "globe_plate"); }
     }
 }

@@ -31,6 +31,24 @@ CONFIGS = [
     ("cube", "hammer", "f_cover", 500, 300),
     ("cube", "stereographic", "f_vfov 90", 300, 500),   # portrait: ps = W
     ("cube", "hammer", None, 7680, 4320),         # BASELINE.json configs[4] (C5); its 64-frame batch below
+    # the second batch of hand transliterations (oracle/oracle_lenses.c): 16 lenses and 4 globes in all come from the
+    # unmodified reference
+    ("cube", "rectilinear", None, 640, 400),
+    ("cube", "equirect", None, 640, 320),
+    ("cube", "mercator", None, 600, 400),
+    ("cube", "cylinder", None, 600, 400),
+    ("cube", "miller", None, 640, 480),
+    ("cube", "fisheye1", None, 512, 512),
+    ("cube", "cubestereo", None, 640, 400),
+    ("cube", "mollweide", None, 800, 400),
+    ("cube", "eckert4", None, 800, 400),          # per-row cache in script globals
+    ("cube", "winkeltripel", None, 800, 500),     # Newton iteration with `break`
+    ("cube", "winkeltripel", None, 1920, 1080),
+    ("cube", "debug", None, 600, 400),            # plate_to_ray, math.modf, table.unpack
+    ("tetra", "debug", None, 512, 512),
+    ("tetra", "panini", None, 640, 400),          # plate vectors computed by the globe script
+    ("fast", "panini", "f_fov 200", 640, 400),    # globe_plate override
+    ("fast", "stereographic", None, 512, 512),
 ]
 # configs whose record also carries `fnv_frames`: one hash per frame of a batch over the LCG globes 0..n-1
 # (SURVEY.md 8(d)).  Frame 0 comes from the unmodified reference; the others from the oracle's render_lensmap

@@ -51,7 +51,11 @@ def test_all_shipped_scripts_load(bk):
     assert ctx.console().startswith("142.05755873")
 
 
-@pytest.mark.parametrize("lens", ["panini", "stereographic", "hammer", "quincuncial", "eckert5"])
+HAND_C = ["panini", "stereographic", "hammer", "quincuncial", "eckert5", "rectilinear", "equirect", "mercator", "cylinder",
+          "miller", "fisheye1", "cubestereo", "mollweide", "eckert4", "winkeltripel", "debug"]
+
+
+@pytest.mark.parametrize("lens", HAND_C)
 def test_lens_globals_equal_hand_transliteration(bk, lens):
     ctx = host_ctx(bk)
     info = S.configure(ctx, "cube", lens)
@@ -62,7 +66,7 @@ def test_lens_globals_equal_hand_transliteration(bk, lens):
     assert info.onload.decode() == want["onload"]
 
 
-@pytest.mark.parametrize("globe", ["cube", "trism"])
+@pytest.mark.parametrize("globe", ["cube", "trism", "tetra", "fast"])
 def test_globe_plates_equal_oracle(bk, globe):
     ctx = host_ctx(bk)
     ctx.load_globe(S.script("globes", globe), globe)
@@ -105,7 +109,7 @@ def test_globals_leak_between_lenses_like_the_reference(bk):
 
 # ---- interpreter == independent hand transliteration (platform libm on both sides) ---------------
 
-@pytest.mark.parametrize("lens", ["panini", "stereographic", "hammer", "quincuncial"])
+@pytest.mark.parametrize("lens", [l for l in HAND_C if l not in ("eckert5", "debug")])
 def test_interpreter_inverse_bit_equals_hand_c(bk, lens):
     ctx = host_ctx(bk)
     S.configure(ctx, "cube", lens)
@@ -117,7 +121,7 @@ def test_interpreter_inverse_bit_equals_hand_c(bk, lens):
             assert np.array(a).tobytes() == np.array(b).tobytes(), (lens, x, y)
 
 
-@pytest.mark.parametrize("lens", ["panini", "stereographic", "hammer", "eckert5"])
+@pytest.mark.parametrize("lens", [l for l in HAND_C if l not in ("quincuncial", "debug")])
 def test_interpreter_forward_bit_equals_hand_c(bk, lens):
     ctx = host_ctx(bk)
     S.configure(ctx, "cube", lens)
@@ -221,22 +225,26 @@ def test_every_shipped_lens_translates_and_compiles(bk):
         assert "bk_build_kernels.h" in src, lens
 
 
-def test_compiled_modules_are_cached_on_disk_when_asked(bk, tmp_path, monkeypatch):
-    """BLINKY_HIP_CACHE=<dir>: the first compile stores the code object, an identical program loads it back, a
-    different lens or size-independent change of the source does not hit it; without the variable nothing is kept."""
+def test_compiled_modules_are_cached_on_disk(bk, tmp_path, monkeypatch):
+    """The disk cache of compiled lens modules: BLINKY_HIP_CACHE=off keeps nothing; with a directory the first compile
+    stores the code object, an identical program loads it back, a different lens does not hit it; bk_set_cache_dir
+    overrides the environment.  (BLINKY_HIP_NO_MEMCACHE: the in-process cache would otherwise answer first.)"""
     import time
-    monkeypatch.delenv("BLINKY_HIP_CACHE", raising=False)
+    monkeypatch.setenv("BLINKY_HIP_NO_MEMCACHE", "1")
+    monkeypatch.setenv("BLINKY_HIP_CACHE", "off")
+    monkeypatch.setenv("HOME", str(tmp_path / "home"))
     ctx = host_ctx(bk)
     S.configure(ctx, "cube", "hammer", None, (320, 240))
     ctx.kernel_source(compile=True)
-    assert not ctx.module_from_cache()
-    cache = tmp_path / "cache"
-    cache.mkdir()
+    assert not ctx.module_from_cache() and not (tmp_path / "home" / ".cache" / "blinky_hip").exists()
+    cache = tmp_path / "cache" / "nested"                          # created on demand
     monkeypatch.setenv("BLINKY_HIP_CACHE", str(cache))
+    ctx1 = host_ctx(bk)
+    S.configure(ctx1, "cube", "hammer", None, (320, 240))
     t0 = time.time()
-    ctx.kernel_source(compile=True)
+    ctx1.kernel_source(compile=True)
     cold = time.time() - t0
-    assert not ctx.module_from_cache()
+    assert not ctx1.module_from_cache()
     files = list(cache.iterdir())
     assert len(files) == 1 and files[0].name.startswith("bk_lens_") and files[0].suffix == ".hsaco" and files[0].stat().st_size > 1000
     ctx2 = host_ctx(bk)
@@ -249,6 +257,23 @@ def test_compiled_modules_are_cached_on_disk_when_asked(bk, tmp_path, monkeypatc
     S.configure(ctx3, "cube", "panini", None, (320, 240))
     ctx3.kernel_source(compile=True)
     assert not ctx3.module_from_cache() and len(list(cache.iterdir())) == 2
+    # the host's own choice (fisheye_hip.c: <basedir>/hipcache) beats the environment; NULL hands it back
+    other = tmp_path / "other"
+    bk.lib.bk_set_cache_dir(str(other).encode())
+    try:
+        ctx4 = host_ctx(bk)
+        S.configure(ctx4, "cube", "panini", None, (320, 240))
+        ctx4.kernel_source(compile=True)
+        assert not ctx4.module_from_cache() and len(list(other.iterdir())) == 1
+    finally:
+        bk.lib.bk_set_cache_dir(None)
+    # unset and without BLINKY_HIP_CACHE the default is $HOME/.cache/blinky_hip
+    monkeypatch.delenv("BLINKY_HIP_CACHE")
+    monkeypatch.delenv("XDG_CACHE_HOME", raising=False)
+    ctx5 = host_ctx(bk)
+    S.configure(ctx5, "cube", "stereographic", None, (320, 240))
+    ctx5.kernel_source(compile=True)
+    assert len(list((tmp_path / "home" / ".cache" / "blinky_hip").iterdir())) == 1
 
 
 def test_min_max_over_an_expanded_call_translate(bk):

@@ -57,6 +57,28 @@ ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs 
     ("trism", "quincuncial", None, 256, 256),
     ("trism", "eckert5", None, 200, 120),
     ("cube", "eckert5", "f_cover", 160, 120),
+    # the second batch of transliterations (oracle_lenses.c): loops with break, repeat-until, a cache in script
+    # globals, plate_to_ray + math.modf + table.unpack, computed plate vectors, a globe_plate override
+    ("cube", "rectilinear", None, 320, 200),
+    ("cube", "equirect", None, 320, 160),
+    ("cube", "mercator", None, 300, 200),
+    ("trism", "cylinder", None, 300, 200),
+    ("cube", "miller", None, 320, 240),
+    ("cube", "fisheye1", None, 256, 256),
+    ("cube", "cubestereo", None, 320, 200),
+    ("cube", "mollweide", None, 400, 200),
+    ("cube", "mollweide", "f_fov 300", 300, 200),       # zoom through lens_forward (repeat ... until)
+    ("cube", "eckert4", None, 400, 200),
+    ("trism", "eckert4", "f_fov 200", 320, 200),
+    ("cube", "winkeltripel", None, 400, 250),
+    ("trism", "winkeltripel", "f_fov 250", 320, 200),
+    ("cube", "debug", None, 300, 200),
+    ("trism", "debug", None, 300, 200),
+    ("tetra", "debug", None, 256, 256),
+    ("tetra", "panini", None, 320, 200),
+    ("tetra", "hammer", None, 300, 150),
+    ("fast", "panini", "f_fov 200", 320, 200),
+    ("fast", "stereographic", None, 300, 300),
 ])
 def test_oracle_equals_unmodified_reference(cfg):
     lm_ref, frame_ref = O.ref_run(*cfg, rubix_on=True)
