@@ -12,7 +12,7 @@ try:
 except ImportError:  # the C host layer (blinky_amd/host) does not need torch at all
     torch = None
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblinkyhip.so")
+LIB_PATH = os.environ.get("BLINKY_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblinkyhip.so")   # (BLINKY_HIP_LIB: developer A/B builds)
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
