@@ -308,7 +308,9 @@ extern "C" __global__ __launch_bounds__(256) void bk_save_plate(BkBuildParams P,
         bk_plate_uv_to_ray(P, plate, u, v, ray);
         BkState S;
         bk_state_init(S, &P);
+        const unsigned char texel = col;
         if (plate != bk_ray_to_plate_index(S, ray)) col = 0xFE;                        /* :1446 */
+        if (S.flag) bk_push_flagged(P, (unsigned int)(i * P.ps + j), texel, 0u, 0u);   /* (a globe_plate script: the host decides) */
     }
     out[(size_t)i * P.ps + j] = col;
 }

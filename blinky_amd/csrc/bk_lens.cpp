@@ -1171,18 +1171,55 @@ extern "C" int bk_save_plate(bk_ctx *ctx, int frame, int plate, int with_margins
     if (int r = compile_module(ctx, P, src)) return r;
     hipFunction_t fn = nullptr;
     BK_HIP(ctx, hipModuleGetFunction(&fn, P->module, "bk_save_plate"));
-    BkBuildParams bp;
-    fill_params(ctx, &bp);
+    if (!ctx->d_flag_list) {
+        BK_HIP(ctx, hipMalloc((void **)&ctx->d_flag_list, (size_t)65536 * 4 * sizeof(uint32_t)));
+        ctx->flag_cap = 65536;
+    }
     const uint8_t *globe = ctx->d_globe + (size_t)frame * ctx->globe_stride();
     uint8_t *out = nullptr;
     BK_HIP(ctx, hipMalloc((void **)&out, (size_t)ctx->ps * ctx->ps));
-    void *args[] = {&bp, &plate, &with_margins, &globe, &out};
-    hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((ctx->ps + 255) / 256), (unsigned)ctx->ps, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+    std::vector<uint32_t> flagged;
+    hipError_t e = hipSuccess;
+    for (;;) {
+        BkBuildParams bp;
+        fill_params(ctx, &bp);
+        void *args[] = {&bp, &plate, &with_margins, &globe, &out};
+        int counters[BK_MAX_PLATES + 2];
+        e = hipMemsetAsync(ctx->d_display, 0, sizeof counters, ctx->stream);
+        if (e == hipSuccess) e = hipModuleLaunchKernel(fn, (unsigned)((ctx->ps + 255) / 256), (unsigned)ctx->ps, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+        if (e == hipSuccess) e = hipMemcpyAsync(counters, ctx->d_display, sizeof counters, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) break;
+        bool retry = false;
+        if (int r = read_flagged(ctx, (unsigned)counters[BK_MAX_PLATES + 1], &flagged, &retry)) { (void)hipFree(out); return r; }
+        if (!retry) break;
+    }
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(dst_host, (size_t)dst_pitch, out, (size_t)ctx->ps, (size_t)ctx->ps, (size_t)ctx->ps, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(out);
     if (e != hipSuccess) return ctx->fail(BK_E_HIP, "bk_save_plate failed: %s", hipGetErrorString(e));
+    // texels whose plate ownership a globe_plate script decides on libm's last bits: the host interpreter has the say
+    if (!flagged.empty()) {
+        BkBuildParams bp;
+        fill_params(ctx, &bp);
+        const size_t nfl = flagged.size() / 4;
+        std::vector<uint8_t> own(nfl);
+        try {
+            for_each_flagged(P, nfl, [&](HostEval &E, size_t k) {
+                const uint32_t id = flagged[4 * k], i = id / (uint32_t)ctx->ps, j = id - i * (uint32_t)ctx->ps;
+                float ray[3];
+                bk::h_plate_uv_to_ray(ctx->plates[plate], (double)j / ctx->ps, (double)i / ctx->ps, ray);
+                own[k] = plate == h_ray_to_plate_index(E, bp, ray);
+            });
+        } catch (const LuaError &err) {
+            return ctx->fail(BK_E_SCRIPT, "%s", err.what());
+        }
+        for (size_t k = 0; k < nfl; ++k) {
+            const uint32_t id = flagged[4 * k], i = id / (uint32_t)ctx->ps, j = id - i * (uint32_t)ctx->ps;
+            dst_host[(size_t)i * dst_pitch + j] = own[k] ? (uint8_t)flagged[4 * k + 1] : 0xFE;
+        }
+    }
     return BK_OK;
 }
 
