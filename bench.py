@@ -165,8 +165,21 @@ def main():
     # communicator's own stream); torch.distributed only ships the unique id.  The gloo developer smoke keeps host tensors.
     comm = None
     if world > 1 and not host_exchange:
-        comm = multigpu.rccl_comm(ctx, world, rank, dev)
-        assert comm.stripe(rank) == (r0, r1)
+        # (should libblinkyhip's own communicator not come up on this node, say so and exchange through the process
+        # group's RCCL instead of losing the measurement; every rank takes the same decision)
+        try:
+            comm = multigpu.rccl_comm(ctx, world, rank, dev)
+            assert comm.stripe(rank) == (r0, r1)
+            ok = 1
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] rank {rank}: bk_comm could not be created ({type(e).__name__}: {e}); using torch.distributed for the exchange",
+                  file=sys.stderr, flush=True)
+            comm, ok = None, 0
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
     if args.variant >= 0:
         ctx.set_apply_variant(args.variant)
 
@@ -228,7 +241,7 @@ def main():
         if comm:
             comm.exchange_rotating(stripes[b].data_ptr(), F, frames_out[b].data_ptr(), H * W, slot=b)
         elif world > 1:
-            pending[b] = multigpu.exchange_rotating(stripes[b].cpu(), bounds, rank, world, frames_out[b], wait=False)
+            pending[b] = multigpu.exchange_rotating(stripes[b].cpu() if host_exchange else stripes[b], bounds, rank, world, frames_out[b], wait=False)
 
     def drain():
         if comm:
@@ -246,7 +259,7 @@ def main():
             comm.gather(stripe.data_ptr(), F, 0, root_frames.data_ptr() if rank == 0 else None, H * W, slot=0)
             return
         ctx.apply_device(origin(stripe), W, rows * W, frame0=first_globe(i), nframes=F)
-        multigpu.gather_stripes(stripe.cpu(), bounds, rank, world, 0, None)
+        multigpu.gather_stripes(stripe.cpu() if host_exchange else stripe, bounds, rank, world, 0, None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -399,7 +412,7 @@ def main():
             "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step from a resident ring of {R} distinct globes "
                                    f"({R * 6 * 2160 * 2176 / 1e9:.2f} GB, advanced every step), one lensmap",
                        "frames_per_step": F, "ring_globes": R,
-                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else (" + bk_comm (librccl grouped ncclSend/ncclRecv behind the C ABI)" if comm else " + gloo host exchange (developer smoke)") +
+                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else (" + bk_comm (librccl grouped ncclSend/ncclRecv behind the C ABI)" if comm else " + gloo host exchange (developer smoke)" if host_exchange else " + torch.distributed RCCL send/recv (bk_comm unavailable)") +
                                                                      (": frame f reassembled on rank f%N" if exchange_mode == "rotating" else ": every frame gathered onto rank 0")),
                        "apply_variant": args.variant},
             "timed_regions": {"count": len(regions), "steps_each": args.steps, "value_is": "median",

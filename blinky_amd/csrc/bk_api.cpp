@@ -285,6 +285,13 @@ extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8])
     return bk::coopmap_traffic_model(ctx, out);
 }
 
+extern "C" int bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups)
+{
+    if (!ctx || !out || nworkgroups < 1) return BK_E_INVALID;
+    if (int r = ensure_device(ctx)) return r;
+    return bk::coopmap_xcd_probe(ctx, out, nworkgroups);
+}
+
 extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }
 
 // ---- lensmap table -------------------------------------------------------------------

@@ -852,6 +852,26 @@ int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8])
     return BK_OK;
 }
 
+// The persistent grid gives XCD k the band k of the screen on the assumption that workgroup b of a launch runs on XCD
+// b % 8 (round-robin dispatch).  It is only a locality assumption - results do not depend on it - but nothing in the
+// programming model promises it, so a test looks: every workgroup reports the XCC it runs on (HW_REG_XCC_ID).
+__global__ void xcd_probe_kernel(int *__restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 0xF);   // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+int coopmap_xcd_probe(bk_ctx *ctx, int *out, int nwg)
+{
+    int *d = nullptr;
+    BK_HIP(ctx, hipMalloc((void **)&d, (size_t)nwg * sizeof(int)));
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)nwg * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return ctx->fail(BK_E_HIP, "xcd probe: %s", hipGetErrorString(e));
+    return BK_OK;
+}
+
 int coopmap_stats(bk_ctx *ctx, int out[6])
 {
     if (int r = ensure_coopmap(ctx)) return r;

@@ -130,6 +130,7 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_o
                       size_t frame_stride, int rubix_on);
 int coopmap_stats(bk_ctx *ctx, int out[6]);   // blocks, direct-gather blocks, empty blocks, LDS bytes per buffer
 int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8]);
+int coopmap_xcd_probe(bk_ctx *ctx, int *out, int nwg);
 void coopmap_free(CoopMap *);
 
 // bk_lens.cpp

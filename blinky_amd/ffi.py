@@ -87,6 +87,7 @@ _SIGS = {
     "bk_debug_traffic_model": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "bk_debug_xcd_of_workgroups": (_i, [_vp, C.POINTER(_i), _i]),
     "bk_debug_set_ablation": (_i, [_vp, _i]),
     "bk_debug_set_tile_shape": (_i, [_vp, _i]),
     "bk_debug_kernel_source": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), _i]),
@@ -329,6 +330,11 @@ class Context:
         tin = np.empty(len(ids), np.uint8)
         self._chk(lib.bk_debug_host_entries(self._h, _ptr(ids), len(ids), _ptr(off), _ptr(tin)))
         return off, tin
+
+    def xcd_of_workgroups(self, n):
+        out = (_i * n)()
+        self._chk(lib.bk_debug_xcd_of_workgroups(self._h, out, n))
+        return list(out)
 
     def traffic_model(self):
         out = (C.c_uint64 * 8)()

@@ -274,6 +274,9 @@ int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
  * 16-byte chunks staged per frame, bytes of block map read per block visit summed over blocks, mapped pixels
  * (= bytes stored per frame), frames served per block visit, blocks, block height in pixels} */
 int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8]);
+/* which XCD (HW_REG_XCC_ID) each workgroup of a 1-D launch of `nworkgroups` runs on: the apply kernel's screen bands
+ * assume workgroup b -> XCD b % 8 (locality only; a test checks the assumption on the box it runs on) */
+int         bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups);
 /* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
  * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);

@@ -613,6 +613,329 @@ static int fast_globe_plate(void *ud, double x, double y, double z, int *plate)
     return 1;
 }
 
+/* =====================================================================================================
+ * The remaining scripts: with these every one of the 31 lenses and 6 globes the reference ships has a
+ * hand transliteration that the unmodified fisheye.c is driven with (oracle/_ref).
+ * ===================================================================================================== */
+
+/* ---- lenses/cube.lua ---------------------------------------------------------------------------------- */
+static void cube_cell(double n, double *i, double *f)       /* col / row :12-28: modf, shifted down for negatives */
+{
+    *f = modf(n, i);
+    if (n < 0) { *i = *i - 1; *f = *f + 1; }
+}
+static int cubelens_inverse(void *ud, double x, double y, double ray[3])
+{
+    const double cols = 4, rows = 3;
+    double r, v, c, u;
+    (void)ud;
+    x = x - 0.5;                                            /* :31 */
+    cube_cell(-y + rows / 2, &r, &v);                       /* :32 */
+    cube_cell(x + cols / 2, &c, &u);                        /* :33 */
+    u = u - 0.5;
+    v = v - 0.5;
+    v = -v;
+    if (r < 0 || r >= rows || c < -1 || c >= cols) return 0;    /* :38-40 */
+    if (r == 0 || r == 2) { if (!(c == 1)) return 0; }      /* :41-45 */
+    if (r == 0) { ray[0] = u; ray[1] = 0.5; ray[2] = -v; }            /* top */
+    else if (r == 2) { ray[0] = u; ray[1] = -0.5; ray[2] = v; }       /* bottom */
+    else if (c == 0) { ray[0] = -0.5; ray[1] = v; ray[2] = u; }       /* left */
+    else if (c == 1) { ray[0] = u; ray[1] = v; ray[2] = 0.5; }        /* front */
+    else if (c == 2) { ray[0] = 0.5; ray[1] = v; ray[2] = -u; }       /* right */
+    else if (c == 3 || c == -1) { ray[0] = -u; ray[1] = v; ray[2] = -0.5; }   /* back */
+    else return 0;
+    return 1;
+}
+static int cubelens_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double ax = fabs(x), ay = fabs(y), az = fabs(z), max, u, v;
+    (void)ud;
+    max = ax;                                               /* math.max(ax,ay,az) :79 */
+    if (ay > max) max = ay;
+    if (az > max) max = az;
+    if (max == ax) {
+        if (x > 0) { u = -z / x * 0.5; v = y / x * 0.5; *ox = 1 + u; *oy = v; }
+        else { u = z / -x * 0.5; v = y / -x * 0.5; *ox = -1 + u; *oy = v; }
+        return 1;
+    } else if (max == ay) {
+        if (y > 0) { u = x / y * 0.5; v = -z / y * 0.5; *ox = u; *oy = 1 + v; }
+        else { u = x / -y * 0.5; v = z / -y * 0.5; *ox = u; *oy = -1 + v; }
+        return 1;
+    } else if (max == az) {
+        if (z > 0) { u = x / z * 0.5; v = y / z * 0.5; *ox = u; *oy = v; }
+        else {
+            u = -x / -z * 0.5; v = y / -z * 0.5;
+            if (u > 0) { *ox = -2 + u; *oy = v; } else { *ox = 2 + u; *oy = v; }
+        }
+        return 1;
+    }
+    return -1;                                              /* falls off the end: no results */
+}
+
+/* ---- eckert1.lua ---------------------------------------------------------------------------------------- */
+static const double e1_FC = 0.92131773192356127802, e1_RP = 0.31830988618379067154;
+static int eckert1_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = e1_FC * lon * (1 - e1_RP * fabs(lat));            /* :17 */
+    *oy = e1_FC * lat;
+    return 1;
+}
+
+/* ---- fahey.lua -------------------------------------------------------------------------------------------- */
+static double fahey_XR, fahey_YR;
+static int fahey_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon, fx, fy;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    fx = tan(0.5 * lat);                                    /* :14 */
+    fy = 1.819152 * fx;                                     /* :15 */
+    fx = 0.819152 * lon * sqrt(1 - fx * fx);                /* :16 */
+    *ox = fx; *oy = fy;
+    return 1;
+}
+static int fahey_inverse(void *ud, double x, double y, double ray[3])
+{
+    double lat, lon;
+    if (x * x / (fahey_XR * fahey_XR) + y * y / (fahey_YR * fahey_YR) >= 1) return 0;   /* :21-23 */
+    y = y / 1.819152;                                       /* :24 */
+    lat = 2 * atan(y);                                      /* :25 */
+    y = 1 - y * y;                                          /* :26 */
+    lon = x / (0.819152 * sqrt(y));                         /* :27 */
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+
+/* ---- fisheye2.lua ------------------------------------------------------------------------------------------- */
+static double fe2_maxr;
+static int fisheye2_inverse(void *ud, double x, double y, double ray[3])
+{
+    double r = sqrt(x * x + y * y), theta, s;
+    (void)ud;
+    if (r > fe2_maxr) return 0;                             /* :13-15 */
+    theta = 2 * asin(r * 0.5);                              /* :17 */
+    s = sin(theta);
+    ray[0] = x / r * s; ray[1] = y / r * s; ray[2] = cos(theta);
+    return 1;
+}
+static int fisheye2_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double theta = acos(z), r = 2 * sin(theta * 0.5), c = r / sqrt(x * x + y * y);   /* :24-28 */
+    (void)ud;
+    *ox = x * c; *oy = y * c;
+    return 1;
+}
+
+/* ---- gallstereo.lua ------------------------------------------------------------------------------------------- */
+static const double gs_YF = 1.70710678118654752440, gs_XF = 0.70710678118654752440, gs_RYF = 0.58578643762690495119,
+                    gs_RXF = 1.41421356237309504880;
+static double gs_maxx, gs_maxy;
+static int gallstereo_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    if (fabs(x) > gs_maxx || fabs(y) > gs_maxy) return 0;   /* :18-20 (the ray's x, y) */
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = gs_XF * lon;
+    *oy = gs_YF * tan(0.5 * lat);
+    return 1;
+}
+static int gallstereo_inverse(void *ud, double x, double y, double ray[3])
+{
+    double lon = gs_RXF * x, lat = 2 * atan(y * gs_RYF);   /* :28-29 */
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+
+/* ---- gins8.lua --------------------------------------------------------------------------------------------------- */
+static int gins8_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    const double Cl = 0.000952426, Cp = 0.162388, C12 = 0.08333333333333333;
+    double lat, lon, t, fx, fy;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    t = lat * lat;                                          /* :13 */
+    fy = lat * (1 + t * C12);
+    fx = lon * (1 - Cp * t);
+    t = lon * lon;
+    fx = fx * (0.87 - Cl * t * t);                          /* :17 */
+    *ox = fx; *oy = fy;
+    return 1;
+}
+
+/* ---- gumby.lua ------------------------------------------------------------------------------------------------------ */
+static const double gumby_d = 1, gumbyScale = 0.75;
+static double gumbyScaleInv;
+static int gumby_inverse(void *ud, double x, double y, double ray[3])
+{
+    double d = gumby_d;
+    double k = x * x / ((d + 1) * (d + 1));
+    double dscr = k * k * d * d - (k + 1) * (k * d * d - 1);
+    double clon = (-k * d + sqrt(dscr)) / (k + 1);
+    double S = (d + 1) / (d + clon);
+    double lon = atan2(x, S * clon);
+    double lat = atan2(y, S);
+    lon = lon * gumbyScaleInv;                              /* :17-18 */
+    lat = lat * gumbyScaleInv;
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+static int gumby_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon, S, d = gumby_d;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    lon = lon * gumbyScale;                                 /* :24-25 */
+    lat = lat * gumbyScale;
+    S = (d + 1) / (d + cos(lon));
+    *ox = S * sin(lon);
+    *oy = S * tan(lat);
+    return 1;
+}
+
+/* ---- kavrayskiy7 / larrivee / polyconic / sinusoidal / wagner6 / winkel1 / winkel2 (forward only) ---------------------- */
+static int kavrayskiy7_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = 3 * lon / (2 * LUA_PI) * sqrt(LUA_PI * LUA_PI / 3 - lat * lat);   /* :12 */
+    *oy = lat;
+    return 1;
+}
+static int larrivee_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = (0.5 + 0.5 * sqrt(cos(lat))) * lon;               /* :12 */
+    *oy = lat / (cos(lat / 2) * cos(lon / 6));              /* :13 */
+    return 1;
+}
+static int polyconic_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    if (lat == 0) { *ox = lon; *oy = 0; return 1; }         /* :9-11 */
+    *ox = 1 / tan(lat) * sin(lon * sin(lat));               /* :12 */
+    *oy = lat + 1 / tan(lat) * (1 - cos(lon * sin(lat)));   /* :13 */
+    return 1;
+}
+static int sinusoidal_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon * cos(lat);
+    *oy = lat;
+    return 1;
+}
+static int wagner6_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon * sqrt(1 - 3 * lat * lat / (LUA_PI * LUA_PI));   /* :12 */
+    *oy = lat;
+    return 1;
+}
+static int winkel1_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon * (2 / LUA_PI + cos(lat)) / 2;                /* :12 */
+    *oy = lat;
+    return 1;
+}
+static int winkel2_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    double lat, lon;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    *ox = lon / 2 * (2 / LUA_PI + sqrt(LUA_PI * LUA_PI - 4 * lat * lat) / LUA_PI);   /* :12 */
+    *oy = lat;
+    return 1;
+}
+
+/* ---- vandergrinten.lua -------------------------------------------------------------------------------------------------- */
+static double vdg_maxr;
+static int vandergrinten_forward(void *ud, double x, double y, double z, double *ox, double *oy)
+{
+    const double pi = LUA_PI;
+    double lat, lon, t, a, g, p, q, fx, fy;
+    H_RAY_TO_LATLON(ud, x, y, z, &lat, &lon);
+    if (lat == 0) { *ox = lon; *oy = 0; return 1; }         /* :9-11 */
+    t = asin(fabs(2 * lat / pi));                           /* :12 */
+    if (fabs(lat) == pi / 2) {                              /* :13-19 */
+        double y2 = pi * tan(t / 2);
+        if (y2 * lat < 0) y2 = -y2;
+        *ox = 0; *oy = y2;
+        return 1;
+    }
+    a = 0.5 * fabs(pi / lon - lon / pi);                    /* :20 */
+    g = cos(t) / (sin(t) + cos(t) - 1);                     /* :21 */
+    p = g * (2 / sin(t) - 1);                               /* :22 */
+    q = a * a + g;                                          /* :23 */
+    fx = pi * (a * (g - p * p) + sqrt(a * a * (g - p * p) * (g - p * p) - (p * p + a * a) * (g * g - p * p))) / (p * p + a * a);   /* :25 */
+    fy = pi * (p * q - a * sqrt((a * a + 1) * (p * p + a * a) - q * q)) / (p * p + a * a);                                         /* :26 */
+    if (lon * fx < 0) fx = -fx;                             /* :28-33 */
+    if (lat * fy < 0) fy = -fy;
+    *ox = fx; *oy = fy;
+    return 1;
+}
+static int vandergrinten_inverse(void *ud, double x, double y, double ray[3])
+{
+    const double pi = LUA_PI;
+    const double TOL = 1.e-10, THIRD = .33333333333333333333, C2_27 = .07407407407407407407, PI4_3 = 4.18879020478639098458,
+                 PISQ = 9.86960440108935861869, TPISQ = 19.73920880217871723738, HPISQ = 4.93480220054467930934;
+    double lat, lon, t, c0, c1, c2, c3, al, r2, r, m, d, ay, x2, y2;
+    if (x * x + y * y > vdg_maxr * vdg_maxr) return 0;      /* :47-49 */
+    x2 = x * x;
+    ay = fabs(y);
+    if (ay < TOL) {                                         /* :55-64 */
+        lat = 0;
+        t = x2 * x2 + TPISQ * (x2 + HPISQ);
+        if (fabs(x) <= TOL) lon = 0;
+        else lon = 0.5 * (x2 - PISQ + sqrt(t)) / x;
+        H_LATLON_TO_RAY(ud, lat, lon, ray);
+        return 1;
+    }
+    y2 = y * y;
+    r = x2 + y2;
+    r2 = r * r;
+    c1 = -pi * ay * (r + PISQ);                             /* :69 */
+    c3 = r2 + (2 * pi) * (ay * r + pi * (y2 + pi * (ay + pi / 2)));
+    c2 = c1 + PISQ * (r - 3 * y2);
+    c0 = pi * ay;
+    c2 = c2 / c3;
+    al = c1 / c3 - THIRD * c2 * c2;
+    m = 2 * sqrt(-THIRD * al);
+    d = C2_27 * c2 * c2 * c2 + (c0 * c0 - THIRD * c2 * c1) / c3;
+    d = 3 * d / (al * m);
+    t = fabs(d);
+    if (t - TOL <= 1) {                                     /* :79 */
+        if (t > 1) d = d > 0 ? 0 : pi;
+        else d = acos(d);
+        lat = pi * (m * cos(d * THIRD + PI4_3) - THIRD * c2);   /* :89 */
+        if (y < 0) lat = -lat;
+        t = r2 + TPISQ * (x2 - y2 + HPISQ);
+        if (fabs(x) <= TOL) lon = 0;
+        else if (t <= 0) lon = 0.5 * (r - PISQ) / x;
+        else lon = 0.5 * (r - PISQ + sqrt(t)) / x;
+    } else {
+        return 0;
+    }
+    H_LATLON_TO_RAY(ud, lat, lon, ray);
+    return 1;
+}
+
+/* rotation used by globes/cube_edge.lua and cube_corner.lua (:17-30 / :17-40) */
+static void rot_xz(double *p, double a)
+{
+    double x = p[0], z = p[2];
+    p[0] = x * cos(a) - z * sin(a);
+    p[2] = x * sin(a) + z * cos(a);
+}
+static void rot_yz(double *p, double a)
+{
+    double y = p[1], z = p[2];
+    p[1] = y * cos(a) - z * sin(a);
+    p[2] = y * sin(a) + z * cos(a);
+}
+
 /* ---- registry ---------------------------------------------------------------- */
 
 static void lens_globals(const char *name, ok_lens_def *d)
@@ -698,6 +1021,83 @@ static void lens_globals(const char *name, ok_lens_def *d)
         wt_lens_height = d->height;
         wt_artifact_x = d->width / 2 * 0.71;                /* :93-94 */
         wt_artifact_y = d->height / 2 * 0.81;
+    } else if (!strcmp(name, "cube")) {
+        d->inverse = cubelens_inverse; d->forward = cubelens_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 4; d->height = 3;                        /* lenses/cube.lua:1-5 */
+    } else if (!strcmp(name, "eckert1")) {
+        d->forward = eckert1_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = e1_FC * LUA_PI * 2; d->height = e1_FC * LUA_PI;
+    } else if (!strcmp(name, "fahey")) {
+        fahey_XR = 0.819152 * LUA_PI; fahey_YR = 1.819152;
+        d->inverse = fahey_inverse; d->forward = fahey_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = fahey_XR * 2; d->height = fahey_YR * 2;
+    } else if (!strcmp(name, "fisheye2")) {
+        fe2_maxr = 2 * sin(LUA_PI * 0.5);
+        d->inverse = fisheye2_inverse; d->forward = fisheye2_forward;
+        d->max_fov = 360; d->max_vfov = 360; d->onload = "f_contain";
+        d->width = fe2_maxr * 2; d->height = fe2_maxr * 2;
+    } else if (!strcmp(name, "gallstereo")) {
+        gs_maxx = gs_XF * LUA_PI;
+        gs_maxy = gs_YF * tan(0.5 * LUA_PI / 2);
+        d->inverse = gallstereo_inverse; d->forward = gallstereo_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = gs_maxx * 2; d->height = gs_maxy * 2;
+    } else if (!strcmp(name, "gins8")) {
+        double r3[3], fx = 0, fy = 0;
+        d->forward = gins8_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        if (load_host) {                                    /* gins8.lua:21-24 */
+            load_host->latlon_to_ray(load_host->ctx, 0, LUA_PI, r3);
+            gins8_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+            d->width = 2 * fabs(fx);
+            load_host->latlon_to_ray(load_host->ctx, LUA_PI / 2, 0, r3);
+            gins8_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+            d->height = 2 * fabs(fy);
+        }
+    } else if (!strcmp(name, "gumby")) {
+        double r3[3], fx = 0, fy = 0;
+        gumbyScaleInv = 1.0 / gumbyScale;
+        d->inverse = gumby_inverse; d->forward = gumby_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        if (load_host) {                                    /* gumby.lua:32-36 */
+            load_host->latlon_to_ray(load_host->ctx, LUA_PI / 2, 0, r3);
+            gumby_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+            d->height = fy * 2;
+            load_host->latlon_to_ray(load_host->ctx, 0, LUA_PI, r3);
+            gumby_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+            d->width = fx * 2;
+        }
+    } else if (!strcmp(name, "kavrayskiy7")) {
+        d->forward = kavrayskiy7_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 3 * LUA_PI / (2 * LUA_PI) * sqrt(LUA_PI * LUA_PI / 3) * 2; d->height = LUA_PI;
+    } else if (!strcmp(name, "larrivee")) {
+        d->forward = larrivee_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 2 * LUA_PI; d->height = LUA_PI / 2 / cos(LUA_PI / 2 / 2) * 2;
+    } else if (!strcmp(name, "polyconic")) {
+        d->forward = polyconic_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_fov 360";
+    } else if (!strcmp(name, "sinusoidal")) {
+        d->forward = sinusoidal_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = 2 * LUA_PI; d->height = LUA_PI;
+    } else if (!strcmp(name, "wagner6")) {
+        d->forward = wagner6_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = LUA_PI * 2; d->height = LUA_PI;
+    } else if (!strcmp(name, "winkel1")) {
+        d->forward = winkel1_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = LUA_PI * (2 / LUA_PI + 1) / 2 * 2; d->height = LUA_PI;
+    } else if (!strcmp(name, "winkel2")) {
+        d->forward = winkel2_forward; d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        d->width = LUA_PI / 2 * (2 / LUA_PI + 1) * 2; d->height = LUA_PI;
+    } else if (!strcmp(name, "vandergrinten")) {
+        double r3[3], fx = 0, fy = 0;
+        d->inverse = vandergrinten_inverse; d->forward = vandergrinten_forward;
+        d->max_fov = 360; d->max_vfov = 180; d->onload = "f_contain";
+        if (load_host) {                                    /* vandergrinten.lua:109-111: maxr = first result */
+            load_host->latlon_to_ray(load_host->ctx, 0, LUA_PI, r3);
+            vandergrinten_forward((void *)load_host, r3[0], r3[1], r3[2], &fx, &fy);
+        }
+        vdg_maxr = fx;
+        d->height = 2 * vdg_maxr; d->width = 2 * vdg_maxr;
     } else if (!strcmp(name, "debug")) {
         int n = load_numplates, maxcols;                    /* debug.lua:1-15 */
         if (n == 4) { dbg_rows = 2; dbg_cols[0] = 2; dbg_cols[1] = 2; }
@@ -746,6 +1146,24 @@ int ok_find_globe(const char *name, ok_globe_def *g)
             g->fov_deg[i] = fov[i];
         }
         g->numplates = 5;
+        return 1;
+    }
+    if (!strcmp(name, "cube_edge") || !strcmp(name, "cube_corner")) {   /* globes/cube_edge.lua, cube_corner.lua */
+        static const double f[6][3] = {{0,0,1},{1,0,0},{-1,0,0},{0,0,-1},{0,1,0},{0,-1,0}};
+        static const double u[6][3] = {{0,1,0},{0,1,0},{0,1,0},{0,1,0},{0,0,-1},{0,0,1}};
+        const int corner = !strcmp(name, "cube_corner");
+        const double a = LUA_PI / 4;
+        int i;
+        for (i = 0; i < 6; ++i) {
+            memcpy(g->forward[i], f[i], sizeof f[i]);
+            memcpy(g->up[i], u[i], sizeof u[i]);
+            rot_xz(g->forward[i], a);
+            if (corner) rot_yz(g->forward[i], a);
+            rot_xz(g->up[i], a);
+            if (corner) rot_yz(g->up[i], a);
+            g->fov_deg[i] = 90;
+        }
+        g->numplates = 6;
         return 1;
     }
     if (!strcmp(name, "tetra")) {                           /* globes/tetra.lua */

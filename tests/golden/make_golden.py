@@ -49,6 +49,24 @@ CONFIGS = [
     ("tetra", "panini", None, 640, 400),          # plate vectors computed by the globe script
     ("fast", "panini", "f_fov 200", 640, 400),    # globe_plate override
     ("fast", "stereographic", None, 512, 512),
+    # the third batch: all 31 lenses and all 6 globes are now recorded from the unmodified reference
+    ("cube", "cube", None, 640, 480),
+    ("cube", "eckert1", None, 400, 240),          # (forward maps: the plate texels are scattered, sizes kept small)
+    ("cube", "fahey", None, 640, 400),
+    ("cube", "fisheye2", None, 512, 512),
+    ("cube", "gallstereo", None, 640, 400),
+    ("cube", "gins8", None, 400, 240),
+    ("cube", "gumby", None, 640, 400),
+    ("cube", "kavrayskiy7", None, 400, 240),
+    ("cube", "larrivee", None, 400, 240),
+    ("cube", "polyconic", None, 400, 300),
+    ("cube", "sinusoidal", None, 400, 240),
+    ("cube", "vandergrinten", None, 600, 600),
+    ("cube", "wagner6", None, 400, 240),
+    ("cube", "winkel1", None, 400, 240),
+    ("cube", "winkel2", None, 400, 240),
+    ("cube_edge", "panini", None, 640, 400),
+    ("cube_corner", "stereographic", None, 640, 400),
 ]
 # configs whose record also carries `fnv_frames`: one hash per frame of a batch over the LCG globes 0..n-1
 # (SURVEY.md 8(d)).  Frame 0 comes from the unmodified reference; the others from the oracle's render_lensmap

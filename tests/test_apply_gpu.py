@@ -123,6 +123,16 @@ def test_upload_download_plate_round_trip(bk):
     ctx.close()
 
 
+def test_workgroups_are_dealt_to_xcds_round_robin(bk):
+    """The apply kernel's XCD bands (bk_apply_coop.hip) assume workgroup b of a launch runs on XCD b % 8.  Nothing but
+    locality depends on it, but it is observed behaviour, not a promise: look at the hardware register on this box."""
+    ctx = bk.Context()
+    ids = ctx.xcd_of_workgroups(2048)
+    ctx.close()
+    assert len(set(ids[:8])) == 8, ids[:16]                       # eight XCDs, each of the first eight workgroups on its own
+    assert all(ids[b] == ids[b % 8] for b in range(len(ids))), "workgroup b is not on the XCD of workgroup b % 8"
+
+
 def test_pipelined_plate_uploads_equal_the_blocking_ones(bk):
     """bk_upload_plate_async: the caller's buffer is free again when the call returns (the engine renders the next plate
     into the same vid.buffer), three staging slots rotate, and the globe ends up byte-identical"""

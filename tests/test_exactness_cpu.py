@@ -43,6 +43,14 @@ def emu_build(globe, lens, zoom, W, H):
     ("cube", "debug", None, 300, 200),             # plate_to_ray: u, v narrowed to float
     ("tetra", "panini", None, 320, 200),
     ("fast", "panini", "f_fov 200", 320, 200),     # globe_plate override: comparisons on u, v
+    ("cube", "cube", None, 320, 240),              # math.modf on the cell coordinates
+    ("cube", "fahey", None, 400, 250),
+    ("cube", "fisheye2", None, 300, 300),
+    ("cube", "gallstereo", None, 400, 250),
+    ("cube", "gumby", None, 400, 250),
+    ("cube", "vandergrinten", None, 360, 360),     # cubic solved with acos / cos, many comparisons against TOL
+    ("cube_corner", "stereographic", None, 320, 200),
+    ("cube_edge", "rectilinear", None, 320, 200),
 ])
 def test_every_libm_dependent_pixel_is_flagged(cfg):
     globe, lens, zoom, W, H = cfg

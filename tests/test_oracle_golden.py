@@ -79,6 +79,27 @@ ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs 
     ("tetra", "hammer", None, 300, 150),
     ("fast", "panini", "f_fov 200", 320, 200),
     ("fast", "stereographic", None, 300, 300),
+    # ... and the rest: every shipped lens and globe goes through the unmodified reference
+    ("cube", "cube", None, 320, 240),
+    ("cube", "cube", "f_fov 300", 320, 240),           # zoom through its lens_forward
+    ("cube", "eckert1", None, 200, 120),
+    ("cube", "fahey", None, 320, 200),
+    ("cube", "fisheye2", None, 256, 256),
+    ("cube", "gallstereo", None, 320, 200),
+    ("cube", "gins8", None, 200, 120),
+    ("cube", "gumby", None, 320, 200),
+    ("cube", "kavrayskiy7", None, 200, 120),
+    ("cube", "larrivee", None, 200, 120),
+    ("cube", "polyconic", None, 200, 150),
+    ("cube", "sinusoidal", None, 200, 120),
+    ("cube", "vandergrinten", None, 300, 300),
+    ("trism", "vandergrinten", "f_fov 200", 300, 200),
+    ("cube", "wagner6", None, 200, 120),
+    ("cube", "winkel1", None, 200, 120),
+    ("cube", "winkel2", None, 200, 120),
+    ("cube_edge", "panini", None, 320, 200),
+    ("cube_corner", "stereographic", None, 320, 200),
+    ("cube_corner", "hammer", None, 300, 150),
 ])
 def test_oracle_equals_unmodified_reference(cfg):
     lm_ref, frame_ref = O.ref_run(*cfg, rubix_on=True)
