@@ -20,6 +20,7 @@ typedef struct { double n; double e; int t; } bkv;
 #define BK_TFALSE 1
 #define BK_TTRUE 2
 #define BK_TNUM 3
+#define BK_TSTR 4                    /* a string CONSTANT of the script: n = its number in the emitter's intern table (equality only) */
 #define BK_MAXRET 8
 #define BK_LOOP_BUDGET (1 << 22)
 #define BK_DEV static __device__ __forceinline__
@@ -38,6 +39,9 @@ BK_DEV bkv bk_num(double d) { bkv v; v.n = d; v.e = 0.0; v.t = BK_TNUM; return v
 BK_DEV bkv bk_nume(double d, double e) { bkv v; v.n = d; v.e = e; v.t = BK_TNUM; return v; }
 BK_DEV bkv bk_nil() { bkv v; v.n = 0.0; v.e = 0.0; v.t = BK_TNIL; return v; }
 BK_DEV bkv bk_bool(bool b) { bkv v; v.n = 0.0; v.e = 0.0; v.t = b ? BK_TTRUE : BK_TFALSE; return v; }
+BK_DEV bkv bk_str(int id) { bkv v; v.n = (double)id; v.e = 0.0; v.t = BK_TSTR; return v; }
+/* type(v): interned ids 1..4 are reserved for "nil", "boolean", "number", "string" (bk_emit.cpp) */
+BK_DEV bkv bk_typeof(bkv v) { return bk_str(v.t == BK_TNIL ? 1 : v.t == BK_TNUM ? 3 : v.t == BK_TSTR ? 4 : 2); }
 BK_DEV bool bk_truthy(bkv v) { return v.t >= BK_TTRUE; }
 BK_DEV bool bk_isnum(bkv v) { return v.t == BK_TNUM; }
 BK_DEV double bk_tonum(BkState &S, bkv v) { if (v.t != BK_TNUM) S.err |= BK_ERR_ARITH; return v.n; }
@@ -143,12 +147,12 @@ BK_DEV void bk_need_apart(BkState &S, bkv a, bkv b)
 BK_DEV bkv bk_eq(BkState &S, bkv a, bkv b)
 {
     if (a.t == BK_TNUM && b.t == BK_TNUM) bk_need_apart(S, a, b);
-    return bk_bool(a.t == b.t && (a.t != BK_TNUM || a.n == b.n));
+    return bk_bool(a.t == b.t && (a.t < BK_TNUM || a.n == b.n));
 }
 BK_DEV bkv bk_ne(BkState &S, bkv a, bkv b)
 {
     if (a.t == BK_TNUM && b.t == BK_TNUM) bk_need_apart(S, a, b);
-    return bk_bool(!(a.t == b.t && (a.t != BK_TNUM || a.n == b.n)));
+    return bk_bool(!(a.t == b.t && (a.t < BK_TNUM || a.n == b.n)));
 }
 BK_DEV bkv bk_lt(BkState &S, bkv a, bkv b)
 {

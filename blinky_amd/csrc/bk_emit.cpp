@@ -60,6 +60,14 @@ struct Emitter {
     std::map<const Table *, std::pair<std::string, int>> const_tables;   // table -> (array name, n)
     std::ostringstream table_code;
     int uid = 0;
+    // string constants: device code only ever compares them, so a string is its number in this table
+    std::map<std::string, int> strings{{"nil", 1}, {"boolean", 2}, {"number", 3}, {"string", 4}};   // (type() results first)
+    std::string str_literal(const std::string &v)
+    {
+        auto it = strings.find(v);
+        if (it == strings.end()) it = strings.emplace(v, (int)strings.size() + 1).first;
+        return "bk_str(" + std::to_string(it->second) + ")";
+    }
 
     explicit Emitter(Interp &i) : I(i) {}
 
@@ -150,6 +158,11 @@ struct Emitter {
                 break;
             case Value::BOOL: snprintf(buf, sizeof buf, ", {0.0, 0.0, %s}", v.b ? "BK_TTRUE" : "BK_TFALSE"); break;
             case Value::NIL: snprintf(buf, sizeof buf, ", {0.0, 0.0, BK_TNIL}"); break;
+            case Value::STR: {
+                const std::string lit = str_literal(*v.s);        // "bk_str(<id>)"
+                snprintf(buf, sizeof buf, ", {%s.0, 0.0, BK_TSTR}", lit.substr(7, lit.size() - 8).c_str());
+                break;
+            }
             default: unsupported(f.chunk, at.line, std::string("table '") + hint + "' holding a " + v.type_name());
             }
             table_code << buf;
@@ -165,6 +178,7 @@ struct Emitter {
         case Value::NIL: return "bk_nil()";
         case Value::BOOL: return v.b ? "bk_bool(true)" : "bk_bool(false)";
         case Value::NUM: return num_literal(v.n);
+        case Value::STR: return str_literal(*v.s);
         default: unsupported(f.chunk, e.line, what + " (a " + v.type_name() + ") used as a value");
         }
     }
@@ -176,7 +190,7 @@ struct Emitter {
         case Expr::True: return "bk_bool(true)";
         case Expr::False: return "bk_bool(false)";
         case Expr::Number: return num_literal(e.num);
-        case Expr::String: unsupported(f.chunk, e.line, "string values");
+        case Expr::String: return str_literal(e.str);       // (compared with == / ~= only; no string operations on the device)
         case Expr::Vararg: unsupported(f.chunk, e.line, "'...'");
         case Expr::Function: unsupported(f.chunk, e.line, "function values / closures");
         case Expr::Table: unsupported(f.chunk, e.line, "table constructors other than 'local t = {a, b, ...}'");
@@ -384,6 +398,7 @@ struct Emitter {
             line(f, "bkv " + *arr + "[2]; bk_f_modf(S, " + A(0) + ", " + *arr + "); const int " + *cnt + " = 2;");
             return;
         }
+        if (bn == "type") { single("bk_typeof(" + A(0) + ")"); return; }
         if (bn == "latlon_to_ray") {
             line(f, "bkv " + *arr + "[3]; const int " + *cnt + " = bk_host_latlon_to_ray(S, " + A(0) + ", " + A(1) + ", " + *arr + ");");
             return;
@@ -545,7 +560,41 @@ struct Emitter {
             line(f, "}");
             return;
         }
-        case Stmt::GenFor: unsupported(f.chunk, s.line, "generic 'for ... in' loops");
+        case Stmt::GenFor: {
+            // `for i, v in ipairs(t)` / `for k, v in pairs(t)` over a table whose size is known when the code is generated:
+            // one made by `local t = {..}` in the same function, or a global / upvalue array table nobody assigns
+            const Expr *call = s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Call ? s.exprs[0].get() : nullptr;
+            Value callee;
+            if (!call || !static_value(f, *call->a, &callee) || callee.t != Value::BUILTIN ||
+                (callee.bi->name != "ipairs" && callee.bi->name != "pairs") || call->args.size() != 1)
+                unsupported(f.chunk, s.line, "generic 'for ... in' other than ipairs(t) / pairs(t)");
+            const bool is_ipairs = callee.bi->name == "ipairs";
+            const Expr &targ = *call->args[0];
+            std::string arr;
+            int n = 0;
+            if (targ.kind == Expr::Name && targ.var == VarKind::Local && f.array_slots.count(targ.slot)) {
+                arr = "A" + std::to_string(targ.slot);
+                n = f.array_slots[targ.slot];
+            } else {
+                Value tv;
+                if (!static_value(f, targ, &tv) || tv.t != Value::TABLE) unsupported(f.chunk, s.line, "iterating a table that is not known when the kernel is generated");
+                auto ct = const_table(f, targ, tv.tab, targ.kind == Expr::Name ? targ.str : "table");
+                arr = ct.first;
+                n = ct.second;
+            }
+            std::string gi = tmp("gi"), gv = tmp("gv");
+            line(f, "for (int " + gi + " = 1; " + gi + " <= " + std::to_string(n) + "; ++" + gi + ") {");
+            f.indent++;
+            line(f, "if (!bk_tick(S)) break;");
+            line(f, "const bkv " + gv + " = " + arr + "[" + gi + "];");
+            line(f, std::string("if (") + gv + ".t == BK_TNIL) " + (is_ipairs ? "break;" : "continue;"));   // ipairs stops at the first nil, pairs skips it
+            for (size_t i = 0; i < s.slots.size(); ++i)
+                line(f, "l" + std::to_string(s.slots[i]) + " = " + (i == 0 ? "bk_num((double)" + gi + ")" : i == 1 ? gv : std::string("bk_nil()")) + ";");
+            emit_block(f, s.body);
+            f.indent--;
+            line(f, "}");
+            return;
+        }
         case Stmt::Return: {
             if (s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Call) {
                 std::string arr, cnt;
@@ -655,9 +704,10 @@ std::string emit_build_source(const EmitRequest &req)
         case Value::NIL: init = "bk_nil()"; break;
         case Value::BOOL: init = v.b ? "bk_bool(true)" : "bk_bool(false)"; break;
         case Value::NUM: init = num_literal(v.n); break;
+        case Value::STR: init = em.str_literal(*v.s); break;
         default:
             throw LuaError("global '" + g + "' is assigned inside a GPU callback but holds a " + v.type_name() +
-                           " when the lensmap build starts; only nil / boolean / number globals can be per-pixel state");
+                           " when the lensmap build starts; only nil / boolean / number / string globals can be per-pixel state");
         }
         src << " (S).g_" << sanitize(g) << " = " << init << ";";
     }

@@ -1372,6 +1372,7 @@ Interp::Interp(const MathLib &m) : math(&m)
         else if (k.t == Value::NUM && k.n >= 1 && k.n <= (double)t.arr.size() && k.n == std::floor(k.n)) ai = (size_t)k.n;
         else after_arr = true;
         if (!after_arr) {
+            while (ai < t.arr.size() && t.arr[ai].t == Value::NIL) ++ai;          // (holes are not entries)
             if (ai < t.arr.size()) { r.push_back(Value::number((double)ai + 1)); r.push_back(t.arr[ai]); return; }
             if (!t.nhash.empty()) { r.push_back(Value::number(t.nhash.begin()->first)); r.push_back(t.nhash.begin()->second); return; }
             if (!t.shash.empty()) { r.push_back(Value::string(t.shash.begin()->first)); r.push_back(t.shash.begin()->second); return; }

@@ -269,6 +269,38 @@ def test_async_compile_answers_pending_and_keeps_the_previous_lensmap(bk, tmp_pa
     ctx.close()
 
 
+def test_generic_for_strings_and_type_on_the_device(bk):
+    """`for .. in ipairs/pairs`, string constants (==, ~=, per-pixel string state) and type(): device results bit-equal to
+    the host interpreter's"""
+    from test_frontend import GENERIC_FOR_LENS
+    ctx = bk.Context()
+    ctx.set_host_math(True)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(GENERIC_FOR_LENS, "gf.lua")
+    ctx.resize(64, 48)
+    rng = np.random.default_rng(4)
+    args = np.concatenate([rng.uniform(-2.5, 2.5, (300, 2)), [[1.95, 0.0], [0.0, 0.0]]])
+    d_out, d_n = ctx.eval_device(0, args)
+    # (a host interpreter carries the global `mode` from call to call; on the device it is per-pixel state - so every
+    #  argument is compared with a FRESH interpreter)
+    flips = args[:, 0] > 1.9
+    fresh = []
+    for a in args:
+        c2 = bk.Context(bk.ffi.DEVICE_NONE)
+        c2.set_host_math(True)
+        c2.load_globe(S.script("globes", "cube"), "cube")
+        c2.load_lens(GENERIC_FOR_LENS, "gf.lua")
+        fresh.append(c2.eval_host(0, *a))
+        c2.close()
+    for i, r in enumerate(fresh):
+        if r is None:
+            assert d_n[i] == -1, (i, args[i])
+        else:
+            assert d_n[i] == 3 and d_out[i, :3].tobytes() == np.array(r).tobytes(), (i, args[i])
+    assert (d_n[flips] == -1).all() and (d_n[~flips] == 3).all()
+    ctx.close()
+
+
 def test_script_runtime_errors_surface_as_errors(bk):
     ctx = bk.Context()
     ctx.load_globe(S.script("globes", "cube"), "cube")

@@ -311,3 +311,46 @@ def test_unsupported_gpu_constructs_are_named(bk):
     ctx = lens_ctx(bk, "function f(n) if n < 1 then return 1 end return f(n-1) end function lens_inverse(x,y) return f(3),0,1 end")
     with pytest.raises(bk.BlinkyError, match="recursion"):
         ctx.kernel_source()
+
+
+# ---- generic for, string constants, type(): host semantics here, device == host in tests/test_build_gpu.py ---------------
+
+GENERIC_FOR_LENS = """
+local names = {"a", "bb", "a"}
+weights = {0.25, 0.5, 0.125, 0.125}
+mode = "wide"
+lens_width = 4 lens_height = 3
+function lens_inverse(x, y)
+  local s = 0
+  for i, w in ipairs(weights) do s = s + w * i end            -- a global array table nobody assigns
+  local t = {x, y, x + y}
+  local m = -100
+  for k, v in pairs(t) do if type(v) == "number" and v > m then m = v end end    -- a table made in this function
+  local c = 0
+  for _, nm in ipairs(names) do if nm == "a" then c = c + 1 end end               -- an upvalue table of strings
+  if mode ~= "wide" or type(mode) ~= "string" or type(nil) ~= "nil" then return nil end
+  if x > 1.9 then mode = "narrow" end                         -- a string global as per-pixel state
+  if mode == "narrow" then return nil end
+  return s, m, c
+end
+"""
+
+
+def test_generic_for_strings_and_type(bk):
+    ctx = lens_ctx(bk, GENERIC_FOR_LENS)
+    assert ctx.eval_host(0, 0.5, 0.25) == (0.25 * 1 + 0.5 * 2 + 0.125 * 3 + 0.125 * 4, 0.75, 2.0)
+    assert ctx.eval_host(0, -1.0, -2.0) == (2.125, -1.0, 2.0)
+    ctx.resize(64, 48)
+    src = ctx.kernel_source(compile=True)                      # translates and compiles for gfx950
+    assert "bk_typeof" in src and "BK_TSTR" in src and "gi" in src
+    # pairs() skips holes, ipairs() stops at the first one (Lua semantics)
+    assert ev(bk, "function lens_inverse(x,y) local t = {1, nil, 3} local a, b = 0, 0 for _, v in pairs(t) do a = a + v end "
+                  "for _, v in ipairs(t) do b = b + v end return a, b, 0 end", 0, 0) == (4.0, 1.0, 0.0)
+
+
+def test_generic_for_over_an_unknown_iterator_is_rejected_with_a_message(bk):
+    ctx = lens_ctx(bk, "lens_width = 2 lens_height = 2 local function it() return nil end "
+                       "function lens_inverse(x,y) for v in it do end return x, y, 1 end")
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match="generic 'for ... in' other than ipairs"):
+        ctx.kernel_source()
