@@ -822,25 +822,23 @@ void for_each_flagged(LensProgram *P, size_t n, Fn fn)
 {
     HostEval main_eval{&P->interp, P->lens_inverse, P->lens_forward, P->globe_plate};
     unsigned hw = std::thread::hardware_concurrency();
-    size_t nthreads = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 64), n / 256);
+    size_t nthreads = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 256), n / 48);      // (a copy of the interpreter costs about as much as 20-50 evaluations)
     if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) nthreads = (size_t)std::max(1, atoi(e));
     if (nthreads <= 1 || n < 2) {
         for (size_t i = 0; i < n; ++i) fn(main_eval, i);
         return;
     }
-    std::vector<std::unique_ptr<Interp>> interps(nthreads);
-    std::vector<HostEval> evals(nthreads);
-    for (size_t t = 0; t < nthreads; ++t) {
-        Values roots;
-        interps[t] = P->interp.clone(Values{P->lens_inverse, P->lens_forward, P->globe_plate}, &roots);
-        evals[t] = HostEval{interps[t].get(), roots[0], roots[1], roots[2]};
-    }
     std::vector<std::string> errors(nthreads);
     std::vector<std::thread> pool;
+    const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
     for (size_t t = 0; t < nthreads; ++t)
         pool.emplace_back([&, t]() {
             try {
-                for (size_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i) fn(evals[t], i);
+                // every worker copies the interpreter for itself (the original is only read meanwhile)
+                Values roots;
+                std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
+                HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
+                for (size_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i) fn(ev, i);
             } catch (const LuaError &e) { errors[t] = e.what(); }
         });
     for (std::thread &th : pool) th.join();

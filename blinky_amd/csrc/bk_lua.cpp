@@ -1,6 +1,8 @@
 // bk_lua.cpp -- lexer, parser and host interpreter for the Lua 5.2 subset (see bk_lua.h).
 #include "bk_lua.h"
 
+#include <mutex>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -271,7 +273,12 @@ struct Parser {
             if (s->f->upvals[i].name == name) return (int)i;
         if (!s->parent) return -1;
         int l = find_local(s->parent, name);
-        if (l >= 0) { s->f->upvals.push_back({true, l, name}); return (int)s->f->upvals.size() - 1; }
+        if (l >= 0) {
+            if (s->parent->f->captured.size() <= (size_t)l) s->parent->f->captured.resize((size_t)l + 1, 0);
+            s->parent->f->captured[(size_t)l] = 1;
+            s->f->upvals.push_back({true, l, name});
+            return (int)s->f->upvals.size() - 1;
+        }
         int u = find_upval(s->parent, name);
         if (u < 0) return -1;
         s->f->upvals.push_back({false, u, name});
@@ -288,6 +295,7 @@ struct Parser {
         int u = find_upval(fs, name);
         if (u >= 0) { e->var = VarKind::Upvalue; e->slot = u; return e; }
         e->var = VarKind::Global;
+        e->slot = global_id(name);
         return e;
     }
 
@@ -396,6 +404,7 @@ struct Parser {
             if (e->kind == Expr::Call || e->kind == Expr::Vararg) {
                 ExprP w = mk(Expr::Unop);
                 w->str = "()";
+                w->op = Expr::OP_PAREN;
                 w->a = std::move(e);
                 return w;
             }
@@ -487,6 +496,7 @@ struct Parser {
         if (un) {
             ExprP u = mk(Expr::Unop);
             u->str = un;
+            u->op = un[0] == 'n' ? Expr::OP_NOT : un[0] == '-' ? Expr::OP_NEG : Expr::OP_LEN;
             advance();
             u->a = subexpr(8);                                   // UNARY_PRIORITY
             // fold -<number literal> like the stock compiler (exact)
@@ -499,6 +509,13 @@ struct Parser {
         while (binop_info(&op) && op.left > limit) {
             ExprP b = mk(Expr::Binop);
             b->str = op.name;
+            {
+                static const std::pair<const char *, Expr::Op> ops[] = {
+                    {"+", Expr::OP_ADD}, {"-", Expr::OP_SUB}, {"*", Expr::OP_MUL}, {"/", Expr::OP_DIV}, {"%", Expr::OP_MOD}, {"^", Expr::OP_POW},
+                    {"..", Expr::OP_CONCAT}, {"==", Expr::OP_EQ}, {"~=", Expr::OP_NE}, {"<", Expr::OP_LT}, {"<=", Expr::OP_LE}, {">", Expr::OP_GT},
+                    {">=", Expr::OP_GE}, {"and", Expr::OP_AND}, {"or", Expr::OP_OR}};
+                for (const auto &o : ops) if (b->str == o.first) b->op = o.second;
+            }
             advance();
             b->a = std::move(e);
             b->b = subexpr(op.right);
@@ -800,7 +817,8 @@ namespace {
 
 struct Frame {
     Closure *cl;
-    std::vector<std::shared_ptr<Value>> cells;
+    Values regs;                                   // locals no inner function refers to
+    std::vector<std::shared_ptr<Value>> cells;     // locals that closures capture (FuncProto::captured)
     Values varargs;
 };
 
@@ -877,8 +895,15 @@ struct Exec {
 
     Value &local_cell(Frame &f, int slot)
     {
+        if (!f.cl->proto->is_captured(slot)) return f.regs[(size_t)slot];
         if (!f.cells[slot]) f.cells[slot] = std::make_shared<Value>();
         return *f.cells[slot];
+    }
+    // a NEW variable in `slot` (a `local`, a loop variable of this iteration): closures made earlier keep the old cell
+    static void fresh_local(Frame &f, int slot, const Value &v)
+    {
+        if (f.cl->proto->is_captured(slot)) f.cells[slot] = std::make_shared<Value>(v);
+        else f.regs[(size_t)slot] = v;
     }
 
     Value eval(Frame &f, const Expr &e)
@@ -893,7 +918,7 @@ struct Exec {
         case Expr::Name:
             if (e.var == VarKind::Local) return local_cell(f, e.slot);
             if (e.var == VarKind::Upvalue) return *f.cl->upvals[e.slot];
-            return I.get_global(e.str);
+            return I.global_ref(e.slot, e.str);
         case Expr::Index: {
             Value o = eval(f, *e.a);
             Value k = eval(f, *e.b);
@@ -942,15 +967,15 @@ struct Exec {
             return v;
         }
         case Expr::Unop: {
-            if (e.str == "()") return eval(f, *e.a);
+            if (e.op == Expr::OP_PAREN) return eval(f, *e.a);
             Value a = eval(f, *e.a);
-            if (e.str == "not") return Value::boolean(!a.truthy());
-            if (e.str == "-") {
+            if (e.op == Expr::OP_NOT) return Value::boolean(!a.truthy());
+            if (e.op == Expr::OP_NEG) {
                 double x;
                 if (!tonumber(a, &x)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + a.type_name() + " value");
                 return Value::number(-x);
             }
-            if (e.str == "#") {
+            if (e.op == Expr::OP_LEN) {
                 if (a.t == Value::STR) return Value::number((double)a.s->size());
                 if (a.t == Value::TABLE) return Value::number((double)a.tab->length());
                 error(e.line, chunk_of(f), std::string("attempt to get length of a ") + a.type_name() + " value");
@@ -959,17 +984,32 @@ struct Exec {
         }
         case Expr::Binop: {
             const std::string &op = e.str;
-            if (op == "and") { Value a = eval(f, *e.a); return a.truthy() ? eval(f, *e.b) : a; }
-            if (op == "or") { Value a = eval(f, *e.a); return a.truthy() ? a : eval(f, *e.b); }
+            if (e.op == Expr::OP_AND) { Value a = eval(f, *e.a); return a.truthy() ? eval(f, *e.b) : a; }
+            if (e.op == Expr::OP_OR) { Value a = eval(f, *e.a); return a.truthy() ? a : eval(f, *e.b); }
             Value a = eval(f, *e.a);
             Value b = eval(f, *e.b);
-            if (op == "==") return Value::boolean(raw_equal(a, b));
-            if (op == "~=") return Value::boolean(!raw_equal(a, b));
-            if (op == "<") return Value::boolean(less(f, e, a, b, false));
-            if (op == "<=") return Value::boolean(less(f, e, a, b, true));
-            if (op == ">") return Value::boolean(less(f, e, b, a, false));
-            if (op == ">=") return Value::boolean(less(f, e, b, a, true));
-            if (op == "..") {
+            if (a.t == Value::NUM && b.t == Value::NUM) {              // the common case, without the generic helpers
+                switch (e.op) {
+                case Expr::OP_ADD: return Value::number(a.n + b.n);
+                case Expr::OP_SUB: return Value::number(a.n - b.n);
+                case Expr::OP_MUL: return Value::number(a.n * b.n);
+                case Expr::OP_DIV: return Value::number(a.n / b.n);
+                case Expr::OP_LT: return Value::boolean(a.n < b.n);
+                case Expr::OP_LE: return Value::boolean(a.n <= b.n);
+                case Expr::OP_GT: return Value::boolean(b.n < a.n);
+                case Expr::OP_GE: return Value::boolean(b.n <= a.n);
+                case Expr::OP_EQ: return Value::boolean(a.n == b.n);
+                case Expr::OP_NE: return Value::boolean(!(a.n == b.n));
+                default: break;
+                }
+            }
+            if (e.op == Expr::OP_EQ) return Value::boolean(raw_equal(a, b));
+            if (e.op == Expr::OP_NE) return Value::boolean(!raw_equal(a, b));
+            if (e.op == Expr::OP_LT) return Value::boolean(less(f, e, a, b, false));
+            if (e.op == Expr::OP_LE) return Value::boolean(less(f, e, a, b, true));
+            if (e.op == Expr::OP_GT) return Value::boolean(less(f, e, b, a, false));
+            if (e.op == Expr::OP_GE) return Value::boolean(less(f, e, b, a, true));
+            if (e.op == Expr::OP_CONCAT) {
                 if ((a.t != Value::STR && a.t != Value::NUM) || (b.t != Value::STR && b.t != Value::NUM))
                     error(e.line, chunk_of(f), std::string("attempt to concatenate a ") + (a.t != Value::STR && a.t != Value::NUM ? a : b).type_name() + " value");
                 return Value::string(I.tostring(a) + I.tostring(b));
@@ -1013,7 +1053,7 @@ struct Exec {
         if (target.kind == Expr::Name) {
             if (target.var == VarKind::Local) local_cell(f, target.slot) = v;
             else if (target.var == VarKind::Upvalue) *f.cl->upvals[target.slot] = v;
-            else I.set_global(target.str, v);
+            else I.global_ref(target.slot, target.str) = v;
             return;
         }
         Value o = eval(f, *target.a);
@@ -1043,12 +1083,12 @@ struct Exec {
         case Stmt::Local: {
             Values v = eval_list(f, s.exprs);
             for (size_t i = 0; i < s.slots.size(); ++i)
-                f.cells[s.slots[i]] = std::make_shared<Value>(i < v.size() ? v[i] : Value());   // fresh cell
+                fresh_local(f, s.slots[i], i < v.size() ? v[i] : Value());
             return F_NORMAL;
         }
         case Stmt::LocalFunction: {
-            f.cells[s.slots[0]] = std::make_shared<Value>();
-            *f.cells[s.slots[0]] = eval(f, *s.exprs[0]);
+            fresh_local(f, s.slots[0], Value());                       // (the function sees itself: declared before it is evaluated)
+            local_cell(f, s.slots[0]) = eval(f, *s.exprs[0]);
             return F_NORMAL;
         }
         case Stmt::Assign: {
@@ -1090,7 +1130,7 @@ struct Exec {
                 idx = idx + step;
                 if (!(0 < step ? idx <= stop : stop <= idx)) break;
                 tick(f, s.line);
-                f.cells[s.slots[0]] = std::make_shared<Value>(Value::number(idx));
+                fresh_local(f, s.slots[0], Value::number(idx));
                 Flow fl = exec_block(f, s.body, ret);
                 if (fl == F_BREAK) break;
                 if (fl == F_RETURN) return fl;
@@ -1108,7 +1148,7 @@ struct Exec {
                 if (r.empty() || r[0].t == Value::NIL) break;
                 ctl = r[0];
                 for (size_t i = 0; i < s.slots.size(); ++i)
-                    f.cells[s.slots[i]] = std::make_shared<Value>(i < r.size() ? r[i] : Value());
+                    fresh_local(f, s.slots[i], i < r.size() ? r[i] : Value());
                 Flow fl = exec_block(f, s.body, ret);
                 if (fl == F_BREAK) break;
                 if (fl == F_RETURN) return fl;
@@ -1124,6 +1164,16 @@ struct Exec {
 
 }  // namespace
 
+int global_id(const std::string &name)
+{
+    static std::mutex m;
+    static std::map<std::string, int> ids;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = ids.find(name);
+    if (it == ids.end()) it = ids.emplace(name, (int)ids.size()).first;
+    return it->second;
+}
+
 Value Interp::get_global(const std::string &name) const
 {
     auto it = globals.find(name);
@@ -1131,7 +1181,7 @@ Value Interp::get_global(const std::string &name) const
 }
 void Interp::set_global(const std::string &name, const Value &v)
 {
-    if (v.t == Value::NIL) globals.erase(name); else globals[name] = v;
+    globals[name] = v;                        // (nil stays as a nil-valued node: gslots point at the nodes)
 }
 void Interp::register_builtin(const std::string &name, BuiltinFn fn)
 {
@@ -1204,9 +1254,8 @@ struct Cloner {
 
 std::unique_ptr<Interp> Interp::clone(const std::vector<Value> &roots, std::vector<Value> *roots_out) const
 {
-    std::unique_ptr<Interp> n(new Interp(*math));
+    std::unique_ptr<Interp> n(new Interp(*math, Empty{}));
     Cloner c;
-    n->globals.clear();
     for (const auto &kv : globals) n->globals[kv.first] = c.value(kv.second);
     n->max_steps = max_steps;
     n->print_sink = nullptr;
@@ -1243,9 +1292,12 @@ Values Interp::call(const Value &fv, const Values &args)
     const FuncProto *p = fv.fn->proto;
     Frame fr;
     fr.cl = fv.fn.get();
-    fr.cells.resize((size_t)p->nslots);
-    for (int i = 0; i < p->nparams; ++i)
-        fr.cells[i] = std::make_shared<Value>((size_t)i < args.size() ? args[i] : Value());
+    fr.regs.resize((size_t)p->nslots);
+    if (!p->captured.empty()) fr.cells.resize((size_t)p->nslots);
+    for (int i = 0; i < p->nparams; ++i) {
+        if (p->is_captured(i)) fr.cells[i] = std::make_shared<Value>((size_t)i < args.size() ? args[i] : Value());
+        else if ((size_t)i < args.size()) fr.regs[(size_t)i] = args[i];
+    }
     if (p->is_vararg && args.size() > (size_t)p->nparams) fr.varargs.assign(args.begin() + p->nparams, args.end());
     Values ret;
     Exec ex(*this);

@@ -50,9 +50,14 @@ struct Expr {
     int line = 0;
     double num = 0;
     std::string str;              // String value / Name / operator
+    // the operator of a Binop / Unop once more as a number: the interpreter dispatches on it (string compares per
+    // evaluated operator were most of its time)
+    enum Op { OP_NONE, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_POW, OP_CONCAT, OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_AND, OP_OR,
+              OP_NOT, OP_NEG, OP_LEN, OP_PAREN };
+    Op op = OP_NONE;
     // Name
     VarKind var = VarKind::Global;
-    int slot = -1;                // local slot or upvalue index
+    int slot = -1;                // local slot or upvalue index; Global: the name's process-wide number (global_id)
     // Index: a[b]; Call: a(args); Binop: a op b; Unop: op a
     ExprP a, b;
     std::vector<ExprP> args;      // Call arguments / Table array items
@@ -85,6 +90,8 @@ struct FuncProto {
     int nslots = 0;                       // local slots (params first)
     std::vector<std::string> slot_names;
     std::vector<UpvalDesc> upvals;
+    std::vector<char> captured;           // by local slot: an inner function refers to it (it then lives in a shared cell)
+    bool is_captured(int slot) const { return (size_t)slot < captured.size() && captured[(size_t)slot]; }
     Block body;
     FuncProto *parent = nullptr;
 };
@@ -96,6 +103,7 @@ struct Chunk {
 };
 
 std::shared_ptr<Chunk> parse(const std::string &src, const std::string &chunkname);
+int global_id(const std::string &name);     // process-wide number of a global name (assigned by the parser)
 
 // ---- runtime values --------------------------------------------------------------------------
 struct Table;
@@ -141,8 +149,18 @@ struct Closure {
 
 struct Interp {
     explicit Interp(const MathLib &m);
+    struct Empty {};
+    Interp(const MathLib &m, Empty) : math(&m) {}        // no standard library: clone() fills the globals itself
     const MathLib *math;                    // swappable: platform libm (reference-faithful) or bkm.h
-    std::map<std::string, Value> globals;
+    std::map<std::string, Value> globals;   // (a nil-valued entry is an absent global; nodes are never erased, see gslots)
+    std::vector<Value *> gslots;            // by Expr::slot of a Global name: its node in `globals` (std::map nodes do not move)
+    Value &global_ref(int gid, const std::string &name)
+    {
+        if ((size_t)gid >= gslots.size()) gslots.resize((size_t)gid + 64, nullptr);
+        Value *&p = gslots[(size_t)gid];
+        if (!p) p = &globals[name];
+        return *p;
+    }
     long steps = 0, max_steps = 200000000;  // runaway-script guard
     int depth = 0;
     std::function<void(const std::string &)> print_sink;   // `print` output (Con_Printf)
