@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <future>
 #include <map>
 #include <memory>
@@ -815,33 +817,96 @@ bool h_texel_owns(bk_ctx *ctx, HostEval &E, const BkBuildParams &bp, uint32_t id
     return (int)plate == h_ray_to_plate_index(E, bp, ray);
 }
 
-/* fn(E, i) for i in [0, n): on the context's interpreter when the list is short, otherwise on per-thread copies of it.
- * The first script error any worker meets is rethrown here. */
+/* A small process-wide pool of worker threads for the host re-evaluation (creating 64-256 threads per build cost more
+ * than the evaluations themselves).  Created on first use, never torn down (its threads sleep on a condition variable). */
+class FixupPool {
+public:
+    static FixupPool &get()
+    {
+        static FixupPool *pool = new FixupPool();            // (leaked on purpose: no destructor races at process exit)
+        return *pool;
+    }
+    size_t size() const { return workers_; }
+    /* run job(worker_index) on `want` workers (<= size()) and wait for all of them */
+    void run(size_t want, const std::function<void(size_t)> &job)
+    {
+        std::unique_lock<std::mutex> submit(submit_mutex_);  // one parallel section at a time
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            job_ = &job;
+            want_ = want;
+            next_ = 0;
+            done_ = 0;
+            ++generation_;
+        }
+        wake_.notify_all();
+        std::unique_lock<std::mutex> lock(m_);
+        finished_.wait(lock, [&] { return done_ == want_; });
+        job_ = nullptr;
+    }
+
+private:
+    FixupPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        workers_ = std::min<size_t>(hw ? hw : 1, 64);
+        if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) workers_ = (size_t)std::max(1, std::min(256, atoi(e)));
+        for (size_t i = 0; i < workers_; ++i) std::thread([this] { loop(); }).detach();
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)> *job = nullptr;
+            size_t mine = 0;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                wake_.wait(lock, [&] { return generation_ != seen && next_ < want_; });
+                job = job_;
+                mine = next_++;
+                if (next_ >= want_) seen = generation_;          // (this generation has handed out all its shares)
+            }
+            (*job)(mine);
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (++done_ == want_) finished_.notify_all();
+            }
+        }
+    }
+    std::mutex m_, submit_mutex_;
+    std::condition_variable wake_, finished_;
+    const std::function<void(size_t)> *job_ = nullptr;
+    size_t want_ = 0, next_ = 0, done_ = 0, workers_ = 1;
+    uint64_t generation_ = 0;
+};
+
+/* fn(E, i) for i in [0, n): on the context's interpreter when the list is short, otherwise on the pool's workers, each
+ * on its own deep copy of the interpreter state.  The first script error any worker meets is rethrown here. */
 template <typename Fn>
 void for_each_flagged(LensProgram *P, size_t n, Fn fn)
 {
     HostEval main_eval{&P->interp, P->lens_inverse, P->lens_forward, P->globe_plate};
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nthreads = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 256), n / 48);      // (a copy of the interpreter costs about as much as 20-50 evaluations)
-    if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) nthreads = (size_t)std::max(1, atoi(e));
-    if (nthreads <= 1 || n < 2) {
+    if (n < 256) {
+        for (size_t i = 0; i < n; ++i) fn(main_eval, i);
+        return;
+    }
+    FixupPool &pool = FixupPool::get();
+    const size_t nthreads = std::max<size_t>(1, std::min(pool.size(), n / 128));
+    if (nthreads <= 1) {
         for (size_t i = 0; i < n; ++i) fn(main_eval, i);
         return;
     }
     std::vector<std::string> errors(nthreads);
-    std::vector<std::thread> pool;
     const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
-    for (size_t t = 0; t < nthreads; ++t)
-        pool.emplace_back([&, t]() {
-            try {
-                // every worker copies the interpreter for itself (the original is only read meanwhile)
-                Values roots;
-                std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
-                HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
-                for (size_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i) fn(ev, i);
-            } catch (const LuaError &e) { errors[t] = e.what(); }
-        });
-    for (std::thread &th : pool) th.join();
+    pool.run(nthreads, [&](size_t t) {
+        try {
+            // every worker copies the interpreter for itself (the original is only read meanwhile)
+            Values roots;
+            std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
+            HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
+            for (size_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i) fn(ev, i);
+        } catch (const LuaError &e) { errors[t] = e.what(); }
+    });
     for (const std::string &e : errors) if (!e.empty()) throw LuaError(e);
 }
 
