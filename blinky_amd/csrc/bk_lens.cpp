@@ -849,7 +849,7 @@ private:
     FixupPool()
     {
         unsigned hw = std::thread::hardware_concurrency();
-        workers_ = std::min<size_t>(hw ? hw : 1, 64);
+        workers_ = std::min<size_t>(hw ? hw : 1, 128);
         if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) workers_ = (size_t)std::max(1, std::min(256, atoi(e)));
         for (size_t i = 0; i < workers_; ++i) std::thread([this] { loop(); }).detach();
     }
