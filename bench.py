@@ -277,20 +277,31 @@ def main():
     # Should the grouped send/recv not be usable on this node, fall back to the plain gather onto rank 0 (and say so)
     # rather than lose the measurement; every rank takes the same decision.
     exchange_mode = "rotating"
-    if world > 1:
+
+    def exchange_works():
         ok = 1
         try:
             step(0)
             drain()
             torch.cuda.synchronize()
         except Exception as e:      # noqa: BLE001
-            print(f"[bench] rank {rank}: rotating exchange failed ({type(e).__name__}: {e}); using gather to rank 0", file=sys.stderr, flush=True)
+            print(f"[bench] rank {rank}: rotating exchange failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
             ok = 0
         t = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0:
+        pending[0], pending[1] = [], []
+        return int(t.item()) == 1
+
+    if world > 1 and not exchange_works():
+        if comm is not None:
+            # libblinkyhip's communicator came up but its exchange did not run: try the process group's RCCL before
+            # giving up on rotating roots (the JSON line says which transport was timed)
+            print(f"[bench] rank {rank}: falling back from bk_comm to torch.distributed", file=sys.stderr, flush=True)
+            comm = None
+            if not exchange_works():
+                exchange_mode = "root"
+        else:
             exchange_mode = "root"
-            pending[0], pending[1] = [], []
     run_step = step if exchange_mode == "rotating" else step_root
 
     def timed_region(first):

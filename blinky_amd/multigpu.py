@@ -26,12 +26,20 @@ def rccl_comm(ctx, world, rank, device):
     """bk_comm for this rank: rank 0 draws the RCCL unique id, the process group broadcasts it, every rank joins
     (ncclCommInitRank inside libblinkyhip).  Also restricts `ctx` to this rank's stripe."""
     from . import ffi
-    t = torch.zeros(128, dtype=torch.uint8, device=device)
+    t = torch.zeros(129, dtype=torch.uint8, device=device)          # [0] = rank 0 has an id, [1:] = the id
     if rank == 0:
-        t.copy_(torch.frombuffer(bytearray(ffi.comm_unique_id()), dtype=torch.uint8))
+        try:
+            uid = ffi.comm_unique_id()
+            t[1:].copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+            t[0] = 1
+        except ffi.BlinkyError as e:                                 # every rank must learn of it, or the others wait forever
+            print(f"[blinky_amd.multigpu] rank 0: {e}", flush=True)
     if world > 1:
         dist.broadcast(t, src=0)
-    return ffi.Comm(ctx, world, rank, bytes(t.cpu().numpy().tobytes()))
+    h = t.cpu().numpy()
+    if h[0] != 1:
+        raise ffi.BlinkyError("rank 0 could not draw an RCCL unique id (bk_comm_unique_id)")
+    return ffi.Comm(ctx, world, rank, bytes(h[1:].tobytes()))
 
 
 def stripe_bounds(height, world):
