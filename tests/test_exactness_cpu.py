@@ -96,8 +96,15 @@ def test_platform_libm_is_within_the_assumed_bound_of_bkm():
         "acos": (math.acos, rng.uniform(-1, 1, 20000)), "atan": (math.atan, rng.uniform(-50, 50, 20000)),
         "exp": (math.exp, rng.uniform(-20, 20, 20000)), "log": (math.log, rng.uniform(1e-6, 1e3, 20000)),
         "sinh": (math.sinh, rng.uniform(-10, 10, 20000)), "cosh": (math.cosh, rng.uniform(-10, 10, 20000)),
-        "tanh": (math.tanh, rng.uniform(-5, 5, 20000)),
+        "tanh": (math.tanh, rng.uniform(-5, 5, 20000)), "log10": (math.log10, rng.uniform(1e-6, 1e3, 20000)),
     }
+    two = {"atan2": (math.atan2, rng.uniform(-5, 5, 20000), rng.uniform(-5, 5, 20000)),
+           "pow": (math.pow, rng.uniform(0.01, 20, 20000), rng.uniform(-6, 6, 20000))}
+    for name, (ref, xs, ys) in two.items():
+        fn = getattr(lib, "bkmh_" + name)
+        fn.restype, fn.argtypes = C.c_double, [C.c_double, C.c_double]
+        worst = max(abs(fn(float(x), float(y)) - ref(float(x), float(y))) / abs(ref(float(x), float(y))) for x, y in zip(xs, ys))
+        assert worst <= 2.0 ** -50, (name, worst)
     for name, (ref, xs) in cases.items():
         fn = getattr(lib, "bkmh_" + name)
         fn.restype, fn.argtypes = C.c_double, [C.c_double]
