@@ -498,19 +498,32 @@ static int ensure_spans(bk_ctx *ctx)
     return BK_OK;
 }
 
-extern "C" int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int x0, int y0,
-                        int rubix_on, const uint8_t pal[BK_MAX_PLATES][256])
+// bk_apply in two halves, so that a host (or bk_multi_apply, over several devices) can do something else while the GPU
+// warps and the frame travels: begin = enqueue the warp of the owned rows into the staging frame and, unless every
+// pixel is mapped, its copy into pinned host memory; end = wait and deliver into the caller's buffer.
+extern "C" int bk_apply_begin(bk_ctx *ctx, int frame, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256])
 {
-    if (!ctx || !dst) return BK_E_INVALID;
+    if (!ctx) return BK_E_INVALID;
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_apply: no lensmap (bk_build / bk_set_lensmap first)");
     if (frame < 0 || frame >= ctx->nframes) return ctx->fail(BK_E_INVALID, "bk_apply: bad frame %d", frame);
     if (int r = ensure_device(ctx)) return r;
     if (int r = ensure_spans(ctx)) return r;
     if (int r = upload_pal(ctx, rubix_on, pal)) return r;
-    // warp the owned rows into a tight staging frame, then merge only the mapped spans
-    // into the caller's buffer (VBUFFER(x+scr_vrect.x, y+scr_vrect.y), fisheye.c:2414-2421)
-    const int rows = ctx->rows();
+    // warp the owned rows into a tight staging frame
     if (int r = bk::launch_apply(ctx, frame, 1, ctx->d_frame, ctx->W, 0, rubix_on)) return r;
+    if (!ctx->fully_mapped)
+        BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * ctx->rows(), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->apply_in_flight = true;
+    return BK_OK;
+}
+
+extern "C" int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, int y0)
+{
+    if (!ctx || !dst) return BK_E_INVALID;
+    if (!ctx->apply_in_flight) return ctx->fail(BK_E_STATE, "bk_apply_end without bk_apply_begin");
+    if (int r = ensure_device(ctx)) return r;
+    ctx->apply_in_flight = false;
+    const int rows = ctx->rows();
     if (ctx->fully_mapped) {
         // nothing to preserve between the mapped pixels: one 2-D copy straight into the caller's buffer, no host merge
         BK_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)(y0 + ctx->row0) * dst_pitch + x0, (size_t)dst_pitch, ctx->d_frame, (size_t)ctx->W,
@@ -518,12 +531,20 @@ extern "C" int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int
         BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return BK_OK;
     }
-    BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
+    // merge only the mapped spans into the caller's buffer (VBUFFER(x+scr_vrect.x, y+scr_vrect.y), fisheye.c:2414-2421)
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (const bk::Span &s : ctx->spans)
         memcpy(dst + (size_t)(y0 + ctx->row0 + s.row) * dst_pitch + x0 + s.x0,
                ctx->h_frame + (size_t)s.row * ctx->W + s.x0, (size_t)(s.x1 - s.x0));
     return BK_OK;
+}
+
+extern "C" int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int x0, int y0,
+                        int rubix_on, const uint8_t pal[BK_MAX_PLATES][256])
+{
+    if (!ctx || !dst) return BK_E_INVALID;
+    if (int r = bk_apply_begin(ctx, frame, rubix_on, pal)) return r;
+    return bk_apply_end(ctx, dst, dst_pitch, x0, y0);
 }
 
 // ---- rubix palettes (fisheye.c:835-908), integer host precompute -----------------------------

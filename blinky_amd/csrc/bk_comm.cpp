@@ -469,20 +469,14 @@ extern "C" int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], doubl
     return BK_OK;
 }
 
-// host destination: every device warps its stripe and copies it straight into the caller's frame (N PCIe links in
-// parallel); no inter-GPU exchange is needed for a host frame
+// host destination: every device warps its stripe (all of them enqueued before any is waited for) and copies its rows
+// straight into the caller's frame; no inter-GPU exchange is needed for a host frame
 extern "C" int bk_multi_apply(bk_multi *m, int frame, uint8_t *dst, int dst_pitch, int x0, int y0, int rubix_on,
                               const uint8_t pal[BK_MAX_PLATES][256])
 {
     if (!m) return BK_E_INVALID;
-    const size_t n = m->ctx.size();
-    std::vector<int> rc(n, BK_OK);
-    std::vector<std::thread> pool;
-    for (size_t i = 0; i < n; ++i)
-        pool.emplace_back([&, i]() { rc[i] = bk_apply(m->ctx[i], frame, dst, dst_pitch, x0, y0, rubix_on, pal); });
-    for (std::thread &t : pool) t.join();
-    for (size_t i = 0; i < n; ++i)
-        if (rc[i] != BK_OK) return m->fail(rc[i], std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]));
+    BK_EACH(m, bk_apply_begin(c, frame, rubix_on, pal));
+    BK_EACH(m, bk_apply_end(c, dst, dst_pitch, x0, y0));
     return BK_OK;
 }
 

@@ -77,6 +77,7 @@ struct bk_ctx {
     bool lensmap_valid = false;
     std::vector<bk::Span> spans;     // mapped spans of the owned rows
     bool spans_valid = false;
+    bool apply_in_flight = false;    // between bk_apply_begin and bk_apply_end
     bool fully_mapped = false;       // every pixel of the owned rows is mapped: bk_apply copies the frame whole
 
     int apply_variant = -1;          // -1 auto (= 2); 0 direct gather, 2 workgroup-cooperative LDS blocks

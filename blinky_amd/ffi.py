@@ -72,6 +72,8 @@ _SIGS = {
     "bk_fill_plate_lcg": (_i, [_vp, _i, _i, C.c_uint32]),
     "bk_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "bk_apply_device": (_i, [_vp, _i, _i, _vp, _i, _sz, _i, _i, _i, _vp]),
+    "bk_apply_begin": (_i, [_vp, _i, _i, _vp]),
+    "bk_apply_end": (_i, [_vp, _vp, _i, _i, _i]),
     "bk_create_palmap": (None, [_vp, _vp]),
     "bk_get_size": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "bk_version": (C.c_char_p, []),
@@ -298,6 +300,16 @@ class Context:
         if pal is not None:
             pal = np.ascontiguousarray(pal, dtype=np.uint8)
         self._chk(lib.bk_apply(self._h, frame, _ptr(dst), pitch, x0, y0, int(rubix_on), _ptr(pal)))
+        return dst
+
+    def apply_begin(self, frame=0, rubix_on=False, pal=None):
+        if pal is not None:
+            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        self._chk(lib.bk_apply_begin(self._h, frame, int(rubix_on), _ptr(pal)))
+
+    def apply_end(self, dst, pitch=None, x0=0, y0=0):
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        self._chk(lib.bk_apply_end(self._h, _ptr(dst), dst.shape[-1] if pitch is None else pitch, x0, y0))
         return dst
 
     def apply_device(self, dst_ptr, pitch, frame_stride, frame0=0, nframes=1, x0=0, y0=0,

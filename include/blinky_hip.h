@@ -172,6 +172,11 @@ int   bk_fill_plate_lcg(bk_ctx *ctx, int frame, int plate, uint32_t seed_frame);
  *                 keeps just its stripe (frame_stride = rows*pitch) passes stripe_base - row0*pitch. */
 int bk_apply(bk_ctx *ctx, int frame, uint8_t *dst, int dst_pitch, int x0, int y0,
              int rubix_on, const uint8_t pal[BK_MAX_PLATES][256]);
+/* bk_apply in two halves: begin enqueues the warp (and the frame's way to pinned host memory) and returns; end waits and
+ * delivers into dst exactly as bk_apply does.  Lets a host overlap the GPU's part with its own work, and is how
+ * bk_multi_apply keeps several devices busy from one thread. */
+int bk_apply_begin(bk_ctx *ctx, int frame, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256]);
+int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, int y0);
 int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst_pitch,
                     size_t frame_stride, int x0, int y0, int rubix_on,
                     const uint8_t pal[BK_MAX_PLATES][256]);

@@ -133,6 +133,25 @@ def test_workgroups_are_dealt_to_xcds_round_robin(bk):
     assert all(ids[b] == ids[b % 8] for b in range(len(ids))), "workgroup b is not on the XCD of workgroup b % 8"
 
 
+def test_apply_in_two_halves(bk):
+    """bk_apply_begin / bk_apply_end == bk_apply (a partly mapped lens: span merge; a fully mapped one: whole-frame copy)"""
+    for lens in ("hammer", "panini"):
+        lm = O.lensmap("cube", lens, None, 640, 480)
+        globe = O.lcg_globe(lm.ps, 6, 2)
+        ctx = make_ctx(bk, lm)
+        upload_globe(ctx, globe)
+        ctx.set_lensmap(lm.offsets, lm.tints)
+        bg = np.full((480, 640), 5, np.uint8)
+        want = O.apply(lm.offsets, lm.tints, 640, 480, globe, bg.copy())
+        ctx.apply_begin(0)
+        scratch = np.arange(1000).sum()                     # (the host is free here)
+        got = ctx.apply_end(bg.copy())
+        np.testing.assert_array_equal(got, want)
+        with pytest.raises(bk.BlinkyError, match="without bk_apply_begin"):
+            ctx.apply_end(bg.copy())
+        ctx.close()
+
+
 def test_pipelined_plate_uploads_equal_the_blocking_ones(bk):
     """bk_upload_plate_async: the caller's buffer is free again when the call returns (the engine renders the next plate
     into the same vid.buffer), three staging slots rotate, and the globe ends up byte-identical"""
