@@ -114,3 +114,43 @@ def test_platform_libm_is_within_the_assumed_bound_of_bkm():
             if b != 0:
                 worst = max(worst, abs(a - b) / abs(b))
         assert worst <= 2.0 ** -50, (name, worst)
+
+
+@pytest.mark.parametrize("seed", [s for s in range(40) if s % 3 != 2])
+def test_random_scripts_every_libm_dependent_pixel_is_flagged(seed):
+    """The same on random lens scripts (the generator of tests/test_script_fuzz_gpu.py: operator soup, loops, tables, script
+    functions, comparisons everywhere): the generated code equals the fisheye.c restatement fed by the interpreter on the
+    PORTABLE libm, and wherever the interpreter on the PLATFORM libm decides an entry differently, the code flagged it."""
+    import blinky_amd
+    from test_script_fuzz_gpu import Gen
+    W, H = 96, 64
+    src = Gen(5000 + seed).script(False).replace('onload = "f_fov 90"', 'lens_width = 5\nlens_height = 3.5\nonload = "f_contain"')
+
+    def host(portable):
+        c = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+        c.set_host_math(portable)
+        c.load_globe(S.script("globes", "cube"), "cube.lua")
+        c.load_lens(src, f"fuzz{seed}.lua")
+        c.set_zoom(blinky_amd.ffi.ZOOM_CONTAIN)
+        c.resize(W, H)
+        return c
+
+    tables = {}
+    for portable in (True, False):
+        c = host(portable)
+        info = c.lens_info()
+        tables[portable] = O.lensmap_with_callbacks("cube", info, lambda x, y: c.eval_host(0, x, y), None, "f_contain", W, H,
+                                                    portable=portable)
+        c.close()
+    if not tables[True].built:
+        pytest.skip("the random script does not build a map")
+    ctx = host(True)
+    off, tin, flagged, err = emu.build_inverse(ctx)
+    ctx.close()
+    if err:
+        pytest.skip("the random script fails at run time (covered by the GPU fuzz)")
+    off = emu.device_to_reference_layout(off, min(W, H))
+    np.testing.assert_array_equal(off, tables[True].offsets, err_msg=src)
+    np.testing.assert_array_equal(tin, tables[True].tints, err_msg=src)
+    differs = np.nonzero((tables[False].offsets != off) | (tables[False].tints != tin))[0]
+    assert set(differs.tolist()) <= set(flagged.tolist()), f"{len(differs)} entries differ, not all flagged\n{src}"
