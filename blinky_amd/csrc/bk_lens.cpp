@@ -660,7 +660,7 @@ extern "C" int bk_debug_module_from_cache(const bk_ctx *ctx) { return ctx && ctx
 extern "C" int bk_set_host_math(bk_ctx *ctx, int portable)
 {
     if (!ctx) return BK_E_INVALID;
-    bk::prog_of(ctx)->interp.math = portable ? &math_portable() : &math_platform();
+    bk::prog_of(ctx)->interp.math = portable >= 2 ? &math_perturbed(ldexp(1.0, -(portable & 63)), portable >> 6) : portable ? &math_portable() : &math_platform();
     return BK_OK;
 }
 

@@ -43,6 +43,36 @@ const MathLib &math_platform()
     return m;
 }
 
+// test-only: bkm.h with every inexact result moved by a pseudo-random relative amount of at most g_perturb_rel, i.e. "some
+// other libm within that distance of bkm.h" (tests/test_exactness_cpu.py checks the device code's exactness flags against
+// it).  Left alone: zeros / non-finite results, sqrt and fmod (correctly rounded / exact everywhere), atan2 on an axis
+// (exact multiples of pi/2 in every libm, which bk_f_atan2 relies on).
+static double g_perturb_rel = 0;
+static int g_perturb_mode = 0;          // 0 pseudo-random, 1 always high, 2 always low
+static double perturb(double r, double x, double y)
+{
+    if (r == 0 || !(r - r == 0)) return r;
+    if (g_perturb_mode) return r + fabs(r) * ((g_perturb_mode == 1 ? 0.999 : -0.999) * g_perturb_rel);   // (the addition rounds)
+    uint64_t a, b, h;
+    memcpy(&a, &x, 8); memcpy(&b, &y, 8); memcpy(&h, &r, 8);
+    h ^= a * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h ^= b * 0xC2B2AE3D27D4EB4Full; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const double u = (double)(h >> 11) * 0x1p-52 - 1.0;      // [-1, 1)
+    return r + r * (u * g_perturb_rel);
+}
+#define BK_PERTURBED1(f) static double q_##f(double x) { return perturb(bkm_##f(x), x, 0); }
+BK_PERTURBED1(sin) BK_PERTURBED1(cos) BK_PERTURBED1(tan) BK_PERTURBED1(asin) BK_PERTURBED1(acos) BK_PERTURBED1(atan)
+BK_PERTURBED1(sinh) BK_PERTURBED1(cosh) BK_PERTURBED1(tanh) BK_PERTURBED1(exp) BK_PERTURBED1(log) BK_PERTURBED1(log10)
+static double q_atan2(double y, double x) { return x == 0 || y == 0 ? bkm_atan2(y, x) : perturb(bkm_atan2(y, x), y, x); }
+static double q_pow(double x, double y) { return perturb(bkm_pow(x, y), x, y); }
+const MathLib &math_perturbed(double rel, int mode)
+{
+    g_perturb_mode = mode;
+    static const MathLib m = {q_sin, q_cos, q_tan, q_asin, q_acos, q_atan, q_atan2, q_sinh, q_cosh, q_tanh,
+                              q_exp, q_log, q_log10, q_pow, p_sqrt, p_fmod};
+    g_perturb_rel = rel;
+    return m;
+}
+
 // ---- lexer -------------------------------------------------------------------------------------
 enum Tok {
     T_EOF, T_NAME, T_NUMBER, T_STRING,

@@ -33,7 +33,8 @@ struct MathLib {
     double (*sqrt)(double), (*fmod)(double, double);
 };
 const MathLib &math_portable();   // bkm.h
-const MathLib &math_platform();   // <cmath>
+const MathLib &math_platform();
+const MathLib &math_perturbed(double rel, int mode);      // test-only, see bk_lua.cpp   // <cmath>
 
 // ---- AST -----------------------------------------------------------------------------------
 struct Expr;

@@ -304,7 +304,10 @@ int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs,
 int         bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout);
 /* host-side script arithmetic (chunk execution, calc_zoom, globe loading): 0 = the platform libm,
  * which is what the reference's Lua VM calls (default: scale, lens_width, plates bit-identical to the
- * reference on the same machine); 1 = the portable bkm.h functions the GPU kernels use */
+ * reference on the same machine); 1 = the portable bkm.h functions the GPU kernels use; n >= 2 is a
+ * test mode: bkm.h with every inexact result moved pseudo-randomly by up to 2^-n relative, standing in
+ * for "another libm" when the tests check the exactness flags (tests/test_exactness_cpu.py); + 64 moves
+ * every result up by that amount instead, + 128 down */
 int         bk_set_host_math(bk_ctx *ctx, int portable);
 /* text the scripts print()ed since the context was created (the reference sends it to stdout) */
 const char *bk_script_console(bk_ctx *ctx);

@@ -15,10 +15,11 @@ CSRC = os.path.join(ROOT, "blinky_amd", "csrc")
 _cache = {}
 
 
-def compile_source(src):
-    """generated source text -> loaded shared object"""
-    key = hashlib.sha1((src + open(os.path.join(CSRC, "bk_device_rt.h")).read() +
-                        open(os.path.join(CSRC, "bk_build_kernels.h")).read()).encode()).hexdigest()[:16]
+def compile_source(src, defines=()):
+    """generated source text -> loaded shared object (defines: extra -D options, e.g. a wider BK_LIBM_REL)"""
+    key = hashlib.sha1((" ".join(defines) + src + open(os.path.join(CSRC, "bk_device_rt.h")).read() +
+                        open(os.path.join(CSRC, "bk_build_kernels.h")).read() +
+                        open(os.path.join(HERE, "emu_driver.inc")).read() + open(os.path.join(HERE, "emu_prelude.h")).read()).encode()).hexdigest()[:16]
     if key in _cache:
         return _cache[key]
     d = os.path.join(tempfile.gettempdir(), "bk_hostemu")
@@ -28,7 +29,7 @@ def compile_source(src):
         with open(cpp, "w") as f:
             f.write('#include "emu_prelude.h"\n' + src + "\n" + open(os.path.join(HERE, "emu_driver.inc")).read())
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-                               "-I", HERE, "-I", CSRC, "-o", so + ".tmp", cpp])
+                               *["-D" + d for d in defines], "-I", HERE, "-I", CSRC, "-o", so + ".tmp", cpp])
         os.replace(so + ".tmp", so)
     lib = C.CDLL(so)
     _cache[key] = lib
@@ -54,10 +55,10 @@ def _field_offsets():
     return _cache["off"]
 
 
-def build_inverse(ctx):
+def build_inverse(ctx, defines=()):
     """ctx: a configured blinky_amd Context (BK_DEVICE_NONE is enough; bk_resize done).  Runs the generated
     bk_build_inverse on the host.  Returns (offsets in DEVICE layout uint32 [rows*W], tints, flagged ids, err bits)."""
-    lib = compile_source(ctx.kernel_source())
+    lib = compile_source(ctx.kernel_source(), defines)
     fo = _field_offsets()
     bp = ctx.build_params()
     assert len(bp) == fo["size"] == lib.emu_sizeof_params()
@@ -124,3 +125,35 @@ def forward_corners(ctx):
     C.memmove(C.addressof(bp) + fo["flag_cap"], C.byref(C.c_uint32(n)), 4)
     lib.emu_forward_corners(bp)
     return xy, ok, flags[: int(misc[7]), 0].copy(), int(misc[6])
+
+
+def inverse_values(ctx, defines=()):
+    """the generated lens_inverse alone over every pixel: dict(nret [n], val [n,8], bound [n,8], tag [n,8], flag [n], err [n],
+    x [n], y [n]) - val +- bound is the device code's claim about what ANY libm within BK_LIBM_REL of bkm.h returns
+    (valid where flag == 0: no decision inside the script was uncertain)"""
+    lib = compile_source(ctx.kernel_source(), defines)
+    bp = ctx.build_params()
+    W, H, ps, r0, r1 = ctx.size()
+    n = W * (r1 - r0)
+    out = dict(nret=np.zeros(n, np.int32), val=np.zeros((n, 8)), bound=np.zeros((n, 8)), tag=np.zeros((n, 8), np.int32),
+               flag=np.zeros(n, np.int32), err=np.zeros(n, np.int32))
+    lib.emu_inverse_values(bp, *[C.c_void_p(out[k].ctypes.data) for k in ("nret", "val", "bound", "tag", "flag", "err")])
+    scale = ctx.calc_zoom()
+    ly, lx = np.divmod(np.arange(n), W)
+    out["x"] = (lx - W // 2).astype(np.float64) * scale
+    out["y"] = (-(ly + r0 - H // 2)).astype(np.float64) * scale
+    return out
+
+
+def forward_values(ctx, rays, defines=()):
+    """the generated lens_forward alone on the given rays [n,3] (float32 values, as the build hands them over): the same
+    dict as inverse_values without x / y"""
+    lib = compile_source(ctx.kernel_source(), defines)
+    bp = ctx.build_params()
+    rays = np.ascontiguousarray(rays, dtype=np.float64)
+    n = len(rays)
+    out = dict(nret=np.zeros(n, np.int32), val=np.zeros((n, 8)), bound=np.zeros((n, 8)), tag=np.zeros((n, 8), np.int32),
+               flag=np.zeros(n, np.int32), err=np.zeros(n, np.int32))
+    lib.emu_forward_values(bp, n, C.c_void_p(rays.ctypes.data),
+                           *[C.c_void_p(out[k].ctypes.data) for k in ("nret", "val", "bound", "tag", "flag", "err")])
+    return out
