@@ -40,6 +40,7 @@ constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's r
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
 constexpr uint32_t BK_COOP_BINS = 65;                  // LDS-need histogram: 1 KiB bins, 0..64 KiB
 constexpr int BK_COOP_STATS = 208;                     // words per stats replica
+constexpr uint32_t BK_COOP_BLOCK_COST = 16;            // what a block costs beyond its lines, in lines (barriers, stores, addresses)
 
 struct CoopHdr {              // 8 bytes per block
     uint32_t nchunks;         // entries of the block's chunk list (0 for direct-gather / empty blocks)
@@ -51,6 +52,15 @@ struct CoopMap {
     uint32_t *d_list = nullptr;     // [nblocks][256*4*RG] byte offsets (16-byte aligned) into a globe frame, ascending
     uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][64 lanes][4] LDS addresses, 0xFFFF = unmapped
     uint8_t *d_tint = nullptr;      // same order (rubix)
+    // Work-balanced walk of the persistent apply: the live (non-empty) blocks in walk order, and where each XCD's band of
+    // them starts - bands of equal COST (128-byte lines staged + a constant per block), not of equal block count.  A lens
+    // that leaves part of the screen unmapped (hammer's ellipse, quincuncial under f_contain) otherwise gives the XCDs that
+    // own the top and the bottom of the screen a fraction of the work of the ones in the middle (4K hammer: 42 K vs 362 K
+    // chunks per band; the launch lasts as long as the fullest band).
+    uint32_t *d_cost = nullptr;     // [nblocks] lines + BK_COOP_BLOCK_COST (0 = empty block)
+    uint32_t *d_order = nullptr;    // [nblocks] block numbers of the live blocks, in walk order (bk_block_at)
+    uint32_t *d_cum = nullptr;      // [nblocks] inclusive cost prefix over d_order (scratch of coop_order_kernel)
+    uint32_t *d_bands = nullptr;    // [9] start of band k in d_order; [8] = live blocks
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
                                     // [3] 128-B lines staged, [4] chunks staged, [8..73) blocks by LDS need (1 KiB bins),
                                     // [73..138) 128-B lines of those blocks, [138..203) chunks of those blocks
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
                                                            int W, int rows, int blocks_x, int nblocks,
                                                            CoopHdr *__restrict__ hdr, uint32_t *__restrict__ list,
                                                            uint16_t *__restrict__ idx, uint8_t *__restrict__ tint_t,
-                                                           uint32_t *__restrict__ stats, int row_stride)
+                                                           uint32_t *__restrict__ stats, int row_stride, uint32_t *__restrict__ cost)
 {
     // row_stride > 1: a SURVEY pass for the cost model - only every row_stride-th row of blocks is looked at and nothing
     // but the statistics is written (ensure_coopmap scales them up); row_stride == 1: the real block map
@@ -202,7 +212,10 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         CoopHdr h;
         h.nchunks = slow ? 0u : nchunks;
         h.flags = wflags | (slow ? CF_SLOW : 0u) | (any_blk ? 0u : CF_EMPTY);
-        if (!survey) hdr[blk] = h;
+        if (!survey) {
+            hdr[blk] = h;
+            cost[blk] = !any_blk ? 0u : slow ? (uint32_t)N / 4u : lines + BK_COOP_BLOCK_COST;
+        }
         uint32_t *st = stats + (blk & 63) * BK_COOP_STATS;
         if (!slow && any_blk) {
             atomicMax(&st[0], nchunks);
@@ -534,7 +547,8 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list, const uint16_t *__restrict__ idx,                          \
     const uint8_t *__restrict__ tint_t, const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, \
     int globe_frames, int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int blocks_x,    \
-    int nblocks, int nframes, int fchunk, int lds_buf, const uint8_t *__restrict__ pal, int kflags
+    int nblocks, int nframes, int fchunk, int lds_buf, const uint8_t *__restrict__ pal, int kflags,                                \
+    const uint32_t *__restrict__ order, const uint32_t *__restrict__ bands
 
 // XCD-banded mapping: workgroup b runs on XCD b % 8 (observed dispatch order); XCD k owns the contiguous band
 // [k*per, (k+1)*per) of blocks.  Correctness does not depend on it.
@@ -551,29 +565,47 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     const int wg_in_band = (int)(blockIdx.x >> 3), wgs_per_band = (int)(gridDim.x >> 3);                                          \
     const int l_end = min(nblocks, (band + 1) * per);                                                                              \
     int l = band * per + wg_in_band;                                                                                               \
-    if (l >= l_end) return;                                                                                                        \
     const int f_begin = blockIdx.y * fchunk, f_end = min(nframes, f_begin + fchunk);                                              \
     const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_pitch | (uintptr_t)frame_stride) & (uintptr_t)(4 * RG - 1)) == 0; \
     constexpr int LPR = 32 / RG;                  /* same pixel -> lane mapping as coop_compile_kernel */                        \
     const int ry = wave * 2 * RG + lane / LPR, cx = lane % LPR
 
-// persistent form: a workgroup walks a strided list of blocks and prefetches the next one
+// persistent form: a workgroup walks a strided list of blocks and prefetches the next one.  By default the list is the
+// XCD's band of the LIVE blocks in walk order, the bands cut at equal cost (CoopMap::d_order / d_bands; ablation bit 64:
+// bands of equal block count over all blocks, empty ones included, as in rounds 1 and 2a).
 template <bool RUBIX, int RG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
-    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l, blocks_x, nblocks, kflags));
+    const bool balanced = (kflags & (16 | 64)) == 0;
+    int l_hi = l_end;
+    if (balanced) {
+        l = (int)bands[band] + wg_in_band;
+        l_hi = (int)bands[band + 1];
+    }
+    if (l >= l_hi) return;
+#define BK_BLOCK_OF(POS) (balanced ? (int)order[POS] : bk_block_at(POS, blocks_x, nblocks, kflags))
+    int b_cur = BK_BLOCK_OF(l);
+    int l_next = l + wgs_per_band;
+    bool has_next = l_next < l_hi;
+    int b_next = has_next ? BK_BLOCK_OF(l_next) : 0;
+    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, b_cur);
     for (;;) {
-        const int l_next = l + wgs_per_band;
-        const bool has_next = l_next < l_end;
         CoopPrefetch<RG> nxt = cur;
-        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l_next, blocks_x, nblocks, kflags));
-        coop_block<RUBIX, RG>(cur, bk_block_at(l, blocks_x, nblocks, kflags), list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
+        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, b_next);
+        const int l_nn = l_next + wgs_per_band;                    // two ahead: its block number is here before it is needed
+        const bool has_nn = has_next && l_nn < l_hi;
+        const int b_nn = has_nn ? BK_BLOCK_OF(l_nn) : 0;
+        coop_block<RUBIX, RG>(cur, b_cur, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
                               dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
         if (!has_next) break;
-        l = l_next;
+        l_next = l_nn;
+        b_cur = b_next;
+        b_next = b_nn;
+        has_next = has_nn;
         cur = nxt;
     }
+#undef BK_BLOCK_OF
 }
 
 // one block per workgroup (launches short enough that the whole grid is resident at once, e.g. the engine's
@@ -582,10 +614,56 @@ template <bool RUBIX, int RG>
 __global__ __launch_bounds__(256) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
-    (void)wgs_per_band;
+    (void)wgs_per_band; (void)order; (void)bands;
+    if (l >= l_end) return;
     const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l, blocks_x, nblocks, kflags));
     coop_block<RUBIX, RG>(cur, bk_block_at(l, blocks_x, nblocks, kflags), list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
                           dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
+}
+
+// The live blocks in walk order and the eight band starts of equal cost (CoopMap::d_order / d_bands): one workgroup
+__global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__restrict__ cost, int nblocks, int blocks_x,
+                                                          uint32_t *__restrict__ order, uint32_t *__restrict__ cum,
+                                                          uint32_t *__restrict__ bands)
+{
+    __shared__ uint32_t s_wn[16], s_wc[16], s_base_n, s_base_c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_base_n = 0; s_base_c = 0; }
+    __syncthreads();
+    for (int l0 = 0; l0 < nblocks; l0 += 1024) {
+        const int l = l0 + (int)threadIdx.x;
+        uint32_t blk = 0, c = 0;
+        if (l < nblocks) { blk = (uint32_t)bk_block_at(l, blocks_x, nblocks, 0); c = cost[blk]; }
+        const uint32_t n = c ? 1u : 0u;
+        uint32_t in = n, ic = c;
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t u = __shfl_up(in, m), v = __shfl_up(ic, m);
+            if (lane >= m) { in += u; ic += v; }
+        }
+        if (lane == 63) { s_wn[wave] = in; s_wc[wave] = ic; }
+        __syncthreads();
+        uint32_t bn = s_base_n, bc = s_base_c;
+        for (int w = 0; w < wave; ++w) { bn += s_wn[w]; bc += s_wc[w]; }
+        if (n) { order[bn + in - 1] = blk; cum[bn + in - 1] = bc + ic; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { s_base_n = bn + in; s_base_c = bc + ic; }
+        __syncthreads();
+    }
+    const uint32_t nlive = s_base_n, total = s_base_c;
+    if (threadIdx.x <= 8) {
+        const uint32_t k = threadIdx.x;
+        uint32_t start = k == 8 ? nlive : 0u;
+        if (k > 0 && k < 8) {                                   // first live block whose cost prefix passes k/8 of the total
+            const uint32_t target = (uint32_t)((uint64_t)total * k / 8);
+            uint32_t lo = 0, hi = nlive;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cum[mid] <= target) lo = mid + 1; else hi = mid;
+            }
+            start = lo;
+        }
+        bands[k] = start;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,6 +676,7 @@ void coopmap_free(CoopMap *cm)
     (void)hipFree(cm->d_list);
     (void)hipFree(cm->d_idx);
     (void)hipFree(cm->d_tint);
+    (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands);
     (void)hipFree(cm->d_stats);
     if (cm->h_stats) (void)hipHostFree(cm->h_stats);
     if (cm->stats_ready) (void)hipEventDestroy(cm->stats_ready);
@@ -629,7 +708,7 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
     BK_HIP(ctx, hipMemsetAsync(st, 0, 64 * BK_COOP_STATS * sizeof(uint32_t), ctx->stream));
     const dim3 grid((unsigned)(bx * sampled_rows)), block(256);
 #define BK_COMPILE(N) hipLaunchKernelGGL((coop_compile_kernel<N>), grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
-                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride)
+                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride, cm->d_cost)
     if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
 #undef BK_COMPILE
     BK_HIP(ctx, hipGetLastError());
@@ -697,12 +776,18 @@ static int ensure_coopmap(bk_ctx *ctx)
     const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
     if (max_px > cm->alloc_px || max_blocks > cm->alloc_blocks) {      // (the header count follows ceil(rows/8), the rest ceil(rows/32))
         (void)hipFree(cm->d_hdr); (void)hipFree(cm->d_list); (void)hipFree(cm->d_idx); (void)hipFree(cm->d_tint);
+        (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands);
         cm->d_hdr = nullptr; cm->d_list = nullptr; cm->d_idx = nullptr; cm->d_tint = nullptr;
+        cm->d_cost = nullptr; cm->d_order = nullptr; cm->d_cum = nullptr; cm->d_bands = nullptr;
         cm->alloc_px = cm->alloc_blocks = 0;
         BK_HIP(ctx, hipMalloc((void **)&cm->d_hdr, max_blocks * sizeof(CoopHdr)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_list, max_px * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_idx, max_px * sizeof(uint16_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_tint, max_px));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_cost, max_blocks * sizeof(uint32_t)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_order, max_blocks * sizeof(uint32_t)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_cum, max_blocks * sizeof(uint32_t)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_bands, 16 * sizeof(uint32_t)));
         cm->alloc_px = max_px;
         cm->alloc_blocks = max_blocks;
     }
@@ -745,6 +830,9 @@ static int ensure_coopmap(bk_ctx *ctx)
     cm->blocks_y = (rows + 8 * best_rg - 1) / (8 * best_rg);
     cm->lds_bytes = best_kb * 1024;
     if (int r = coop_compile_launch(ctx, cm, best_rg, 1, 0)) return r;
+    hipLaunchKernelGGL(coop_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, cm->d_cost, cm->blocks_x * cm->blocks_y, cm->blocks_x,
+                       cm->d_order, cm->d_cum, cm->d_bands);
+    BK_HIP(ctx, hipGetLastError());
     BK_HIP(ctx, hipMemcpyAsync(cm->h_stats, cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipEventRecord(cm->stats_ready, ctx->stream));
     cm->stats_pending = true;
@@ -777,7 +865,7 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, cm->lds_bytes,     \
-                                           ctx->d_pal, ctx->apply_flags)
+                                           ctx->d_pal, ctx->apply_flags, cm->d_order, cm->d_bands)
 #define BK_APPLY(RBX, N) do { if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
     if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
     else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }

@@ -54,7 +54,7 @@ for v, abl, shp, wg, fc, kb in [(v, a, sh, wg, fc, kb) for v in variants for sh 
         if os.environ.get("BK_MODEL"):
             m = ctx.traffic_model()
             print(f"   model: unique lines {m['unique_globe_lines']} ({m['unique_globe_lines'] * 128 / 1e6:.1f} MB/frame), staged lines {m['staged_lines']} "
-                  f"(x{m['staged_lines'] / max(1, m['unique_globe_lines']):.2f}), mapped px {m['mapped_pixels']}, block map {m['blockmap_bytes_per_visit'] / 1e6:.1f} MB/visit", flush=True)
+                  f"(x{m['staged_lines'] / max(1, m['unique_globe_lines']):.2f}), staged chunks {m['staged_chunks']} ({m['staged_chunks'] / max(1, m['staged_lines']):.2f} per staged line), mapped px {m['mapped_pixels']}, block map {m['blockmap_bytes_per_visit'] / 1e6:.1f} MB/visit", flush=True)
     for nf in sorted(set([1, F])):
         for _ in range(3):
             ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)

@@ -33,6 +33,29 @@ __global__ __launch_bounds__(256) void probe_mix(const uint4 *__restrict__ a, ui
     }
 }
 
+// whole 128-byte lines (8 lanes x 16 bytes) at pseudo-random places: runs of `run` consecutive lines, then a jump.
+// What a gather that has nothing to re-use can expect from the memory system, against the streaming numbers above.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__global__ __launch_bounds__(256) void probe_gather(const uint4 *__restrict__ a, uint32_t nlines, uint32_t run, int iters, uint32_t *sink, uint32_t useful)
+{
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, group = gid >> 3, sub = gid & 7, groups = gridDim.x * 32;
+    const uint32_t nruns = nlines / run;
+    uint32_t acc = 0;
+    for (int k = 0; k < iters; k += 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t seq = group + (uint32_t)(k + u) * groups;
+            const uint32_t line = (mix32(seq / run) % nruns) * run + seq % run;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (((sub * 5u + line) & 7u) < useful) v[u] = a[(size_t)line * 8 + sub];      // `useful` of the line's 8 chunks, a different set per line
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
+
 int main(int argc, char **argv)
 {
     const size_t bytes = (argc > 1 ? (size_t)atol(argv[1]) : 1024) << 20;
@@ -58,6 +81,43 @@ int main(int argc, char **argv)
             const double moved = k == 2 ? 2.0 * bytes : k == 3 ? bytes * (1.0 + 5.0 / 8.0) : (double)bytes;
             printf("%-5s grid %5d: %8.3f ms  %7.2f TB/s (bytes moved %.0f MiB)\n",
                    k == 0 ? "read" : k == 1 ? "write" : k == 2 ? "copy" : "mix", g, best, moved / best / 1e9, moved / 1048576.0);
+        }
+    }
+    // random-line gather: 2 GiB of distinct lines (beyond the 256 MiB Infinity Cache), runs of 1..64 lines
+    {
+        const uint32_t nlines = (uint32_t)(bytes / 128);
+        for (int g : {256 * 8, 256 * 16}) {
+            for (uint32_t run : {1u, 2u, 4u, 8u, 16u, 64u, 1024u}) {
+                const int iters = (int)((size_t)nlines / ((size_t)g * 32)) & ~3;
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(probe_gather, dim3(g), dim3(256), 0, 0, a, nlines, run, iters, sink, 8u);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                const double moved = (double)iters * g * 32 * 128;
+                printf("gather grid %5d runs of %4u lines: %8.3f ms  %7.2f TB/s (%.0f MiB)\n", g, run, best, moved / best / 1e9, moved / 1048576.0);
+            }
+        }
+    }
+    // partial lines: only `useful` of a line's eight 16-byte chunks are requested (the line still travels whole)
+    {
+        const uint32_t nlines = (uint32_t)(bytes / 128);
+        const int g = 256 * 8;
+        for (uint32_t useful : {8u, 6u, 5u, 4u, 2u, 1u}) {
+            const int iters = (int)((size_t)nlines / ((size_t)g * 32)) & ~3;
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(probe_gather, dim3(g), dim3(256), 0, 0, a, nlines, 1u, iters, sink, useful);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            const double moved = (double)iters * g * 32 * 128;
+            printf("gather single lines, %u of 8 chunks requested: %8.3f ms  %7.2f TB/s of lines (%.2f TB/s of requested bytes)\n", useful, best, moved / best / 1e9, moved / best / 1e9 * useful / 8);
         }
     }
     return 0;
