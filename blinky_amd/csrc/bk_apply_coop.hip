@@ -40,7 +40,8 @@ constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's r
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
 constexpr uint32_t BK_COOP_BINS = 65;                  // LDS-need histogram: 1 KiB bins, 0..64 KiB
 constexpr int BK_COOP_STATS = 208;                     // words per stats replica
-constexpr uint32_t BK_COOP_BLOCK_COST = 16;            // what a block costs beyond its lines, in lines (barriers, stores, addresses)
+constexpr int BK_KF_WGMAP = 1 << 30;                   // kflags (set by the launcher): one-block form reads CoopMap::d_wgmap
+constexpr int BK_COOP_BLOCK_COST = 4;                  // what a block costs beyond its lines and pixels, in lines (barriers, header)
 
 struct CoopHdr {              // 8 bytes per block
     uint32_t nchunks;         // entries of the block's chunk list (0 for direct-gather / empty blocks)
@@ -61,6 +62,8 @@ struct CoopMap {
     uint32_t *d_order = nullptr;    // [nblocks] block numbers of the live blocks, in walk order (bk_block_at)
     uint32_t *d_cum = nullptr;      // [nblocks] inclusive cost prefix over d_order (scratch of coop_order_kernel)
     uint32_t *d_bands = nullptr;    // [9] start of band k in d_order; [8] = live blocks
+    uint32_t *d_wgmap = nullptr;    // [8 * ceil(nblocks / 8)] one-block-per-workgroup form: the block of workgroup b (XCD b % 8 takes
+                                    // band b % 8), 0xFFFFFFFF = none; used when equal-count bands would be uneven (stats[7])
     uint32_t *d_stats = nullptr;    // 64 replicas of: [0] max chunks, [1] direct-gather blocks, [2] empty blocks,
                                     // [3] 128-B lines staged, [4] chunks staged, [8..73) blocks by LDS need (1 KiB bins),
                                     // [73..138) 128-B lines of those blocks, [138..203) chunks of those blocks
@@ -84,14 +87,15 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
                                                            int W, int rows, int blocks_x, int nblocks,
                                                            CoopHdr *__restrict__ hdr, uint32_t *__restrict__ list,
                                                            uint16_t *__restrict__ idx, uint8_t *__restrict__ tint_t,
-                                                           uint32_t *__restrict__ stats, int row_stride, uint32_t *__restrict__ cost)
+                                                           uint32_t *__restrict__ stats, int row_stride, uint32_t *__restrict__ cost,
+                                                           int block_cost)
 {
     // row_stride > 1: a SURVEY pass for the cost model - only every row_stride-th row of blocks is looked at and nothing
     // but the statistics is written (ensure_coopmap scales them up); row_stride == 1: the real block map
     constexpr int NP = 4 * RG, N = 256 * NP;      // pixels per thread / per block
     __shared__ uint32_t key[N];                   // chunk numbers, sorted in place
     __shared__ uint32_t uniq[N];                  // unique chunk numbers, ascending
-    __shared__ uint32_t s_wsum[4], s_wlines[4];
+    __shared__ uint32_t s_wsum[4], s_wlines[4], s_wpx[4];
     __shared__ uint32_t s_flags;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool survey = row_stride > 1;
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     uint32_t o[NP];
     uint8_t tn[NP];
     bool all_l = true, any_l = false;
+    uint32_t npx = 0;                             // mapped pixels of this lane
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int row = oy + ry, x = x0 + i;
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         key[threadIdx.x * NP + i] = o[i] == BK_NULL_OFFSET ? 0xFFFFFFFFu : o[i] >> 4;
         all_l = all_l && o[i] != BK_NULL_OFFSET;
         any_l = any_l || o[i] != BK_NULL_OFFSET;
+        npx += o[i] != BK_NULL_OFFSET ? 1u : 0u;
     }
     const bool all = __all(all_l), any = __any(any_l);
     __syncthreads();
@@ -151,14 +157,15 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         const uint32_t u = __shfl_up(incl, m);
         if (lane >= m) incl += u;
     }
-    for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m);
+    for (int m = 32; m >= 1; m >>= 1) { lsum += __shfl_xor(lsum, m); npx += __shfl_xor(npx, m); }
     if (lane == 63) s_wsum[wave] = incl;
-    if (lane == 0) s_wlines[wave] = lsum;
+    if (lane == 0) { s_wlines[wave] = lsum; s_wpx[wave] = npx; }
     __syncthreads();
     uint32_t base = incl - cnt;
     for (int w = 0; w < wave; ++w) base += s_wsum[w];
     const uint32_t nchunks = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     const uint32_t lines = s_wlines[0] + s_wlines[1] + s_wlines[2] + s_wlines[3];
+    const uint32_t mapped = s_wpx[0] + s_wpx[1] + s_wpx[2] + s_wpx[3];
     const bool slow = nchunks > BK_COOP_MAX_CHUNKS;        // (only a 128x32 block whose 4096 pixels all read different chunks)
     {
         uint32_t k = base;
@@ -214,7 +221,8 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         h.flags = wflags | (slow ? CF_SLOW : 0u) | (any_blk ? 0u : CF_EMPTY);
         if (!survey) {
             hdr[blk] = h;
-            cost[blk] = !any_blk ? 0u : slow ? (uint32_t)N / 4u : lines + BK_COOP_BLOCK_COST;
+            // in units of one 128-byte line: the lines staged, the pixels stored (+ their share of the 2-byte addresses), a constant
+            cost[blk] = !any_blk ? 0u : slow ? (uint32_t)N / 4u : lines + mapped * 5u / 512u + (uint32_t)block_cost;
         }
         uint32_t *st = stats + (blk & 63) * BK_COOP_STATS;
         if (!slow && any_blk) {
@@ -548,7 +556,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     const uint8_t *__restrict__ tint_t, const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride, \
     int globe_frames, int frame0, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride, int W, int rows, int blocks_x,    \
     int nblocks, int nframes, int fchunk, int lds_buf, const uint8_t *__restrict__ pal, int kflags,                                \
-    const uint32_t *__restrict__ order, const uint32_t *__restrict__ bands
+    const uint32_t *__restrict__ order, const uint32_t *__restrict__ bands, const uint32_t *__restrict__ wgmap
 
 // XCD-banded mapping: workgroup b runs on XCD b % 8 (observed dispatch order); XCD k owns the contiguous band
 // [k*per, (k+1)*per) of blocks.  Correctness does not depend on it.
@@ -577,6 +585,7 @@ template <bool RUBIX, int RG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
+    (void)wgmap;
     const bool balanced = (kflags & (16 | 64)) == 0;
     int l_hi = l_end;
     if (balanced) {
@@ -615,26 +624,39 @@ __global__ __launch_bounds__(256) void apply_coop_once_kernel(BK_COOP_KERNEL_ARG
 {
     BK_COOP_PROLOGUE;
     (void)wgs_per_band; (void)order; (void)bands;
-    if (l >= l_end) return;
-    const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, bk_block_at(l, blocks_x, nblocks, kflags));
-    coop_block<RUBIX, RG>(cur, bk_block_at(l, blocks_x, nblocks, kflags), list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
+    int blk;
+    if (kflags & BK_KF_WGMAP) {                       // bands of equal cost (only where equal counts would be uneven: one more
+        const uint32_t m = wgmap[blockIdx.x];         // dependent load in front of the header)
+        if (m == 0xFFFFFFFFu) return;
+        blk = (int)m;
+    } else {
+        if (l >= l_end) return;
+        blk = bk_block_at(l, blocks_x, nblocks, kflags);
+    }
+    const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, blk);
+    coop_block<RUBIX, RG>(cur, blk, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
                           dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
 }
 
-// The live blocks in walk order and the eight band starts of equal cost (CoopMap::d_order / d_bands): one workgroup
-__global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__restrict__ cost, int nblocks, int blocks_x,
+// The live blocks in walk order, the eight band starts of equal cost (no band longer than `per` = ceil(nblocks / 8)
+// blocks, so that the one-block-per-workgroup grid of 8 * per workgroups can hold it), that grid's workgroup -> block map,
+// and whether bands of equal block COUNT would be more than 10 % uneven (-> stats[7] of replica 0).  One workgroup.
+__global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__restrict__ cost, int nblocks, int blocks_x, int per,
                                                           uint32_t *__restrict__ order, uint32_t *__restrict__ cum,
-                                                          uint32_t *__restrict__ bands)
+                                                          uint32_t *__restrict__ bands, uint32_t *__restrict__ wgmap,
+                                                          uint32_t *__restrict__ stats)
 {
-    __shared__ uint32_t s_wn[16], s_wc[16], s_base_n, s_base_c;
+    __shared__ uint32_t s_wn[16], s_wc[16], s_base_n, s_base_c, s_ucost[8], s_start[9];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_base_n = 0; s_base_c = 0; }
+    if (threadIdx.x < 8) s_ucost[threadIdx.x] = 0;
     __syncthreads();
     for (int l0 = 0; l0 < nblocks; l0 += 1024) {
         const int l = l0 + (int)threadIdx.x;
         uint32_t blk = 0, c = 0;
         if (l < nblocks) { blk = (uint32_t)bk_block_at(l, blocks_x, nblocks, 0); c = cost[blk]; }
         const uint32_t n = c ? 1u : 0u;
+        if (c) atomicAdd(&s_ucost[min(7, l / per)], c);
         uint32_t in = n, ic = c;
         for (int m = 1; m < 64; m <<= 1) {
             const uint32_t u = __shfl_up(in, m), v = __shfl_up(ic, m);
@@ -662,7 +684,27 @@ __global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__rest
             }
             start = lo;
         }
-        bands[k] = start;
+        s_start[k] = start;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 8; ++k) {                           // no band longer than `per`, the rest must still fit
+            const int64_t need = (int64_t)nlive - (int64_t)(8 - k) * per;
+            int64_t st = s_start[k];
+            if (st < need) st = need;
+            if (st < (int64_t)s_start[k - 1]) st = s_start[k - 1];
+            if (st > (int64_t)s_start[k - 1] + per) st = (int64_t)s_start[k - 1] + per;
+            s_start[k] = (uint32_t)st;
+        }
+        uint32_t umax = 0;
+        for (int k = 0; k < 8; ++k) umax = max(umax, s_ucost[k]);
+        stats[7] = (uint64_t)umax * 80u > (uint64_t)total * 11u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x <= 8) bands[threadIdx.x] = s_start[threadIdx.x];
+    for (int b = (int)threadIdx.x; b < 8 * per; b += 1024) {
+        const uint32_t l = s_start[b & 7] + (uint32_t)(b >> 3);
+        wgmap[b] = l < s_start[(b & 7) + 1] ? order[l] : 0xFFFFFFFFu;
     }
 }
 
@@ -676,7 +718,7 @@ void coopmap_free(CoopMap *cm)
     (void)hipFree(cm->d_list);
     (void)hipFree(cm->d_idx);
     (void)hipFree(cm->d_tint);
-    (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands);
+    (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands); (void)hipFree(cm->d_wgmap);
     (void)hipFree(cm->d_stats);
     if (cm->h_stats) (void)hipHostFree(cm->h_stats);
     if (cm->stats_ready) (void)hipEventDestroy(cm->stats_ready);
@@ -708,7 +750,7 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
     BK_HIP(ctx, hipMemsetAsync(st, 0, 64 * BK_COOP_STATS * sizeof(uint32_t), ctx->stream));
     const dim3 grid((unsigned)(bx * sampled_rows)), block(256);
 #define BK_COMPILE(N) hipLaunchKernelGGL((coop_compile_kernel<N>), grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
-                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride, cm->d_cost)
+                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride, cm->d_cost, ctx->apply_block_cost >= 0 ? ctx->apply_block_cost : BK_COOP_BLOCK_COST)
     if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
 #undef BK_COMPILE
     BK_HIP(ctx, hipGetLastError());
@@ -776,9 +818,9 @@ static int ensure_coopmap(bk_ctx *ctx)
     const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
     if (max_px > cm->alloc_px || max_blocks > cm->alloc_blocks) {      // (the header count follows ceil(rows/8), the rest ceil(rows/32))
         (void)hipFree(cm->d_hdr); (void)hipFree(cm->d_list); (void)hipFree(cm->d_idx); (void)hipFree(cm->d_tint);
-        (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands);
+        (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands); (void)hipFree(cm->d_wgmap);
         cm->d_hdr = nullptr; cm->d_list = nullptr; cm->d_idx = nullptr; cm->d_tint = nullptr;
-        cm->d_cost = nullptr; cm->d_order = nullptr; cm->d_cum = nullptr; cm->d_bands = nullptr;
+        cm->d_cost = nullptr; cm->d_order = nullptr; cm->d_cum = nullptr; cm->d_bands = nullptr; cm->d_wgmap = nullptr;
         cm->alloc_px = cm->alloc_blocks = 0;
         BK_HIP(ctx, hipMalloc((void **)&cm->d_hdr, max_blocks * sizeof(CoopHdr)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_list, max_px * sizeof(uint32_t)));
@@ -788,6 +830,7 @@ static int ensure_coopmap(bk_ctx *ctx)
         BK_HIP(ctx, hipMalloc((void **)&cm->d_order, max_blocks * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_cum, max_blocks * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_bands, 16 * sizeof(uint32_t)));
+        BK_HIP(ctx, hipMalloc((void **)&cm->d_wgmap, (max_blocks + 8) * sizeof(uint32_t)));
         cm->alloc_px = max_px;
         cm->alloc_blocks = max_blocks;
     }
@@ -830,8 +873,11 @@ static int ensure_coopmap(bk_ctx *ctx)
     cm->blocks_y = (rows + 8 * best_rg - 1) / (8 * best_rg);
     cm->lds_bytes = best_kb * 1024;
     if (int r = coop_compile_launch(ctx, cm, best_rg, 1, 0)) return r;
-    hipLaunchKernelGGL(coop_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, cm->d_cost, cm->blocks_x * cm->blocks_y, cm->blocks_x,
-                       cm->d_order, cm->d_cum, cm->d_bands);
+    {
+        const int nb = cm->blocks_x * cm->blocks_y;
+        hipLaunchKernelGGL(coop_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, cm->d_cost, nb, cm->blocks_x, (nb + 7) / 8,
+                           cm->d_order, cm->d_cum, cm->d_bands, cm->d_wgmap, cm->d_stats);
+    }
     BK_HIP(ctx, hipGetLastError());
     BK_HIP(ctx, hipMemcpyAsync(cm->h_stats, cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipEventRecord(cm->stats_ready, ctx->stream));
@@ -862,10 +908,17 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
     const size_t shmem = (size_t)cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
     const bool once = wgs_per_band == per && !(ctx->apply_flags & 32);     // every workgroup has exactly one block (ablation bit 32: persistent form anyway)
+    // one-block form: take the cost-balanced workgroup -> block map if bands of equal block count are known to be uneven
+    // (the block map's statistics arrive asynchronously: until they are here, the direct mapping)
+    int kflags = ctx->apply_flags & ~BK_KF_WGMAP;
+    if (once && !(kflags & (16 | 64))) {
+        if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
+        if (!cm->stats_pending && cm->stats[7]) kflags |= BK_KF_WGMAP;
+    }
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, cm->lds_bytes,     \
-                                           ctx->d_pal, ctx->apply_flags, cm->d_order, cm->d_bands)
+                                           ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
 #define BK_APPLY(RBX, N) do { if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
     if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
     else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }

@@ -41,8 +41,9 @@ WGS = [int(x) for x in os.environ.get("BK_WGS", "6").split(",")]
 FCH = [int(x) for x in os.environ.get("BK_FCHUNK", "0").split(",")]      # frames per tile visit (0 = default)
 REPS = int(os.environ.get("BK_REPS", "20"))
 LDSKB = [int(x) for x in os.environ.get("BK_LDSKB", "0").split(",")]    # coop apply: staging buffer KiB (0 = cost model)
-for v, abl, shp, wg, fc, kb in [(v, a, sh, wg, fc, kb) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])
-                               for fc in (FCH if v != 0 else [0]) for kb in (LDSKB if v == 2 else [0])]:
+BCOST = [int(x) for x in os.environ.get("BK_BCOST", "-1").split(",")]   # band balance: constant cost per block in lines (-1 = default)
+for v, abl, shp, wg, fc, kb, bc in [(v, a, sh, wg, fc, kb, bc) for v in variants for sh in (SHAPES if v != 0 else [0]) for a in (ABL if v != 0 else [0]) for wg in (WGS if v != 0 else [6])
+                                   for fc in (FCH if v != 0 else [0]) for kb in (LDSKB if v == 2 else [0]) for bc in (BCOST if v == 2 else [-1])]:
     ctx.set_apply_variant(v)
     if v != 0:
         ctx.set_tile_shape(shp)
@@ -50,7 +51,8 @@ for v, abl, shp, wg, fc, kb in [(v, a, sh, wg, fc, kb) for v in variants for sh 
         ctx.set_ablation(abl)             # 2 no globe loads, 4 no stores, 8 no load pipelining
         ctx.set_tile_shape(300 + fc)
         ctx.set_tile_shape(400 + kb)
-        print(f"shape {shp} ablation {abl} wgs/cu {wg} fchunk {fc} ldskb {kb}; tile stats:", ctx.tile_stats(), flush=True)
+        ctx.set_tile_shape(601 + bc)
+        print(f"shape {shp} ablation {abl} wgs/cu {wg} fchunk {fc} ldskb {kb} bcost {bc}; tile stats:", ctx.tile_stats(), flush=True)
         if os.environ.get("BK_MODEL"):
             m = ctx.traffic_model()
             print(f"   model: unique lines {m['unique_globe_lines']} ({m['unique_globe_lines'] * 128 / 1e6:.1f} MB/frame), staged lines {m['staged_lines']} "
