@@ -286,6 +286,14 @@ extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8])
     return bk::coopmap_traffic_model(ctx, out);
 }
 
+extern "C" int bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18])
+{
+    if (!ctx || !out) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "no lensmap");
+    if (int r = ensure_device(ctx)) return r;
+    return bk::coopmap_band_balance(ctx, out);
+}
+
 extern "C" int bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups)
 {
     if (!ctx || !out || nworkgroups < 1) return BK_E_INVALID;

@@ -29,6 +29,7 @@
 //
 // replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
 #include <cmath>
+#include <vector>
 
 #include "bk_internal.h"
 
@@ -638,8 +639,8 @@ __global__ __launch_bounds__(256) void apply_coop_once_kernel(BK_COOP_KERNEL_ARG
                           dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
 }
 
-// The live blocks in walk order, the eight band starts of equal cost (no band longer than `per` = ceil(nblocks / 8)
-// blocks, so that the one-block-per-workgroup grid of 8 * per workgroups can hold it), that grid's workgroup -> block map,
+// The live blocks in walk order, the eight band starts of equal cost, the workgroup -> block map of the one-block-per-workgroup
+// grid (8 * per workgroups, per = ceil(nblocks / 8): the same bands, none longer than `per` blocks),
 // and whether bands of equal block COUNT would be more than 10 % uneven (-> stats[7] of replica 0).  One workgroup.
 __global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__restrict__ cost, int nblocks, int blocks_x, int per,
                                                           uint32_t *__restrict__ order, uint32_t *__restrict__ cum,
@@ -687,8 +688,11 @@ __global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__rest
         s_start[k] = start;
     }
     __syncthreads();
+    if (threadIdx.x <= 8) bands[threadIdx.x] = s_start[threadIdx.x];      // the strided walk: any band length will do
+    __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 8; ++k) {                           // no band longer than `per`, the rest must still fit
+        // the one-block grid has `per` workgroups per XCD: there no band may be longer than that, and the rest must still fit
+        for (int k = 1; k < 8; ++k) {
             const int64_t need = (int64_t)nlive - (int64_t)(8 - k) * per;
             int64_t st = s_start[k];
             if (st < need) st = need;
@@ -701,7 +705,6 @@ __global__ __launch_bounds__(1024) void coop_order_kernel(const uint32_t *__rest
         stats[7] = (uint64_t)umax * 80u > (uint64_t)total * 11u ? 1u : 0u;
     }
     __syncthreads();
-    if (threadIdx.x <= 8) bands[threadIdx.x] = s_start[threadIdx.x];
     for (int b = (int)threadIdx.x; b < 8 * per; b += 1024) {
         const uint32_t l = s_start[b & 7] + (uint32_t)(b >> 3);
         wgmap[b] = l < s_start[(b & 7) + 1] ? order[l] : 0xFFFFFFFFu;
@@ -1014,6 +1017,24 @@ int coopmap_xcd_probe(bk_ctx *ctx, int *out, int nwg)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return ctx->fail(BK_E_HIP, "xcd probe: %s", hipGetErrorString(e));
+    return BK_OK;
+}
+
+int coopmap_band_balance(bk_ctx *ctx, uint32_t out[18])
+{
+    if (int r = ensure_coopmap(ctx)) return r;
+    CoopMap *cm = ctx->coopmap;
+    if (int r = coop_stats_wait(ctx, cm)) return r;
+    const int nb = cm->blocks_x * cm->blocks_y;
+    std::vector<uint32_t> cum((size_t)nb);
+    BK_HIP(ctx, hipMemcpyAsync(out, cm->d_bands, 9 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipMemcpyAsync(cum.data(), cm->d_cum, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out[9] = cm->stats[7] ? 1u : 0u;
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t a = out[k], b = out[k + 1];
+        out[10 + k] = b > a ? cum[b - 1] - (a ? cum[a - 1] : 0u) : 0u;
+    }
     return BK_OK;
 }
 

@@ -133,6 +133,7 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_o
 int coopmap_stats(bk_ctx *ctx, int out[6]);   // blocks, direct-gather blocks, empty blocks, LDS bytes per buffer
 int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8]);
 int coopmap_xcd_probe(bk_ctx *ctx, int *out, int nwg);
+int coopmap_band_balance(bk_ctx *ctx, uint32_t out[18]);
 void coopmap_free(CoopMap *);
 
 // bk_lens.cpp

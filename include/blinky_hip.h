@@ -269,7 +269,8 @@ int         bk_set_apply_variant(bk_ctx *ctx, int variant);
  * in the environment bypasses the in-process cache so that the disk path can be observed). */
 int         bk_debug_module_from_cache(const bk_ctx *ctx);
 /* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
- * pipelining); results are wrong while bits 2/4 are set.  0 restores normal operation. */
+ * pipelining; 16 row-major block walk, 32 persistent form always, 64 XCD bands of equal block count instead of equal
+ * cost - results stay exact for 8..64); results are wrong while bits 2/4 are set.  0 restores normal operation. */
 int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
 /* staged apply statistics of the current lensmap: out = {blocks, blocks on the direct-gather fallback,
  * empty blocks, bytes of one LDS staging buffer, 128000 + block height in pixels, 128-byte lines staged per frame} */
@@ -279,11 +280,17 @@ int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
  * 16-byte chunks staged per frame, bytes of block map read per block visit summed over blocks, mapped pixels
  * (= bytes stored per frame), frames served per block visit, blocks, block height in pixels} */
 int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8]);
+/* How the staged apply splits the current lensmap's blocks over the 8 XCDs: out[0..8] = where each XCD's band starts in
+ * the list of live (non-empty) blocks in walk order - bands of equal cost, not of equal block count - with out[8] = live
+ * blocks; out[9] = 1 if bands of equal block count would be more than 10 % uneven (single-frame launches then take the
+ * balanced workgroup -> block map too); out[10 + k] = cost of band k (128-byte lines staged + pixel and block terms) */
+int         bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18]);
 /* which XCD (HW_REG_XCC_ID) each workgroup of a 1-D launch of `nworkgroups` runs on: the apply kernel's screen bands
  * assume workgroup b -> XCD b % 8 (locality only; a test checks the assumption on the box it runs on) */
 int         bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups);
 /* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
- * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB */
+ * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB;
+ * 600 / 601+n = default / n as the constant term of a block's cost in the band balance */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);

@@ -198,6 +198,46 @@ def test_apply_device_batch_distinct_globes(bk, variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("lens,uneven", [("hammer", True), ("quincuncial", True), ("panini", False)])
+def test_xcd_bands_of_equal_cost(bk, lens, uneven):
+    """The persistent apply gives each XCD a band of the LIVE blocks of equal cost (not of equal block count): the bands
+    partition the live blocks, their costs are level, and every path over them - the strided walk with few and with many
+    workgroups, the one-block-per-workgroup form with and without the balanced workgroup map, the equal-count bands of the
+    ablation - produces the oracle's frames."""
+    import torch
+    lm = O.lensmap("cube", lens, None, 1280, 720)
+    W, H, F = lm.W, lm.H, 5
+    ctx = make_ctx(bk, lm, nframes=F)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for f in range(F):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, seed_frame=f)
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    want = [O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, f), np.full((H, W), 9, np.uint8)) for f in range(F)]
+    for shape in (1, 2, 4):
+        ctx.set_tile_shape(shape)
+        st = ctx.tile_stats()                              # (waits for the block map's statistics: the balance is known from here on)
+        bal = ctx.band_balance()
+        starts = bal["starts"]
+        assert starts[0] == 0 and starts == sorted(starts) and bal["live_blocks"] == st["tiles"] - st["empty"]
+        assert bal["equal_count_bands_uneven"] or not uneven, bal      # (a fully mapped lens may or may not be: panini's blocks differ in cost too)
+        cost = bal["band_cost"]
+        if bal["live_blocks"] >= 64:
+            assert max(cost) <= 1.15 * (sum(cost) / 8), cost                # level to a block or two
+        for wgs, abl in ((1, 0), (1, 64), (2, 0), (16, 0), (16, 64), (16, 32), (16, 16)):
+            ctx.set_tile_shape(100 + wgs)
+            ctx.set_ablation(abl)
+            for nf in (1, F):
+                out = torch.full((nf, H, W), 9, dtype=torch.uint8, device="cuda")
+                ctx.apply_device(out.data_ptr(), W, H * W, frame0=0, nframes=nf)
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                for f in range(nf):
+                    np.testing.assert_array_equal(got[f], want[f], err_msg=f"{lens} shape {shape} wgs/cu {wgs} ablation {abl} frames {nf} frame {f}")
+    ctx.set_ablation(0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_row_stripes_reassemble_to_full_frame(bk, variant):
     """Multi-GPU sharding unit: a context owning rows [r0,r1) touches only those rows and the
