@@ -903,17 +903,34 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     const int fchunk = nframes < fmax ? nframes : fmax;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     const int per = (nblocks + 7) / 8;
+    const size_t shmem = (size_t)cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
+    // Grid.  One block per workgroup (the finest split, dealt to the CUs by the hardware as they free up) when that many
+    // workgroups are about what the chip holds - `apply_wgs_per_cu` = 16 per CU, deliberately generous: 4K panini x16 runs
+    // 3.93 us/frame that way against 4.08 for a strided walk by the 7 per CU that are truly resident - and otherwise a strided
+    // walk in which every workgroup prefetches its next block's header and list behind the current block.  Single frames are
+    // judged against the true residency (LDS, registers): the prefetch is worth more when a visit is one frame long (4K
+    // hammer: 12.4 us strided against 13.4; at 1440p and below, where the grid fits, the one-block form wins by 5-20 %).
     int wgs_per_band = per;
-    const int resident_per_band = ctx->num_cus * ctx->apply_wgs_per_cu / 8;
-    if (fblocks * wgs_per_band > resident_per_band) wgs_per_band = (resident_per_band + fblocks - 1) / fblocks;
+    int per_cu = ctx->apply_wgs_per_cu;
+    if (fchunk == 1 && ctx->apply_wgs_per_cu == 16) {
+        const int by_lds = (int)((160u * 1024u) / (shmem ? shmem : 1));
+        const int by_regs = cm->rg == 4 ? 7 : 8;            // (one-block form: 67 / 50 / 45 VGPRs for 128x32 / 16 / 8 blocks)
+        per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
+        if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
+        const int live = cm->stats_pending ? nblocks : nblocks - (int)cm->stats[2];
+        // (up to 1.5 x what is resident the one-block form still wins: 4K panini, 2040 blocks on 1792 places, 9.0 against 9.3 us)
+        if (2 * live <= 3 * ctx->num_cus * per_cu) per_cu = 1 << 20;         // one block each
+    }
+    {
+        const long long resident_per_band = (long long)ctx->num_cus * per_cu / 8;
+        if ((long long)fblocks * wgs_per_band > resident_per_band) wgs_per_band = (int)((resident_per_band + fblocks - 1) / fblocks);
+    }
     // ... but no workgroup should walk more than about three blocks: the strided walk is a static split, and the longer a
-    // workgroup lives the more the slowest one sets the end of the launch; the hardware deals queued workgroups to CUs as
-    // they free up (8K hammer x 64 frames: 31.5 -> 29.9 us/frame)
+    // workgroup lives the more the slowest one sets the end of the launch
     if (wgs_per_band < (per + 2) / 3) wgs_per_band = (per + 2) / 3;
     if (wgs_per_band < 1) wgs_per_band = 1;
     if (wgs_per_band > per) wgs_per_band = per;
     dim3 grid((unsigned)(wgs_per_band * 8), (unsigned)fblocks);
-    const size_t shmem = (size_t)cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
     const bool once = wgs_per_band == per && !(ctx->apply_flags & 32);     // every workgroup has exactly one block (ablation bit 32: persistent form anyway)
     // one-block form: take the cost-balanced workgroup -> block map if bands of equal block count are known to be uneven
     // (the block map's statistics arrive asynchronously: until they are here, the direct mapping)

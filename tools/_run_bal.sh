@@ -1,6 +1,8 @@
-mkdir -p gpurun_out; rm -f gpurun_out/bal6_probe.log
-BK_RING=64 BK_REPS=10 BK_WGS=16,128 timeout 300 python tools/apply_probe.py hammer 7680 4320 64 2 2>&1 | grep -E "ablation|frames/launch" | sed "s/; tile stats: / /" >> gpurun_out/bal6_probe.log
-BK_RING=64 BK_REPS=20 BK_WGS=16 timeout 300 python tools/apply_probe.py panini 7680 4320 16 2 2>&1 | grep -E "ablation|frames/launch" | sed "s/; tile stats: / /" >> gpurun_out/bal6_probe.log
-for l in hammer quincuncial stereographic; do BK_RING=64 BK_REPS=100 BK_WGS=16 timeout 300 python tools/apply_probe.py $l 3840 2160 16 2 2>&1 | grep -E "ablation|frames/launch" | sed "s/; tile stats: / /" >> gpurun_out/bal6_probe.log; done
-BK_RING=64 BK_REPS=100 BK_WGS=16 timeout 300 python tools/apply_probe.py hammer 3840 2160 64 2 2>&1 | grep -E "ablation|frames/launch" | sed "s/; tile stats: / /" >> gpurun_out/bal6_probe.log
-cat gpurun_out/bal6_probe.log
+mkdir -p gpurun_out; rm -f gpurun_out/r2e.log
+run() { echo "== $*" >> gpurun_out/r2e.log; "$@" 2>&1 | grep -E "frames/launch" >> gpurun_out/r2e.log; }
+export BK_RING=64 BK_REPS=300 BK_WGS=16,17,16,17
+run python tools/apply_probe.py panini 3840 2160 1 2
+run python tools/apply_probe.py quincuncial 3840 2160 1 2
+run python tools/apply_probe.py hammer 3840 2160 1 2
+BK_GLOBE=trism run python tools/apply_probe.py panini 3840 2160 1 2
+cat gpurun_out/r2e.log
