@@ -20,6 +20,26 @@ __global__ __launch_bounds__(256) void probe_write(uint4 *__restrict__ a, size_t
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         a[i] = make_uint4((uint32_t)i, 1, 2, 3);
 }
+__global__ __launch_bounds__(256) void probe_write_nt(uint4 *__restrict__ a, size_t n)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        v4u v = {(uint32_t)i, 1, 2, 3};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(a) + i);
+    }
+}
+// the apply's mix, streaming: read 13 bytes for every 8 written (non-temporal stores)
+__global__ __launch_bounds__(256) void probe_mix_nt(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n, uint32_t *sink)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 v = a[i];
+        acc ^= v.x ^ v.w;
+        if ((i >> 6) % 13 < 8) { v4u w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<v4u *>(b) + i); }
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
 __global__ __launch_bounds__(256) void probe_copy(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
@@ -81,6 +101,21 @@ int main(int argc, char **argv)
             const double moved = k == 2 ? 2.0 * bytes : k == 3 ? bytes * (1.0 + 5.0 / 8.0) : (double)bytes;
             printf("%-5s grid %5d: %8.3f ms  %7.2f TB/s (bytes moved %.0f MiB)\n",
                    k == 0 ? "read" : k == 1 ? "write" : k == 2 ? "copy" : "mix", g, best, moved / best / 1e9, moved / 1048576.0);
+        }
+    }
+    for (int g : {256 * 4, 256 * 8, 256 * 16}) {
+        for (int k = 0; k < 2; ++k) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; ++rep) {
+                CK(hipEventRecord(e0));
+                if (k == 0) hipLaunchKernelGGL(probe_write_nt, dim3(g), dim3(256), 0, 0, b, n);
+                if (k == 1) hipLaunchKernelGGL(probe_mix_nt, dim3(g), dim3(256), 0, 0, a, b, n, sink);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            const double moved = k == 0 ? (double)bytes : bytes * (1.0 + 8.0 / 13.0);
+            printf("%-8s grid %5d: %8.3f ms  %7.2f TB/s (bytes moved %.0f MiB)\n", k == 0 ? "write-nt" : "mix-nt", g, best, moved / best / 1e9, moved / 1048576.0);
         }
     }
     // random-line gather: 2 GiB of distinct lines (beyond the 256 MiB Infinity Cache), runs of 1..64 lines
