@@ -415,6 +415,22 @@ def main():
             except Exception as e:      # noqa: BLE001
                 traffic_src = {"stale": True, "why": f"unreadable record: {e}"}
         t_launch = k_med * 1e-3
+        # calibration: a plain streaming kernel with the apply's read : write ratio (compulsory model), on this box, now
+        stream_mix = None
+        try:
+            wr = F * model["mapped_pixels"]
+            rd = max(1, compulsory - wr)
+            period = 64
+            writes = max(0, min(period, int(round(period * wr / rd))))
+            gbps = ctx.stream_mix(1 << 30, period, writes)
+            used = traffic if traffic else compulsory
+            stream_mix = {"GB/s": round(gbps, 1), "read_KiB_per_written_KiB": round(period / max(1, writes), 3),
+                          "what": "plain streaming kernel, 16-byte loads, non-temporal stores, the apply's read : write ratio, "
+                                  "1 GiB read (bk_debug_stream_mix): the practical roofline of this memory system for that mix",
+                          "apply_traffic_over_it": round(used / t_launch / 1e9 / gbps, 4),
+                          "apply_traffic_is": "traffic (PMC)" if traffic else "compulsory model"}
+        except Exception as e:      # noqa: BLE001
+            stream_mix = {"error": f"{type(e).__name__}: {e}"}
         out = {
             "metric": "warped Mpixels/s (lensmap apply)", "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -440,6 +456,7 @@ def main():
                          "frac_traffic": round(traffic / t_launch / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "compulsory_bytes_per_launch": int(compulsory),
                          "frac_compulsory": round(compulsory / t_launch / 1e9 / HBM_PEAK_GBS, 4),
+                         "stream_mix": stream_mix,
                          "kernel_ms_per_launch": round(k_med, 5), "kernel_ms_min": round(k_min, 5), "kernel_ms_max": round(k_max, 5),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "ring_globes": R, "model": {k: int(v) for k, v in model.items()},

@@ -1,0 +1,63 @@
+// blinky-hip: a calibration kernel, not part of the warp.  bench.py prices the apply kernel's measured traffic against the
+// nominal HBM peak (the contract) and, beside it, against what a plain streaming kernel with the SAME read : write ratio
+// reaches on the box it runs on: no gather, no LDS, 16-byte accesses, non-temporal stores - the practical roofline of this
+// memory system for that mix (tools/membw_probe.hip is the stand-alone version with more kernels).
+#include "bk_internal.h"
+
+namespace bk {
+
+__global__ __launch_bounds__(256) void stream_mix_kernel(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n, uint32_t period,
+                                                         uint32_t writes, uint32_t *sink)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 v = a[i];
+        acc ^= v.x ^ v.w;
+        if ((uint32_t)((i >> 6) % period) < writes) {       // whole 1 KiB wave-stores: `writes` of every `period` of them
+            v4u w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, reinterpret_cast<v4u *>(b) + i);
+        }
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
+
+}  // namespace bk
+
+// best of 5 passes over `bytes` read, writes / period of it written; *gbps = (bytes read + bytes written) / time
+extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps)
+{
+    if (!ctx || !gbps || bytes < (1u << 20) || period < 1 || writes < 0 || writes > period) return BK_E_INVALID;
+    if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_debug_stream_mix: this context has no device");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    uint4 *a = nullptr, *b = nullptr;
+    uint32_t *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&a, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&b, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&sink, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 2, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const size_t n = bytes / 16;
+    float best = 0;
+    for (int rep = 0; rep < 5 && e == hipSuccess; ++rep) {
+        e = hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(bk::stream_mix_kernel, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, ctx->stream, a, b, n, (uint32_t)period,
+                           (uint32_t)writes, sink);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && (best == 0 || ms < best)) best = ms;
+    }
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess || best <= 0) return ctx->fail(BK_E_HIP, "bk_debug_stream_mix: %s", hipGetErrorString(e));
+    const double waves = (double)(n / 64), written = (waves / period) * writes * 1024.0;     // (to within one period)
+    *gbps = ((double)bytes + written) / ((double)best * 1e-3) / 1e9;
+    return BK_OK;
+}

@@ -88,6 +88,7 @@ _SIGS = {
     "bk_debug_tile_stats": (_i, [_vp, C.POINTER(_i)]),
     "bk_debug_traffic_model": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "bk_debug_band_balance": (_i, [_vp, C.POINTER(C.c_uint32)]),
+    "bk_debug_stream_mix": (_i, [_vp, _sz, _i, _i, C.POINTER(_d)]),
     "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "bk_debug_xcd_of_workgroups": (_i, [_vp, C.POINTER(_i), _i]),
@@ -354,6 +355,12 @@ class Context:
         self._chk(lib.bk_debug_traffic_model(self._h, out))
         return dict(unique_globe_lines=out[0], staged_lines=out[1], staged_chunks=out[2], blockmap_bytes_per_visit=out[3],
                     mapped_pixels=out[4], frames_per_visit=out[5], blocks=out[6], block_height=out[7])
+
+    def stream_mix(self, nbytes, period, writes):
+        """GB/s of a plain streaming kernel with `writes` KiB written per `period` KiB read (calibration for bench.py)"""
+        out = _d()
+        self._chk(lib.bk_debug_stream_mix(self._h, nbytes, period, writes, C.byref(out)))
+        return out.value
 
     def band_balance(self):
         """how the staged apply splits the live blocks over the 8 XCDs: band starts, whether equal-count bands would be uneven, band costs"""

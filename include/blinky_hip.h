@@ -285,6 +285,10 @@ int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8]);
  * blocks; out[9] = 1 if bands of equal block count would be more than 10 % uneven (single-frame launches then take the
  * balanced workgroup -> block map too); out[10 + k] = cost of band k (128-byte lines staged + pixel and block terms) */
 int         bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18]);
+/* calibration (bench.py): GB/s of a plain streaming kernel that reads `bytes` with 16-byte loads and writes `writes` of
+ * every `period` KiB of it back with non-temporal stores - what this memory system gives a kernel with that read : write
+ * ratio and nothing else to do (best of 5 passes; allocates and frees 2 x bytes) */
+int         bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps);
 /* which XCD (HW_REG_XCC_ID) each workgroup of a 1-D launch of `nworkgroups` runs on: the apply kernel's screen bands
  * assume workgroup b -> XCD b % 8 (locality only; a test checks the assumption on the box it runs on) */
 int         bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups);

@@ -36,6 +36,10 @@ def test_bench_line_and_check_single_gpu():
     rf = out["roofline"]
     assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "compulsory_bytes_per_launch",
                        "frac_compulsory", "ring_globes", "warm_ring"}
+    # the calibration beside it: a streaming kernel with the apply's read : write ratio, measured in the same run
+    sm = rf["stream_mix"]
+    assert "error" not in sm, sm
+    assert 2000 < sm["GB/s"] < 8000 and 0.5 < sm["apply_traffic_over_it"] < 1.5, sm
     # the timed ring is larger than the 256 MiB Infinity Cache, and what the kernel must move cannot exceed the HBM peak
     assert rf["ring_globes"] * 6 * 2160 * 2176 > 4 * 256 * 2 ** 20
     assert 0 < rf["frac_compulsory"] <= 1.0
@@ -66,3 +70,15 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 2
+
+
+def test_stream_mix_calibration_entry():
+    import blinky_amd
+    ctx = blinky_amd.Context()
+    ro = ctx.stream_mix(256 << 20, 8, 0)          # read-only
+    cp = ctx.stream_mix(256 << 20, 8, 8)          # a copy: as much written as read
+    assert 2000 < ro < 8000 and 2000 < cp < 8000, (ro, cp)
+    for bad in ((1 << 10, 8, 0), (256 << 20, 0, 0), (256 << 20, 8, 9)):
+        with pytest.raises(blinky_amd.BlinkyError):
+            ctx.stream_mix(*bad)
+    ctx.close()
