@@ -28,7 +28,10 @@
 // lines (bk_build_params.h) a block's slanted footprint touches about half the lines it did row-major.
 //
 // replaces render_lensmap (engine/NQ/fisheye.c:2406-2424); byte-exact.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "bk_internal.h"
@@ -760,12 +763,21 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
     return BK_OK;
 }
 
+static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns);
+
 // the statistics of the last full compile, once somebody needs them (the apply launch itself does not)
 static int coop_stats_wait(bk_ctx *ctx, CoopMap *cm)
 {
     if (!cm->stats_pending) return BK_OK;
     BK_HIP(ctx, hipEventSynchronize(cm->stats_ready));
     fold_stats(cm->h_stats, cm->stats, 1);
+    // the buffer size was chosen on a survey (every 2nd / 8th row of blocks); now that the exact histogram is here, let the
+    // model look again - the buffer is a launch parameter, nothing in the block map depends on it
+    if (ctx->apply_lds_kb <= 0 && (int)(cm->stats[0] * 16u) > cm->lds_bytes) {
+        double c = 0;
+        const int kb = coop_choose_buffer(cm, cm->rg, (double)ctx->W * ctx->rows(), ctx->num_cus, &c);
+        if (kb * 1024 > cm->lds_bytes) cm->lds_bytes = kb * 1024;
+    }
     uint64_t over = 0;                         // blocks that take more than one pass through the buffer
     for (int b = cm->lds_bytes / 1024 + 1; b < (int)BK_COOP_BINS; ++b) over += cm->stats[8 + b];
     cm->slow_blocks = (int)(cm->stats[1] + over);
@@ -777,21 +789,30 @@ static int coop_stats_wait(bk_ctx *ctx, CoopMap *cm)
 // buffer sizes.  Throughput side: a staged 128-byte line ~13 ps, a staged block ~0.08 ns, a pixel ~0.5 ps.
 // Latency side: a workgroup spends ~0.9 us per chunk-per-thread and frame on a block (load -> LDS -> barrier ->
 // gather -> store) plus ~0.1 us per row group, and a CU overlaps only as many blocks as it holds workgroups
-// (one staging buffer each; registers allow 7 / 6 / 5 for 128x8 / 128x16 / 128x32 blocks).  The two sides
+// (one staging buffer each; registers allow 8 / 8 / 7 for 128x8 / 128x16 / 128x32 blocks in the one-block form) - and
+// no more than the launch has: a small map does not fill the chip.  The two sides
 // combine as a 3-norm; a block larger than the buffer takes ceil(need/buffer) passes; a block on the direct-gather
 // path (no chunk list at all) adds ~16 ns per row group.  Returns the best buffer size in KiB.
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns)
 {
-    const int vg = rg == 4 ? 5 : rg == 2 ? 6 : 7;
+    const int vg = rg == 4 ? 7 : 8;       // workgroups per CU the registers allow (one-block form: 67 / 50 / 45 VGPRs)
     int best_bin = 1;
     double best_c = -1;
-    for (int bin = 1; bin * 1024 <= BK_COOP_LDS_CAP; ++bin) {
+    // (from the largest buffer down, strictly better wins: among buffers of equal cost - all those that hold every block
+    // and leave the CU its register-limited number of workgroups - the LARGEST is taken.  The statistics may come from a
+    // survey of every 2nd or 8th block row, which underestimates the largest block; a block that does not fit is a
+    // multi-pass straggler, and in a launch of a round or two of workgroups one straggler sets the end: 1080p
+    // stereographic x16 with 10 such blocks of 510 ran 2.24 us/frame, without them 1.15)
+    double live_all = 0;
+    for (int b = 0; b < (int)BK_COOP_BINS; ++b) live_all += cm->stats[8 + b];
+    for (int bin = BK_COOP_LDS_CAP / 1024; bin >= 1; --bin) {
         // blocks that need more than the buffer go through it in ceil(need / buffer) passes (slower per chunk:
         // no register plan, the list is re-read every frame)
-        double lines_fit = 0, blocks_fit = 0, chunks_fit = 0, over_passes = 0;
+        double lines_fit = 0, blocks_fit = 0, chunks_fit = 0, over_passes = 0, max_passes = 1, live = 0;
         for (int b = 0; b < (int)BK_COOP_BINS; ++b) {
             const double passes = b <= bin ? 1.0 : (double)((b + bin - 1) / bin);
             if (b > bin) over_passes += passes * cm->stats[8 + b];
+            if (cm->stats[8 + b]) { live += cm->stats[8 + b]; if (passes > max_passes) max_passes = passes; }
             lines_fit += cm->stats[8 + BK_COOP_BINS + b];
             blocks_fit += passes * cm->stats[8 + b];
             chunks_fit += (b <= bin ? 1.0 : 1.5) * cm->stats[8 + 2 * BK_COOP_BINS + b];
@@ -800,9 +821,14 @@ static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num
         if (wgs > vg) wgs = vg;
         if (wgs < 1) wgs = 1;
         const double t_thr = 0.013 * lines_fit + 0.08 * blocks_fit + 0.00048 * npixels;
-        const double t_lat = (900.0 * chunks_fit / 256.0 + 100.0 * rg * blocks_fit) / ((double)num_cus * wgs);
-        // (multi-pass blocks are long-running stragglers of the persistent grid: charged ~12 ns per pass and row group)
-        const double c = cbrt(t_thr * t_thr * t_thr + t_lat * t_lat * t_lat) + 12.0 * rg * over_passes + 16.0 * rg * (double)cm->stats[1];
+        // (... of which a batch launch - two frame groups - only fills 2 x live blocks: a small map does not fill the chip)
+        const double slots = std::min((double)num_cus * wgs, std::max(1.0, 2.0 * live_all));
+        const double t_lat = (900.0 * chunks_fit / 256.0 + 100.0 * rg * blocks_fit) / slots;
+        // multi-pass blocks are long-running stragglers: ~12 ns per pass and row group in the throughput, and the slowest of
+        // them sets the end of a launch that is only a few rounds of workgroups long (~1.2 us per extra pass, per round)
+        const double rounds = 2.0 * live / ((double)num_cus * wgs);
+        const double straggler = (max_passes - 1.0) * 1200.0 / (rounds > 1.0 ? rounds : 1.0);
+        const double c = cbrt(t_thr * t_thr * t_thr + t_lat * t_lat * t_lat) + 12.0 * rg * over_passes + 16.0 * rg * (double)cm->stats[1] + straggler;
         if (best_c < 0 || c < best_c) { best_c = c; best_bin = bin; }
     }
     *cost_ns = best_c;
@@ -852,7 +878,10 @@ static int ensure_coopmap(bk_ctx *ctx)
     int best_rg = cand[0], best_kb = 0;
     if (ncand > 1 || ctx->apply_lds_kb <= 0) {
         const int by_min = (rows + 31) / 32;
-        const int stride = by_min >= 32 ? 8 : by_min >= 8 ? 2 : 1;       // (small maps: look at everything)
+        // (every 8th row of blocks at 4K and above, every 2nd from 1080p up, everything below: the largest block decides the
+        // buffer, and a sparse survey of a small map misses it - 1080p quincuncial, surveyed every 8th row: 40 of 306 blocks
+        // did not fit the buffer chosen, 5.0 instead of 2.1 us/frame)
+        const int stride = by_min >= 64 ? 8 : by_min >= 32 ? 2 : 1;
         for (int i = 0; i < ncand; ++i)
             if (int r = coop_compile_launch(ctx, cm, cand[i], stride, 1 + i)) return r;
         BK_HIP(ctx, hipMemcpyAsync(cm->h_stats + 64 * BK_COOP_STATS, cm->d_stats + 64 * BK_COOP_STATS, (size_t)ncand * 64 * BK_COOP_STATS * sizeof(uint32_t),
@@ -866,6 +895,13 @@ static int ensure_coopmap(bk_ctx *ctx)
             fold_stats(cm->h_stats + (size_t)(1 + i) * 64 * BK_COOP_STATS, cm->stats, scale);
             double c = 0;
             const int kb = coop_choose_buffer(cm, cand[i], (double)ctx->W * rows, ctx->num_cus, &c);
+            if (getenv("BLINKY_HIP_DEBUG_MODEL")) {       // developer: the cost model's inputs, one line per candidate
+                fprintf(stderr, "MODEL %dx%d rg %d kb %d cost %.1f maxchunks %u slow %u empty %u bins", ctx->W, rows, cand[i], kb, c, cm->stats[0],
+                        cm->stats[1], cm->stats[2]);
+                for (int b = 0; b < (int)BK_COOP_BINS; ++b)
+                    if (cm->stats[8 + b]) fprintf(stderr, " %d:%u:%u:%u", b, cm->stats[8 + b], cm->stats[8 + BK_COOP_BINS + b], cm->stats[8 + 2 * BK_COOP_BINS + b]);
+                fprintf(stderr, "\n");
+            }
             if (best_cost < 0 || c < best_cost) { best_cost = c; best_rg = cand[i]; best_kb = kb; }
         }
     }
