@@ -623,8 +623,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
 // one block per workgroup (launches short enough that the whole grid is resident at once, e.g. the engine's
 // single frames): no next-block state, fewer registers, more workgroups per CU - every block starts at once
+// (8 waves per SIMD = 8 workgroups per CU: the 128x32 form would take 67 VGPRs and 7; at 4K that is 1792 places for 2040
+// blocks, and the 248 left over wait a whole block's latency for theirs - single frame 9.4 -> 8.4 us at <= 64 VGPRs)
 template <bool RUBIX, int RG>
-__global__ __launch_bounds__(256) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
     (void)wgs_per_band; (void)order; (void)bands;
@@ -789,13 +791,13 @@ static int coop_stats_wait(bk_ctx *ctx, CoopMap *cm)
 // buffer sizes.  Throughput side: a staged 128-byte line ~13 ps, a staged block ~0.08 ns, a pixel ~0.5 ps.
 // Latency side: a workgroup spends ~0.9 us per chunk-per-thread and frame on a block (load -> LDS -> barrier ->
 // gather -> store) plus ~0.1 us per row group, and a CU overlaps only as many blocks as it holds workgroups
-// (one staging buffer each; registers allow 8 / 8 / 7 for 128x8 / 128x16 / 128x32 blocks in the one-block form) - and
+// (one staging buffer each; registers allow 8 in the one-block form) - and
 // no more than the launch has: a small map does not fill the chip.  The two sides
 // combine as a 3-norm; a block larger than the buffer takes ceil(need/buffer) passes; a block on the direct-gather
 // path (no chunk list at all) adds ~16 ns per row group.  Returns the best buffer size in KiB.
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns)
 {
-    const int vg = rg == 4 ? 7 : 8;       // workgroups per CU the registers allow (one-block form: 67 / 50 / 45 VGPRs)
+    const int vg = 8;                     // workgroups per CU the registers allow (one-block form: <= 64 VGPRs)
     int best_bin = 1;
     double best_c = -1;
     // (from the largest buffer down, strictly better wins: among buffers of equal cost - all those that hold every block
@@ -950,7 +952,7 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     int per_cu = ctx->apply_wgs_per_cu;
     if (fchunk == 1 && ctx->apply_wgs_per_cu == 16) {
         const int by_lds = (int)((160u * 1024u) / (shmem ? shmem : 1));
-        const int by_regs = cm->rg == 4 ? 7 : 8;            // (one-block form: 67 / 50 / 45 VGPRs for 128x32 / 16 / 8 blocks)
+        const int by_regs = 8;                              // (one-block form: <= 64 VGPRs)
         per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
         if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
         const int live = cm->stats_pending ? nblocks : nblocks - (int)cm->stats[2];

@@ -26,10 +26,11 @@ ctx.set_lensmap(lm.offsets, lm.tints)
 outs = [torch.zeros((F, H, W), dtype=torch.uint8, device="cuda") for _ in range(NB)]
 streams = [torch.cuda.Stream() for _ in range(4)]
 ctx.set_stream(streams[0].cuda_stream)
+ctx.set_tile_shape(300 + int(os.environ.get("BK_FCHUNK", "0")))      # frames per block visit (0 = default 8)
 ctx.tile_stats()
 ctx.apply_device(outs[0].data_ptr(), W, H * W, 0, F)
 torch.cuda.synchronize()
-for ns in (1, 2, 1, 2, 3):
+for ns in (1, 2, 2):
     for rep in range(2):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
