@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer probe: lensmap BUILD kernel time (bk_last_build_ms) of every bundled lens at a given size, and the
-host-buffer (PCIe-inclusive) cost of the drop-in calls bk_upload_plate / bk_apply.
+"""Developer probe: lensmap BUILD kernel time (bk_last_build_ms) of every bundled lens at a given size, the APPLY
+time of the map it built (16-frame and single-frame launches over a cold ring of 64 globes), and the host-buffer
+(PCIe-inclusive) cost of the drop-in calls bk_upload_plate / bk_apply.
 usage: python tools/build_times.py [W] [H]"""
 import os
 import sys
@@ -10,13 +11,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import torch
 
 import blinky_amd
 import scripts as S
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 3840
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 2160
+RING, F = 64, 16
 ctx = blinky_amd.Context()
+ctx.set_frames(RING)
+ctx.resize(W, H)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+for f in range(RING):
+    for p in range(6):
+        ctx.fill_plate_lcg(f, p, f)
+out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
+
+
+def apply_us(nf, reps=60):
+    for _ in range(3):
+        ctx.apply_device(out.data_ptr(), W, H * W, 0, nf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(reps):
+        ctx.apply_device(out.data_ptr(), W, H * W, (r * nf) % RING, nf)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3 / nf
+
+
 rows = []
 for lens in S.names("lenses"):
     try:
@@ -28,8 +53,12 @@ for lens in S.names("lenses"):
         display, scale = ctx.build()
         wall = (time.time() - t0) * 1e3
         st = ctx.tile_stats()
-        rows.append((lens, info.map_type, ctx.last_build_ms(), wall, first, sum(display)))
-        print(f"{lens:16s} map {info.map_type} build kernel {ctx.last_build_ms():8.3f} ms  wall {wall:8.2f} ms  first (hiprtc) {first:8.1f} ms  plates {sum(display)}  blocks {st['tiles']} slow {st['slow']} lds {st['lds_bytes_per_wave']}", flush=True)
+        kms = ctx.last_build_ms()
+        a16, a1 = apply_us(F), apply_us(1)
+        st = ctx.tile_stats()
+        rows.append((lens, info.map_type, kms, wall, first, sum(display)))
+        print(f"{lens:16s} map {info.map_type} build kernel {kms:8.3f} ms  wall {wall:8.2f} ms  first (hiprtc) {first:8.1f} ms  plates {sum(display)}  "
+              f"apply x{F} {a16:6.2f} us/frame  x1 {a1:6.2f} us  blocks {st['tiles']} h {st['tile_h'] - 128000} slow {st['slow']} empty {st['empty']} lds {st['lds_bytes_per_wave']}", flush=True)
     except Exception as e:      # a lens without a usable default zoom at this size
         print(f"{lens:16s} {type(e).__name__}: {str(e)[:100]}", flush=True)
 
