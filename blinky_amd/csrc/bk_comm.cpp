@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <array>
 #include <cstring>
 #include <memory>
@@ -101,8 +102,13 @@ struct bk_comm {
     hipEvent_t ev_done[BK_COMM_SLOTS] = {};         // exchange stream: the exchange last posted with that slot has finished
     std::string err;
 
+    // stripe bounds: rank r owns rows [bounds[r], bounds[r+1]); equal shares (multigpu.stripe_bounds) until bk_comm_rebalance /
+    // bk_multi_rebalance cut them by work
+    std::vector<int> bounds;
+
     int fail(int code, const std::string &m) { err = m; return code; }
-    int row0(int r) const { return (int)((long long)ctx->H * r / nranks); }      // multigpu.stripe_bounds
+    void equal_bounds() { bounds.resize((size_t)nranks + 1); for (int r = 0; r <= nranks; ++r) bounds[(size_t)r] = (int)((long long)ctx->H * r / nranks); }
+    int row0(int r) const { return bounds[(size_t)r]; }
     int rows(int r) const { return row0(r + 1) - row0(r); }
 };
 
@@ -198,6 +204,7 @@ static bk_comm *comm_shell(bk_ctx *ctx, int nranks, int rank)
     if (nranks > ctx->H) { g_comm_create_error = "bk_comm_create: more ranks than output rows"; return nullptr; }
     std::unique_ptr<bk_comm> c(new bk_comm());
     c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    c->equal_bounds();
     bool ok = hipSetDevice(ctx->device) == hipSuccess && hipMalloc((void **)&c->d_flags, BK_MAX_PLATES * sizeof(int)) == hipSuccess &&
               hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) == hipSuccess &&
@@ -253,6 +260,7 @@ extern "C" int bk_comm_stripe(const bk_comm *c, int rank, int *row0, int *row1)
 extern "C" int bk_comm_restripe(bk_comm *c)
 {
     if (!c) return BK_E_INVALID;
+    c->equal_bounds();                      // (a new size: equal shares again)
     if (int r = bk_set_rows(c->ctx, c->row0(c->rank), c->row0(c->rank + 1))) return c->fail(r, bk_last_error(c->ctx));
     return BK_OK;
 }
@@ -323,6 +331,55 @@ extern "C" int bk_comm_exchange_rotating(bk_comm *c, const void *stripe_dev, int
     std::vector<BkOp> ops;
     ops_rotating(c, stripe_dev, nframes, frames_dev, frame_stride, &ops);
     return run_rank(c, ops, slot);
+}
+
+// Stripes of equal WORK instead of equal height.  A lens that leaves part of the screen unmapped (hammer's ellipse,
+// quincuncial under f_contain) gives the ranks that own the top and the bottom of the screen a fraction of the middle
+// ranks' pixels; the frame is done when the slowest stripe is.  Row cost = mapped pixels + W/32 (so that empty rows are
+// still dealt out), bounds at equal shares of the prefix sum, multiples of 8 rows (the apply's smallest block height),
+// at least 8 rows each.  Deterministic: every rank computes the same bounds from the same sums.
+static std::vector<int> bounds_from_costs(const std::vector<uint32_t> &cost, int W, int nranks)
+{
+    const int H = (int)cost.size();
+    std::vector<uint64_t> pre((size_t)H + 1, 0);
+    const uint64_t base = (uint64_t)std::max(1, W / 32);
+    for (int y = 0; y < H; ++y) pre[(size_t)y + 1] = pre[(size_t)y] + cost[(size_t)y] + base;
+    std::vector<int> b((size_t)nranks + 1, 0);
+    b[(size_t)nranks] = H;
+    const int q = H >= 16 * nranks ? 8 : 1;                 // (tiny frames: any row)
+    for (int k = 1; k < nranks; ++k) {
+        const uint64_t target = pre[(size_t)H] * (uint64_t)k / (uint64_t)nranks;
+        int y = (int)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin());
+        y = (y + q / 2) / q * q;
+        const int lo = b[(size_t)k - 1] + q, hi = H - (nranks - k) * q;
+        b[(size_t)k] = std::min(std::max(y, lo), hi);
+    }
+    return b;
+}
+
+// this rank's row costs, summed over the ranks, -> new bounds -> bk_set_rows.  The lensmap of the new stripe has to be
+// built afterwards (bk_build; every rank), stripe buffers re-sized from bk_comm_stripe.  Collective: every rank calls it.
+extern "C" int bk_comm_rebalance(bk_comm *c)
+{
+    if (!c || !c->ctx) return BK_E_INVALID;
+    bk_ctx *ctx = c->ctx;
+    if (c->nranks == 1) return BK_OK;
+    if (!c->comm) return c->fail(BK_E_STATE, "this rank belongs to a copy-transport bk_multi: use bk_multi_rebalance");
+    BK_CHIP(c, hipSetDevice(ctx->device));
+    uint32_t *d = nullptr;
+    BK_CHIP(c, hipMalloc((void **)&d, (size_t)ctx->H * sizeof(uint32_t)));
+    std::vector<uint32_t> cost((size_t)ctx->H);
+    int rc = bk_row_costs_device(ctx, d);
+    if (rc != BK_OK) { (void)hipFree(d); return c->fail(rc, bk_last_error(ctx)); }
+    const ncclResult_t nr = rccl().AllReduce(d, d, (size_t)ctx->H, ncclUint32, ncclSum, c->comm, ctx->stream);
+    hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(cost.data(), d, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (nr != ncclSuccess) return c->fail(BK_E_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+    if (e != hipSuccess) return c->fail(BK_E_HIP, std::string("bk_comm_rebalance: ") + hipGetErrorString(e));
+    c->bounds = bounds_from_costs(cost, ctx->W, c->nranks);
+    if (int r = bk_set_rows(ctx, c->row0(c->rank), c->row0(c->rank + 1))) return c->fail(r, bk_last_error(ctx));
+    return BK_OK;
 }
 
 // ---- single-process group ------------------------------------------------------------------------------------
@@ -442,6 +499,35 @@ extern "C" int bk_multi_resize(bk_multi *m, int width, int height)
     } else {
         for (bk_comm *c : m->comm) if (int r = bk_comm_restripe(c)) return m->fail(r, c->err);
     }
+    return BK_OK;
+}
+
+// stripes of equal work (see bk_comm_rebalance): the row costs of every stripe's current lensmap, new bounds for all, and
+// bk_set_rows on every context - call bk_multi_build again afterwards.  bounds_out (nullable) gets the N+1 row bounds.
+extern "C" int bk_multi_rebalance(bk_multi *m, int *bounds_out)
+{
+    if (!m || m->ctx.empty() || !m->comm[0]) return BK_E_INVALID;
+    const int n = (int)m->ctx.size(), H = m->ctx[0]->H, W = m->ctx[0]->W;
+    std::vector<uint32_t> cost((size_t)H, 0), part((size_t)H);
+    for (int i = 0; i < n; ++i) {
+        bk_ctx *c = m->ctx[(size_t)i];
+        uint32_t *d = nullptr;
+        if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&d, (size_t)H * sizeof(uint32_t)) != hipSuccess)
+            return m->fail(BK_E_HIP, "bk_multi_rebalance: allocation failed");
+        int rc = bk_row_costs_device(c, d);
+        hipError_t e = rc == BK_OK ? hipMemcpyAsync(part.data(), d, part.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        if (rc != BK_OK) return m->fail(rc, std::string("device ") + std::to_string(c->device) + ": " + bk_last_error(c));
+        if (e != hipSuccess) return m->fail(BK_E_HIP, std::string("bk_multi_rebalance: ") + hipGetErrorString(e));
+        for (int y = 0; y < H; ++y) cost[(size_t)y] += part[(size_t)y];
+    }
+    const std::vector<int> b = bounds_from_costs(cost, W, n);
+    for (int i = 0; i < n; ++i) {
+        m->comm[(size_t)i]->bounds = b;
+        if (int r = bk_set_rows(m->ctx[(size_t)i], b[(size_t)i], b[(size_t)i + 1])) return m->fail(r, bk_last_error(m->ctx[(size_t)i]));
+    }
+    if (bounds_out) for (int i = 0; i <= n; ++i) bounds_out[i] = b[(size_t)i];
     return BK_OK;
 }
 

@@ -22,7 +22,33 @@ __global__ __launch_bounds__(256) void stream_mix_kernel(const uint4 *__restrict
     if (acc == 0x12345679u) *sink = acc;
 }
 
+// mapped pixels of every owned row (the cost of a row in a multi-GPU stripe split, bk_comm_rebalance)
+__global__ __launch_bounds__(256) void row_cost_kernel(const uint32_t *__restrict__ lmap, int W, uint32_t *__restrict__ cost)
+{
+    __shared__ uint32_t s_sum[4];
+    const uint32_t *row = lmap + (size_t)blockIdx.x * W;
+    uint32_t n = 0;
+    for (int x = threadIdx.x; x < W; x += 256) n += row[x] != BK_NULL_OFFSET ? 1u : 0u;
+    for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) cost[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
 }  // namespace bk
+
+// cost_dev: device uint32 [H]; the owned rows get their mapped-pixel counts, every other row 0 (on the context stream)
+int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev)
+{
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "row costs: no lensmap (call bk_build first)");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    BK_HIP(ctx, hipMemsetAsync(cost_dev, 0, (size_t)ctx->H * sizeof(uint32_t), ctx->stream));
+    if (ctx->rows() > 0) {
+        hipLaunchKernelGGL(bk::row_cost_kernel, dim3((unsigned)ctx->rows()), dim3(256), 0, ctx->stream, ctx->d_offsets, ctx->W, cost_dev + ctx->row0);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    return BK_OK;
+}
 
 // best of 5 passes over `bytes` read, writes / period of it written; *gbps = (bytes read + bytes written) / time
 extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps)

@@ -109,6 +109,8 @@ _SIGS = {
     "bk_comm_last_error": (C.c_char_p, [_vp]),
     "bk_comm_stripe": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "bk_comm_restripe": (_i, [_vp]),
+    "bk_comm_rebalance": (_i, [_vp]),
+    "bk_multi_rebalance": (_i, [_vp, C.POINTER(_i)]),
     "bk_comm_or_display": (_i, [_vp, C.POINTER(_i)]),
     "bk_comm_gather": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i]),
     "bk_comm_exchange_rotating": (_i, [_vp, _vp, _i, _vp, _sz, _i]),
@@ -488,6 +490,11 @@ class Comm:
         self._chk(lib.bk_comm_stripe(self._h, rank, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def rebalance(self):
+        """collective: stripes of equal work instead of equal height (then build again); returns this rank's new rows"""
+        self._chk(lib.bk_comm_rebalance(self._h))
+        return self.stripe(self.rank) if hasattr(self, "rank") else None
+
     def or_display(self, display):
         arr = (_i * MAX_PLATES)(*display)
         self._chk(lib.bk_comm_or_display(self._h, arr))
@@ -541,6 +548,12 @@ class Multi:
 
     def resize(self, w, h):
         self._chk(lib.bk_multi_resize(self._h, w, h))
+
+    def rebalance(self):
+        """stripes of equal work (mapped pixels) instead of equal height; returns the N+1 row bounds.  build() again afterwards."""
+        out = (_i * (self.n + 1))()
+        self._chk(lib.bk_multi_rebalance(self._h, out))
+        return list(out)
 
     def set_frames(self, n):
         self._chk(lib.bk_multi_set_frames(self._h, n))

@@ -492,6 +492,17 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
         }
         for (i = 0; i < BK_MAX_PLATES; ++i) newdisplay[i] = 0;
         rc = DEV(bk_build(bk, newdisplay, NULL), bk_multi_build(mg, newdisplay, NULL));      /* create_lensmap, fisheye.c:2367-2397 */
+        if (mg && rc == BK_OK) {
+            /* several GPUs: cut the stripes by work, not by height (a lens that leaves part of the screen unmapped would
+             * give the first and last GPU next to nothing), and build the lensmap of the new stripes.  Builds are
+             * sub-millisecond; when the bounds do not move bk_set_rows keeps the maps and the second build is skipped. */
+            static int last_bounds[BK_MAX_PLATES * 8 + 1];
+            int bounds[BK_MAX_PLATES * 8 + 1], n = bk_multi_size(mg), moved = 0;
+            if (n > 1 && n < (int)(sizeof bounds / sizeof bounds[0]) && bk_multi_rebalance(mg, bounds) == BK_OK) {
+                for (i = 0; i <= n; ++i) { moved |= bounds[i] != last_bounds[i]; last_bounds[i] = bounds[i]; }
+                if (moved) rc = bk_multi_build(mg, newdisplay, NULL);
+            }
+        }
         build_pending = rc == BK_PENDING;
         if (!build_pending) {                    /* (while the new lens compiles the previous lensmap and its plates stay) */
             for (i = 0; i < BK_MAX_PLATES; ++i) display[i] = newdisplay[i];

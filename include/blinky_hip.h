@@ -203,6 +203,12 @@ void        bk_comm_destroy(bk_comm *c);
 const char *bk_comm_last_error(const bk_comm *c);                                  /* c may be NULL: last failed create */
 int         bk_comm_stripe(const bk_comm *c, int rank, int *row0, int *row1);      /* any rank's rows */
 int         bk_comm_restripe(bk_comm *c);                                          /* after a later bk_resize */
+/* stripes of equal WORK instead of equal height (collective: every rank calls it after a bk_build): the mapped pixels of
+ * every row are summed over the ranks (ncclAllReduce), the rows are cut into shares of equal cost (multiples of 8 rows)
+ * and this rank's context gets its new stripe (bk_set_rows).  Build again afterwards; bk_comm_stripe tells the new
+ * stripes.  For lenses that leave part of the screen unmapped (hammer's ellipse): with equal heights the ranks that own
+ * the top and the bottom of the screen have a fraction of the middle ranks' pixels. */
+int         bk_comm_rebalance(bk_comm *c);
 /* display[] |= every other rank's (which plates the WHOLE frame reads, fisheye.c:1976): ncclAllReduce(MAX); synchronous */
 int         bk_comm_or_display(bk_comm *c, int display[BK_MAX_PLATES]);
 /* every frame of the batch onto `root` (what a single display needs): grouped ncclSend / ncclRecv; frames_dev is
@@ -234,6 +240,7 @@ int bk_multi_load_lens(bk_multi *m, const char *src, size_t len, const char *chu
 int bk_multi_clear_lens(bk_multi *m);
 int bk_multi_clear_globe(bk_multi *m);
 int bk_multi_resize(bk_multi *m, int width, int height);          /* + stripes: context i owns rows [H*i/N, H*(i+1)/N) */
+int bk_multi_rebalance(bk_multi *m, int *bounds_out /* [N+1], nullable */);   /* bk_comm_rebalance for the group; then bk_multi_build again */
 int bk_multi_set_frames(bk_multi *m, int nframes);
 int bk_multi_set_zoom(bk_multi *m, int zoom_type, int fov_degrees);
 int bk_multi_set_rubixgrid(bk_multi *m, int numcells, double cell_size, double pad_size);

@@ -92,6 +92,53 @@ def test_multi_from_python_with_rubix_and_double_buffering(bk):
     m.close()
 
 
+def test_stripes_of_equal_work(bk):
+    """bk_multi_rebalance: hammer's ellipse leaves the top and bottom stripes of an equal-height split nearly empty; cut by
+    mapped pixels instead, every stripe gets its share, and the reassembled frames are still the oracle's."""
+    import torch
+    globe, lens, W, H, F, N = "cube", "hammer", 640, 400, 4, 4
+    m = bk.Multi([0] * N)
+    m.set_frames(F)
+    m.load_globe(S.script("globes", globe), globe)
+    m.load_lens(S.script("lenses", lens), lens)
+    m.set_zoom(bk.ffi.ZOOM_CONTAIN)
+    m.resize(W, H)
+    m.build()
+    lm = O.lensmap(globe, lens, None, W, H)
+    mapped = (lm.offsets.reshape(H, W) != 0xFFFFFFFF).sum(axis=1)
+    equal = [H * r // N for r in range(N + 1)]
+    share_eq = [mapped[equal[r]:equal[r + 1]].sum() for r in range(N)]
+    assert max(share_eq) > 1.25 * (mapped.sum() / N)                      # the reason to do it
+    bounds = m.rebalance()
+    assert bounds[0] == 0 and bounds[-1] == H and bounds == sorted(bounds) and all(b % 8 == 0 for b in bounds[1:-1])
+    share = [mapped[bounds[r]:bounds[r + 1]].sum() + (bounds[r + 1] - bounds[r]) * (W // 32) for r in range(N)]
+    assert max(share) < 1.12 * (sum(share) / N), (bounds, share)
+    with pytest.raises(bk.BlinkyError):                                   # the stripes' lensmaps are gone: build again
+        m.apply(np.zeros((H, W), np.uint8))
+    m.build()
+    for r in range(N):
+        off, tin = m.ctx(r).read_lensmap()
+        np.testing.assert_array_equal(off, lm.offsets.reshape(H, W)[bounds[r]:bounds[r + 1]].ravel())
+        assert m.ctx(r).size()[3:] == (bounds[r], bounds[r + 1])
+    for f in range(F):
+        for p in range(6):
+            m.fill_plate_lcg(f, p, f)
+    want = [O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, f), np.zeros((H, W), np.uint8)) for f in range(F)]
+    np.testing.assert_array_equal(m.apply(np.zeros((H, W), np.uint8), frame=1), want[1])
+    stripes = [torch.zeros((F, bounds[r + 1] - bounds[r], W), dtype=torch.uint8, device="cuda") for r in range(N)]
+    frames = [torch.zeros(((F + N - 1) // N, H, W), dtype=torch.uint8, device="cuda") for r in range(N)]
+    torch.cuda.synchronize()
+    m.apply_stripes([t.data_ptr() for t in stripes], frame0=0, nframes=F)
+    m.exchange_rotating([t.data_ptr() for t in stripes], F, [t.data_ptr() for t in frames], H * W, slot=0)
+    m.synchronize()
+    for f in range(F):
+        np.testing.assert_array_equal(frames[f % N][f // N].cpu().numpy(), want[f], err_msg=f"frame {f}")
+    # a new size starts from equal shares again
+    m.resize(320, 200)
+    assert [m.ctx(r).size()[3] for r in range(N)] == [200 * r // N for r in range(N)]
+    m.close()
+
+
 def test_rccl_is_reachable_and_a_single_rank_communicator_works(bk):
     import torch
     uid = bk.ffi.comm_unique_id()                    # dlopen(librccl) + ncclGetUniqueId
