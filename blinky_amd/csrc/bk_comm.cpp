@@ -357,6 +357,15 @@ static std::vector<int> bounds_from_costs(const std::vector<uint32_t> &cost, int
     return b;
 }
 
+/* test hook (no device needed): the stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs */
+extern "C" int bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, int nranks, int *bounds_out)
+{
+    if (!row_cost || !bounds_out || H < 1 || W < 1 || nranks < 1 || nranks > H) return BK_E_INVALID;
+    const std::vector<int> b = bounds_from_costs(std::vector<uint32_t>(row_cost, row_cost + H), W, nranks);
+    for (int i = 0; i <= nranks; ++i) bounds_out[i] = b[(size_t)i];
+    return BK_OK;
+}
+
 // this rank's row costs, summed over the ranks, -> new bounds -> bk_set_rows.  The lensmap of the new stripe has to be
 // built afterwards (bk_build; every rank), stripe buffers re-sized from bk_comm_stripe.  Collective: every rank calls it.
 extern "C" int bk_comm_rebalance(bk_comm *c)

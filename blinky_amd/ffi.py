@@ -110,6 +110,7 @@ _SIGS = {
     "bk_comm_stripe": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "bk_comm_restripe": (_i, [_vp]),
     "bk_comm_rebalance": (_i, [_vp]),
+    "bk_debug_stripe_bounds": (_i, [C.POINTER(C.c_uint32), _i, _i, _i, C.POINTER(_i)]),
     "bk_multi_rebalance": (_i, [_vp, C.POINTER(_i)]),
     "bk_comm_or_display": (_i, [_vp, C.POINTER(_i)]),
     "bk_comm_gather": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i]),
@@ -604,6 +605,16 @@ class Multi:
 
     def wait(self, slot=0):
         self._chk(lib.bk_multi_wait(self._h, slot))
+
+
+def stripe_bounds_from_costs(row_cost, W, nranks):
+    """the stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs (host logic, no device)"""
+    row_cost = np.ascontiguousarray(row_cost, dtype=np.uint32)
+    out = (_i * (nranks + 1))()
+    rc = lib.bk_debug_stripe_bounds(row_cost.ctypes.data_as(C.POINTER(C.c_uint32)), len(row_cost), W, nranks, out)
+    if rc != OK:
+        raise BlinkyError(f"[{rc}] bk_debug_stripe_bounds")
+    return list(out)
 
 
 def create_palmap(basepal):

@@ -209,6 +209,8 @@ int         bk_comm_restripe(bk_comm *c);                                       
  * stripes.  For lenses that leave part of the screen unmapped (hammer's ellipse): with equal heights the ranks that own
  * the top and the bottom of the screen have a fraction of the middle ranks' pixels. */
 int         bk_comm_rebalance(bk_comm *c);
+/* test hook, no device needed: the N+1 stripe bounds those two derive from per-row costs (mapped pixels of each of H rows) */
+int         bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, int nranks, int *bounds_out);
 /* display[] |= every other rank's (which plates the WHOLE frame reads, fisheye.c:1976): ncclAllReduce(MAX); synchronous */
 int         bk_comm_or_display(bk_comm *c, int display[BK_MAX_PLATES]);
 /* every frame of the batch onto `root` (what a single display needs): grouped ncclSend / ncclRecv; frames_dev is
