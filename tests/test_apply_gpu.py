@@ -198,8 +198,9 @@ def test_apply_device_batch_distinct_globes(bk, variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("rows", [None, (104, 613)], ids=["frame", "stripe"])
 @pytest.mark.parametrize("lens,uneven", [("hammer", True), ("quincuncial", True), ("panini", False)])
-def test_xcd_bands_of_equal_cost(bk, lens, uneven):
+def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
     """The persistent apply gives each XCD a band of the LIVE blocks of equal cost (not of equal block count): the bands
     partition the live blocks, their costs are level, and every path over them - the strided walk with few and with many
     workgroups, the one-block-per-workgroup form with and without the balanced workgroup map, the equal-count bands of the
@@ -207,13 +208,19 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven):
     import torch
     lm = O.lensmap("cube", lens, None, 1280, 720)
     W, H, F = lm.W, lm.H, 5
-    ctx = make_ctx(bk, lm, nframes=F)
+    ctx = make_ctx(bk, lm, nframes=F, rows=rows)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     for f in range(F):
         for p in range(6):
             ctx.fill_plate_lcg(f, p, seed_frame=f)
-    ctx.set_lensmap(lm.offsets, lm.tints)
+    r0, r1 = rows if rows else (0, H)
+    ctx.set_lensmap(lm.offsets.reshape(H, W)[r0:r1].ravel(), lm.tints.reshape(H, W)[r0:r1].ravel())
     want = [O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, f), np.full((H, W), 9, np.uint8)) for f in range(F)]
+    for w in want:                                          # a stripe context writes its rows only
+        w[:r0] = 9
+        w[r1:] = 9
+    if rows:
+        uneven = False                                      # (the stripe cuts the ellipse's caps off: may or may not be uneven)
     for shape in (1, 2, 4):
         ctx.set_tile_shape(shape)
         st = ctx.tile_stats()                              # (waits for the block map's statistics: the balance is known from here on)
