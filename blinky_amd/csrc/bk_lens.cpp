@@ -1208,6 +1208,29 @@ extern "C" int bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n,
     return BK_OK;
 }
 
+/* the same for the forward build's texel corners (ids: corner number plate * (ps+1)^2 + j * (ps+1) + i): screen x, y and
+ * whether lens_forward gave a position */
+extern "C" int bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n, int32_t *sx, int32_t *sy, uint8_t *ok)
+{
+    if (!ctx || !ids || !sx || !sy || !ok) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid || !P->lens_forward.is_function()) return ctx->fail(BK_E_STATE, "no lens_forward");
+    if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
+    if (int r = bk_calc_zoom(ctx, nullptr)) return r;
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    const size_t n1 = (size_t)ctx->ps + 1, total = (size_t)ctx->numplates * n1 * n1;
+    for (size_t i = 0; i < n; ++i) if (ids[i] >= total) return ctx->fail(BK_E_INVALID, "bk_debug_host_corners: index out of range");
+    std::vector<int> err(n, 0), x(n), y(n);
+    try {
+        for_each_flagged(P, n, [&](HostEval &E, size_t i) { h_corner_entry(ctx, E, bp, ids[i], &x[i], &y[i], &ok[i], &err[i]); });
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "%s", e.what());
+    }
+    for (size_t i = 0; i < n; ++i) { sx[i] = x[i]; sy[i] = y[i]; }
+    return BK_OK;
+}
+
 extern "C" int bk_last_build_fixups(const bk_ctx *ctx, int *flagged, int *changed)
 {
     if (!ctx) return BK_E_INVALID;

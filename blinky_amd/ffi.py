@@ -91,6 +91,7 @@ _SIGS = {
     "bk_debug_stream_mix": (_i, [_vp, _sz, _i, _i, C.POINTER(_d)]),
     "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "bk_debug_host_corners": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "bk_debug_xcd_of_workgroups": (_i, [_vp, C.POINTER(_i), _i]),
     "bk_debug_set_ablation": (_i, [_vp, _i]),
     "bk_debug_set_tile_shape": (_i, [_vp, _i]),
@@ -347,6 +348,15 @@ class Context:
         tin = np.empty(len(ids), np.uint8)
         self._chk(lib.bk_debug_host_entries(self._h, _ptr(ids), len(ids), _ptr(off), _ptr(tin)))
         return off, tin
+
+    def host_corners(self, ids):
+        """the host fix-up's value for the given texel corners of the forward build: (sx, sy, ok)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        sx = np.empty(len(ids), np.int32)
+        sy = np.empty(len(ids), np.int32)
+        ok = np.empty(len(ids), np.uint8)
+        self._chk(lib.bk_debug_host_corners(self._h, _ptr(ids), len(ids), _ptr(sx), _ptr(sy), _ptr(ok)))
+        return sx, sy, ok
 
     def xcd_of_workgroups(self, n):
         out = (_i * n)()

@@ -316,6 +316,9 @@ int         bk_debug_build_params(bk_ctx *ctx, void *out, size_t cap, size_t *ne
 /* test hook: the host re-evaluation bk_build applies to the pixels it flags (bk_last_build_fixups), over any pixel
  * indices (row-major inside the owned rows); offsets in the reference layout.  Works without a device. */
 int         bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n, uint32_t *offsets, uint8_t *tints);
+/* the same for the texel corners of the forward build (corner number plate * (ps+1)^2 + j * (ps+1) + i): screen x, y, and
+ * whether lens_forward gave a position */
+int         bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n, int32_t *sx, int32_t *sy, uint8_t *ok);
 /* evaluate a callback with the HOST interpreter, for diagnosing a script: which 0 = lens_inverse(x,y),
  * 1 = lens_forward(x,y,z), 2 = globe_plate(x,y,z); *nout = number of results, -1 for a single nil */
 int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs, double out[8], int *nout);

@@ -101,9 +101,9 @@ def device_to_reference_layout(off, ps):
     return out
 
 
-def forward_corners(ctx):
+def forward_corners(ctx, defines=()):
     """the generated bk_forward_corners on the host: (corner_xy int32 [n,2], corner_ok uint8 [n], flagged ids, err)"""
-    lib = compile_source(ctx.kernel_source())
+    lib = compile_source(ctx.kernel_source(), defines)
     fo = _field_offsets()
     bp = ctx.build_params()
     W, H, ps, r0, r1 = ctx.size()

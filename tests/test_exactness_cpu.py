@@ -300,3 +300,28 @@ def test_forward_error_bounds_hold_against_an_adversarial_libm(lens, mode):
     dev = emu.forward_values(ctx, rays, defines=("BK_LIBM_REL=0x1p-30",))
     check_bounds(ctx, 1, dev, rays, range(len(rays)), f"{lens}/{mode}")
     ctx.close()
+
+
+@pytest.mark.parametrize("lens", ["eckert1", "eckert5", "gins8", "kavrayskiy7", "larrivee", "polyconic", "sinusoidal", "wagner6", "winkel1",
+                                  "winkel2"])
+def test_forward_corner_flags_cover_an_adversarial_libm(lens):
+    """The forward build's discrete step - a texel corner's screen position (int)(x / scale + W/2), (int)(-y / scale + H/2),
+    or none - against a stand-in libm of 2^-22 (coarser than elsewhere: a corner changes pixel only when x / scale lands
+    within ~100 * 2^-22 of an integer): every corner the host interpreter places differently from the generated code is in
+    the generated code's flagged list (the 10 lenses that only have lens_forward)."""
+    import blinky_amd
+    W, H = 200, 150
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    ctx.set_host_math(22)
+    S.configure(ctx, "cube", lens, None, (W, H))
+    xy, ok, flagged, err = emu.forward_corners(ctx, defines=("BK_LIBM_REL=0x1p-22",))
+    assert err == 0
+    n = len(ok)
+    hx, hy, hok = ctx.host_corners(np.arange(n, dtype=np.uint32))
+    ctx.close()
+    same = (hok == ok) & ((ok == 0) | ((hx == xy[:, 0]) & (hy == xy[:, 1])))
+    differs = np.nonzero(~same)[0]
+    missed = np.setdiff1d(differs, flagged)
+    print(f"{lens}: {len(differs)} of {n} corners differ, {len(flagged)} flagged")
+    assert len(missed) == 0, (len(differs), len(flagged), missed[:10])
+    assert len(flagged) < n                                    # (and the flags are not simply everything)
