@@ -612,6 +612,12 @@ static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out)
     rq.globe_plate = P->globe_plate;
     try {
         *out = bk::emit_build_source(rq);
+        // test hook: a wider assumed libm discrepancy (tests pair it with bk_set_host_math(ctx, n): the host interpreter on a
+        // stand-in libm 2^-n away from bkm.h), so that the flag -> host fix-up path is exercised on thousands of pixels
+        if (const char *e = getenv("BLINKY_HIP_TEST_LIBM_REL_LOG2")) {
+            const int n = atoi(e);
+            if (n >= 8 && n <= 52) *out = "#define BK_LIBM_REL 0x1p-" + std::to_string(n) + "\n" + *out;
+        }
     } catch (const LuaError &e) {
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }

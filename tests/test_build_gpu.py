@@ -323,3 +323,38 @@ def test_script_runtime_errors_surface_as_errors(bk):
         ctx.build()
     assert (ctx.read_lensmap()[0] == O.NULL).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("lens,W,H", [("quincuncial", 640, 480), ("stereographic", 640, 400), ("hammer", 640, 360), ("winkeltripel", 480, 300),
+                                      ("fisheye1", 400, 400), ("sinusoidal", 480, 300), ("gins8", 480, 300)])
+def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monkeypatch):
+    """The whole mechanism on the GPU, with the libm discrepancy scaled up until it bites thousands of times: the host
+    interpreter runs on a stand-in libm 2^-30 away from bkm.h (bk_set_host_math(ctx, 30)), the kernels are generated with
+    BK_LIBM_REL = 2^-30 to match, and the table bk_build delivers - device results, flagged entries re-derived on the host
+    and patched - must be, entry for entry, what the host interpreter alone derives for every pixel."""
+    monkeypatch.setenv("BLINKY_HIP_TEST_LIBM_REL_LOG2", "30")
+    monkeypatch.setenv("BLINKY_HIP_CACHE", "off")
+    ctx = bk.Context()
+    ctx.set_host_math(30)
+    info = S.configure(ctx, "cube", lens, None, (W, H))
+    ctx.build()
+    off, tin = ctx.read_lensmap()
+    flagged, changed = ctx.last_build_fixups()
+    if info.map_type == 1:                                   # inverse map: every pixel has a host-side value to compare with
+        hoff, htin = ctx.host_entries(np.arange(W * H, dtype=np.uint32))
+        np.testing.assert_array_equal(off, hoff)
+        np.testing.assert_array_equal(tin, htin)
+        assert flagged > 100, (flagged, changed)              # the scaled-up discrepancy does bite
+    # and the same map built with the kernels' normal assumption (2^-50) on the same stand-in libm is NOT that table where
+    # the stand-in disagrees with bkm.h by more than the kernels allow for: the flags are what makes the difference
+    monkeypatch.delenv("BLINKY_HIP_TEST_LIBM_REL_LOG2")
+    ctx2 = bk.Context()
+    ctx2.set_host_math(30)
+    S.configure(ctx2, "cube", lens, None, (W, H))
+    ctx2.build()
+    off2, tin2 = ctx2.read_lensmap()
+    f2, c2 = ctx2.last_build_fixups()
+    assert f2 <= flagged
+    print(f"{lens}: 2^-30 kernels flagged {flagged} changed {changed}; 2^-50 kernels flagged {f2} changed {c2}, entries that differ between the two tables {int((off != off2).sum())}")
+    ctx.close()
+    ctx2.close()
