@@ -5,4 +5,4 @@ host layer in ``blinky_amd/host``.  This Python package is only the ctypes bindi
 tests/ and bench.py use; it never computes anything itself and has no CPU fallback:
 importing :mod:`blinky_amd.ffi` raises if the HIP library has not been built.
 """
-from .ffi import Context, Comm, Multi, BlinkyError, lib, LIB_PATH  # noqa: F401
+from .ffi import Context, Comm, Multi, BlinkyError, lib, LIB_PATH, debug_set_option  # noqa: F401

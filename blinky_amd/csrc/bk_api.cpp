@@ -149,6 +149,22 @@ static int alloc_globe(bk_ctx *ctx)
     return BK_OK;
 }
 
+// leave a context EMPTY (W = H = 0, every size-dependent buffer freed; ctx->err is kept): what a failed bk_resize does,
+// and what bk_multi_resize does to the contexts that had already taken the new size when a later one failed
+void bk::empty_context(bk_ctx *ctx)
+{
+    const std::string msg = ctx->err;
+    if (ctx->device >= 0) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    free_maps(ctx);
+    (void)hipFree(ctx->d_globe); ctx->d_globe = nullptr; ctx->globe_bytes = 0;
+    (void)hipFree(ctx->d_plate_stage); ctx->d_plate_stage = nullptr;
+    ctx->W = ctx->H = ctx->ps = ctx->gp = ctx->ph = 0;
+    ctx->row0 = ctx->row1 = 0;
+    ctx->lensmap_valid = false;
+    ctx->spans_valid = false;
+    ctx->err = msg;
+}
+
 extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
 {
     if (!ctx) return BK_E_INVALID;
@@ -170,13 +186,7 @@ extern "C" int bk_resize(bk_ctx *ctx, int width, int height)
     // device entry point answers BK_E_STATE) and a later bk_resize of the same size tries again; the reference
     // exits the process instead (fisheye.c:723-726)
     auto fail_empty = [&](int rc) {
-        const std::string msg = ctx->err;
-        free_maps(ctx);
-        (void)hipFree(ctx->d_globe); ctx->d_globe = nullptr; ctx->globe_bytes = 0;
-        (void)hipFree(ctx->d_plate_stage); ctx->d_plate_stage = nullptr;
-        ctx->W = ctx->H = ctx->ps = ctx->gp = ctx->ph = 0;
-        ctx->row0 = ctx->row1 = 0;
-        ctx->err = msg;
+        bk::empty_context(ctx);
         return rc;
     };
     ctx->W = width; ctx->H = height; ctx->ps = ps; ctx->gp = gp; ctx->ph = ph;
@@ -250,13 +260,28 @@ extern "C" int bk_set_apply_variant(bk_ctx *ctx, int variant)
     return BK_OK;
 }
 
+bk::DebugOptions bk::g_debug;
+#if BK_DEBUG_API
+extern "C" int bk_debug_set_option(const char *name, int value)
+{
+    if (!name) return BK_E_INVALID;
+    if (!strcmp(name, "no_memcache")) bk::g_debug.no_memcache = value;
+    else if (!strcmp(name, "libm_rel_log2")) bk::g_debug.libm_rel_log2 = value;
+    else if (!strcmp(name, "print_model")) bk::g_debug.print_model = value;
+    else return BK_E_INVALID;
+    return BK_OK;
+}
+#endif
+#if BK_DEBUG_API
 extern "C" int bk_debug_set_ablation(bk_ctx *ctx, int bits)
 {
     if (!ctx) return BK_E_INVALID;
     ctx->apply_flags = bits;
     return BK_OK;
 }
+#endif
 
+#if BK_DEBUG_API
 extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
 {
     if (!ctx) return BK_E_INVALID;
@@ -269,7 +294,9 @@ extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
     bk::coopmap_invalidate(ctx);
     return BK_OK;
 }
+#endif
 
+#if BK_DEBUG_API
 extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
 {
     if (!ctx || !out) return BK_E_INVALID;
@@ -277,7 +304,9 @@ extern "C" int bk_debug_tile_stats(bk_ctx *ctx, int out[6])
     if (int r = ensure_device(ctx)) return r;
     return bk::coopmap_stats(ctx, out);
 }
+#endif
 
+#if BK_DEBUG_API
 extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8])
 {
     if (!ctx || !out) return BK_E_INVALID;
@@ -285,7 +314,9 @@ extern "C" int bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8])
     if (int r = ensure_device(ctx)) return r;
     return bk::coopmap_traffic_model(ctx, out);
 }
+#endif
 
+#if BK_DEBUG_API
 extern "C" int bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18])
 {
     if (!ctx || !out) return BK_E_INVALID;
@@ -293,13 +324,16 @@ extern "C" int bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18])
     if (int r = ensure_device(ctx)) return r;
     return bk::coopmap_band_balance(ctx, out);
 }
+#endif
 
+#if BK_DEBUG_API
 extern "C" int bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups)
 {
     if (!ctx || !out || nworkgroups < 1) return BK_E_INVALID;
     if (int r = ensure_device(ctx)) return r;
     return bk::coopmap_xcd_probe(ctx, out, nworkgroups);
 }
+#endif
 
 extern "C" double bk_last_build_ms(const bk_ctx *ctx) { return ctx ? ctx->last_build_ms : 0; }
 

@@ -897,7 +897,7 @@ static int ensure_coopmap(bk_ctx *ctx)
             fold_stats(cm->h_stats + (size_t)(1 + i) * 64 * BK_COOP_STATS, cm->stats, scale);
             double c = 0;
             const int kb = coop_choose_buffer(cm, cand[i], (double)ctx->W * rows, ctx->num_cus, &c);
-            if (getenv("BLINKY_HIP_DEBUG_MODEL")) {       // developer: the cost model's inputs, one line per candidate
+            if (g_debug.print_model) {       // developer: the cost model's inputs, one line per candidate
                 fprintf(stderr, "MODEL %dx%d rg %d kb %d cost %.1f maxchunks %u slow %u empty %u bins", ctx->W, rows, cand[i], kb, c, cm->stats[0],
                         cm->stats[1], cm->stats[2]);
                 for (int b = 0; b < (int)BK_COOP_BINS; ++b)
@@ -941,7 +941,12 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     const int fchunk = nframes < fmax ? nframes : fmax;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     const int per = (nblocks + 7) / 8;
-    const size_t shmem = (size_t)cm->lds_bytes + (rubix_on ? BK_MAX_PLATES * 256 : 0);
+    // Fold the block map's statistics in FIRST if they have arrived: coop_stats_wait may enlarge cm->lds_bytes (the exact
+    // histogram can show a block the strided survey missed), and the dynamic-LDS size of the launch, the staging-buffer
+    // size the kernel is told and the palette's place behind it must all come from the same value.
+    if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
+    const int lds_buf = cm->lds_bytes;
+    const size_t shmem = (size_t)lds_buf + (rubix_on ? BK_MAX_PLATES * 256 : 0);
     // Grid.  One block per workgroup (the finest split, dealt to the CUs by the hardware as they free up) when that many
     // workgroups are about what the chip holds - `apply_wgs_per_cu` = 16 per CU, deliberately generous: 4K panini x16 runs
     // 3.93 us/frame that way against 4.08 for a strided walk by the 7 per CU that are truly resident - and otherwise a strided
@@ -954,7 +959,6 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
         const int by_lds = (int)((160u * 1024u) / (shmem ? shmem : 1));
         const int by_regs = 8;                              // (one-block form: <= 64 VGPRs)
         per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
-        if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
         const int live = cm->stats_pending ? nblocks : nblocks - (int)cm->stats[2];
         // (up to 1.5 x what is resident the one-block form still wins: 4K panini, 2040 blocks on 1792 places, 9.0 against 9.3 us)
         if (2 * live <= 3 * ctx->num_cus * per_cu) per_cu = 1 << 20;         // one block each
@@ -973,13 +977,10 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     // one-block form: take the cost-balanced workgroup -> block map if bands of equal block count are known to be uneven
     // (the block map's statistics arrive asynchronously: until they are here, the direct mapping)
     int kflags = ctx->apply_flags & ~BK_KF_WGMAP;
-    if (once && !(kflags & (16 | 64))) {
-        if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
-        if (!cm->stats_pending && cm->stats[7]) kflags |= BK_KF_WGMAP;
-    }
+    if (once && !(kflags & (16 | 64)) && !cm->stats_pending && cm->stats[7]) kflags |= BK_KF_WGMAP;
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
-                                           dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, cm->lds_bytes,     \
+                                           dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
 #define BK_APPLY(RBX, N) do { if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
     if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }

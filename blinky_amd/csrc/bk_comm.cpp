@@ -357,6 +357,7 @@ static std::vector<int> bounds_from_costs(const std::vector<uint32_t> &cost, int
     return b;
 }
 
+#if BK_DEBUG_API
 /* test hook (no device needed): the stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs */
 extern "C" int bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, int nranks, int *bounds_out)
 {
@@ -365,6 +366,7 @@ extern "C" int bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, in
     for (int i = 0; i <= nranks; ++i) bounds_out[i] = b[(size_t)i];
     return BK_OK;
 }
+#endif
 
 // this rank's row costs, summed over the ranks, -> new bounds -> bk_set_rows.  The lensmap of the new stripe has to be
 // built afterwards (bk_build; every rank), stripe buffers re-sized from bk_comm_stripe.  Collective: every rank calls it.
@@ -482,33 +484,61 @@ extern "C" int bk_multi_wait(bk_multi *m, int slot)
     return BK_OK;
 }
 
-// (re)size every stripe context and (re)build the communicators' stripes: rank i owns rows [H*i/N, H*(i+1)/N)
+// (re)size every stripe context and (re)build the communicators' stripes: rank i owns rows [H*i/N, H*(i+1)/N).
+// Failure-atomic like bk_resize: if any device fails, EVERY context is left empty (W = H = 0) and no communicator is kept,
+// so that a later bk_multi_resize starts from scratch.
 extern "C" int bk_multi_resize(bk_multi *m, int width, int height)
 {
     if (!m) return BK_E_INVALID;
     const int n = (int)m->ctx.size();
     if (height < n) return m->fail(BK_E_INVALID, "bk_multi_resize: fewer rows than devices");
-    BK_EACH(m, bk_resize(c, width, height));
-    if (!m->comm[0]) {
-        std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    auto undo = [&](int rc, const std::string &msg) {
+        Rccl &R = rccl();
+        for (int i = 0; i < n; ++i) {
+            bk_comm *c = m->comm[(size_t)i];
+            ncclComm_t raw = c ? c->comm : comms[(size_t)i];             // attached to a shell or still loose
+            if (c) c->comm = nullptr;
+            if (raw && R.ok) { (void)hipSetDevice(m->ctx[(size_t)i]->device); (void)R.CommDestroy(raw); }
+            bk_comm_destroy(c);
+            m->comm[(size_t)i] = nullptr;
+            bk::empty_context(m->ctx[(size_t)i]);
+        }
+        return m->fail(rc, msg);
+    };
+    for (bk_ctx *c : m->ctx)
+        if (int r = bk_resize(c, width, height)) return undo(r, std::string("device ") + std::to_string(c->device) + ": " + bk_last_error(c));
+    bool have_all = true;
+    for (bk_comm *c : m->comm) have_all = have_all && c;
+    if (!have_all) {
+        for (bk_comm *c : m->comm) if (c) return undo(BK_E_STATE, "bk_multi_resize: incomplete communicator set");     // (cannot happen: undo clears all)
         if (n > 1 && !m->copy_transport) {
             Rccl &R = rccl();
-            if (!R.ok) return m->fail(BK_E_STATE, R.error);
+            if (!R.ok) return undo(BK_E_STATE, R.error);
             std::vector<int> devs;
             for (bk_ctx *c : m->ctx) devs.push_back(c->device);
             const ncclResult_t r = R.CommInitAll(comms.data(), n, devs.data());
-            if (r != ncclSuccess) return m->fail(BK_E_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
+            if (r != ncclSuccess) { std::fill(comms.begin(), comms.end(), nullptr); return undo(BK_E_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r)); }
         }
         for (int i = 0; i < n; ++i) {
             m->comm[(size_t)i] = comm_shell(m->ctx[(size_t)i], n, i);
-            if (!m->comm[(size_t)i]) return m->fail(BK_E_HIP, g_comm_create_error);
+            if (!m->comm[(size_t)i]) return undo(BK_E_HIP, g_comm_create_error);
             m->comm[(size_t)i]->comm = comms[(size_t)i];
+            comms[(size_t)i] = nullptr;
             m->comm[(size_t)i]->owns_comm = false;              // destroyed by bk_destroy_multi
         }
     } else {
-        for (bk_comm *c : m->comm) if (int r = bk_comm_restripe(c)) return m->fail(r, c->err);
+        for (bk_comm *c : m->comm) if (int r = bk_comm_restripe(c)) return undo(r, c->err);
     }
     return BK_OK;
+}
+
+// 1 when every stripe context holds a valid lensmap for its current rows (bk_set_rows / bk_resize invalidate it)
+extern "C" int bk_multi_lensmap_valid(const bk_multi *m)
+{
+    if (!m || m->ctx.empty()) return 0;
+    for (const bk_ctx *c : m->ctx) if (!c->lensmap_valid) return 0;
+    return 1;
 }
 
 // stripes of equal work (see bk_comm_rebalance): the row costs of every stripe's current lensmap, new bounds for all, and
@@ -546,6 +576,18 @@ extern "C" int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], doubl
 {
     if (!m) return BK_E_INVALID;
     const size_t n = m->ctx.size();
+    // Asynchronous compilation: the generated source is the same for every stripe, so ask ONCE whether its module is there
+    // and answer BK_PENDING before any stripe clears or rebuilds its map - otherwise the stripes whose module happened to
+    // be cached would show the new lens next to stripes still showing the old one.  Once the code is in the process-wide
+    // cache every context loads it from there without waiting.
+    std::vector<char> was_async(n, 0);
+    bool any_async = false;
+    for (size_t i = 0; i < n; ++i) { was_async[i] = m->ctx[i]->async_compile; any_async = any_async || was_async[i]; }
+    if (any_async) {
+        for (size_t i = 0; i < n; ++i)
+            if (was_async[i]) { if (bk::build_module_ready(m->ctx[i]) == BK_PENDING) return BK_PENDING; break; }
+        for (size_t i = 0; i < n; ++i) m->ctx[i]->async_compile = false;      // (the code object is cached now: no stall)
+    }
     std::vector<int> rc(n, BK_OK);
     std::vector<std::array<int, BK_MAX_PLATES>> disp(n);
     std::vector<double> scale(n, 0.0);
@@ -553,6 +595,7 @@ extern "C" int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], doubl
     for (size_t i = 0; i < n; ++i)
         pool.emplace_back([&, i]() { rc[i] = bk_build(m->ctx[i], disp[i].data(), &scale[i]); });
     for (std::thread &t : pool) t.join();
+    for (size_t i = 0; i < n; ++i) m->ctx[i]->async_compile = was_async[i] != 0;
     int all[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; ++i) {
         if (rc[i] != BK_OK) return m->fail(rc[i], std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]));

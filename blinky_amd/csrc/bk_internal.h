@@ -10,9 +10,19 @@
 #include <vector>
 
 #include "../../include/blinky_hip.h"
+#ifndef BK_DEBUG_API
+#define BK_DEBUG_API 0
+#endif
+#if BK_DEBUG_API
+#include "../../include/blinky_hip_debug.h"
+#endif
 #include "bk_build_params.h"      // the device globe layout (bk_texel_offset)
 
 namespace bk {
+
+// process-wide developer / test switches (bk_debug_set_option, debug API builds only; always 0 otherwise)
+struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0; };
+extern DebugOptions g_debug;
 
 // A run of mapped pixels in one output row (host-side, for merging a warped
 // frame into the caller's vid.buffer without touching unmapped pixels).
@@ -141,5 +151,10 @@ void coopmap_free(CoopMap *);
 
 // bk_lens.cpp
 void lensprogram_free(LensProgram *);
+// BK_OK when the current lens + globe's kernels are loaded (or were found in a cache just now), BK_PENDING while hiprtc is
+// still compiling them on another thread (asynchronous compilation only; nothing of the context's lensmap is touched)
+int build_module_ready(bk_ctx *ctx);
+// bk_api.cpp
+void empty_context(bk_ctx *ctx);
 
 }  // namespace bk

@@ -32,6 +32,8 @@ struct CodeResult {
     bool from_disk = false;
 };
 
+static void park_compile(std::shared_future<::CodeResult> &f);      // (below, next to the code caches)
+
 namespace bk {
 
 struct LensProgram {
@@ -150,6 +152,7 @@ void lensprogram_free(LensProgram *p)
 {
     if (!p) return;
     if (p->module) (void)hipModuleUnload(p->module);
+    park_compile(p->pending);           // a compile still running must not stall the teardown
     delete p;
 }
 
@@ -491,7 +494,7 @@ static CodeResult cached_code(const std::string &source, const std::string &arch
 {
     CodeResult r;
     std::lock_guard<std::mutex> lock(g_rtc_mutex);
-    const bool use_mem = !getenv("BLINKY_HIP_NO_MEMCACHE");         // (tests of the disk cache switch the memory cache off)
+    const bool use_mem = !bk::g_debug.no_memcache;                  // (tests of the disk cache switch the memory cache off)
     auto hit = g_rtc_cache.find(code_key(source, arch));
     if (use_mem && hit != g_rtc_cache.end()) { r.code = hit->second; return r; }
     std::vector<char> code;
@@ -511,7 +514,7 @@ static CodeResult compile_code(const std::string &source, const std::string &arc
     if (r.code) return r;
     std::lock_guard<std::mutex> lock(g_rtc_mutex);
     auto hit = g_rtc_cache.find(code_key(source, arch));
-    if (hit != g_rtc_cache.end() && !getenv("BLINKY_HIP_NO_MEMCACHE")) { r.code = hit->second; return r; }   // another thread was faster
+    if (hit != g_rtc_cache.end() && !bk::g_debug.no_memcache) { r.code = hit->second; return r; }   // another thread was faster
     std::vector<const char *> hnames, htexts;
     for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) {
         hnames.push_back(bk::kEmbeddedHeaders[i].name);
@@ -577,6 +580,23 @@ static int compile_module(bk_ctx *ctx, LensProgram *P, const std::string &source
     return load_module(ctx, P, source, compile_code(source, target_arch(ctx)));
 }
 
+// Compilations nobody waits for any more (the lens or zoom changed while hiprtc was still busy, or the context went away).
+// A std::async future blocks in its destructor until its thread is done, so a superseded one is not dropped - that would
+// stall the render thread for the rest of the compile - but parked here and reaped once ready; its result still lands in the
+// memory / disk caches.  (At process exit the list's destructor joins whatever is still running: defined after the caches
+// above, it is destroyed before them.)
+static std::mutex g_parked_mutex;
+static std::vector<std::shared_future<::CodeResult>> g_parked;
+static void park_compile(std::shared_future<::CodeResult> &f)
+{
+    std::lock_guard<std::mutex> lock(g_parked_mutex);
+    for (size_t i = 0; i < g_parked.size();)
+        if (g_parked[i].wait_for(std::chrono::seconds(0)) == std::future_status::ready) { g_parked[i] = g_parked.back(); g_parked.pop_back(); }
+        else ++i;
+    if (f.valid() && f.wait_for(std::chrono::seconds(0)) != std::future_status::ready) g_parked.push_back(f);
+    f = std::shared_future<::CodeResult>();
+}
+
 // bk_build with asynchronous compilation (bk_set_async_compile): BK_PENDING while hiprtc works on another thread
 static int compile_module_async(bk_ctx *ctx, LensProgram *P, const std::string &source)
 {
@@ -586,14 +606,29 @@ static int compile_module_async(bk_ctx *ctx, LensProgram *P, const std::string &
         if (P->pending.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return BK_PENDING;
         CodeResult cr = P->pending.get();
         P->pending_source.clear();
+        P->pending = std::shared_future<::CodeResult>();
         return load_module(ctx, P, source, cr);
     }
     CodeResult cr = cached_code(source, arch);                      // memory / disk: no reason to wait a frame
     if (cr.code) return load_module(ctx, P, source, cr);
-    // (a compilation still running for an older source finishes on its own thread and lands in the caches)
+    park_compile(P->pending);                                       // (an older source's compile finishes on its own thread)
     P->pending_source = source;
     P->pending = std::async(std::launch::async, [source, arch]() { return compile_code(source, arch); }).share();
     return BK_PENDING;
+}
+
+// the asynchronous-compile gate of bk_build / bk_multi_build: is the module for the current lens + globe there?
+int bk::build_module_ready(bk_ctx *ctx)
+{
+    LensProgram *P = ctx->prog;
+    if (!(ctx->async_compile && P && P->lens_valid && ctx->globe_valid && P->info.map_type != BK_MAP_NONE)) return BK_OK;
+    // a lens that still has to go through hiprtc (0.2-1.1 s): compile on another thread and leave the previous
+    // lensmap untouched until the module is there - the caller keeps drawing with it and calls bk_build again
+    std::string psrc;
+    bk::EmitRequest rq;
+    rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
+    try { psrc = bk::emit_build_source(rq); } catch (const LuaError &) { return BK_OK; }      // (reported by the normal path)
+    return compile_module_async(ctx, P, psrc) == BK_PENDING ? BK_PENDING : BK_OK;
 }
 
 extern "C" int bk_set_async_compile(bk_ctx *ctx, int on)
@@ -614,10 +649,8 @@ static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out)
         *out = bk::emit_build_source(rq);
         // test hook: a wider assumed libm discrepancy (tests pair it with bk_set_host_math(ctx, n): the host interpreter on a
         // stand-in libm 2^-n away from bkm.h), so that the flag -> host fix-up path is exercised on thousands of pixels
-        if (const char *e = getenv("BLINKY_HIP_TEST_LIBM_REL_LOG2")) {
-            const int n = atoi(e);
+        if (const int n = bk::g_debug.libm_rel_log2)
             if (n >= 8 && n <= 52) *out = "#define BK_LIBM_REL 0x1p-" + std::to_string(n) + "\n" + *out;
-        }
     } catch (const LuaError &e) {
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }
@@ -625,6 +658,7 @@ static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out)
     return BK_OK;
 }
 
+#if BK_DEBUG_API
 // debug / test hook: the generated HIP translation unit for the current lens + globe
 extern "C" int bk_debug_kernel_source(bk_ctx *ctx, char *buf, size_t cap, size_t *needed, int compile)
 {
@@ -638,7 +672,9 @@ extern "C" int bk_debug_kernel_source(bk_ctx *ctx, char *buf, size_t cap, size_t
     if (compile) return compile_module(ctx, P, src);
     return BK_OK;
 }
+#endif
 
+#if BK_DEBUG_API
 // debug / test hook: evaluate a callback with the HOST interpreter (the same AST the GPU code was
 // generated from).  which: 0 = lens_inverse(x,y), 1 = lens_forward(x,y,z), 2 = globe_plate(x,y,z)
 extern "C" int bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs, double *out, int *nout)
@@ -659,14 +695,25 @@ extern "C" int bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nar
     }
     return BK_OK;
 }
+#endif
 
+#if BK_DEBUG_API
 /* test hook: 1 if the current lens module came from the BLINKY_HIP_CACHE directory instead of hiprtc */
 extern "C" int bk_debug_module_from_cache(const bk_ctx *ctx) { return ctx && ctx->prog && ctx->prog->module_from_cache ? 1 : 0; }
+#endif
 
 extern "C" int bk_set_host_math(bk_ctx *ctx, int portable)
 {
     if (!ctx) return BK_E_INVALID;
-    bk::prog_of(ctx)->interp.math = portable >= 2 ? &math_perturbed(ldexp(1.0, -(portable & 63)), portable >> 6) : portable ? &math_portable() : &math_platform();
+#if BK_DEBUG_API
+    if (portable >= 2) {            // the test suite's stand-in libms (include/blinky_hip_debug.h)
+        bk::prog_of(ctx)->interp.math = &math_perturbed(ldexp(1.0, -(portable & 63)), portable >> 6);
+        return BK_OK;
+    }
+#else
+    if (portable >= 2) return ctx->fail(BK_E_INVALID, "bk_set_host_math: %d is a test mode of debug-API builds", portable);
+#endif
+    bk::prog_of(ctx)->interp.math = portable ? &math_portable() : &math_platform();
     return BK_OK;
 }
 
@@ -947,16 +994,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     if (!ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_build: call bk_resize first");
     BK_HIP(ctx, hipSetDevice(ctx->device));
     LensProgram *P = ctx->prog;
-    if (ctx->async_compile && P && P->lens_valid && ctx->globe_valid && P->info.map_type != BK_MAP_NONE) {
-        // a lens that still has to go through hiprtc (0.2-1.1 s): compile on another thread and leave the previous
-        // lensmap untouched until the module is there - the caller keeps drawing with it and calls bk_build again
-        std::string psrc;
-        bk::EmitRequest rq;
-        rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
-        bool emitted = true;
-        try { psrc = bk::emit_build_source(rq); } catch (const LuaError &) { emitted = false; }      // (reported by the normal path below)
-        if (emitted && compile_module_async(ctx, P, psrc) == BK_PENDING) return BK_PENDING;
-    }
+    if (bk::build_module_ready(ctx) == BK_PENDING) return BK_PENDING;
     const size_t px = (size_t)ctx->W * ctx->rows();
     // F_RenderView clears the maps before (re)building, fisheye.c:731-732; whatever fails below,
     // the lensmap stays valid-and-empty so that bk_apply draws nothing, as the reference does.
@@ -1167,6 +1205,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     return BK_OK;
 }
 
+#if BK_DEBUG_API
 /* test hook: the kernel-argument block bk_build would launch with (calc_zoom done, device pointers as they are -
  * null on a BK_DEVICE_NONE context).  tests/hostemu compiles the generated translation unit for the host and runs it
  * on this block to inspect the device code's results and flags without a GPU. */
@@ -1185,7 +1224,9 @@ extern "C" int bk_debug_build_params(bk_ctx *ctx, void *out, size_t cap, size_t 
     memcpy(out, &bp, sizeof bp);
     return BK_OK;
 }
+#endif
 
+#if BK_DEBUG_API
 /* test hook: the host re-evaluation bk_build applies to flagged pixels, run over ANY pixel indices of the owned rows
  * (works on a BK_DEVICE_NONE context).  offsets come back in the reference layout plate*ps*ps + py*ps + px. */
 extern "C" int bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n, uint32_t *offsets, uint8_t *tints)
@@ -1213,7 +1254,9 @@ extern "C" int bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n,
     }
     return BK_OK;
 }
+#endif
 
+#if BK_DEBUG_API
 /* the same for the forward build's texel corners (ids: corner number plate * (ps+1)^2 + j * (ps+1) + i): screen x, y and
  * whether lens_forward gave a position */
 extern "C" int bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n, int32_t *sx, int32_t *sy, uint8_t *ok)
@@ -1236,6 +1279,7 @@ extern "C" int bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n,
     for (size_t i = 0; i < n; ++i) { sx[i] = x[i]; sy[i] = y[i]; }
     return BK_OK;
 }
+#endif
 
 extern "C" int bk_last_build_fixups(const bk_ctx *ctx, int *flagged, int *changed)
 {
@@ -1315,6 +1359,7 @@ extern "C" int bk_save_plate(bk_ctx *ctx, int frame, int plate, int with_margins
     return BK_OK;
 }
 
+#if BK_DEBUG_API
 extern "C" int bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout)
 {
     if (!ctx || !args || !out || !nout || nargs < 1 || nargs > 4 || n < 1) return BK_E_INVALID;
@@ -1344,3 +1389,4 @@ extern "C" int bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, 
     if (e != hipSuccess) return ctx->fail(BK_E_HIP, "bk_debug_eval_device: %s", hipGetErrorString(e));
     return BK_OK;
 }
+#endif

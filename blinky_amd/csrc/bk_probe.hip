@@ -50,6 +50,7 @@ int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev)
     return BK_OK;
 }
 
+#if BK_DEBUG_API
 // best of 5 passes over `bytes` read, writes / period of it written; *gbps = (bytes read + bytes written) / time
 extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps)
 {
@@ -87,3 +88,4 @@ extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int wr
     *gbps = ((double)bytes + written) / ((double)best * 1e-3) / 1e9;
     return BK_OK;
 }
+#endif

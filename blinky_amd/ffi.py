@@ -1,4 +1,4 @@
-"""ctypes binding of include/blinky_hip.h (1:1, no logic of its own)."""
+"""ctypes binding of include/blinky_hip.h and include/blinky_hip_debug.h (1:1, no logic of its own)."""
 import ctypes as C
 import os
 
@@ -79,6 +79,8 @@ _SIGS = {
     "bk_version": (C.c_char_p, []),
     "bk_set_apply_variant": (_i, [_vp, _i]),
     "bk_debug_module_from_cache": (_i, [_vp]),
+    "bk_debug_set_option": (_i, [C.c_char_p, _i]),
+    "bk_multi_lensmap_valid": (_i, [_vp]),
     "bk_last_build_ms": (_d, [_vp]),
     "bk_globe_pitch": (_i, [_vp]),
     "bk_globe_rows": (_i, [_vp]),
@@ -152,6 +154,12 @@ EXPORTS = tuple(_SIGS)
 
 class BlinkyError(RuntimeError):
     pass
+
+
+def debug_set_option(name, value):
+    """process-wide developer / test switch (include/blinky_hip_debug.h: bk_debug_set_option)"""
+    if lib.bk_debug_set_option(name.encode(), int(value)) != OK:
+        raise ValueError(f"bk_debug_set_option: unknown option {name!r}")
 
 
 def _ptr(a):

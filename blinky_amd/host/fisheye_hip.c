@@ -496,11 +496,11 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
             /* several GPUs: cut the stripes by work, not by height (a lens that leaves part of the screen unmapped would
              * give the first and last GPU next to nothing), and build the lensmap of the new stripes.  Builds are
              * sub-millisecond; when the bounds do not move bk_set_rows keeps the maps and the second build is skipped. */
-            static int last_bounds[BK_MAX_PLATES * 8 + 1];
-            int bounds[BK_MAX_PLATES * 8 + 1], n = bk_multi_size(mg), moved = 0;
+            int bounds[BK_MAX_PLATES * 8 + 1], n = bk_multi_size(mg);
             if (n > 1 && n < (int)(sizeof bounds / sizeof bounds[0]) && bk_multi_rebalance(mg, bounds) == BK_OK) {
-                for (i = 0; i <= n; ++i) { moved |= bounds[i] != last_bounds[i]; last_bounds[i] = bounds[i]; }
-                if (moved) rc = bk_multi_build(mg, newdisplay, NULL);
+                /* bk_set_rows invalidates the lensmap of every context whose stripe actually moved (also after a resize put
+                 * the stripes back to equal shares): ask the contexts, not a remembered set of bounds */
+                if (!bk_multi_lensmap_valid(mg)) rc = bk_multi_build(mg, newdisplay, NULL);
             }
         }
         build_pending = rc == BK_PENDING;

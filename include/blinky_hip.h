@@ -209,8 +209,6 @@ int         bk_comm_restripe(bk_comm *c);                                       
  * stripes.  For lenses that leave part of the screen unmapped (hammer's ellipse): with equal heights the ranks that own
  * the top and the bottom of the screen have a fraction of the middle ranks' pixels. */
 int         bk_comm_rebalance(bk_comm *c);
-/* test hook, no device needed: the N+1 stripe bounds those two derive from per-row costs (mapped pixels of each of H rows) */
-int         bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, int nranks, int *bounds_out);
 /* display[] |= every other rank's (which plates the WHOLE frame reads, fisheye.c:1976): ncclAllReduce(MAX); synchronous */
 int         bk_comm_or_display(bk_comm *c, int display[BK_MAX_PLATES]);
 /* every frame of the batch onto `root` (what a single display needs): grouped ncclSend / ncclRecv; frames_dev is
@@ -236,6 +234,7 @@ int         bk_multi_size(const bk_multi *m);
 bk_ctx     *bk_multi_ctx(bk_multi *m, int i);        /* stripe context i (introspection, per-context calls) */
 bk_comm    *bk_multi_comm(bk_multi *m, int i);       /* after bk_multi_resize */
 int         bk_multi_uses_rccl(const bk_multi *m);
+int         bk_multi_lensmap_valid(const bk_multi *m);   /* 1 when every stripe context holds a lensmap built for its current rows */
 /* the per-context calls applied to every stripe context (same meaning as their bk_* namesakes) */
 int bk_multi_load_globe(bk_multi *m, const char *src, size_t len, const char *chunkname);
 int bk_multi_load_lens(bk_multi *m, const char *src, size_t len, const char *chunkname);
@@ -269,68 +268,19 @@ int   bk_dev_read(bk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
 /* rubix palettes: create_palmap / find_closest_pal_index (fisheye.c:835-908); basepal = 768 bytes */
 void bk_create_palmap(const uint8_t *basepal, uint8_t pal_out[BK_MAX_PLATES][256]);
 
-/* ---- introspection (tests, bench) ------------------------------------------------------ */
+/* ---- introspection ---------------------------------------------------------------------
+ * (developer knobs, ablations, statistics and test hooks - the bk_debug_* entry points - are declared in
+ *  include/blinky_hip_debug.h and exist only when the library is built with BK_DEBUG_API, the Makefile's default) */
 int         bk_get_size(const bk_ctx *ctx, int *width, int *height, int *platesize, int *row0, int *row1);
 const char *bk_version(void);
 /* selects the apply kernel: 0 = direct gather, 2 = workgroup-cooperative LDS staging (default) */
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
-/* bk_debug_module_from_cache: 1 if the current module was loaded from the disk cache (test hook; BLINKY_HIP_NO_MEMCACHE
- * in the environment bypasses the in-process cache so that the disk path can be observed). */
-int         bk_debug_module_from_cache(const bk_ctx *ctx);
-/* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
- * pipelining; 16 row-major block walk, 32 persistent form always, 64 XCD bands of equal block count instead of equal
- * cost - results stay exact for 8..64); results are wrong while bits 2/4 are set.  0 restores normal operation. */
-int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
-/* staged apply statistics of the current lensmap: out = {blocks, blocks on the direct-gather fallback,
- * empty blocks, bytes of one LDS staging buffer, 128000 + block height in pixels, 128-byte lines staged per frame} */
-int         bk_debug_tile_stats(bk_ctx *ctx, int out[6]);
-/* What the staged apply has to move for the current lensmap (bench.py's compulsory-traffic roofline):
- * out = {distinct 128-byte globe lines the owned rows read per frame, lines staged per frame summed over blocks,
- * 16-byte chunks staged per frame, bytes of block map read per block visit summed over blocks, mapped pixels
- * (= bytes stored per frame), frames served per block visit, blocks, block height in pixels} */
-int         bk_debug_traffic_model(bk_ctx *ctx, uint64_t out[8]);
-/* How the staged apply splits the current lensmap's blocks over the 8 XCDs: out[0..8] = where each XCD's band starts in
- * the list of live (non-empty) blocks in walk order - bands of equal cost, not of equal block count - with out[8] = live
- * blocks; out[9] = 1 if bands of equal block count would be more than 10 % uneven (single-frame launches then take the
- * balanced workgroup -> block map too); out[10 + k] = cost of band k (128-byte lines staged + pixel and block terms) */
-int         bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18]);
-/* calibration (bench.py): GB/s of a plain streaming kernel that reads `bytes` with 16-byte loads and writes `writes` of
- * every `period` KiB of it back with non-temporal stores - what this memory system gives a kernel with that read : write
- * ratio and nothing else to do (best of 5 passes; allocates and frees 2 x bytes) */
-int         bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps);
-/* which XCD (HW_REG_XCC_ID) each workgroup of a 1-D launch of `nworkgroups` runs on: the apply kernel's screen bands
- * assume workgroup b -> XCD b % 8 (locality only; a test checks the assumption on the box it runs on) */
-int         bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups);
-/* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
- * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB;
- * 600 / 601+n = default / n as the constant term of a block's cost in the band balance */
-int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);
-/* the HIP translation unit generated for the current lens + globe scripts (needed = strlen+1);
- * compile != 0 also runs it through hiprtc (works on a BK_DEVICE_NONE context) */
-int         bk_debug_kernel_source(bk_ctx *ctx, char *buf, size_t cap, size_t *needed, int compile);
-/* test hook: the kernel-argument block (BkBuildParams, blinky_amd/csrc/bk_build_params.h) bk_build would launch the
- * current lens + globe with; works on a BK_DEVICE_NONE context (tests/hostemu runs the generated code on the host) */
-int         bk_debug_build_params(bk_ctx *ctx, void *out, size_t cap, size_t *needed);
-/* test hook: the host re-evaluation bk_build applies to the pixels it flags (bk_last_build_fixups), over any pixel
- * indices (row-major inside the owned rows); offsets in the reference layout.  Works without a device. */
-int         bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n, uint32_t *offsets, uint8_t *tints);
-/* the same for the texel corners of the forward build (corner number plate * (ps+1)^2 + j * (ps+1) + i): screen x, y, and
- * whether lens_forward gave a position */
-int         bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n, int32_t *sx, int32_t *sy, uint8_t *ok);
-/* evaluate a callback with the HOST interpreter, for diagnosing a script: which 0 = lens_inverse(x,y),
- * 1 = lens_forward(x,y,z), 2 = globe_plate(x,y,z); *nout = number of results, -1 for a single nil */
-int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs, double out[8], int *nout);
-/* the same on the DEVICE (the generated code), over n argument tuples of nargs doubles: out gets 8
- * doubles per tuple, nout the result count (-1 = a single nil, <= -100 = runtime error bits) */
-int         bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout);
-/* host-side script arithmetic (chunk execution, calc_zoom, globe loading): 0 = the platform libm,
- * which is what the reference's Lua VM calls (default: scale, lens_width, plates bit-identical to the
- * reference on the same machine); 1 = the portable bkm.h functions the GPU kernels use; n >= 2 is a
- * test mode: bkm.h with every inexact result moved pseudo-randomly by up to 2^-n relative, standing in
- * for "another libm" when the tests check the exactness flags (tests/test_exactness_cpu.py); + 64 moves
- * every result up by that amount instead, + 128 down */
+/* host-side script arithmetic (chunk execution, calc_zoom, globe loading, re-derivation of flagged pixels): 0 = the
+ * platform libm, which is what the reference's Lua VM calls (default: scale, lens_width, plates bit-identical to the
+ * reference on the same machine); 1 = the portable bkm.h functions the GPU kernels use.  (Values >= 2 select the
+ * stand-in libms of the test suite and exist only in builds with the debug API: include/blinky_hip_debug.h.) */
 int         bk_set_host_math(bk_ctx *ctx, int portable);
 /* text the scripts print()ed since the context was created (the reference sends it to stdout) */
 const char *bk_script_console(bk_ctx *ctx);

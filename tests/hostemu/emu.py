@@ -26,11 +26,15 @@ def compile_source(src, defines=()):
     os.makedirs(d, exist_ok=True)
     cpp, so = os.path.join(d, key + ".cpp"), os.path.join(d, key + ".so")
     if not os.path.exists(so):
+        # per-process scratch names + atomic rename: pytest-xdist workers may want the same key at once
+        cpp = os.path.join(d, "%s.%d.cpp" % (key, os.getpid()))
+        tmp = "%s.%d.tmp" % (so, os.getpid())
         with open(cpp, "w") as f:
             f.write('#include "emu_prelude.h"\n' + src + "\n" + open(os.path.join(HERE, "emu_driver.inc")).read())
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-                               *["-D" + d for d in defines], "-I", HERE, "-I", CSRC, "-o", so + ".tmp", cpp])
-        os.replace(so + ".tmp", so)
+                               *["-D" + d for d in defines], "-I", HERE, "-I", CSRC, "-o", tmp, cpp])
+        os.replace(tmp, so)
+        os.unlink(cpp)
     lib = C.CDLL(so)
     _cache[key] = lib
     return lib
@@ -42,13 +46,13 @@ def _field_offsets():
         return _cache["off"]
     d = os.path.join(tempfile.gettempdir(), "bk_hostemu")
     os.makedirs(d, exist_ok=True)
-    src = os.path.join(d, "offs.c")
+    src = os.path.join(d, "offs.%d.c" % os.getpid())
     with open(src, "w") as f:
         f.write('#include <stddef.h>\n#include <stdio.h>\n#include "bk_build_params.h"\nint main(){'
                 'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", offsetof(BkBuildParams, offsets), offsetof(BkBuildParams, tints),'
                 'offsetof(BkBuildParams, display), offsetof(BkBuildParams, err), offsetof(BkBuildParams, flag_list),'
                 'offsetof(BkBuildParams, flag_count), offsetof(BkBuildParams, flag_cap), sizeof(BkBuildParams), offsetof(BkBuildParams, corner_xy), offsetof(BkBuildParams, corner_ok));return 0;}')
-    exe = os.path.join(d, "offs")
+    exe = os.path.join(d, "offs.%d" % os.getpid())
     subprocess.check_call(["gcc", "-I", CSRC, "-o", exe, src])
     vals = [int(v) for v in subprocess.check_output([exe]).split()]
     _cache["off"] = dict(zip(["offsets", "tints", "display", "err", "flag_list", "flag_count", "flag_cap", "size", "corner_xy", "corner_ok"], vals))

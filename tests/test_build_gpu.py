@@ -224,10 +224,11 @@ def test_globe_plate_override_fast_globe(bk):
     ctx.close()
 
 
-def test_module_cache_round_trip_builds_the_same_table(bk, tmp_path, monkeypatch):
+def test_module_cache_round_trip_builds_the_same_table(bk, tmp_path, monkeypatch, request):
     """a lens module loaded back from BLINKY_HIP_CACHE builds the identical lensmap"""
     monkeypatch.setenv("BLINKY_HIP_CACHE", str(tmp_path))
-    monkeypatch.setenv("BLINKY_HIP_NO_MEMCACHE", "1")          # (otherwise the second context is served from the process' own cache)
+    bk.debug_set_option("no_memcache", 1)                      # (otherwise the second context is served from the process' own cache)
+    request.addfinalizer(lambda: bk.debug_set_option("no_memcache", 0))
     tables = []
     for i in range(2):
         ctx = bk.Context()
@@ -327,12 +328,13 @@ def test_script_runtime_errors_surface_as_errors(bk):
 
 @pytest.mark.parametrize("lens,W,H", [("quincuncial", 640, 480), ("stereographic", 640, 400), ("hammer", 640, 360), ("winkeltripel", 480, 300),
                                       ("fisheye1", 400, 400), ("sinusoidal", 480, 300), ("gins8", 480, 300)])
-def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monkeypatch):
+def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monkeypatch, request):
     """The whole mechanism on the GPU, with the libm discrepancy scaled up until it bites thousands of times: the host
     interpreter runs on a stand-in libm 2^-30 away from bkm.h (bk_set_host_math(ctx, 30)), the kernels are generated with
     BK_LIBM_REL = 2^-30 to match, and the table bk_build delivers - device results, flagged entries re-derived on the host
     and patched - must be, entry for entry, what the host interpreter alone derives for every pixel."""
-    monkeypatch.setenv("BLINKY_HIP_TEST_LIBM_REL_LOG2", "30")
+    bk.debug_set_option("libm_rel_log2", 30)
+    request.addfinalizer(lambda: bk.debug_set_option("libm_rel_log2", 0))
     monkeypatch.setenv("BLINKY_HIP_CACHE", "off")
     ctx = bk.Context()
     ctx.set_host_math(30)
@@ -347,7 +349,7 @@ def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monk
         assert flagged > 100, (flagged, changed)              # the scaled-up discrepancy does bite
     # and the same map built with the kernels' normal assumption (2^-50) on the same stand-in libm is NOT that table where
     # the stand-in disagrees with bkm.h by more than the kernels allow for: the flags are what makes the difference
-    monkeypatch.delenv("BLINKY_HIP_TEST_LIBM_REL_LOG2")
+    bk.debug_set_option("libm_rel_log2", 0)
     ctx2 = bk.Context()
     ctx2.set_host_math(30)
     S.configure(ctx2, "cube", lens, None, (W, H))

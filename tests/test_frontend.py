@@ -225,12 +225,13 @@ def test_every_shipped_lens_translates_and_compiles(bk):
         assert "bk_build_kernels.h" in src, lens
 
 
-def test_compiled_modules_are_cached_on_disk(bk, tmp_path, monkeypatch):
+def test_compiled_modules_are_cached_on_disk(bk, tmp_path, monkeypatch, request):
     """The disk cache of compiled lens modules: BLINKY_HIP_CACHE=off keeps nothing; with a directory the first compile
     stores the code object, an identical program loads it back, a different lens does not hit it; bk_set_cache_dir
-    overrides the environment.  (BLINKY_HIP_NO_MEMCACHE: the in-process cache would otherwise answer first.)"""
+    overrides the environment.  (debug option no_memcache: the in-process cache would otherwise answer first.)"""
     import time
-    monkeypatch.setenv("BLINKY_HIP_NO_MEMCACHE", "1")
+    bk.debug_set_option("no_memcache", 1)
+    request.addfinalizer(lambda: bk.debug_set_option("no_memcache", 0))
     monkeypatch.setenv("BLINKY_HIP_CACHE", "off")
     monkeypatch.setenv("HOME", str(tmp_path / "home"))
     ctx = host_ctx(bk)
