@@ -17,8 +17,12 @@ stripes travel to rank f % N (blinky_amd.multigpu.exchange_rotating), overlapped
 `python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
 `python -m torch.distributed.run --nproc-per-node N`; a world size that differs from --gpus is an error.
 
-The timed region of K steps is repeated (--repeats, default 31 regions, each bracketed by barrier + synchronize,
-max over ranks); `value` is the MEDIAN region, min / max are printed beside it.
+The timed region of K steps is repeated (--repeats; by default as many regions as it takes to keep the GPU busy for
+--min-gpu-seconds, at least 31; each bracketed by barrier + synchronize, max over ranks); `value` is the MEDIAN region,
+min / max are printed beside it.  `value_one_stream` is the same measurement with every launch on one stream - the figure
+`roofline.kernel_ms_per_launch` (the kernel alone, HIP events) must be consistent with.
+At N = 1 the line also carries `configs_extra` (BASELINE.json configs[1], 1920x1080 cube/stereographic, timed the same
+way) and `predicted_stripe_complete` (rank r's stripe for N = 2 / 4 / 8 timed on this GPU, max over ranks).
 Prints ONE JSON line (rank 0).  `value` = whole-job Mpixels/s = W*H*frames*steps / time.
 """
 import argparse
@@ -94,6 +98,133 @@ def cpu_baseline(frames_budget_s=6.0):
             "build_ms": round(build_s * 1e3, 1)}
 
 
+def compulsory_bytes(model, F):
+    """what the staged apply has to move per F-frame launch: every mapped pixel stored once, every distinct globe line the
+    lensmap touches read once per frame, the block map (headers + chunk lists + 16-bit pixel addresses) once per block visit"""
+    visits = -(-F // int(model["frames_per_visit"])) if F >= 8 else 1
+    if 8 <= F < 16:
+        visits = 2
+    return F * (model["mapped_pixels"] + 128 * model["unique_globe_lines"]) + visits * model["blockmap_bytes_per_visit"]
+
+
+class OneGpuWorkload:
+    """One lensmap + a resident ring of LCG globes on one GPU, timed the way the headline is: K-step regions between
+    synchronizes (wall clock, steps alternating between two streams) and the kernel alone under HIP events."""
+
+    def __init__(self, torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=None, ring_bytes=1.8e9, ring_max=64):
+        self.torch, self.W, self.H, self.F = torch, W, H, F
+        self.ctx = ctx = blinky_amd.Context(device_index)
+        self.stream = torch.cuda.current_stream()
+        ctx.set_stream(self.stream.cuda_stream)
+        S.configure(ctx, globe, lens, zoom, (W, H))
+        ps = min(W, H)
+        globe_bytes = 6 * ((ps + 63) // 64 * 64) * ((ps + 7) // 8 * 8)
+        self.R = R = max(F, min(ring_max * 4, max(ring_max, int(ring_bytes // globe_bytes))))     # well past the 256 MiB Infinity Cache
+        ctx.set_frames(R)
+        ctx.resize(W, H)
+        self.r0, self.r1 = rows if rows else (0, H)
+        ctx.set_rows(self.r0, self.r1)
+        self.rows = self.r1 - self.r0
+        self.display, self.scale = ctx.build()
+        self.build_ms = ctx.last_build_ms()
+        self.tile_stats = ctx.tile_stats()
+        for f in range(R):
+            for p in range(6):
+                ctx.fill_plate_lcg(f, p, f)
+        self.out = [torch.zeros((F, self.rows, W), dtype=torch.uint8, device=torch.device("cuda", device_index)) for _ in range(4)]
+        self.streams = [self.stream, torch.cuda.Stream(device=torch.device("cuda", device_index))]
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+
+    def origin(self, t):
+        return t.data_ptr() - self.r0 * self.W
+
+    def launch(self, i, nframes=None, ring=None):
+        nf = nframes or self.F
+        self.ctx.apply_device(self.origin(self.out[i % 4]), self.W, self.rows * self.W, frame0=(i * nf) % (ring or self.R), nframes=nf)
+
+    def kernel_ms(self, nframes=None, launches=50, repeats=9, ring=None):
+        """median / min / max over `repeats` of HIP events around `launches` back-to-back launches on one stream"""
+        torch = self.torch
+        self.ctx.set_stream(self.stream.cuda_stream)
+        out = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            self.e0.record(self.stream)
+            for i in range(launches):
+                self.launch(i, nframes, ring)
+            self.e1.record(self.stream)
+            torch.cuda.synchronize()
+            out.append(self.e0.elapsed_time(self.e1) / launches)
+        return statistics.median(out), min(out), max(out)
+
+    def job_seconds_per_step(self, steps=50, repeats=31, nstreams=2):
+        """median wall-clock seconds per step over `repeats` regions of `steps` steps (synchronize on both sides)"""
+        torch = self.torch
+        out = []
+        for k in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                st = self.streams[i % nstreams]
+                with torch.cuda.stream(st):
+                    self.ctx.set_stream(st.cuda_stream)
+                    self.launch(k * steps + i)
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / steps)
+        self.ctx.set_stream(self.stream.cuda_stream)
+        return statistics.median(out)
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        self.ctx.close()
+        self.out = None
+
+
+def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W, H, F, steps):
+    """one more BASELINE.json configuration, driver-timed beside the headline (N = 1 only)"""
+    wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F)
+    for i in range(5):
+        wl.launch(i)
+    k_med, k_min, k_max = wl.kernel_ms(launches=steps)
+    s_med, _, _ = wl.kernel_ms(nframes=1, launches=steps)
+    job2 = wl.job_seconds_per_step(steps=steps, nstreams=2)
+    job1 = wl.job_seconds_per_step(steps=steps, repeats=11, nstreams=1)
+    model = wl.ctx.traffic_model()
+    comp = compulsory_bytes(model, F)
+    algo = ALGO_BYTES_PER_PX * W * H * F
+    rec = {"name": name, "workload": f"{W}x{H} {globe}/{lens} {zoom or 'onload zoom'}, {F} frames/step from a ring of {wl.R} distinct globes",
+           "value": round(W * H * F / job2 / 1e6, 1), "value_one_stream": round(W * H * F / job1 / 1e6, 1), "unit": "Mpixels/s",
+           "ms_per_step": round(job2 * 1e3, 5), "kernel_us_per_launch": round(k_med * 1e3, 3), "kernel_us_min": round(k_min * 1e3, 3),
+           "kernel_us_max": round(k_max * 1e3, 3), "us_per_frame": round(k_med * 1e3 / F, 4),
+           "algorithmic_frac": round(algo / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "frac_compulsory": round(comp / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "compulsory_bytes_per_launch": int(comp),
+           "single_frame": {"us": round(s_med * 1e3, 3),
+                            "algorithmic_frac": round(ALGO_BYTES_PER_PX * W * H / (s_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "lensmap_build_ms": round(wl.build_ms, 3), "tile_stats": wl.tile_stats, "lens_scale": wl.scale}
+    wl.close()
+    return rec
+
+
+def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, steps, t1_ms):
+    """What row-striping would give on N GPUs, measured on ONE: for N = 2 / 4 / 8 every rank's stripe [H*r/N, H*(r+1)/N) is
+    built and its F-frame launch timed here; a step of the N-GPU job lasts as long as its slowest rank's launch
+    (stripe-complete throughput: nothing is exchanged)."""
+    out = {}
+    for n in (2, 4, 8):
+        per_rank = []
+        for r in range(n):
+            wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=(H * r // n, H * (r + 1) // n), ring_max=32)
+            for i in range(3):
+                wl.launch(i)
+            per_rank.append(wl.kernel_ms(launches=max(10, steps // 2), repeats=5)[0])
+            wl.close()
+        worst = max(per_rank)
+        out[str(n)] = {"slowest_rank_us_per_launch": round(worst * 1e3, 2), "fastest_rank_us_per_launch": round(min(per_rank) * 1e3, 2),
+                       "stripe_complete_mpx_s": round(W * H * F / (worst * 1e-3) / 1e6, 1), "speedup_vs_1": round(t1_ms / worst, 3)}
+    return out
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` outside torchrun: one process per GPU, this node, RCCL"""
     s = socket.socket()
@@ -113,7 +244,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=16, help="frames per step (batch warped by one launch)")
     ap.add_argument("--ring", type=int, default=64, help="distinct resident globes the steps cycle through")
-    ap.add_argument("--repeats", type=int, default=31, help="how many times the K-step timed region is measured (median reported)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the K-step timed region is measured (median reported); 0 = as many as keep the GPU busy "
+                         "for --min-gpu-seconds, at least 31")
+    ap.add_argument("--min-gpu-seconds", type=float, default=3.0,
+                    help="with --repeats 0: total GPU-timed seconds the regions should add up to (a 50-step region is ~3 ms)")
+    ap.add_argument("--no-extra", action="store_true", help="skip configs_extra (1080p C2) and predicted_stripe_complete")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps alternate between: the tail of a batch launch (its last, partly filled round of "
                          "workgroups) then overlaps the ramp of the next; 1 = every launch on one stream")
@@ -335,8 +471,23 @@ def main():
     for i in range(args.warmup):
         run_step(i)
     drain()
-    regions = [timed_region(args.warmup + k * args.steps) for k in range(max(1, args.repeats))]
+    nrep = args.repeats
+    if nrep <= 0:
+        # as many regions as keep the GPU busy for --min-gpu-seconds (a 50-step 4K region is ~3 ms: 31 of them would be
+        # 0.1 s of GPU work inside a run of several seconds); every rank derives the same count from the max over ranks
+        probe = timed_region(args.warmup)
+        nrep = int(min(20000, max(31, args.min_gpu_seconds / max(probe, 1e-6))))
+    regions = [timed_region(args.warmup + k * args.steps) for k in range(max(1, nrep))]
     elapsed = statistics.median(regions)
+    # the same job with every launch on ONE stream (what roofline.kernel_ms_per_launch is to be compared with)
+    one_stream_elapsed = None
+    if nstreams > 1:
+        nstreams_saved, nstreams = nstreams, 1
+        for i in range(args.warmup):
+            run_step(i)
+        drain()
+        one_stream_elapsed = statistics.median([timed_region(args.warmup + k * args.steps) for k in range(max(1, nrep // 4))])
+        nstreams = nstreams_saved
     root_elapsed = None
     if world > 1:
         # extra (not `value`): all frames assembled on rank 0 - bounded by one GPU's xGMI ingest
@@ -355,7 +506,7 @@ def main():
     # ---- the dominant kernel alone, HIP events on the launch stream (roofline) ------------------------
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def kernel_ms(ring, nframes=F, launches=args.steps, repeats=max(1, min(args.repeats, 15))):
+    def kernel_ms(ring, nframes=F, launches=args.steps, repeats=15):
         """median over `repeats` of: HIP events around `launches` back-to-back launches cycling a ring of `ring` globes"""
         out = []
         for k in range(repeats):
@@ -386,7 +537,7 @@ def main():
         full_ctx.set_frames(F)
         S.configure(full_ctx, GLOBE, LENS, ZOOM, (W, H))
         full_ctx.build()
-        last_i = args.warmup + max(1, args.repeats) * args.steps - 1          # the last step of the last timed region
+        last_i = args.warmup + max(1, nrep // 4 if one_stream_elapsed is not None else nrep) * args.steps - 1   # the last step of the last timed region
         g0 = first_globe(last_i)
         for f in range(F):
             for p in range(6):
@@ -415,10 +566,7 @@ def main():
         achieved = algo_bytes / (k_med * 1e-3) / 1e9
         # what the kernel has to move per launch: every mapped pixel stored once, every distinct globe line the lensmap
         # touches read once per frame, the block map (headers + chunk lists + 16-bit pixel addresses) once per block visit
-        visits = -(-F // int(model["frames_per_visit"])) if F >= 8 else 1
-        if 8 <= F < 16:
-            visits = 2
-        compulsory = F * (model["mapped_pixels"] + 128 * model["unique_globe_lines"]) + visits * model["blockmap_bytes_per_visit"]
+        compulsory = compulsory_bytes(model, F)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "apply_traffic.json")
         if os.path.exists(tpath) and world == 1:
@@ -454,6 +602,8 @@ def main():
             stream_mix = {"error": f"{type(e).__name__}: {e}"}
         out = {
             "metric": "warped Mpixels/s (lensmap apply)", "value": round(value, 1), "unit": "Mpixels/s",
+            "value_one_stream": round(px_per_step * args.steps / one_stream_elapsed / 1e6, 1) if one_stream_elapsed else round(value, 1),
+            "ms_per_step_one_stream": round(one_stream_elapsed / args.steps * 1e3, 4) if one_stream_elapsed else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -465,12 +615,16 @@ def main():
                        "apply_variant": args.variant, "streams": nstreams,
                        "streams_note": "consecutive steps alternate between this many HIP streams, so the tail of one batch launch "
                                        "overlaps the ramp of the next; roofline.* is the kernel alone on one stream"},
-            "timed_regions": {"count": len(regions), "steps_each": args.steps, "value_is": "median",
+            "timed_regions": {"count": len(regions), "steps_each": args.steps, "value_is": "median", "gpu_timed_seconds": round(sum(regions), 3),
                               "mpx_s_median": round(value, 1),
                               "mpx_s_min": round(px_per_step * args.steps / max(regions) / 1e6, 1),
                               "mpx_s_max": round(px_per_step * args.steps / min(regions) / 1e6, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # the engine's real call: ONE frame per launch, nothing amortised - the one contract-formula figure <= 1
+                         "single_frame": {"us": round(single_ms * 1e3, 3),
+                                          "algorithmic_frac": round(ALGO_BYTES_PER_PX * W * rows / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "target_us_at_0.70": round(ALGO_BYTES_PER_PX * W * rows / (0.70 * HBM_PEAK_GBS * 1e9) * 1e6, 3)},
                          "frac_is": "ALGORITHMIC bytes (6 B/px, SURVEY.md 8(d)) / kernel time / peak, as the bench contract defines it; the "
                                     "kernel moves fewer bytes than that (2-byte LDS addresses read once per 8 frames instead of a 4-byte "
                                     "index per pixel and frame), so this ratio can exceed 1 and is NOT a bandwidth utilisation - "
@@ -510,6 +664,19 @@ def main():
             "single_frame_mpx_s": round(W * rows / (single_ms * 1e-3) / 1e6, 1),
             "lens_scale": scale,
         }
+        if world == 1 and not args.no_extra:
+            try:
+                out["configs_extra"] = [extra_config(torch, blinky_amd, S, local_rank, "C2 (BASELINE.json configs[1])", "cube", "stereographic",
+                                                     None, 1920, 1080, F, args.steps)]
+            except Exception as e:      # noqa: BLE001
+                out["configs_extra"] = [{"error": f"{type(e).__name__}: {e}"}]
+            try:
+                out["predicted_stripe_complete"] = dict(
+                    what="rank r's stripe for N = 2 / 4 / 8 built and timed on this one GPU (same launch as roofline.kernel_ms_per_launch); "
+                         "a step lasts as long as the slowest rank; no exchange", one_gpu_us_per_launch=round(k_med * 1e3, 2),
+                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, F, args.steps, k_med))
+            except Exception as e:      # noqa: BLE001
+                out["predicted_stripe_complete"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -67,6 +67,14 @@ CONFIGS = [
     ("cube", "winkel2", None, 400, 240),
     ("cube_edge", "panini", None, 640, 400),
     ("cube_corner", "stereographic", None, 640, 400),
+    # round 3: the forward map at BASELINE sizes (the reference's own scatter takes 1.7 s at 1080p and ~7 s at 4K) - the
+    # write-order keys, the 20-pixel guards and the stripe-filtered commit above 0.3 Mpx
+    ("cube", "eckert5", None, 1920, 1080),
+    ("cube", "eckert5", None, 3840, 2160),
+    ("cube", "winkel2", None, 1920, 1080),
+    ("cube", "winkel2", None, 3840, 2160),
+    ("trism", "eckert5", None, 1920, 1080),
+    ("cube", "sinusoidal", None, 2560, 1440),
 ]
 # configs whose record also carries `fnv_frames`: one hash per frame of a batch over the LCG globes 0..n-1
 # (SURVEY.md 8(d)).  Frame 0 comes from the unmodified reference; the others from the oracle's render_lensmap
@@ -75,8 +83,17 @@ BATCH = {("cube", "hammer", None, 7680, 4320): 64, ("cube", "panini", None, 3840
 
 
 def main():
+    # incremental by default: configurations already recorded are kept (`--all` derives every record again)
+    path = os.path.join(HERE, "lensmaps.json")
+    have = {}
+    if "--all" not in sys.argv and os.path.exists(path):
+        for r in json.load(open(path))["lensmaps"]:
+            have[(r["globe"], r["lens"], r["zoom"], r["W"], r["H"])] = r
     out = []
     for globe, lens, zoom, W, H in CONFIGS:
+        if (globe, lens, zoom, W, H) in have:
+            out.append(have[(globe, lens, zoom, W, H)])
+            continue
         lm, frame = O.ref_run(globe, lens, zoom, W, H)
         rec = dict(globe=globe, lens=lens, zoom=zoom, W=W, H=H, built=bool(lm.built), scale=repr(lm.scale),
                    display=lm.display, nonnull=lm.nonnull, fnv_offsets=O.fnv(lm.offsets),
@@ -95,7 +112,7 @@ def main():
     pal = O.ref_palettes()
     doc = dict(source="oracle/_ref = unmodified /root/reference/engine/NQ/fisheye.c, gcc 11.4 -O2, glibc 2.35",
                lensmaps=out, fnv_palettes=O.fnv(pal))
-    with open(os.path.join(HERE, "lensmaps.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(doc, f, indent=1)
 
 

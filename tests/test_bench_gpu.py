@@ -46,6 +46,20 @@ def test_bench_line_and_check_single_gpu():
     assert rf["traffic"] is None or rf["frac_traffic"] <= 1.0
     assert out["timed_regions"]["count"] == 3
     assert out["timed_regions"]["mpx_s_min"] <= out["value"] <= out["timed_regions"]["mpx_s_max"]
+    # like for like: the kernel alone (HIP events, one stream) cannot take longer than a step of the one-stream job
+    assert out["value_one_stream"] > 0 and rf["kernel_ms_per_launch"] <= out["ms_per_step_one_stream"] * 1.15, (rf["kernel_ms_per_launch"], out["ms_per_step_one_stream"])
+    # the engine's real call inside `roofline`: one frame per launch, the contract's algorithmic formula, <= 1
+    sf = rf["single_frame"]
+    assert sf["us"] > 0 and 0 < sf["algorithmic_frac"] <= 1.0, sf
+    # BASELINE.json configs[1] (1920x1080 cube/stereographic) timed in the same run
+    (c2,) = out["configs_extra"]
+    assert "error" not in c2, c2
+    assert c2["workload"].startswith("1920x1080 cube/stereographic") and c2["value"] > 0 and c2["kernel_us_per_launch"] > 0
+    assert 0 < c2["frac_compulsory"] <= 1.0 and 0 < c2["single_frame"]["algorithmic_frac"] <= 1.0
+    # the scaling curve predicted on one GPU: rank r's stripe for N = 2 / 4 / 8, slowest rank
+    ps = out["predicted_stripe_complete"]
+    assert "error" not in ps, ps
+    assert all(ps[n]["speedup_vs_1"] > 0.5 for n in ("2", "4", "8")), ps
 
 
 def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():

@@ -59,6 +59,27 @@ def test_build_equals_reference_golden(bk, rec):
     ctx.close()
 
 
+@pytest.mark.parametrize("globe,lens,W,H,N", [("cube", "eckert5", 3840, 2160, 8), ("cube", "winkel2", 1920, 1080, 3),
+                                               ("cube", "quincuncial", 3840, 2160, 8)])
+def test_stripe_local_builds_concatenate_to_the_reference_table(bk, globe, lens, W, H, N):
+    """Multi-GPU build at BASELINE sizes: rank r builds only rows [H*r/N, H*(r+1)/N) - for the forward map by replicated
+    evaluation with a stripe-filtered commit (every rank walks all plate texels, keeps the writes that land in its rows;
+    fisheye.c:2126-2338) - and the stripes put end to end are the unmodified reference's table, display flags OR-ed."""
+    rec = next(r for r in GOLD if (r["globe"], r["lens"], r["zoom"], r["W"], r["H"]) == (globe, lens, None, W, H))
+    offs, tins, disp = [], [], [0] * 6
+    for r in range(N):
+        ctx, display, scale, off, tin = build(bk, globe, lens, None, W, H, rows=(H * r // N, H * (r + 1) // N))
+        assert repr(scale) == rec["scale"]
+        disp = [a | b for a, b in zip(disp, display)]
+        offs.append(off)
+        tins.append(tin)
+        ctx.close()
+    off, tin = np.concatenate(offs), np.concatenate(tins)
+    assert disp[: len(rec["display"])] == rec["display"]
+    assert int((off != O.NULL).sum()) == rec["nonnull"]
+    assert O.fnv(off) == rec["fnv_offsets"] and O.fnv(tin) == rec["fnv_tints"]
+
+
 @pytest.mark.parametrize("cfg", [
     ("cube", "panini", "f_fov 90", 200, 150),
     ("cube", "panini", "f_vfov 100", 257, 129),

@@ -92,6 +92,57 @@ def test_multi_from_python_with_rubix_and_double_buffering(bk):
     m.close()
 
 
+def test_c4_eight_stripes_full_size(bk):
+    """BASELINE.json configs[3] as stated: 3840x2160 trism/panini row-striped over EIGHT ranks (270 rows each; here eight
+    stripe contexts on the one GPU, copy transport): stripe-local build, stripe apply, gather onto rank 0 and the rotating
+    exchange.  The concatenated stripe tables hash to the reference's 4K golden and every reassembled frame to the golden
+    frame (frame 0: the unmodified reference's; the others: the oracle applied to the golden-checked table)."""
+    import json
+    import torch
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "lensmaps.json")))["lensmaps"]
+    rec = next(r for r in gold if r["globe"] == "trism" and r["lens"] == "panini" and r["W"] == 3840)
+    globe, lens, W, H, F, N = "trism", "panini", 3840, 2160, 3, 8
+    m = bk.Multi([0] * N)
+    m.set_frames(F)
+    m.load_globe(S.script("globes", globe), globe)
+    m.load_lens(S.script("lenses", lens), lens)
+    m.set_zoom(bk.ffi.ZOOM_FOV, 180)
+    m.resize(W, H)
+    display, scale = m.build()
+    assert repr(scale) == rec["scale"] and display[: len(rec["display"])] == rec["display"]
+    bounds = [H * r // N for r in range(N + 1)]
+    offs, tins = [], []
+    for r in range(N):
+        assert m.ctx(r).size()[3:5] == (bounds[r], bounds[r + 1])
+        off, tin = m.ctx(r).read_lensmap()
+        assert off.size == (bounds[r + 1] - bounds[r]) * W
+        offs.append(off)
+        tins.append(tin)
+    off, tin = np.concatenate(offs), np.concatenate(tins)
+    assert O.fnv(off) == rec["fnv_offsets"] and O.fnv(tin) == rec["fnv_tints"] and int((off != O.NULL).sum()) == rec["nonnull"]
+    for f in range(F):
+        for p in range(5):
+            m.fill_plate_lcg(f, p, f)
+    want = [O.apply(off, tin, W, H, O.lcg_globe(2160, 5, f), np.zeros((H, W), np.uint8)) for f in range(F)]
+    assert O.fnv(want[0]) == rec["fnv_frame"]
+    # host frame (what the engine drop-in does with N GPUs)
+    assert O.fnv(m.apply(np.zeros((H, W), np.uint8), frame=0)) == rec["fnv_frame"]
+    # device frames: gather onto rank 0, then the rotating exchange
+    stripes = [torch.zeros((F, bounds[r + 1] - bounds[r], W), dtype=torch.uint8, device="cuda") for r in range(N)]
+    gathered = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
+    frames = [torch.zeros(((F + N - 1) // N, H, W), dtype=torch.uint8, device="cuda") for r in range(N)]
+    torch.cuda.synchronize()
+    m.apply_stripes([t.data_ptr() for t in stripes], frame0=0, nframes=F)
+    m.gather([t.data_ptr() for t in stripes], F, 0, gathered.data_ptr(), H * W, slot=0)
+    m.exchange_rotating([t.data_ptr() for t in stripes], F, [t.data_ptr() for t in frames], H * W, slot=1)
+    m.synchronize()
+    for f in range(F):
+        np.testing.assert_array_equal(gathered[f].cpu().numpy(), want[f], err_msg=f"gather, frame {f}")
+        np.testing.assert_array_equal(frames[f % N][f // N].cpu().numpy(), want[f], err_msg=f"rotating exchange, frame {f}")
+    assert O.fnv(gathered[0].cpu().numpy()) == rec["fnv_frame"]
+    m.close()
+
+
 def test_stripes_of_equal_work(bk):
     """bk_multi_rebalance: hammer's ellipse leaves the top and bottom stripes of an equal-height split nearly empty; cut by
     mapped pixels instead, every stripe gets its share, and the reassembled frames are still the oracle's."""
