@@ -322,13 +322,27 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
 {
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;     // (scalars, not an array: they must stay in VGPRs)
     const bool pipe = (kflags & 8) == 0;      // issue frame f+1's loads before frame f's gather (ablation bit 8 turns it off)
+    typedef uint32_t bk_v4u __attribute__((ext_vector_type(4)));
+    // kflags bit 128: the globe chunks are fetched with the non-temporal hint (streamed through L2, evicted first), so that
+    // what L2 keeps from one launch to the next is the block map - headers, chunk lists, pixel addresses: the same bytes every
+    // launch, and with the XCD bands fixed, the same XCD's L2 - instead of globe lines nobody will ask for again
+    const bool nt_globe = (kflags & 128) != 0;
+#define BK_COOP_LD(Q, PTR)                                                                                 \
+    do {                                                                                                   \
+        if (nt_globe) {                                                                                    \
+            const bk_v4u t_ = __builtin_nontemporal_load(reinterpret_cast<const bk_v4u *>(PTR));           \
+            Q = make_uint4(t_.x, t_.y, t_.z, t_.w);                                                        \
+        } else {                                                                                           \
+            Q = *reinterpret_cast<const uint4 *>(PTR);                                                     \
+        }                                                                                                  \
+    } while (0)
 #define BK_COOP_LOADS(F)                                                                                   \
     do {                                                                                                   \
         const uint8_t *gl_ = globe + (size_t)((frame0 + (F)) % globe_frames) * globe_stride;              \
-        q0 = *reinterpret_cast<const uint4 *>(gl_ + s0);                                                   \
-        if (NQ > 1) q1 = *reinterpret_cast<const uint4 *>(gl_ + s1);                                       \
-        if (NQ > 2) q2 = *reinterpret_cast<const uint4 *>(gl_ + s2);                                       \
-        if (NQ > 3) q3 = *reinterpret_cast<const uint4 *>(gl_ + s3);                                       \
+        BK_COOP_LD(q0, gl_ + s0);                                                                          \
+        if (NQ > 1) BK_COOP_LD(q1, gl_ + s1);                                                              \
+        if (NQ > 2) BK_COOP_LD(q2, gl_ + s2);                                                              \
+        if (NQ > 3) BK_COOP_LD(q3, gl_ + s3);                                                              \
     } while (0)
     if (pipe && f_begin < f_end) BK_COOP_LOADS(f_begin);
     for (int f = f_begin; f < f_end; ++f) {
@@ -345,10 +359,10 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                 const bool m0 = c < nchunks, m1 = c + 256u < nchunks, m2 = c + 512u < nchunks, m3 = c + 768u < nchunks;
                 const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
                                a3 = m3 ? blist[c + 768u] : 0u;
-                q0 = *reinterpret_cast<const uint4 *>(gl + a0);
-                q1 = *reinterpret_cast<const uint4 *>(gl + a1);
-                q2 = *reinterpret_cast<const uint4 *>(gl + a2);
-                q3 = *reinterpret_cast<const uint4 *>(gl + a3);
+                BK_COOP_LD(q0, gl + a0);
+                BK_COOP_LD(q1, gl + a1);
+                BK_COOP_LD(q2, gl + a2);
+                BK_COOP_LD(q3, gl + a3);
                 uint8_t *md = mine + (size_t)c0 * 16u;
                 if (m0) *reinterpret_cast<uint4 *>(md) = q0;
                 if (m1) *reinterpret_cast<uint4 *>(md + 4096) = q1;
@@ -404,6 +418,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
 }
 
 #undef BK_COOP_LOADS
+#undef BK_COOP_LD
 
 // Frames of a block whose chunk list is larger than the launch's staging buffer: the list goes through
 // LDS in passes of lds_buf/16 chunks; a pixel picks its texel up in the pass that holds its slot and the packed

@@ -98,7 +98,7 @@ struct Emitter {
         }
         if (e.kind == Expr::Index && e.b->kind == Expr::String) {
             Value o;
-            if (static_value(f, *e.a, &o) && o.t == Value::TABLE) { *v = o.tab->get(Value::string(e.b->str)); return true; }
+            if (static_value(f, *e.a, &o) && o.t == Value::TABLE) { *v = o.tab()->get(Value::string(e.b->str)); return true; }
         }
         return false;
     }
@@ -116,9 +116,9 @@ struct Emitter {
             bool known = false;
             if (e->a->kind == Expr::Name && e->a->var == VarKind::Global) { callee = I.get_global(e->a->str); known = true; }
             else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) { callee = *cl->upvals[e->a->slot]; known = true; }
-            if (known && callee.t == Value::FUNC && !seen.count(callee.fn->proto)) {
-                seen.insert(callee.fn->proto);
-                scan_block(callee.fn->proto->body, callee.fn.get(), seen);
+            if (known && callee.t == Value::FUNC && !seen.count(callee.fn()->proto)) {
+                seen.insert(callee.fn()->proto);
+                scan_block(callee.fn()->proto->body, callee.fn(), seen);
             }
         }
         scan_expr(e->a.get(), cl, seen);
@@ -159,7 +159,7 @@ struct Emitter {
             case Value::BOOL: snprintf(buf, sizeof buf, ", {0.0, 0.0, %s}", v.b ? "BK_TTRUE" : "BK_TFALSE"); break;
             case Value::NIL: snprintf(buf, sizeof buf, ", {0.0, 0.0, BK_TNIL}"); break;
             case Value::STR: {
-                const std::string lit = str_literal(*v.s);        // "bk_str(<id>)"
+                const std::string lit = str_literal(v.str());        // "bk_str(<id>)"
                 snprintf(buf, sizeof buf, ", {%s.0, 0.0, BK_TSTR}", lit.substr(7, lit.size() - 8).c_str());
                 break;
             }
@@ -178,7 +178,7 @@ struct Emitter {
         case Value::NIL: return "bk_nil()";
         case Value::BOOL: return v.b ? "bk_bool(true)" : "bk_bool(false)";
         case Value::NUM: return num_literal(v.n);
-        case Value::STR: return str_literal(*v.s);
+        case Value::STR: return str_literal(v.str());
         default: unsupported(f.chunk, e.line, what + " (a " + v.type_name() + ") used as a value");
         }
     }
@@ -215,7 +215,7 @@ struct Emitter {
             if (static_value(f, e, &sv)) return const_value(f, e, sv, "field '" + e.b->str + "'");
             Value o;
             if (static_value(f, *e.a, &o) && o.t == Value::TABLE) {
-                auto ct = const_table(f, e, o.tab, e.a->kind == Expr::Name ? e.a->str : "table");
+                auto ct = const_table(f, e, o.tab_ptr(), e.a->kind == Expr::Name ? e.a->str : "table");
                 std::string k = emit_expr(f, *e.b), t = tmp();
                 line(f, "bkv " + t + " = bk_aget(S, " + ct.first + ", " + std::to_string(ct.second) + ", " + k + ");");
                 return t;
@@ -328,7 +328,7 @@ struct Emitter {
     {
         Value callee;
         if (e.kind != Expr::Call || !static_value(f, *e.a, &callee) || callee.t != Value::BUILTIN) return false;
-        const std::string &bn = callee.bi->name;
+        const std::string &bn = callee.bi()->name;
         return bn.compare(0, 5, "math.") == 0 && bn != "math.modf" && bn != "math.frexp";
     }
 
@@ -343,7 +343,7 @@ struct Emitter {
         *arr = tmp("r");
         *cnt = tmp("n");
         if (callee.t == Value::FUNC) {
-            const FnInfo &fi = ensure_function(callee.fn.get(), e.line, f.chunk);
+            const FnInfo &fi = ensure_function(callee.fn(), e.line, f.chunk);
             Args a = emit_args(f, e.args);
             auto packed = pack(f, a, 1);
             line(f, "bkv " + *arr + "[BK_MAXRET];");
@@ -354,7 +354,7 @@ struct Emitter {
             std::string n = e.a->kind == Expr::Name ? e.a->str : "?";
             unsupported(f.chunk, e.line, "attempt to call '" + n + "' (a " + callee.type_name() + " value)");
         }
-        const std::string &bn = callee.bi->name;
+        const std::string &bn = callee.bi()->name;
         if (bn == "print") {                              // no console on the device: drop the call
             line(f, "bkv " + *arr + "[1]; const int " + *cnt + " = 0; (void)" + *arr + ";");
             return;
@@ -566,9 +566,9 @@ struct Emitter {
             const Expr *call = s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Call ? s.exprs[0].get() : nullptr;
             Value callee;
             if (!call || !static_value(f, *call->a, &callee) || callee.t != Value::BUILTIN ||
-                (callee.bi->name != "ipairs" && callee.bi->name != "pairs") || call->args.size() != 1)
+                (callee.bi()->name != "ipairs" && callee.bi()->name != "pairs") || call->args.size() != 1)
                 unsupported(f.chunk, s.line, "generic 'for ... in' other than ipairs(t) / pairs(t)");
-            const bool is_ipairs = callee.bi->name == "ipairs";
+            const bool is_ipairs = callee.bi()->name == "ipairs";
             const Expr &targ = *call->args[0];
             std::string arr;
             int n = 0;
@@ -578,7 +578,7 @@ struct Emitter {
             } else {
                 Value tv;
                 if (!static_value(f, targ, &tv) || tv.t != Value::TABLE) unsupported(f.chunk, s.line, "iterating a table that is not known when the kernel is generated");
-                auto ct = const_table(f, targ, tv.tab, targ.kind == Expr::Name ? targ.str : "table");
+                auto ct = const_table(f, targ, tv.tab_ptr(), targ.kind == Expr::Name ? targ.str : "table");
                 arr = ct.first;
                 n = ct.second;
             }
@@ -676,9 +676,9 @@ std::string emit_build_source(const EmitRequest &req)
     std::set<const FuncProto *> seen;
     const Value *roots[3] = {&req.lens_inverse, &req.lens_forward, &req.globe_plate};
     for (const Value *v : roots)
-        if (v->t == Value::FUNC && !seen.count(v->fn->proto)) {
-            seen.insert(v->fn->proto);
-            em.scan_block(v->fn->proto->body, v->fn.get(), seen);
+        if (v->t == Value::FUNC && !seen.count(v->fn()->proto)) {
+            seen.insert(v->fn()->proto);
+            em.scan_block(v->fn()->proto->body, v->fn(), seen);
         }
     for (const Value *v : roots)
         if (v->t != Value::NIL && v->t != Value::FUNC)
@@ -686,7 +686,7 @@ std::string emit_build_source(const EmitRequest &req)
 
     std::string names[3];
     for (int i = 0; i < 3; ++i)
-        if (roots[i]->t == Value::FUNC) names[i] = em.ensure_function(roots[i]->fn.get(), 0, "callback").cname;
+        if (roots[i]->t == Value::FUNC) names[i] = em.ensure_function(roots[i]->fn(), 0, "callback").cname;
 
     std::ostringstream src;
     src << "/* generated by libblinkyhip (bk_emit.cpp) */\n";
@@ -704,7 +704,7 @@ std::string emit_build_source(const EmitRequest &req)
         case Value::NIL: init = "bk_nil()"; break;
         case Value::BOOL: init = v.b ? "bk_bool(true)" : "bk_bool(false)"; break;
         case Value::NUM: init = num_literal(v.n); break;
-        case Value::STR: init = em.str_literal(*v.s); break;
+        case Value::STR: init = em.str_literal(v.str()); break;
         default:
             throw LuaError("global '" + g + "' is assigned inside a GPU callback but holds a " + v.type_name() +
                            " when the lensmap build starts; only nil / boolean / number / string globals can be per-pixel state");

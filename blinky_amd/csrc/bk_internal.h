@@ -101,6 +101,7 @@ struct bk_ctx {
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
+    double last_host_eval_ms = 0;    // of that: wall time of the host re-evaluation of the flagged entries
     bool async_compile = false;      // bk_set_async_compile: bk_build returns BK_PENDING instead of waiting for hiprtc
 
     int fail(int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)))

@@ -4,6 +4,7 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <chrono>
 #include <condition_variable>
@@ -121,9 +122,9 @@ LensProgram::LensProgram(bk_ctx *ctx) : interp(math_platform())
     static const char *alias[] = {"cos", "sin", "tan", "asin", "acos", "atan", "atan2", "sinh", "cosh", "tanh",
                                   "log", "log10", "abs", "sqrt", "exp", "pow"};
     Value math = interp.get_global("math");
-    for (const char *a : alias) interp.set_global(a, math.tab->get(Value::string(a)));
-    interp.set_global("pi", math.tab->get(Value::string("pi")));
-    interp.set_global("tau", Value::number(math.tab->get(Value::string("pi")).n * 2));
+    for (const char *a : alias) interp.set_global(a, math.tab()->get(Value::string(a)));
+    interp.set_global("pi", math.tab()->get(Value::string("pi")));
+    interp.set_global("tau", Value::number(math.tab()->get(Value::string("pi")).n * 2));
     // the three C functions scripts may call (fisheye.c:1257-1264, 1494-1537)
     interp.register_builtin("latlon_to_ray", [](Interp &I, const Values &a, Values &r) {
         float ray[3];
@@ -196,12 +197,13 @@ extern "C" int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const cha
         Value gp = I.get_global("globe_plate");
         if (gp.is_function()) P->globe_plate = gp;                              /* :1778-1782 */
         Value plates = I.get_global("plates");
-        if (plates.t != Value::TABLE || plates.tab->length() < 1)
+        if (plates.t != Value::TABLE || plates.tab()->length() < 1)
             return ctx->fail(BK_E_SCRIPT, "plates must be an array of one or more elements");   /* :1788 */
         // lua_next order: array part, then the rest (:1796)
-        Values items = plates.tab->arr;
-        for (auto &kv : plates.tab->nhash) items.push_back(kv.second);
-        for (auto &kv : plates.tab->shash) items.push_back(kv.second);
+        Values items;
+        items.append(plates.tab()->arr.data(), plates.tab()->arr.data() + plates.tab()->arr.size());
+        for (auto &kv : plates.tab()->nhash) items.push_back(kv.second);
+        for (auto &kv : plates.tab()->shash) items.push_back(kv.second);
         if (items.size() > BK_MAX_PLATES)
             return ctx->fail(BK_E_SCRIPT, "globe defines %zu plates; at most %d are supported (MAX_PLATES, fisheye.c:352)",
                              items.size(), BK_MAX_PLATES);
@@ -211,17 +213,17 @@ extern "C" int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const cha
             static const char *vname[2] = {"forward", "up"};
             if (plate.t != Value::TABLE) return ctx->fail(BK_E_SCRIPT, "plate %d: not a table", i + 1);
             for (int k = 0; k < 2; ++k) {
-                Value v = plate.tab->get(Value::number(k + 1));
-                if (v.t != Value::TABLE || v.tab->length() != 3)
+                Value v = plate.tab()->get(Value::number(k + 1));
+                if (v.t != Value::TABLE || v.tab()->length() != 3)
                     return ctx->fail(BK_E_SCRIPT, "plate %d: %s vector is not a 3d vector", i + 1, vname[k]);   /* :1804,1829 */
                 for (int j = 0; j < 3; ++j) {
-                    Value e = v.tab->get(Value::number(j + 1));
+                    Value e = v.tab()->get(Value::number(j + 1));
                     if (e.t != Value::NUM)
                         return ctx->fail(BK_E_SCRIPT, "plate %d: %s vector: element %d not a number", i + 1, vname[k], j + 1);
                     vec[k][j] = e.n;
                 }
             }
-            Value fov = plate.tab->get(Value::number(3));
+            Value fov = plate.tab()->get(Value::number(3));
             bool fov_ok = false;
             bk::fill_plate(*I.math, ctx->plates[i], vec[0], vec[1], fov.t == Value::NUM ? fov.n : 0.0, &fov_ok);
             if (!fov_ok) return ctx->fail(BK_E_SCRIPT, "plate %d: fov must > 0", i + 1);                       /* :1863 */
@@ -871,15 +873,17 @@ bool h_texel_owns(bk_ctx *ctx, HostEval &E, const BkBuildParams &bp, uint32_t id
 }
 
 /* A small process-wide pool of worker threads for the host re-evaluation (creating 64-256 threads per build cost more
- * than the evaluations themselves).  Created on first use, never torn down (its threads sleep on a condition variable). */
+ * than the evaluations themselves).  Created on first use; its threads sleep on a condition variable and are JOINED when
+ * the library is unloaded or the process exits (a function-local static: destroyed by dlclose / exit handlers, after which
+ * no code of this library runs any more). */
 class FixupPool {
 public:
     static FixupPool &get()
     {
-        static FixupPool *pool = new FixupPool();            // (leaked on purpose: no destructor races at process exit)
-        return *pool;
+        static FixupPool pool;
+        return pool;
     }
-    size_t size() const { return workers_; }
+    size_t size() const { return threads_.size(); }
     /* run job(worker_index) on `want` workers (<= size()) and wait for all of them */
     void run(size_t want, const std::function<void(size_t)> &job)
     {
@@ -892,32 +896,41 @@ public:
             done_ = 0;
             ++generation_;
         }
-        wake_.notify_all();
+        if (want >= threads_.size() / 2) wake_.notify_all();
+        else for (size_t i = 0; i < want; ++i) wake_.notify_one();
         std::unique_lock<std::mutex> lock(m_);
         finished_.wait(lock, [&] { return done_ == want_; });
         job_ = nullptr;
+    }
+    ~FixupPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread &t : threads_) if (t.joinable()) t.join();
     }
 
 private:
     FixupPool()
     {
         unsigned hw = std::thread::hardware_concurrency();
-        workers_ = std::min<size_t>(hw ? hw : 1, 128);
-        if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) workers_ = (size_t)std::max(1, std::min(256, atoi(e)));
-        for (size_t i = 0; i < workers_; ++i) std::thread([this] { loop(); }).detach();
+        size_t workers = std::min<size_t>(hw ? hw : 1, 128);
+        if (const char *e = getenv("BLINKY_HIP_FIXUP_THREADS")) workers = (size_t)std::max(1, std::min(256, atoi(e)));
+        for (size_t i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); });
     }
     void loop()
     {
-        uint64_t seen = 0;
         for (;;) {
             const std::function<void(size_t)> *job = nullptr;
             size_t mine = 0;
             {
                 std::unique_lock<std::mutex> lock(m_);
-                wake_.wait(lock, [&] { return generation_ != seen && next_ < want_; });
+                wake_.wait(lock, [&] { return stop_ || next_ < want_; });
+                if (stop_) return;
                 job = job_;
                 mine = next_++;
-                if (next_ >= want_) seen = generation_;          // (this generation has handed out all its shares)
             }
             (*job)(mine);
             {
@@ -929,12 +942,44 @@ private:
     std::mutex m_, submit_mutex_;
     std::condition_variable wake_, finished_;
     const std::function<void(size_t)> *job_ = nullptr;
-    size_t want_ = 0, next_ = 0, done_ = 0, workers_ = 1;
+    size_t want_ = 0, next_ = 0, done_ = 0;
     uint64_t generation_ = 0;
+    bool stop_ = false;
+    std::vector<std::thread> threads_;
 };
 
+/* the flag list (records of four words, [0] = entry id) in ascending id order: the order the reference's scan meets the
+ * entries in (fisheye.c:2084-2124), which is also what keeps a script's own caches warm - eckert4 solves its outline once
+ * per ROW and remembers it in globals; met in the arbitrary order the kernel appended them every flagged pixel would solve
+ * it again (20 Newton steps), an order of magnitude more host time on the rows it flags whole */
+void sort_flagged(std::vector<uint32_t> &rec)
+{
+    const size_t n = rec.size() / 4;
+    if (n < 2) return;
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; ++i) sorted = rec[4 * (i - 1)] <= rec[4 * i];
+    if (sorted) return;
+    std::vector<uint64_t> key(n), tmp(n);
+    for (size_t i = 0; i < n; ++i) key[i] = ((uint64_t)rec[4 * i] << 32) | (uint64_t)i;
+    if (n < 4096) std::sort(key.begin(), key.end());
+    else {
+        for (int shift = 32; shift < 64; shift += 11) {           // LSD radix on the id, 11 bits a pass (stable)
+            size_t count[2049] = {0};
+            for (size_t i = 0; i < n; ++i) ++count[((key[i] >> shift) & 2047u) + 1];
+            for (int b = 0; b < 2048; ++b) count[b + 1] += count[b];
+            for (size_t i = 0; i < n; ++i) tmp[count[(key[i] >> shift) & 2047u]++] = key[i];
+            key.swap(tmp);
+        }
+    }
+    std::vector<uint32_t> out(rec.size());
+    for (size_t i = 0; i < n; ++i) memcpy(&out[4 * i], &rec[4 * (size_t)(key[i] & 0xFFFFFFFFu)], 16);
+    rec.swap(out);
+}
+
 /* fn(E, i) for i in [0, n): on the context's interpreter when the list is short, otherwise on the pool's workers, each
- * on its own deep copy of the interpreter state.  The first script error any worker meets is rethrown here. */
+ * on its own deep copy of the interpreter state; the workers take runs of consecutive entries from a shared counter (the
+ * entries cost very different amounts - a nil-test that fails at once, a Newton iteration - so equal static shares leave
+ * most workers waiting for the unluckiest).  The first script error any worker meets is rethrown here. */
 template <typename Fn>
 void for_each_flagged(LensProgram *P, size_t n, Fn fn)
 {
@@ -944,11 +989,13 @@ void for_each_flagged(LensProgram *P, size_t n, Fn fn)
         return;
     }
     FixupPool &pool = FixupPool::get();
-    const size_t nthreads = std::max<size_t>(1, std::min(pool.size(), n / 128));
+    const size_t nthreads = std::max<size_t>(1, std::min(pool.size(), n / 96));
     if (nthreads <= 1) {
         for (size_t i = 0; i < n; ++i) fn(main_eval, i);
         return;
     }
+    const size_t run = std::max<size_t>(32, std::min<size_t>(2048, n / (nthreads * 6)));
+    std::atomic<size_t> next{0};
     std::vector<std::string> errors(nthreads);
     const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
     pool.run(nthreads, [&](size_t t) {
@@ -957,7 +1004,11 @@ void for_each_flagged(LensProgram *P, size_t n, Fn fn)
             Values roots;
             std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
             HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
-            for (size_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i) fn(ev, i);
+            for (;;) {
+                const size_t i0 = next.fetch_add(run, std::memory_order_relaxed);
+                if (i0 >= n) break;
+                for (size_t i = i0, e = std::min(n, i0 + run); i < e; ++i) fn(ev, i);
+            }
         } catch (const LuaError &e) { errors[t] = e.what(); }
     });
     for (const std::string &e : errors) if (!e.empty()) throw LuaError(e);
@@ -984,6 +1035,7 @@ static int read_flagged(bk_ctx *ctx, unsigned int count, std::vector<uint32_t> *
     list->resize((size_t)count * 4);
     BK_HIP(ctx, hipMemcpyAsync(list->data(), ctx->d_flag_list, (size_t)count * 16, hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sort_flagged(*list);
     return BK_OK;
 }
 
@@ -1006,6 +1058,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     bk::coopmap_invalidate(ctx);
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
     ctx->last_build_ms = 0;
+    ctx->last_host_eval_ms = 0;
     ctx->last_flagged = ctx->last_changed = 0;
 
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
@@ -1067,9 +1120,11 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 std::vector<uint32_t> roff(nfl);
                 std::vector<uint8_t> rtint(nfl);
                 std::vector<int> rshown(nfl), rerr(nfl, 0);
+                const auto th0 = std::chrono::steady_clock::now();
                 for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
                     h_inverse_entry(E, bp, flagged[4 * i], &roff[i], &rtint[i], &rshown[i], &rerr[i]);
                 });
+                ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
                 for (size_t i = 0; i < nfl; ++i) {
                     host_err |= rerr[i];
                     if (rshown[i] >= 0) host_display[rshown[i]] = 1;
@@ -1114,9 +1169,11 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 const size_t nfl = flagged.size() / 4;
                 std::vector<int> rsx(nfl), rsy(nfl), rerr(nfl, 0);
                 std::vector<uint8_t> rok(nfl);
+                const auto th0 = std::chrono::steady_clock::now();
                 for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
                     h_corner_entry(ctx, E, bp, flagged[4 * i], &rsx[i], &rsy[i], &rok[i], &rerr[i]);
                 });
+                ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
                 for (size_t i = 0; i < nfl; ++i) {
                     const size_t k = 4 * i;
                     const int sx = rsx[i], sy = rsy[i];
@@ -1277,6 +1334,18 @@ extern "C" int bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n,
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }
     for (size_t i = 0; i < n; ++i) { sx[i] = x[i]; sy[i] = y[i]; }
+    return BK_OK;
+}
+#endif
+
+#if BK_DEBUG_API
+extern "C" int bk_debug_build_breakdown(const bk_ctx *ctx, double out[4])
+{
+    if (!ctx || !out) return BK_E_INVALID;
+    out[0] = ctx->last_build_ms;
+    out[1] = ctx->last_host_eval_ms;
+    out[2] = (double)ctx->last_flagged;
+    out[3] = (double)FixupPool::get().size();
     return BK_OK;
 }
 #endif

@@ -801,7 +801,7 @@ Value Table::get(const Value &k) const
         return it == nhash.end() ? Value() : it->second;
     }
     if (k.t == Value::STR) {
-        auto it = shash.find(*k.s);
+        auto it = shash.find(k.str());
         return it == shash.end() ? Value() : it->second;
     }
     return Value();
@@ -835,7 +835,7 @@ void Table::set(const Value &k, const Value &v)
         return;
     }
     if (k.t == Value::STR) {
-        if (v.t == Value::NIL) shash.erase(*k.s); else shash[*k.s] = v;
+        if (v.t == Value::NIL) shash.erase(k.str()); else shash[k.str()] = v;
         return;
     }
     if (k.t == Value::NIL) throw LuaError("table index is nil");
@@ -847,7 +847,7 @@ namespace {
 
 struct Frame {
     Closure *cl;
-    Values regs;                                   // locals no inner function refers to
+    ValuesN<16> regs;                              // locals no inner function refers to
     std::vector<std::shared_ptr<Value>> cells;     // locals that closures capture (FuncProto::captured)
     Values varargs;
 };
@@ -868,7 +868,7 @@ struct Exec {
     {
         if (v.t == Value::NUM) { *out = v.n; return true; }
         if (v.t == Value::STR) {
-            const char *s = v.s->c_str();
+            const char *s = v.str().c_str();
             char *end = nullptr;
             while (isspace((unsigned char)*s)) ++s;
             if (!*s) return false;
@@ -903,22 +903,20 @@ struct Exec {
         case Value::NIL: return true;
         case Value::BOOL: return a.b == b.b;
         case Value::NUM: return a.n == b.n;
-        case Value::STR: return *a.s == *b.s;
-        case Value::TABLE: return a.tab == b.tab;
-        case Value::FUNC: return a.fn == b.fn;
-        default: return a.bi == b.bi;
+        case Value::STR: return a.str() == b.str();
+        default: return a.p == b.p;            // tables, closures, builtins: identity
         }
     }
     bool less(Frame &f, const Expr &e, const Value &a, const Value &b, bool or_equal)
     {
         if (a.t == Value::NUM && b.t == Value::NUM) return or_equal ? a.n <= b.n : a.n < b.n;
-        if (a.t == Value::STR && b.t == Value::STR) return or_equal ? *a.s <= *b.s : *a.s < *b.s;
+        if (a.t == Value::STR && b.t == Value::STR) return or_equal ? a.str() <= b.str() : a.str() < b.str();
         error(e.line, chunk_of(f), std::string("attempt to compare ") + a.type_name() + " with " + b.type_name());
     }
 
     Value index(Frame &f, const Expr &e, const Value &obj, const Value &key)
     {
-        if (obj.t == Value::TABLE) return obj.tab->get(key);
+        if (obj.t == Value::TABLE) return obj.tab()->get(key);
         std::string what = e.a && e.a->kind == Expr::Name ? " (" + std::string(e.a->var == VarKind::Global ? "global" : "local") + " '" + e.a->str + "')" : "";
         error(e.line, chunk_of(f), std::string("attempt to index a ") + obj.type_name() + " value" + what);
     }
@@ -954,28 +952,22 @@ struct Exec {
             Value k = eval(f, *e.b);
             return index(f, e, o, k);
         }
-        case Expr::Call: {
-            Values r = eval_multi(f, e);
-            return r.empty() ? Value() : r[0];
-        }
+        case Expr::Call: return eval_call1(f, e);
         case Expr::Function: {
-            Value v;
-            v.t = Value::FUNC;
-            v.fn = std::make_shared<Closure>();
-            v.fn->proto = e.proto;
-            v.fn->chunk = f.cl->chunk;
+            auto cl = std::make_shared<Closure>();
+            cl->proto = e.proto;
+            cl->chunk = f.cl->chunk;
             for (const UpvalDesc &u : e.proto->upvals) {
                 if (u.from_parent_local) {
                     if (!f.cells[u.index]) f.cells[u.index] = std::make_shared<Value>();
-                    v.fn->upvals.push_back(f.cells[u.index]);
-                } else v.fn->upvals.push_back(f.cl->upvals[u.index]);
+                    cl->upvals.push_back(f.cells[u.index]);
+                } else cl->upvals.push_back(f.cl->upvals[u.index]);
             }
-            return v;
+            return Value::closure(std::move(cl));
         }
         case Expr::Table: {
-            Value v;
-            v.t = Value::TABLE;
-            v.tab = std::make_shared<Table>();
+            Value v = Value::table(std::make_shared<Table>());
+            v.tab()->arr.reserve(e.args.size());
             double next = 1;
             for (size_t oi = 0; oi < e.item_order.size(); ++oi) {
                 int o = e.item_order[oi];
@@ -983,15 +975,15 @@ struct Exec {
                     bool last = oi + 1 == e.item_order.size();
                     const Expr &item = *e.args[o];
                     if (last && (item.kind == Expr::Call || item.kind == Expr::Vararg)) {
-                        for (const Value &x : eval_multi(f, item)) { v.tab->set(Value::number(next), x); next += 1; }
+                        for (const Value &x : eval_multi(f, item)) { v.tab()->set(Value::number(next), x); next += 1; }
                     } else {
-                        v.tab->set(Value::number(next), eval(f, item));
+                        v.tab()->set(Value::number(next), eval(f, item));
                         next += 1;
                     }
                 } else {
                     const auto &fld = e.fields[-1 - o];
                     Value k = eval(f, *fld.first);
-                    v.tab->set(k, eval(f, *fld.second));
+                    v.tab()->set(k, eval(f, *fld.second));
                 }
             }
             return v;
@@ -1006,8 +998,8 @@ struct Exec {
                 return Value::number(-x);
             }
             if (e.op == Expr::OP_LEN) {
-                if (a.t == Value::STR) return Value::number((double)a.s->size());
-                if (a.t == Value::TABLE) return Value::number((double)a.tab->length());
+                if (a.t == Value::STR) return Value::number((double)a.str().size());
+                if (a.t == Value::TABLE) return Value::number((double)a.tab()->length());
                 error(e.line, chunk_of(f), std::string("attempt to get length of a ") + a.type_name() + " value");
             }
             error(e.line, chunk_of(f), "bad unary operator");
@@ -1057,10 +1049,41 @@ struct Exec {
             const Expr &e = *list[i];
             if (i + 1 == list.size() && (e.kind == Expr::Call || e.kind == Expr::Vararg)) {
                 Values m = eval_multi(f, e);
-                out.insert(out.end(), m.begin(), m.end());
+                out.append(m.begin(), m.end());
             } else out.push_back(eval(f, e));
         }
         return out;
+    }
+
+    [[noreturn]] void not_callable(Frame &f, const Expr &e, const Value &fn)
+    {
+        std::string what;
+        if (e.a->kind == Expr::Name) what = std::string(" (") + (e.a->var == VarKind::Global ? "global" : "local") + " '" + e.a->str + "')";
+        else if (e.a->kind == Expr::Index && e.a->b->kind == Expr::String) what = " (field '" + e.a->b->str + "')";
+        error(e.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value" + what);
+    }
+    // sin(x), sqrt(x) ...: a one-argument math builtin on a number needs no argument or result lists
+    bool call_f1(Frame &f, const Expr &e, const Value &fn, Value *out, Values *args)
+    {
+        if (fn.t != Value::BUILTIN || !fn.bi()->f1 || e.args.size() != 1) return false;
+        const Expr &ae = *e.args[0];
+        if (ae.kind == Expr::Call || ae.kind == Expr::Vararg) return false;      // (may expand to no value at all: the generic path reports it)
+        Value a = eval(f, ae);
+        if (a.t == Value::NUM) { *out = Value::number((I.math->*(fn.bi()->f1))(a.n)); return true; }
+        args->push_back(std::move(a));                                            // evaluated once: the generic path takes it from here
+        return false;
+    }
+    // a call of which only the first result is wanted
+    Value eval_call1(Frame &f, const Expr &e)
+    {
+        Value fn = eval(f, *e.a);
+        Value out;
+        Values args;
+        if (call_f1(f, e, fn, &out, &args)) return out;
+        if (args.empty()) args = eval_list(f, e.args);
+        if (!fn.is_function()) not_callable(f, e, fn);
+        Values r = I.call(fn, args);
+        return r.empty() ? Value() : std::move(r[0]);
     }
 
     Values eval_multi(Frame &f, const Expr &e)
@@ -1068,13 +1091,11 @@ struct Exec {
         if (e.kind == Expr::Vararg) return f.varargs;
         if (e.kind != Expr::Call) return Values{eval(f, e)};
         Value fn = eval(f, *e.a);
-        Values args = eval_list(f, e.args);
-        if (!fn.is_function()) {
-            std::string what;
-            if (e.a->kind == Expr::Name) what = std::string(" (") + (e.a->var == VarKind::Global ? "global" : "local") + " '" + e.a->str + "')";
-            else if (e.a->kind == Expr::Index && e.a->b->kind == Expr::String) what = " (field '" + e.a->b->str + "')";
-            error(e.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value" + what);
-        }
+        Value out;
+        Values args;
+        if (call_f1(f, e, fn, &out, &args)) return Values{out};
+        if (args.empty()) args = eval_list(f, e.args);
+        if (!fn.is_function()) not_callable(f, e, fn);
         return I.call(fn, args);
     }
 
@@ -1089,7 +1110,7 @@ struct Exec {
         Value o = eval(f, *target.a);
         Value k = eval(f, *target.b);
         if (o.t != Value::TABLE) error(target.line, chunk_of(f), std::string("attempt to index a ") + o.type_name() + " value");
-        try { o.tab->set(k, v); } catch (LuaError &err) { error(target.line, chunk_of(f), err.what()); }
+        try { o.tab()->set(k, v); } catch (LuaError &err) { error(target.line, chunk_of(f), err.what()); }
     }
 
     void tick(Frame &f, int line)
@@ -1111,6 +1132,7 @@ struct Exec {
         tick(f, s.line);
         switch (s.kind) {
         case Stmt::Local: {
+            if (s.slots.size() == 1 && s.exprs.size() == 1) { fresh_local(f, s.slots[0], eval(f, *s.exprs[0])); return F_NORMAL; }
             Values v = eval_list(f, s.exprs);
             for (size_t i = 0; i < s.slots.size(); ++i)
                 fresh_local(f, s.slots[i], i < v.size() ? v[i] : Value());
@@ -1122,6 +1144,7 @@ struct Exec {
             return F_NORMAL;
         }
         case Stmt::Assign: {
+            if (s.targets.size() == 1 && s.exprs.size() == 1) { assign(f, *s.targets[0], eval(f, *s.exprs[0])); return F_NORMAL; }
             Values v = eval_list(f, s.exprs);
             for (size_t i = 0; i < s.targets.size(); ++i) assign(f, *s.targets[i], i < v.size() ? v[i] : Value());
             return F_NORMAL;
@@ -1217,15 +1240,16 @@ void Interp::register_builtin(const std::string &name, BuiltinFn fn)
 {
     Value v;
     v.t = Value::BUILTIN;
-    v.bi = std::make_shared<Builtin>();
-    v.bi->name = name;
-    v.bi->fn = std::move(fn);
+    auto bp = std::make_shared<Builtin>();
+    bp->name = name;
+    bp->fn = std::move(fn);
+    v.p = std::move(bp);
     size_t dot = name.find('.');
     if (dot == std::string::npos) { globals[name] = v; return; }
     std::string tname = name.substr(0, dot), field = name.substr(dot + 1);
     Value t = get_global(tname);
-    if (t.t != Value::TABLE) { t = Value(); t.t = Value::TABLE; t.tab = std::make_shared<Table>(); globals[tname] = t; }
-    t.tab->shash[field] = v;
+    if (t.t != Value::TABLE) { t = Value::table(std::make_shared<Table>()); globals[tname] = t; }
+    t.tab()->shash[field] = v;
 }
 
 namespace {
@@ -1237,15 +1261,15 @@ struct Cloner {
     Value value(const Value &v)
     {
         Value o = v;
-        if (v.t == Value::TABLE) o.tab = table(v.tab);
-        else if (v.t == Value::FUNC) o.fn = closure(v.fn);
-        else if (v.t == Value::BUILTIN && v.bi) {
+        if (v.t == Value::TABLE) o.p = table(v.tab_ptr());
+        else if (v.t == Value::FUNC) o.p = closure(v.fn_ptr());
+        else if (v.t == Value::BUILTIN && v.p) {
             // (immutable, but every evaluation of `sin` copies the Value: a private copy keeps the reference count -
             // an atomic - out of the other threads' cache lines)
-            auto it = bis.find(v.bi.get());
-            if (it == bis.end()) it = bis.emplace(v.bi.get(), std::make_shared<Builtin>(*v.bi)).first;
-            o.bi = it->second;
-        } else if (v.t == Value::STR && v.s) o.s = std::make_shared<std::string>(*v.s);
+            auto it = bis.find(v.bi());
+            if (it == bis.end()) it = bis.emplace(v.bi(), std::make_shared<Builtin>(*v.bi())).first;
+            o.p = it->second;
+        } else if (v.t == Value::STR && v.p) o.p = std::make_shared<std::string>(v.str());
         return o;
     }
     std::shared_ptr<Table> table(const std::shared_ptr<Table> &t)
@@ -1282,7 +1306,7 @@ struct Cloner {
 };
 }  // namespace
 
-std::unique_ptr<Interp> Interp::clone(const std::vector<Value> &roots, std::vector<Value> *roots_out) const
+std::unique_ptr<Interp> Interp::clone(const Values &roots, Values *roots_out) const
 {
     std::unique_ptr<Interp> n(new Interp(*math, Empty{}));
     Cloner c;
@@ -1303,10 +1327,10 @@ std::string Interp::tostring(const Value &v) const
     case Value::NIL: return "nil";
     case Value::BOOL: return v.b ? "true" : "false";
     case Value::NUM: snprintf(buf, sizeof buf, "%.14g", v.n); return buf;     // LUA_NUMBER_FMT
-    case Value::STR: return *v.s;
-    case Value::TABLE: snprintf(buf, sizeof buf, "table: %p", (void *)v.tab.get()); return buf;
-    case Value::FUNC: snprintf(buf, sizeof buf, "function: %p", (void *)v.fn.get()); return buf;
-    default: return "function: builtin: " + v.bi->name;
+    case Value::STR: return v.str();
+    case Value::TABLE: snprintf(buf, sizeof buf, "table: %p", (void *)v.tab()); return buf;
+    case Value::FUNC: snprintf(buf, sizeof buf, "function: %p", (void *)v.fn()); return buf;
+    default: return "function: builtin: " + v.bi()->name;
     }
 }
 
@@ -1314,14 +1338,14 @@ Values Interp::call(const Value &fv, const Values &args)
 {
     if (fv.t == Value::BUILTIN) {
         Values rets;
-        fv.bi->fn(*this, args, rets);
+        fv.bi()->fn(*this, args, rets);
         return rets;
     }
     if (fv.t != Value::FUNC) throw LuaError(std::string("attempt to call a ") + fv.type_name() + " value");
     if (depth > 180) throw LuaError("stack overflow (recursion too deep)");
-    const FuncProto *p = fv.fn->proto;
+    const FuncProto *p = fv.fn()->proto;
     Frame fr;
-    fr.cl = fv.fn.get();
+    fr.cl = fv.fn();
     fr.regs.resize((size_t)p->nslots);
     if (!p->captured.empty()) fr.cells.resize((size_t)p->nslots);
     for (int i = 0; i < p->nparams; ++i) {
@@ -1344,9 +1368,10 @@ void Interp::run(const std::string &src, const std::string &chunkname)
     std::shared_ptr<Chunk> ch = parse(src, chunkname);
     Value f;
     f.t = Value::FUNC;
-    f.fn = std::make_shared<Closure>();
-    f.fn->proto = ch->main();
-    f.fn->chunk = ch;
+    auto cl = std::make_shared<Closure>();
+    cl->proto = ch->main();
+    cl->chunk = ch;
+    f.p = std::move(cl);
     call(f, Values());
 }
 
@@ -1367,6 +1392,7 @@ Interp::Interp(const MathLib &m) : math(&m)
         register_builtin(n, [this, fp, n](Interp &, const Values &a, Values &r) {
             r.push_back(Value::number((math->*fp)(argnum(a, 0, n.c_str() + 5))));
         });
+        get_global("math").tab()->get(Value::string(name)).bi()->f1 = fp;       // (the interpreter's shortcut for a number argument)
     };
     m1("sin", &MathLib::sin); m1("cos", &MathLib::cos); m1("tan", &MathLib::tan);
     m1("asin", &MathLib::asin); m1("acos", &MathLib::acos); m1("atan", &MathLib::atan);
@@ -1401,18 +1427,18 @@ Interp::Interp(const MathLib &m) : math(&m)
         for (size_t i = 1; i < a.size(); ++i) { double d = argnum(a, i, "min"); if (d < m) m = d; }
         r.push_back(Value::number(m));
     });
-    get_global("math").tab->shash["pi"] = Value::number(3.14159265358979323846);
-    get_global("math").tab->shash["huge"] = Value::number(HUGE_VAL);
+    get_global("math").tab()->shash["pi"] = Value::number(3.14159265358979323846);
+    get_global("math").tab()->shash["huge"] = Value::number(HUGE_VAL);
 
     register_builtin("table.unpack", [](Interp &, const Values &a, Values &r) {
         if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'unpack' (table expected)");
         double i = a.size() > 1 && a[1].t != Value::NIL ? argnum(a, 1, "unpack") : 1;
-        double e = a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "unpack") : (double)a[0].tab->length();
-        for (double k = i; k <= e; k += 1) r.push_back(a[0].tab->get(Value::number(k)));
+        double e = a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "unpack") : (double)a[0].tab()->length();
+        for (double k = i; k <= e; k += 1) r.push_back(a[0].tab()->get(Value::number(k)));
     });
     register_builtin("table.insert", [](Interp &, const Values &a, Values &) {
         if (a.size() < 2 || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'insert' (table expected)");
-        Table &t = *a[0].tab;
+        Table &t = *a[0].tab();
         if (a.size() == 2) { t.set(Value::number((double)t.length() + 1), a[1]); return; }
         size_t pos = (size_t)argnum(a, 1, "insert");
         if (pos < 1 || pos > t.length() + 1) throw LuaError("bad argument #2 to 'insert' (position out of bounds)");
@@ -1438,14 +1464,14 @@ Interp::Interp(const MathLib &m) : math(&m)
     });
     register_builtin("error", [](Interp &I, const Values &a, Values &) { throw LuaError(a.empty() ? "nil" : I.tostring(a[0])); });
     register_builtin("select", [](Interp &, const Values &a, Values &r) {
-        if (!a.empty() && a[0].t == Value::STR && *a[0].s == "#") { r.push_back(Value::number((double)a.size() - 1)); return; }
+        if (!a.empty() && a[0].t == Value::STR && a[0].str() == "#") { r.push_back(Value::number((double)a.size() - 1)); return; }
         double n = argnum(a, 0, "select");
         if (n < 1) throw LuaError("bad argument #1 to 'select' (index out of range)");
         for (size_t i = (size_t)n; i < a.size(); ++i) r.push_back(a[i]);
     });
     register_builtin("next", [](Interp &, const Values &a, Values &r) {
         if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'next' (table expected)");
-        const Table &t = *a[0].tab;
+        const Table &t = *a[0].tab();
         const Value k = a.size() > 1 ? a[1] : Value();
         // order: array part, numeric hash, string hash
         size_t ai = 0;
@@ -1469,7 +1495,7 @@ Interp::Interp(const MathLib &m) : math(&m)
             return;
         }
         if (k.t == Value::STR) {
-            auto it = t.shash.find(*k.s);
+            auto it = t.shash.find(k.str());
             if (it != t.shash.end() && ++it != t.shash.end()) { r.push_back(Value::string(it->first)); r.push_back(it->second); return; }
         }
         r.push_back(Value());
@@ -1484,16 +1510,17 @@ Interp::Interp(const MathLib &m) : math(&m)
         if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'ipairs' (table expected)");
         Value it;
         it.t = Value::BUILTIN;
-        it.bi = std::make_shared<Builtin>();
-        it.bi->name = "ipairs_iter";
-        it.bi->fn = [](Interp &, const Values &x, Values &out) {
+        auto itb = std::make_shared<Builtin>();
+        itb->name = "ipairs_iter";
+        itb->fn = [](Interp &, const Values &x, Values &out) {
             double i = x[1].n + 1;
-            Value v = x[0].tab->get(Value::number(i));
+            Value v = x[0].tab()->get(Value::number(i));
             if (v.t == Value::NIL) { out.push_back(Value()); return; }
             out.push_back(Value::number(i));
             out.push_back(v);
         };
         (void)I;
+        it.p = std::move(itb);
         r.push_back(it);
         r.push_back(a[0]);
         r.push_back(Value::number(0));

@@ -110,28 +110,101 @@ int global_id(const std::string &name);     // process-wide number of a global n
 struct Table;
 struct Closure;
 struct Interp;
-struct Value;
-using Values = std::vector<Value>;
-using BuiltinFn = std::function<void(Interp &, const Values &args, Values &rets)>;
-struct Builtin { std::string name; BuiltinFn fn; };
+struct Builtin;
 
+// A Lua value: 32 bytes - tag, number / boolean, and ONE reference for the heap kinds (string, table, closure, builtin).
+// Numbers and booleans - nearly everything a lens callback touches - copy without touching a reference count.
 struct Value {
-    enum T { NIL, BOOL, NUM, STR, TABLE, FUNC, BUILTIN } t = NIL;
-    double n = 0;
+    enum T : uint8_t { NIL, BOOL, NUM, STR, TABLE, FUNC, BUILTIN } t = NIL;
     bool b = false;
-    std::shared_ptr<std::string> s;
-    std::shared_ptr<Table> tab;
-    std::shared_ptr<Closure> fn;
-    std::shared_ptr<Builtin> bi;
+    double n = 0;
+    std::shared_ptr<void> p;                // STR: std::string, TABLE: Table, FUNC: Closure, BUILTIN: Builtin
 
     static Value nil() { return Value(); }
     static Value boolean(bool v) { Value x; x.t = BOOL; x.b = v; return x; }
     static Value number(double v) { Value x; x.t = NUM; x.n = v; return x; }
-    static Value string(const std::string &v) { Value x; x.t = STR; x.s = std::make_shared<std::string>(v); return x; }
+    static Value string(const std::string &v) { Value x; x.t = STR; x.p = std::make_shared<std::string>(v); return x; }
+    static Value table(std::shared_ptr<Table> tp) { Value x; x.t = TABLE; x.p = std::move(tp); return x; }
+    static Value closure(std::shared_ptr<Closure> c) { Value x; x.t = FUNC; x.p = std::move(c); return x; }
+    static Value builtin(std::shared_ptr<Builtin> bp) { Value x; x.t = BUILTIN; x.p = std::move(bp); return x; }
+    const std::string &str() const { return *static_cast<const std::string *>(p.get()); }
+    Table *tab() const { return static_cast<Table *>(p.get()); }
+    Closure *fn() const { return static_cast<Closure *>(p.get()); }
+    Builtin *bi() const { return static_cast<Builtin *>(p.get()); }
+    std::shared_ptr<Table> tab_ptr() const { return std::static_pointer_cast<Table>(p); }
+    std::shared_ptr<Closure> fn_ptr() const { return std::static_pointer_cast<Closure>(p); }
+    std::shared_ptr<Builtin> bi_ptr() const { return std::static_pointer_cast<Builtin>(p); }
     bool truthy() const { return !(t == NIL || (t == BOOL && !b)); }
     bool is_function() const { return t == FUNC || t == BUILTIN; }
     const char *type_name() const;
 };
+
+// Argument / result lists: a vector with room for a few values inside the object - a callback evaluation makes
+// dozens of calls, and a heap allocation per argument list, result list and frame was most of its time.
+template <size_t kInline>
+class ValuesN {
+    using Values = ValuesN;
+public:
+    ValuesN() {}
+    ValuesN(std::initializer_list<Value> il) { reserve(il.size()); for (const Value &v : il) push_back(v); }
+    ValuesN(const Values &o) { reserve(o.n_); for (size_t i = 0; i < o.n_; ++i) new (data_ + i) Value(o.data_[i]); n_ = o.n_; }
+    ValuesN(Values &&o) noexcept { steal(o); }
+    Values &operator=(const Values &o) { if (this != &o) { clear(); reserve(o.n_); for (size_t i = 0; i < o.n_; ++i) new (data_ + i) Value(o.data_[i]); n_ = o.n_; } return *this; }
+    Values &operator=(Values &&o) noexcept { if (this != &o) { clear(); release(); steal(o); } return *this; }
+    ~ValuesN() { clear(); release(); }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    Value &operator[](size_t i) { return data_[i]; }
+    const Value &operator[](size_t i) const { return data_[i]; }
+    Value &back() { return data_[n_ - 1]; }
+    const Value &back() const { return data_[n_ - 1]; }
+    Value *begin() { return data_; }
+    Value *end() { return data_ + n_; }
+    const Value *begin() const { return data_; }
+    const Value *end() const { return data_ + n_; }
+    void clear() { for (size_t i = 0; i < n_; ++i) data_[i].~Value(); n_ = 0; }
+    void reserve(size_t want)
+    {
+        if (want <= cap_) return;
+        size_t cap = cap_ * 2 > want ? cap_ * 2 : want;
+        Value *nd = static_cast<Value *>(::operator new(cap * sizeof(Value)));
+        for (size_t i = 0; i < n_; ++i) { new (nd + i) Value(std::move(data_[i])); data_[i].~Value(); }
+        release();
+        data_ = nd;
+        cap_ = cap;
+    }
+    void push_back(const Value &v) { if (n_ == cap_) { Value tmp(v); reserve(n_ + 1); new (data_ + n_++) Value(std::move(tmp)); return; } new (data_ + n_++) Value(v); }
+    void push_back(Value &&v) { if (n_ == cap_) { Value tmp(std::move(v)); reserve(n_ + 1); new (data_ + n_++) Value(std::move(tmp)); return; } new (data_ + n_++) Value(std::move(v)); }
+    void resize(size_t n)
+    {
+        reserve(n);
+        while (n_ > n) data_[--n_].~Value();
+        while (n_ < n) new (data_ + n_++) Value();
+    }
+    void append(const Value *first, const Value *last) { reserve(n_ + (size_t)(last - first)); for (; first != last; ++first) new (data_ + n_++) Value(*first); }
+    void assign(const Value *first, const Value *last) { clear(); append(first, last); }
+
+private:
+    bool inlined() const { return data_ == reinterpret_cast<const Value *>(buf_); }
+    void release() { if (!inlined()) ::operator delete(data_); data_ = reinterpret_cast<Value *>(buf_); cap_ = kInline; }
+    void steal(Values &o)
+    {
+        if (o.inlined()) {
+            data_ = reinterpret_cast<Value *>(buf_); cap_ = kInline;
+            for (size_t i = 0; i < o.n_; ++i) { new (data_ + i) Value(std::move(o.data_[i])); o.data_[i].~Value(); }
+        } else { data_ = o.data_; cap_ = o.cap_; o.data_ = reinterpret_cast<Value *>(o.buf_); o.cap_ = kInline; }
+        n_ = o.n_;
+        o.n_ = 0;
+    }
+    alignas(Value) unsigned char buf_[kInline * sizeof(Value)];
+    Value *data_ = reinterpret_cast<Value *>(buf_);
+    size_t n_ = 0, cap_ = kInline;
+};
+using Values = ValuesN<4>;
+
+using BuiltinFn = std::function<void(Interp &, const Values &args, Values &rets)>;
+// a builtin; `f1` set: a one-argument math function (math.sin ...) the interpreter calls without building argument lists
+struct Builtin { std::string name; BuiltinFn fn; double (*MathLib::*f1)(double) = nullptr; };
 
 struct Table {
     std::vector<Value> arr;                 // t[1..n]
@@ -178,7 +251,7 @@ struct Interp {
     // upvalue cells are deep-copied (ASTs, strings and builtins are immutable and stay shared); `roots` are values
     // of this interpreter (e.g. the lens callbacks) whose counterparts in the copy are returned in roots_out.
     // print() in the copy is silent.
-    std::unique_ptr<Interp> clone(const std::vector<Value> &roots, std::vector<Value> *roots_out) const;
+    std::unique_ptr<Interp> clone(const Values &roots, Values *roots_out) const;
 };
 
 }  // namespace bklua

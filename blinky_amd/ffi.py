@@ -80,6 +80,7 @@ _SIGS = {
     "bk_set_apply_variant": (_i, [_vp, _i]),
     "bk_debug_module_from_cache": (_i, [_vp]),
     "bk_debug_set_option": (_i, [C.c_char_p, _i]),
+    "bk_debug_build_breakdown": (_i, [_vp, C.POINTER(_d)]),
     "bk_multi_lensmap_valid": (_i, [_vp]),
     "bk_last_build_ms": (_d, [_vp]),
     "bk_globe_pitch": (_i, [_vp]),
@@ -272,6 +273,11 @@ class Context:
         a, b = _i(), _i()
         self._chk(lib.bk_last_build_fixups(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def build_breakdown(self):
+        out = (_d * 4)()
+        self._chk(lib.bk_debug_build_breakdown(self._h, out))
+        return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]))
 
     def last_build_ms(self):
         return lib.bk_last_build_ms(self._h)

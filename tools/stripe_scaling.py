@@ -38,9 +38,15 @@ CONFIGS = {
 }
 
 
+SHAPE = 0          # --shape: force the block height (1 / 2 / 4 = 128x8 / 128x16 / 128x32), 0 = the cost model
+
+
 def time_stripe(globe, lens, zoom, W, H, F, rows, single):
     ring_max = 16 if W > 4000 else 32
     wl = bench.OneGpuWorkload(torch, blinky_amd, S, 0, globe, lens, zoom, W, H, F, rows=rows, ring_bytes=1.2e9 if W < 4000 else 3.0e9, ring_max=ring_max)
+    if SHAPE:
+        wl.ctx.set_tile_shape(SHAPE)
+        wl.tile_stats = wl.ctx.tile_stats()
     for i in range(3):
         wl.launch(i)
     launches = 30 if W < 4000 else 6
@@ -65,13 +71,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="panini4k,hammer4k,c5")
     ap.add_argument("--single", action="store_true", help="also time single-frame launches of every stripe")
+    ap.add_argument("--shape", type=int, default=0)
+    ap.add_argument("--ranks", default="1,2,4,8")
     args = ap.parse_args()
+    global SHAPE
+    SHAPE = args.shape
     print(f"# {torch.cuda.get_device_name(0)}; one GPU; every rank's stripe timed in turn; us per launch (HIP events, median of 5)")
     for name in args.configs.split(","):
         globe, lens, zoom, W, H, F, unmapped = CONFIGS[name]
         base = None
         for mode in (["equal", "balanced"] if unmapped else ["equal"]):
-            for n in (1, 2, 4, 8):
+            for n in [int(v) for v in args.ranks.split(',')]:
                 if mode == "balanced" and n == 1:
                     continue
                 bounds = [H * r // n for r in range(n + 1)] if mode == "equal" else balanced_bounds(globe, lens, zoom, W, H, n)
@@ -81,8 +91,8 @@ def main():
                     ts.append(t * 1e3)
                     t1s.append(t1 * 1e3 if t1 else 0.0)
                     shapes.append(f"128x{stats['tile_h'] % 1000}/{stats['lds_bytes_per_wave'] // 1024}K/{stats['tiles']}blk")
-                if n == 1:
-                    base = ts[0]
+                if base is None:
+                    base = ts[0] * n if n > 1 else ts[0]
                 worst = max(ts)
                 line = (f"{name:14s} {W}x{H} x{F} N={n} {mode:8s} slowest {worst:9.2f} us  fastest {min(ts):9.2f} us  "
                         f"predicted stripe_complete speed-up {base / worst:5.2f}x  ({W * H * F / worst:9.1f} Mpx/s)  per-rank us: "
