@@ -312,7 +312,7 @@ __device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict_
 
 // Frames of one staged block.  A thread's first four chunks (16 KiB per block) are in registers;
 // blocks with more read the rest of their list each frame (it stays in L2).
-template <int NQ, bool RUBIX, int RG>
+template <int NQ, bool RUBIX, int RG, bool DMA>
 __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
                                             int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
                                             uint8_t *buf, const uint32_t *__restrict__ blist,
@@ -344,16 +344,34 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
         if (NQ > 2) BK_COOP_LD(q2, gl_ + s2);                                                              \
         if (NQ > 3) BK_COOP_LD(q3, gl_ + s3);                                                              \
     } while (0)
-    if (pipe && f_begin < f_end) BK_COOP_LOADS(f_begin);
+    // DMA form (single-frame launches): the chunks go HBM -> LDS directly (global_load_lds_dwordx4: a wave-uniform LDS base
+    // + lane * 16 - exactly "list entry i -> slot i"), no staging registers, no ds_write pass; the barrier's fence waits for them
+    typedef __attribute__((address_space(3))) void *bk_lds_ptr;
+    typedef const __attribute__((address_space(1))) void *bk_glb_ptr;
+#define BK_COOP_DMA(SRC, SLOT0) __builtin_amdgcn_global_load_lds((bk_glb_ptr)(SRC), (bk_lds_ptr)(buf + ((SLOT0) + (threadIdx.x & ~63u)) * 16u), 16, 0, 0)
+    if (!DMA && pipe && f_begin < f_end) BK_COOP_LOADS(f_begin);
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
         uint8_t *mine = buf + threadIdx.x * 16u;
+        if (DMA) {
+            if (k0) BK_COOP_DMA(gl + s0, 0u);
+            if (NQ > 1 && k1) BK_COOP_DMA(gl + s1, 256u);
+            if (NQ > 2 && k2) BK_COOP_DMA(gl + s2, 512u);
+            if (NQ > 3 && k3) BK_COOP_DMA(gl + s3, 768u);
+            if (NQ > 3) {
+                for (uint32_t c0 = 1024; c0 < nchunks; c0 += 256) {
+                    const uint32_t c = c0 + threadIdx.x;
+                    if (c < nchunks) BK_COOP_DMA(gl + blist[c], c0);
+                }
+            }
+        } else {
         if (!pipe && !(kflags & 2)) BK_COOP_LOADS(f);
         if (k0) *reinterpret_cast<uint4 *>(mine) = q0;
         if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(mine + 4096) = q1;
         if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(mine + 8192) = q2;
         if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(mine + 12288) = q3;
-        if (NQ > 3) {
+        }
+        if (!DMA && NQ > 3) {
             for (uint32_t c0 = 1024; c0 < nchunks; c0 += 1024) {      // blocks above 16 KiB: rounds of four loads
                 const uint32_t c = c0 + threadIdx.x;
                 const bool m0 = c < nchunks, m1 = c + 256u < nchunks, m2 = c + 512u < nchunks, m3 = c + 768u < nchunks;
@@ -371,7 +389,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
             }
         }
         __syncthreads();                      // the block's chunks are in `buf`
-        if (pipe && f + 1 < f_end) BK_COOP_LOADS(f + 1);
+        if (!DMA && pipe && f + 1 < f_end) BK_COOP_LOADS(f + 1);
         if (tile_empty) { __syncthreads(); continue; }
         if (!RUBIX && fast_store) {
             uint32_t w[RG];
@@ -419,6 +437,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
 
 #undef BK_COOP_LOADS
 #undef BK_COOP_LD
+#undef BK_COOP_DMA
 
 // Frames of a block whose chunk list is larger than the launch's staging buffer: the list goes through
 // LDS in passes of lds_buf/16 chunks; a pixel picks its texel up in the pass that holds its slot and the packed
@@ -527,7 +546,7 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
 __device__ __forceinline__ int lane_of() { return (int)(threadIdx.x & 63u); }
 
 // everything a workgroup does for one block: `cur` holds the block's header and list head
-template <bool RUBIX, int RG>
+template <bool RUBIX, int RG, bool DMA = false>
 __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, const uint32_t *__restrict__ list,
                                            const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
                                            const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
@@ -559,7 +578,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
         const uint32_t s0 = k0 ? cur.c[0] : 0u, s1 = k1 ? cur.c[1] : 0u, s2 = k2 ? cur.c[2] : 0u, s3 = k3 ? cur.c[3] : 0u;
         const bool fast_store = tile_all && aligned;
         const uint32_t nq = (nchunks + 255u) >> 8;
-#define BK_COOP(NQ_) coop_frames<NQ_, RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, smem, \
+#define BK_COOP(NQ_) coop_frames<NQ_, RUBIX, RG, DMA>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, smem, \
                                                 list + (size_t)l * N, nchunks, s0, s1, s2, s3, k0, k1, k2, k3,                    \
                                                 ix, fast_store, tile_empty, pal_s, row0, x, kflags)
         if (nq <= 1) BK_COOP(1);
@@ -640,7 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // single frames): no next-block state, fewer registers, more workgroups per CU - every block starts at once
 // (8 waves per SIMD = 8 workgroups per CU: the 128x32 form would take 67 VGPRs and 7; at 4K that is 1792 places for 2040
 // blocks, and the 248 left over wait a whole block's latency for theirs - single frame 9.4 -> 8.4 us at <= 64 VGPRs)
-template <bool RUBIX, int RG>
+template <bool RUBIX, int RG, bool DMA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
@@ -655,8 +674,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         blk = bk_block_at(l, blocks_x, nblocks, kflags);
     }
     const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, blk);
-    coop_block<RUBIX, RG>(cur, blk, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
-                          dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
+    coop_block<RUBIX, RG, DMA>(cur, blk, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
+                               dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
 }
 
 // The live blocks in walk order, the eight band starts of equal cost, the workgroup -> block map of the one-block-per-workgroup
@@ -993,14 +1012,20 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     // (the block map's statistics arrive asynchronously: until they are here, the direct mapping)
     int kflags = ctx->apply_flags & ~BK_KF_WGMAP;
     if (once && !(kflags & (16 | 64)) && !cm->stats_pending && cm->stats[7]) kflags |= BK_KF_WGMAP;
+    const bool dma = fchunk == 1 && (kflags & 256) != 0;        // developer bit 256: LDS-DMA staging in single-frame launches
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
-#define BK_APPLY(RBX, N) do { if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
+#define BK_APPLY_KD(RBX, N) hipLaunchKernelGGL((apply_coop_once_kernel<RBX, N, true>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
+                                           cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
+                                           dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
+                                           ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
+#define BK_APPLY(RBX, N) do { if (once && dma) BK_APPLY_KD(RBX, N); else if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
     if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
     else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
 #undef BK_APPLY_K
+#undef BK_APPLY_KD
 #undef BK_APPLY
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;

@@ -847,6 +847,7 @@ namespace {
 
 struct Frame {
     Closure *cl;
+    bool any_captured = false;                     // (some local of this function lives in a shared cell)
     ValuesN<16> regs;                              // locals no inner function refers to
     std::vector<std::shared_ptr<Value>> cells;     // locals that closures capture (FuncProto::captured)
     Values varargs;
@@ -923,14 +924,14 @@ struct Exec {
 
     Value &local_cell(Frame &f, int slot)
     {
-        if (!f.cl->proto->is_captured(slot)) return f.regs[(size_t)slot];
+        if (!f.any_captured || !f.cl->proto->is_captured(slot)) return f.regs[(size_t)slot];
         if (!f.cells[slot]) f.cells[slot] = std::make_shared<Value>();
         return *f.cells[slot];
     }
     // a NEW variable in `slot` (a `local`, a loop variable of this iteration): closures made earlier keep the old cell
     static void fresh_local(Frame &f, int slot, const Value &v)
     {
-        if (f.cl->proto->is_captured(slot)) f.cells[slot] = std::make_shared<Value>(v);
+        if (f.any_captured && f.cl->proto->is_captured(slot)) f.cells[slot] = std::make_shared<Value>(v);
         else f.regs[(size_t)slot] = v;
     }
 
@@ -1073,6 +1074,27 @@ struct Exec {
         args->push_back(std::move(a));                                            // evaluated once: the generic path takes it from here
         return false;
     }
+    // a script function called with plain arguments: they are evaluated straight into the callee's frame
+    bool call_direct(Frame &f, const Expr &e, const Value &fn, Values *rets)
+    {
+        if (fn.t != Value::FUNC) return false;
+        Closure *cl = fn.fn();
+        const FuncProto *p = cl->proto;
+        if (p->is_vararg || !p->captured.empty()) return false;
+        if (!e.args.empty()) { const Expr &last = *e.args.back(); if (last.kind == Expr::Call || last.kind == Expr::Vararg) return false; }
+        if (I.depth > 180) throw LuaError("stack overflow (recursion too deep)");
+        Frame fr;
+        fr.cl = cl;
+        fr.regs.resize((size_t)p->nslots);
+        for (size_t i = 0; i < e.args.size(); ++i) {
+            Value v = eval(f, *e.args[i]);                     // (arguments beyond the parameters are evaluated and dropped)
+            if ((int)i < p->nparams) fr.regs[i] = std::move(v);
+        }
+        ++I.depth;
+        try { exec_block(fr, p->body, *rets); } catch (...) { --I.depth; throw; }
+        --I.depth;
+        return true;
+    }
     // a call of which only the first result is wanted
     Value eval_call1(Frame &f, const Expr &e)
     {
@@ -1080,6 +1102,10 @@ struct Exec {
         Value out;
         Values args;
         if (call_f1(f, e, fn, &out, &args)) return out;
+        if (args.empty()) {
+            Values r;
+            if (call_direct(f, e, fn, &r)) return r.empty() ? Value() : std::move(r[0]);
+        }
         if (args.empty()) args = eval_list(f, e.args);
         if (!fn.is_function()) not_callable(f, e, fn);
         Values r = I.call(fn, args);
@@ -1094,6 +1120,10 @@ struct Exec {
         Value out;
         Values args;
         if (call_f1(f, e, fn, &out, &args)) return Values{out};
+        if (args.empty()) {
+            Values r;
+            if (call_direct(f, e, fn, &r)) return r;
+        }
         if (args.empty()) args = eval_list(f, e.args);
         if (!fn.is_function()) not_callable(f, e, fn);
         return I.call(fn, args);
@@ -1347,7 +1377,10 @@ Values Interp::call(const Value &fv, const Values &args)
     Frame fr;
     fr.cl = fv.fn();
     fr.regs.resize((size_t)p->nslots);
-    if (!p->captured.empty()) fr.cells.resize((size_t)p->nslots);
+    if (!p->captured.empty()) {
+        fr.cells.resize((size_t)p->nslots);
+        for (char c : p->captured) fr.any_captured = fr.any_captured || c;
+    }
     for (int i = 0; i < p->nparams; ++i) {
         if (p->is_captured(i)) fr.cells[i] = std::make_shared<Value>((size_t)i < args.size() ? args[i] : Value());
         else if ((size_t)i < args.size()) fr.regs[(size_t)i] = args[i];

@@ -231,7 +231,8 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
         cost = bal["band_cost"]
         if bal["live_blocks"] >= 64:
             assert max(cost) <= 1.15 * (sum(cost) / 8), cost                # level to a block or two
-        for wgs, abl in ((1, 0), (1, 64), (2, 0), (16, 0), (16, 64), (16, 32), (16, 16)):
+        # (128: non-temporal globe loads; 256: LDS-DMA staging in single-frame launches - results must not change)
+        for wgs, abl in ((1, 0), (1, 64), (2, 0), (16, 0), (16, 64), (16, 32), (16, 16), (16, 128), (16, 256), (16, 384), (1, 256 + 64)):
             ctx.set_tile_shape(100 + wgs)
             ctx.set_ablation(abl)
             for nf in (1, F):
@@ -451,6 +452,17 @@ def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb):
                 want = np.full((H + 4, pitch), 77, np.uint8)
                 O.apply(off, tints, W, H, globes[(1 + f) % F], want, pitch, x0, y0, rubix, pal)
                 np.testing.assert_array_equal(got[f], want, err_msg=f"{kind} shape {shape} ldskb {ldskb} rubix {rubix} frame {f} stats {stats}")
+    # single-frame launches (the engine's call), also with the non-temporal globe loads (128) and the LDS-DMA staging (256)
+    for abl in (0, 128, 256, 384, 512):
+        ctx.set_ablation(abl)
+        for rubix in (False, True):
+            out = torch.full((1, H + 4, W + 5), 77, dtype=torch.uint8, device="cuda")
+            ctx.apply_device(out.data_ptr(), W + 5, (H + 4) * (W + 5), frame0=2, nframes=1, x0=3, y0=2, rubix_on=rubix, pal=pal)
+            torch.cuda.synchronize()
+            want = np.full((H + 4, W + 5), 77, np.uint8)
+            O.apply(off, tints, W, H, globes[2 % F], want, W + 5, 3, 2, rubix, pal)
+            np.testing.assert_array_equal(out.cpu().numpy()[0], want, err_msg=f"{kind} shape {shape} ldskb {ldskb} single frame, ablation {abl} rubix {rubix}")
+    ctx.set_ablation(0)
     if kind == "random" and (shape, ldskb) == (2, 1):
         assert stats["slow"] > 0            # 2048 chunks per block against a 1 KiB buffer: the fallback ran
     ctx.close()

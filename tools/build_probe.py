@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Developer probe: bk_build of given lenses at a size, several times - kernel + host fix-up breakdown
+(bk_debug_build_breakdown).  Also the target of the build-kernel counter passes (tools/pmc_build.sh).
+usage: python tools/build_probe.py [--lenses panini,hammer,quincuncial] [--size 3840x2160] [--reps 5]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import blinky_amd  # noqa: E402
+import scripts as S  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lenses", default="panini,hammer,quincuncial")
+    ap.add_argument("--size", default="3840x2160")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    W, H = [int(v) for v in args.size.split("x")]
+    for lens in args.lenses.split(","):
+        ctx = blinky_amd.Context()
+        S.configure(ctx, "cube", lens, "f_fov 180" if lens == "panini" else None, (W, H))
+        t0 = time.time()
+        ctx.build()
+        first = (time.time() - t0) * 1e3
+        walls, recs = [], []
+        for _ in range(args.reps):
+            t0 = time.time()
+            ctx.build()
+            walls.append((time.time() - t0) * 1e3)
+            recs.append(ctx.build_breakdown())
+        best = min(range(args.reps), key=lambda i: walls[i])
+        b = recs[best]
+        flagged, changed = ctx.last_build_fixups()
+        print(f"{lens:14s} {W}x{H} first {first:8.1f} ms | wall best {walls[best]:7.3f} median {sorted(walls)[len(walls) // 2]:7.3f} ms | "
+              f"device+fixup events {b['build_ms']:7.3f} ms, host re-evaluation {b['host_eval_ms']:7.3f} ms of it | flagged {flagged} changed {changed} "
+              f"| pool threads {b['pool_threads']}", flush=True)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,10 @@ if __name__ == "__main__":
         for p in sys.argv[2:]:
             pmc_sequence(p)
         sys.exit(0)
+    if sys.argv[1] == "--seq-like":           # --seq-like <pattern> <db>...
+        for p in sys.argv[3:]:
+            pmc_sequence(p, sys.argv[2])
+        sys.exit(0)
     kernel_table(sys.argv[1])
     for p in sys.argv[2:]:
         pmc_table(p)
