@@ -260,6 +260,14 @@ extern "C" int bk_set_apply_variant(bk_ctx *ctx, int variant)
     return BK_OK;
 }
 
+extern "C" int bk_set_blockmap_tuning(bk_ctx *ctx, int measured)
+{
+    if (!ctx) return BK_E_INVALID;
+    ctx->blockmap_tuning = measured != 0;
+    bk::coopmap_invalidate(ctx);
+    return BK_OK;
+}
+
 bk::DebugOptions bk::g_debug;
 #if BK_DEBUG_API
 extern "C" int bk_debug_set_option(const char *name, int value)

@@ -74,6 +74,7 @@ struct CoopMap {
     int blocks_x = 0, blocks_y = 0;
     int rg = 4;
     int lds_bytes = 0;              // bytes of the staging buffer of the apply launch
+    int tuned_frames = 0;           // frames per launch the block height was measured with (0 = cost model alone)
     uint32_t stats[BK_COOP_STATS] = {0};
     uint32_t *h_stats = nullptr;    // pinned [64][BK_COOP_STATS]: the full compile's statistics land here asynchronously ...
     hipEvent_t stats_ready = nullptr;   // ... and are folded into `stats` when somebody asks (coopmap_stats / traffic model)
@@ -800,6 +801,7 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
 }
 
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns);
+static int ensure_coopmap(bk_ctx *ctx, int launch_frames = 0);
 
 // the statistics of the last full compile, once somebody needs them (the apply launch itself does not)
 static int coop_stats_wait(bk_ctx *ctx, CoopMap *cm)
@@ -871,7 +873,9 @@ static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num
     return best_bin;
 }
 
-static int ensure_coopmap(bk_ctx *ctx)
+static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on);
+
+static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
 {
     if (!ctx->coopmap) ctx->coopmap = new CoopMap();
     CoopMap *cm = ctx->coopmap;
@@ -912,6 +916,8 @@ static int ensure_coopmap(bk_ctx *ctx)
     int cand[3] = {4, 2, 1}, ncand = 3;
     if (forced) { cand[0] = forced; ncand = 1; }
     int best_rg = cand[0], best_kb = 0;
+    int c_rg[3] = {0, 0, 0}, c_kb[3] = {0, 0, 0}, nc = 0;          // the candidates with the staging buffer the model gives each,
+    double c_cost[3] = {0, 0, 0};                                   // cheapest (by the model) first
     if (ncand > 1 || ctx->apply_lds_kb <= 0) {
         const int by_min = (rows + 31) / 32;
         // (every 8th row of blocks at 4K and above, every 2nd from 1080p up, everything below: the largest block decides the
@@ -923,7 +929,6 @@ static int ensure_coopmap(bk_ctx *ctx)
         BK_HIP(ctx, hipMemcpyAsync(cm->h_stats + 64 * BK_COOP_STATS, cm->d_stats + 64 * BK_COOP_STATS, (size_t)ncand * 64 * BK_COOP_STATS * sizeof(uint32_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
         BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        double best_cost = -1;
         for (int i = 0; i < ncand; ++i) {
             const int by = (rows + 8 * cand[i] - 1) / (8 * cand[i]), sampled = (by + stride - 1) / stride;
             // scale the sampled rows up to all rows (integer factor on the counts; the cost model is smooth in them)
@@ -931,28 +936,82 @@ static int ensure_coopmap(bk_ctx *ctx)
             fold_stats(cm->h_stats + (size_t)(1 + i) * 64 * BK_COOP_STATS, cm->stats, scale);
             double c = 0;
             const int kb = coop_choose_buffer(cm, cand[i], (double)ctx->W * rows, ctx->num_cus, &c);
-            if (g_debug.print_model) {       // developer: the cost model's inputs, one line per candidate
+            if (g_debug.print_model) {                    // developer: the cost model's inputs, one line per candidate
                 fprintf(stderr, "MODEL %dx%d rg %d kb %d cost %.1f maxchunks %u slow %u empty %u bins", ctx->W, rows, cand[i], kb, c, cm->stats[0],
                         cm->stats[1], cm->stats[2]);
                 for (int b = 0; b < (int)BK_COOP_BINS; ++b)
                     if (cm->stats[8 + b]) fprintf(stderr, " %d:%u:%u:%u", b, cm->stats[8 + b], cm->stats[8 + BK_COOP_BINS + b], cm->stats[8 + 2 * BK_COOP_BINS + b]);
                 fprintf(stderr, "\n");
             }
-            if (best_cost < 0 || c < best_cost) { best_cost = c; best_rg = cand[i]; best_kb = kb; }
+            int at = nc++;
+            while (at > 0 && c_cost[at - 1] > c) { c_rg[at] = c_rg[at - 1]; c_kb[at] = c_kb[at - 1]; c_cost[at] = c_cost[at - 1]; --at; }
+            c_rg[at] = cand[i]; c_kb[at] = kb; c_cost[at] = c;
         }
+        best_rg = c_rg[0]; best_kb = c_kb[0];
     }
-    if (ctx->apply_lds_kb > 0) best_kb = ctx->apply_lds_kb > BK_COOP_LDS_CAP / 1024 ? BK_COOP_LDS_CAP / 1024 : ctx->apply_lds_kb;   // developer knob
-    if (best_kb < 1) best_kb = 1;
-    cm->rg = best_rg;
-    cm->blocks_x = (ctx->W + 127) / 128;
-    cm->blocks_y = (rows + 8 * best_rg - 1) / (8 * best_rg);
-    cm->lds_bytes = best_kb * 1024;
-    if (int r = coop_compile_launch(ctx, cm, best_rg, 1, 0)) return r;
-    {
+    auto clamp_kb = [&](int kb) {
+        if (ctx->apply_lds_kb > 0) kb = ctx->apply_lds_kb > BK_COOP_LDS_CAP / 1024 ? BK_COOP_LDS_CAP / 1024 : ctx->apply_lds_kb;   // developer knob
+        return kb < 1 ? 1 : kb;
+    };
+    auto compile_full = [&](int rg, int kb) -> int {
+        cm->rg = rg;
+        cm->blocks_x = (ctx->W + 127) / 128;
+        cm->blocks_y = (rows + 8 * rg - 1) / (8 * rg);
+        cm->lds_bytes = clamp_kb(kb) * 1024;
+        if (int r = coop_compile_launch(ctx, cm, rg, 1, 0)) return r;
         const int nb = cm->blocks_x * cm->blocks_y;
         hipLaunchKernelGGL(coop_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, cm->d_cost, nb, cm->blocks_x, (nb + 7) / 8,
                            cm->d_order, cm->d_cum, cm->d_bands, cm->d_wgmap, cm->d_stats);
+        BK_HIP(ctx, hipGetLastError());
+        return BK_OK;
+    };
+    // MEASURED choice (bk_set_blockmap_tuning, on by default): the cost model ranks the block heights, but its picks miss by
+    // 10-17 % where the launch is small (1080p hammer / quincuncial: 128x8 beats the 128x16 it picks; which side wins also moves
+    // with how cold the globe ring is).  So the candidates the model puts within 30 % of its best are compiled in full and the very
+    // launch the caller is about to make - same frame count, the context's own globe - is timed on each; the fastest stays.
+    // A lensmap is built once per lens / zoom change and applied every frame: ~0.7 ms more here for up to 17 % per frame.
+    int measured = 0;
+    if (ctx->blockmap_tuning && !forced && nc > 1 && ctx->d_globe && !(ctx->apply_flags & (2 | 4))) {
+        int keep = 1;
+        while (keep < nc && c_cost[keep] <= 1.3 * c_cost[0]) ++keep;
+        if (keep > 1) {
+            const int nf = launch_frames > 0 ? (launch_frames < 16 ? launch_frames : 16) : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
+            uint8_t *scratch = nullptr;
+            hipEvent_t t0, t1;
+            BK_HIP(ctx, hipMallocAsync((void **)&scratch, (size_t)nf * rows * ctx->W, ctx->stream));
+            BK_HIP(ctx, hipEventCreate(&t0));
+            BK_HIP(ctx, hipEventCreate(&t1));
+            int rc = BK_OK, win = 0;
+            float best_ms = -1;
+            for (int i = 0; i < keep && rc == BK_OK; ++i) {
+                rc = compile_full(c_rg[i], c_kb[i]);
+                float ms_min = -1;
+                for (int rep = 0; rep < 3 && rc == BK_OK; ++rep) {            // one warm-up, two timed: the faster counts
+                    const int f0 = ctx->nframes > nf ? (rep * nf) % (ctx->nframes - nf + 1) : 0;
+                    if (hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
+                    if (rc == BK_OK) rc = launch_compiled(ctx, cm, f0, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
+                    float ms = 0;
+                    if (rc == BK_OK && (hipEventRecord(t1, ctx->stream) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
+                                        hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
+                        rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
+                    if (rep > 0 && (ms_min < 0 || ms < ms_min)) ms_min = ms;
+                }
+                if (g_debug.print_model) fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d: %.2f us\n", ctx->W, rows, nf, c_rg[i], c_kb[i], ms_min * 1e3);
+                if (rc == BK_OK && (best_ms < 0 || ms_min < best_ms)) { best_ms = ms_min; win = i; }
+                measured = i;
+            }
+            (void)hipEventDestroy(t0);
+            (void)hipEventDestroy(t1);
+            (void)hipFreeAsync(scratch, ctx->stream);
+            if (rc != BK_OK) return rc;
+            best_rg = c_rg[win]; best_kb = c_kb[win];
+            cm->tuned_frames = nf;
+            if (win == measured) measured = -1;           // the winner is what is compiled right now
+            else measured = 0;
+        }
     }
+    if (measured != -1)
+        if (int r = compile_full(best_rg, best_kb)) return r;
     BK_HIP(ctx, hipGetLastError());
     BK_HIP(ctx, hipMemcpyAsync(cm->h_stats, cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipEventRecord(cm->stats_ready, ctx->stream));
@@ -961,12 +1020,20 @@ static int ensure_coopmap(bk_ctx *ctx)
     return BK_OK;
 }
 
+static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on);
+
 int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on)
 {
     const int rows = ctx->rows();
     if (rows <= 0 || nframes <= 0) return BK_OK;
-    if (int r = ensure_coopmap(ctx)) return r;
-    CoopMap *cm = ctx->coopmap;
+    if (int r = ensure_coopmap(ctx, nframes)) return r;
+    return launch_compiled(ctx, ctx->coopmap, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
+}
+
+// the apply launch over an already compiled block map
+static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on)
+{
+    const int rows = ctx->rows();
     const int blocks_x = cm->blocks_x, nblocks = blocks_x * cm->blocks_y;
     // frames per block visit: 8, but a batch of 8..15 frames is split in two groups so that the grid has more
     // workgroups than one scheduling round holds (8 frames: 3.86 -> 3.70 us/frame)
@@ -1012,7 +1079,12 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
     // (the block map's statistics arrive asynchronously: until they are here, the direct mapping)
     int kflags = ctx->apply_flags & ~BK_KF_WGMAP;
     if (once && !(kflags & (16 | 64)) && !cm->stats_pending && cm->stats[7]) kflags |= BK_KF_WGMAP;
-    const bool dma = fchunk == 1 && (kflags & 256) != 0;        // developer bit 256: LDS-DMA staging in single-frame launches
+    // Single-frame launches fetch the globe chunks non-temporally: between two of them it is the block map L2 should keep
+    // (4K hammer 12.4 -> 11.6 us, quincuncial 12.8 -> 11.8, panini 8.4 -> 8.2); batch launches lose 3-10 % that way.
+    // LDS-DMA staging (bit 256) measured neutral (panini 8.39 -> 8.26, hammer 12.42 -> 12.41): the launch is bound by what
+    // crosses the fabric, not by the staging instructions - it stays a developer bit.  Bit 512 leaves both to the caller.
+    if (fchunk == 1 && !(kflags & 512)) kflags |= 128;
+    const bool dma = fchunk == 1 && (kflags & 256) != 0;
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \

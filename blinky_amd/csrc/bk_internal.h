@@ -97,11 +97,14 @@ struct bk_ctx {
     int apply_lds_kb = 0;            // coop apply: force the staging buffer size in KiB (0 = cost model; knob 400+n)
     int apply_fchunk = 0;            // frames a workgroup keeps a block for (0 = default 8; knob 300+n)
     int apply_wgs_per_cu = 16;       // persistent apply grid: workgroups per CU (tunable, bk_debug_set_tile_shape)
+    bool blockmap_tuning = true;     // bk_set_blockmap_tuning: block height of the staged apply chosen by timing the candidates
     int tile_shape = 0;              // coop apply: 0 = block height by cost model, 1/2/4 = force 128x8 / 128x16 / 128x32
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
     double last_host_eval_ms = 0;    // of that: wall time of the host re-evaluation of the flagged entries
+    double last_kernel_wall_ms = 0;  // inverse build: wall time of the kernel launch(es) + counter / flag-list read-back (sorted)
+    int last_kernel_retries = 0;     // kernel re-runs because the flag list had to grow
     bool async_compile = false;      // bk_set_async_compile: bk_build returns BK_PENDING instead of waiting for hiprtc
 
     int fail(int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)))

@@ -1058,7 +1058,8 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     bk::coopmap_invalidate(ctx);
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
     ctx->last_build_ms = 0;
-    ctx->last_host_eval_ms = 0;
+    ctx->last_host_eval_ms = ctx->last_kernel_wall_ms = 0;
+    ctx->last_kernel_retries = 0;
     ctx->last_flagged = ctx->last_changed = 0;
 
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
@@ -1103,15 +1104,18 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         if (P->info.map_type == BK_MAP_INVERSE) {
             if (!P->k_inverse) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_inverse (map = \"lens_inverse\" without the function)"); }
             BK_HIP_C(hipEventRecord(e0, ctx->stream));
+            const auto tk0 = std::chrono::steady_clock::now();
             for (;;) {
                 BK_HIP_C(hipModuleLaunchKernel(P->k_inverse, (unsigned)((ctx->W + 255) / 256), (unsigned)ctx->rows(), 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
                 BK_HIP_C(read_counters());
                 bool retry = false;
                 BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
                 if (!retry) break;
+                ++ctx->last_kernel_retries;
                 fill_params(ctx, &bp);                       // (the list moved)
                 BK_HIP_C(reset_counters());
             }
+            ctx->last_kernel_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count();
             // re-derive the flagged pixels on the host and patch the ones that differ
             std::vector<uint32_t> idx, voff;
             std::vector<uint8_t> vtint;
@@ -1339,13 +1343,15 @@ extern "C" int bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n,
 #endif
 
 #if BK_DEBUG_API
-extern "C" int bk_debug_build_breakdown(const bk_ctx *ctx, double out[4])
+extern "C" int bk_debug_build_breakdown(const bk_ctx *ctx, double out[6])
 {
     if (!ctx || !out) return BK_E_INVALID;
     out[0] = ctx->last_build_ms;
     out[1] = ctx->last_host_eval_ms;
     out[2] = (double)ctx->last_flagged;
     out[3] = (double)FixupPool::get().size();
+    out[4] = ctx->last_kernel_wall_ms;
+    out[5] = (double)ctx->last_kernel_retries;
     return BK_OK;
 }
 #endif

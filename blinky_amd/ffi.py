@@ -78,6 +78,7 @@ _SIGS = {
     "bk_get_size": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "bk_version": (C.c_char_p, []),
     "bk_set_apply_variant": (_i, [_vp, _i]),
+    "bk_set_blockmap_tuning": (_i, [_vp, _i]),
     "bk_debug_module_from_cache": (_i, [_vp]),
     "bk_debug_set_option": (_i, [C.c_char_p, _i]),
     "bk_debug_build_breakdown": (_i, [_vp, C.POINTER(_d)]),
@@ -275,9 +276,9 @@ class Context:
         return a.value, b.value
 
     def build_breakdown(self):
-        out = (_d * 4)()
+        out = (_d * 6)()
         self._chk(lib.bk_debug_build_breakdown(self._h, out))
-        return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]))
+        return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4], retries=int(out[5]))
 
     def last_build_ms(self):
         return lib.bk_last_build_ms(self._h)
@@ -338,6 +339,9 @@ class Context:
             pal = np.ascontiguousarray(pal, dtype=np.uint8)
         self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
                                       int(rubix_on), _ptr(pal)))
+
+    def set_blockmap_tuning(self, measured):
+        self._chk(lib.bk_set_blockmap_tuning(self._h, int(measured)))
 
     def set_ablation(self, bits):
         self._chk(lib.bk_debug_set_ablation(self._h, bits))

@@ -73,8 +73,9 @@ int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs,
  * doubles per tuple, nout the result count (-1 = a single nil, <= -100 = runtime error bits) */
 int         bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout);
 /* where the last bk_build's time went: out = {bk_last_build_ms (HIP events around the whole build: kernels + host fix-up),
- * wall ms of the host re-evaluation of the flagged entries inside it, flagged entries, worker threads of the fix-up pool} */
-int         bk_debug_build_breakdown(const bk_ctx *ctx, double out[4]);
+ * wall ms of the host re-evaluation of the flagged entries inside it, flagged entries, worker threads of the fix-up pool,
+ * wall ms of the inverse kernel launch(es) + read-back and sorting of the flag list, kernel re-runs because the list grew} */
+int         bk_debug_build_breakdown(const bk_ctx *ctx, double out[6]);
 /* bk_set_host_math(ctx, n >= 2), test mode: the host interpreter's libm becomes bkm.h with every inexact result moved
  * pseudo-randomly by up to 2^-n relative, standing in for "another libm" when the tests check the exactness flags
  * (tests/test_exactness_cpu.py); + 64 moves every result up by that amount instead, + 128 down. */

@@ -468,6 +468,36 @@ def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb):
     ctx.close()
 
 
+@pytest.mark.parametrize("lens,W,H", [("hammer", 1920, 1080), ("panini", 1280, 720)])
+def test_measured_block_height_changes_speed_not_pixels(bk, lens, W, H):
+    """bk_set_blockmap_tuning: with the block height chosen by timing the candidates (default) or by the cost model alone the
+    frames are the same bytes - single-frame and batch launches, after re-tuning for either"""
+    import torch
+    lm = O.lensmap("cube", lens, None, W, H)
+    F = 8
+    want = [O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, f), np.zeros((H, W), np.uint8)) for f in range(F)]
+    heights = {}
+    for measured in (1, 0):
+        for first in (1, F):                     # what the map is tuned for: the first launch after the build
+            ctx = make_ctx(bk, lm, nframes=F)
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.set_blockmap_tuning(measured)
+            for f in range(F):
+                for p in range(6):
+                    ctx.fill_plate_lcg(f, p, seed_frame=f)
+            ctx.set_lensmap(lm.offsets, lm.tints)
+            for nf in (first, F + 1 - first):
+                out = torch.zeros((nf, H, W), dtype=torch.uint8, device="cuda")
+                ctx.apply_device(out.data_ptr(), W, H * W, frame0=0, nframes=nf)
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                for f in range(nf):
+                    np.testing.assert_array_equal(got[f], want[f], err_msg=f"{lens} measured {measured} tuned for {first} frames, launch of {nf}, frame {f}")
+            heights[(measured, first)] = ctx.tile_stats()["tile_h"] % 1000
+            ctx.close()
+    assert all(h in (8, 16, 32) for h in heights.values()), heights
+
+
 def test_errors_are_reported_not_fatal(bk):
     ctx = bk.Context()
     with pytest.raises(bk.BlinkyError):

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--lenses", default="panini,hammer,quincuncial")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--host-entries", type=int, default=0)
     args = ap.parse_args()
     W, H = [int(v) for v in args.size.split("x")]
     for lens in args.lenses.split(","):
@@ -39,7 +40,17 @@ def main():
         flagged, changed = ctx.last_build_fixups()
         print(f"{lens:14s} {W}x{H} first {first:8.1f} ms | wall best {walls[best]:7.3f} median {sorted(walls)[len(walls) // 2]:7.3f} ms | "
               f"device+fixup events {b['build_ms']:7.3f} ms, host re-evaluation {b['host_eval_ms']:7.3f} ms of it | flagged {flagged} changed {changed} "
-              f"| pool threads {b['pool_threads']}", flush=True)
+              f"| kernel + read-back wall {b['kernel_wall_ms']:7.3f} ms, {b['retries']} retries | pool threads {b['pool_threads']}", flush=True)
+        if args.host_entries:
+            import numpy as np
+            ids = np.random.default_rng(1).integers(0, W * H, args.host_entries).astype(np.uint32)
+            ids.sort()
+            ts = []
+            for _ in range(3):
+                t0 = time.time()
+                ctx.host_entries(ids)
+                ts.append((time.time() - t0) * 1e3)
+            print(f"{'':14s} host re-evaluation of {args.host_entries} random pixels (bk_debug_host_entries, worker pool): best {min(ts):.3f} ms", flush=True)
         ctx.close()
 
 
