@@ -276,6 +276,7 @@ extern "C" int bk_debug_set_option(const char *name, int value)
     if (!strcmp(name, "no_memcache")) bk::g_debug.no_memcache = value;
     else if (!strcmp(name, "libm_rel_log2")) bk::g_debug.libm_rel_log2 = value;
     else if (!strcmp(name, "print_model")) bk::g_debug.print_model = value;
+    else if (!strcmp(name, "host_module")) bk::g_debug.host_module = value;
     else return BK_E_INVALID;
     return BK_OK;
 }

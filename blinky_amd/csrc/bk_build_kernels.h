@@ -53,6 +53,7 @@ BK_DEV unsigned int bk_padded_offset(const BkBuildParams &P, int plate, int px, 
     return bk_texel_offset((unsigned int)P.gp, (unsigned int)P.ph, (unsigned int)plate, (unsigned int)px, (unsigned int)py);
 }
 
+#ifndef BK_HOST_MODULE
 /* a pixel / corner / texel whose outcome the host has to re-derive on the platform libm */
 __device__ __forceinline__ void bk_push_flagged(const BkBuildParams &P, unsigned int id, unsigned int a, unsigned int b, unsigned int c)
 {
@@ -71,9 +72,53 @@ __device__ __forceinline__ void bk_publish_flags(const int *s_disp, int *display
     }
     if (serr) atomicOr(err, serr);
 }
+#endif
 
 #ifdef BK_HAS_INVERSE
-/* resume_lensmap_inverse + LUAtoC_lens_inverse + set_lensmap_from_ray (fisheye.c:2084-2124, 1545-1588, 1995-2013) */
+/* one pixel of resume_lensmap_inverse + LUAtoC_lens_inverse + set_lensmap_from_ray (fisheye.c:2084-2124, 1545-1588, 1995-2013):
+ * the lensmap entry of screen pixel (lx, ly) and the plate it shows (-1: none).  Shared by the build kernel and - compiled for
+ * the host against the platform libm - by the re-derivation of the flagged pixels (bk_hostmod_driver.inc). */
+BK_DEV void bk_inverse_entry(const BkBuildParams &P, BkState &S, int lx, int ly, unsigned int *off_out, unsigned char *tint_out, int *plate_out)
+{
+    unsigned int off = 0xFFFFFFFFu;
+    unsigned char tint = 255;
+    int shown = -1;
+    const double y = (double)(-(ly - P.H / 2)) * P.scale;     /* :2100, integer H/2 */
+    const double x = (double)(lx - P.W / 2) * P.scale;        /* :2105 */
+    bkv a[2] = {bk_num(x), bk_num(y)};
+    bkv r[BK_MAXRET];
+    const int n = LF_lens_inverse(S, a, 2, r);
+    if (n == 3 && bk_isnum(r[0]) && bk_isnum(r[1]) && bk_isnum(r[2])) {
+        float ray[3] = {bk_narrow(S, r[0].n, r[0].e), bk_narrow(S, r[1].n, r[1].e), bk_narrow(S, r[2].n, r[2].e)};   /* :1559-1561 */
+        bk_vector_normalize(ray);                                        /* :1562 */
+        const int plate = bk_ray_to_plate_index(S, ray);
+        /* from the float ray on, every step is an IEEE operation the reference performs identically */
+        if (plate >= 0) {
+            const BkPlateDev &p = P.plates[plate];
+            const double px_ = (double)bk_dot3(p.right, ray);            /* :2055-2057 */
+            const double py_ = (double)bk_dot3(p.up, ray);
+            const double pz_ = (double)bk_dot3(p.forward, ray);
+            const double u = px_ / pz_ * p.dist64 + 0.5;                 /* :2061 */
+            const double v = -py_ / pz_ * p.dist64 + 0.5;                /* :2062 */
+            if (u >= 0 && u <= 1 && v >= 0 && v <= 1) {                  /* :2065 */
+                const int px = bk_trunc_to_int(u * P.ps);                /* :1988 */
+                const int py = bk_trunc_to_int(v * P.ps);
+                if (px >= 0 && px < P.ps && py >= 0 && py < P.ps) {      /* :1971 */
+                    shown = plate;                                       /* :1976 */
+                    off = bk_padded_offset(P, plate, px, py);            /* :1979 */
+                    if (bk_offgrid(P, px, py)) tint = (unsigned char)plate;   /* :1959 */
+                }
+            }
+        }
+    } else if (!(n == 1 && r[0].t == BK_TNIL)) {
+        S.err |= BK_ERR_RESULT;                                          /* status -1  :1565-1584 */
+    }
+    *off_out = off;
+    *tint_out = tint;
+    *plate_out = shown;
+}
+
+#ifndef BK_HOST_MODULE
 extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams P)
 {
     __shared__ int s_disp[6];
@@ -84,40 +129,13 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
     const int ly = P.row0 + lyl;
     int err = 0;
     if (lx < P.W) {
-        unsigned int off = 0xFFFFFFFFu;
-        unsigned char tint = 255;
+        unsigned int off;
+        unsigned char tint;
+        int plate;
         BkState S;
         bk_state_init(S, &P);
-        const double y = (double)(-(ly - P.H / 2)) * P.scale;     /* :2100, integer H/2 */
-        const double x = (double)(lx - P.W / 2) * P.scale;        /* :2105 */
-        bkv a[2] = {bk_num(x), bk_num(y)};
-        bkv r[BK_MAXRET];
-        const int n = LF_lens_inverse(S, a, 2, r);
-        if (n == 3 && bk_isnum(r[0]) && bk_isnum(r[1]) && bk_isnum(r[2])) {
-            float ray[3] = {bk_narrow(S, r[0].n, r[0].e), bk_narrow(S, r[1].n, r[1].e), bk_narrow(S, r[2].n, r[2].e)};   /* :1559-1561 */
-            bk_vector_normalize(ray);                                        /* :1562 */
-            const int plate = bk_ray_to_plate_index(S, ray);
-            /* from the float ray on, every step is an IEEE operation the reference performs identically */
-            if (plate >= 0) {
-                const BkPlateDev &p = P.plates[plate];
-                const double px_ = (double)bk_dot3(p.right, ray);            /* :2055-2057 */
-                const double py_ = (double)bk_dot3(p.up, ray);
-                const double pz_ = (double)bk_dot3(p.forward, ray);
-                const double u = px_ / pz_ * p.dist64 + 0.5;                 /* :2061 */
-                const double v = -py_ / pz_ * p.dist64 + 0.5;                /* :2062 */
-                if (u >= 0 && u <= 1 && v >= 0 && v <= 1) {                  /* :2065 */
-                    const int px = bk_trunc_to_int(u * P.ps);                /* :1988 */
-                    const int py = bk_trunc_to_int(v * P.ps);
-                    if (px >= 0 && px < P.ps && py >= 0 && py < P.ps) {      /* :1971 */
-                        if (!S.flag) s_disp[plate] = 1;                      /* :1976 (a flagged pixel's plate is the host's to say) */
-                        off = bk_padded_offset(P, plate, px, py);            /* :1979 */
-                        if (bk_offgrid(P, px, py)) tint = (unsigned char)plate;   /* :1959 */
-                    }
-                }
-            }
-        } else if (!(n == 1 && r[0].t == BK_TNIL)) {
-            S.err |= BK_ERR_RESULT;                                          /* status -1  :1565-1584 */
-        }
+        bk_inverse_entry(P, S, lx, ly, &off, &tint, &plate);
+        if (plate >= 0 && !S.flag) s_disp[plate] = 1;    /* (a flagged pixel's plate is the host's to say) */
         err = S.err;
         const size_t o = (size_t)lyl * P.W + lx;
         P.offsets[o] = off;
@@ -128,23 +146,19 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
     bk_publish_flags(s_disp, P.display, err, P.err);
 }
 #endif
+#endif
 
 #ifdef BK_HAS_FORWARD
 /* uv_to_screen (fisheye.c:2227-2243) for every texel-corner of every plate:
  * corner (i,j), i,j in 0..ps, is (u,v) = ((i-0.5)/ps, (j-0.5)/ps) */
-extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildParams P)
+BK_DEV void bk_corner_entry(const BkBuildParams &P, BkState &S, long long id, int *sx_out, int *sy_out, unsigned char *ok_out)
 {
     const int n1 = P.ps + 1;
-    const long long total = (long long)P.numplates * n1 * n1;
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
     const int plate = (int)(id / ((long long)n1 * n1));
     const int rem = (int)(id - (long long)plate * n1 * n1);
     const int j = rem / n1, i = rem - j * n1;
     const double u = ((double)i - 0.5) / P.ps;
     const double v = ((double)j - 0.5) / P.ps;
-    BkState S;
-    bk_state_init(S, &P);
     float ray[3];
     bk_plate_uv_to_ray(P, plate, u, v, ray);
     bkv a[3] = {bk_num((double)ray[0]), bk_num((double)ray[1]), bk_num((double)ray[2])};
@@ -162,6 +176,38 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
     } else if (!(n == 1 && r[0].t == BK_TNIL)) {
         S.err |= BK_ERR_RESULT;
     }
+    *sx_out = sx;
+    *sy_out = sy;
+    *ok_out = ok;
+}
+
+/* forward build: does the ray through texel `id` select its own plate (fisheye.c:2193-2196) */
+BK_DEV bool bk_texel_owns(const BkBuildParams &P, BkState &S, long long id)
+{
+    const int plate = (int)(id / ((long long)P.ps * P.ps));
+    const int rem = (int)(id - (long long)plate * P.ps * P.ps);
+    const int py = rem / P.ps, px = rem - py * P.ps;
+    float ray[3];
+    bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
+    return plate == bk_ray_to_plate_index(S, ray);                              /* :2196 */
+}
+
+#endif
+
+/* ---- everything below is device-only (the host module of the flagged-entry re-derivation stops here) ---- */
+#ifndef BK_HOST_MODULE
+#ifdef BK_HAS_FORWARD
+extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildParams P)
+{
+    const int n1 = P.ps + 1;
+    const long long total = (long long)P.numplates * n1 * n1;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    BkState S;
+    bk_state_init(S, &P);
+    unsigned char ok;
+    int sx, sy;
+    bk_corner_entry(P, S, id, &sx, &sy, &ok);
     P.corner_xy[2 * id] = sx;
     P.corner_xy[2 * id + 1] = sy;
     P.corner_ok[id] = ok;
@@ -241,9 +287,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
         const int py = rem / P.ps, px = rem - py * P.ps;
         BkState S;
         bk_state_init(S, &P);
-        float ray[3];
-        bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
-        bool own = plate == bk_ray_to_plate_index(S, ray);                          /* :2196 */
+        bool own = bk_texel_owns(P, S, id);
 #ifdef BK_HAS_GLOBE_PLATE
         if (P.ovr_count) {                          /* second pass: the host's answers for the texels the first pass flagged */
             unsigned int lo = 0, hi = P.ovr_count;
@@ -341,3 +385,4 @@ extern "C" __global__ __launch_bounds__(256) void bk_eval_callback(BkBuildParams
     for (int k = 0; k < BK_MAXRET; ++k) out[(size_t)i * BK_MAXRET + k] = (k < m && r[k].t == BK_TNUM) ? r[k].n : __builtin_nan("");
     nout[i] = S.err ? -100 - S.err : (m == 1 && r[0].t == BK_TNIL) ? -1 : m;
 }
+#endif  /* !BK_HOST_MODULE */

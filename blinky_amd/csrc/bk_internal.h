@@ -21,7 +21,7 @@
 namespace bk {
 
 // process-wide developer / test switches (bk_debug_set_option, debug API builds only; always 0 otherwise)
-struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0; };
+struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0, host_module = 0; };
 extern DebugOptions g_debug;
 
 // A run of mapped pixels in one output row (host-side, for merging a warped
@@ -105,6 +105,7 @@ struct bk_ctx {
     double last_host_eval_ms = 0;    // of that: wall time of the host re-evaluation of the flagged entries
     double last_kernel_wall_ms = 0;  // inverse build: wall time of the kernel launch(es) + counter / flag-list read-back (sorted)
     int last_kernel_retries = 0;     // kernel re-runs because the flag list had to grow
+    bool last_fixup_compiled = false;   // the flagged entries were re-derived by the compiled host module (not the interpreter)
     bool async_compile = false;      // bk_set_async_compile: bk_build returns BK_PENDING instead of waiting for hiprtc
 
     int fail(int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)))

@@ -14,7 +14,11 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "bk_build_params.h"
@@ -24,6 +28,7 @@
 #include "bkm.h"
 
 using namespace bklua;
+extern char **environ;
 
 // a compiled lens module (or why there is none): what the memory cache, the disk cache or hiprtc hands back
 struct CodeResult {
@@ -548,6 +553,165 @@ static CodeResult compile_code(const std::string &source, const std::string &arc
     return r;
 }
 
+
+// ---- host module: the generated lens code compiled for the HOST ----------------------------------------------------
+// The entries a build flags are re-derived on the platform libm.  The script interpreter does that at 4-10 us per entry;
+// the very translation unit hiprtc receives, compiled by the system's C++ compiler against the platform libm
+// (bk_hostmod_bkm.h in place of bkm.h, bk_hostmod_driver.inc appended) and dlopen'ed, does it in a fraction of a
+// microsecond - the same per-entry functions the kernels call, the same IEEE operations in the same order, libm calls
+// resolved in this process's libm.  The compiler runs on another thread and its output is cached next to the device code
+// objects; until it is there (or if the machine has no compiler) the interpreter answers, so nothing ever waits for it and
+// results are the same either way (tests/test_hostmod.py holds the two against each other entry for entry).
+struct HostModule {
+    void *dl = nullptr;
+    void (*inverse)(const BkBuildParams *, const unsigned int *, int, unsigned long, unsigned int *, unsigned char *, int *, int *) = nullptr;
+    void (*corners)(const BkBuildParams *, const unsigned int *, int, unsigned long, int *, int *, unsigned char *, int *) = nullptr;
+    void (*texel_owns)(const BkBuildParams *, const unsigned int *, int, unsigned long, unsigned char *) = nullptr;
+    ~HostModule() { if (dl) dlclose(dl); }
+};
+using HostModuleP = std::shared_ptr<HostModule>;
+
+static std::mutex g_hostmod_mutex;
+static std::map<uint64_t, HostModuleP> g_hostmods;                          // ready (nullptr = failed: do not try again)
+static std::map<uint64_t, std::shared_future<HostModuleP>> g_hostmod_jobs;  // compiling
+static int g_hostmod_enabled = 1;                                           // bk_set_host_compile
+
+extern "C" int bk_set_host_compile(int on)
+{
+    std::lock_guard<std::mutex> lock(g_hostmod_mutex);
+    g_hostmod_enabled = on != 0;
+    return BK_OK;
+}
+
+// the C++ compiler to run: $BLINKY_HIP_HOSTCXX ("off" / "" = none), else the first of c++ / g++ / clang++ on $PATH, else ROCm's clang
+static std::string host_compiler()
+{
+    auto on_path = [](const char *name) -> std::string {
+        const char *path = getenv("PATH");
+        if (!path) return std::string();
+        std::string p(path);
+        for (size_t b = 0; b <= p.size();) {
+            size_t e = p.find(':', b);
+            if (e == std::string::npos) e = p.size();
+            const std::string cand = p.substr(b, e - b) + "/" + name;
+            if (e > b && access(cand.c_str(), X_OK) == 0) return cand;
+            b = e + 1;
+        }
+        return std::string();
+    };
+    if (const char *e = getenv("BLINKY_HIP_HOSTCXX")) {
+        if (!*e || !strcmp(e, "off")) return std::string();
+        if (strchr(e, '/')) return access(e, X_OK) == 0 ? std::string(e) : std::string();
+        return on_path(e);
+    }
+    for (const char *name : {"c++", "g++", "clang++"}) { std::string c = on_path(name); if (!c.empty()) return c; }
+    for (const char *abs : {"/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/bin/amdclang++"}) if (access(abs, X_OK) == 0) return abs;
+    return std::string();
+}
+
+static const char *embedded_text(const char *name)
+{
+    for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) if (!strcmp(bk::kEmbeddedHeaders[i].name, name)) return bk::kEmbeddedHeaders[i].text;
+    return "";
+}
+
+static HostModuleP load_host_module(const std::string &so)
+{
+    void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return nullptr;
+    HostModuleP m = std::make_shared<HostModule>();
+    m->dl = dl;
+    auto abi = (int (*)(void))dlsym(dl, "bk_hostmod_abi");
+    m->inverse = (decltype(m->inverse))dlsym(dl, "bk_hostmod_inverse");
+    m->corners = (decltype(m->corners))dlsym(dl, "bk_hostmod_corners");
+    m->texel_owns = (decltype(m->texel_owns))dlsym(dl, "bk_hostmod_texel_owns");
+    if (!abi || abi() != 3 + (int)sizeof(BkBuildParams) * 16 || !m->inverse || !m->corners || !m->texel_owns) return nullptr;
+    return m;
+}
+
+static bool write_text(const std::string &path, const std::string &text)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+    fclose(f);
+    return ok;
+}
+
+// compile `source` for the host with `cxx`; the shared object ends up at `so_path` (atomically)
+static HostModuleP compile_host_module(const std::string &source, const std::string &cxx, const std::string &so_path)
+{
+    const std::string dir = so_path + ".build" + std::to_string((long long)getpid());
+    make_dirs(dir);
+    bool ok = write_text(dir + "/bkm.h", embedded_text("bk_hostmod_bkm.h"));
+    for (const char *h : {"bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h"}) ok = ok && write_text(dir + "/" + h, embedded_text(h));
+    const std::string unit = std::string("#define BK_HOST_MODULE 1\n#define __device__\n#define __forceinline__ inline\n") + source + "\n" +
+                             embedded_text("bk_hostmod_driver.inc");
+    ok = ok && write_text(dir + "/unit.cpp", unit);
+    HostModuleP m;
+    if (ok) {
+        const std::string out = dir + "/unit.so", inc = "-I" + dir, src = dir + "/unit.cpp";
+        const char *argv[] = {cxx.c_str(), "-O2", "-std=c++17", "-ffp-contract=off", "-fno-builtin", "-fno-fast-math", "-fPIC", "-shared", "-w",
+                              inc.c_str(), "-o", out.c_str(), src.c_str(), nullptr};
+        pid_t pid = 0;
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+        posix_spawn_file_actions_addopen(&fa, 2, "/dev/null", O_WRONLY, 0);
+        int status = -1;
+        if (posix_spawn(&pid, cxx.c_str(), &fa, nullptr, const_cast<char *const *>(argv), environ) == 0) {
+            while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+        }
+        posix_spawn_file_actions_destroy(&fa);
+        if (status == 0 && rename(out.c_str(), so_path.c_str()) == 0) m = load_host_module(so_path);
+    }
+    for (const char *f : {"bkm.h", "bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h", "unit.cpp", "unit.so"}) remove((dir + "/" + f).c_str());
+    rmdir(dir.c_str());
+    return m;
+}
+
+// the host module for this generated source: ready -> returned; otherwise a compile is started (once) and nullptr returned,
+// unless `wait`.  Never throws; nullptr simply means "use the interpreter".
+static HostModuleP host_module_for(const std::string &source, bool wait)
+{
+    uint64_t key = fnv1a64(source.data(), source.size());                  // (source + everything it is compiled with)
+    for (const char *h : {"bk_hostmod_bkm.h", "bk_hostmod_driver.inc", "bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h"}) {
+        const char *t = embedded_text(h);
+        key = fnv1a64(t, strlen(t), key);
+    }
+    std::shared_future<HostModuleP> job;
+    {
+        std::lock_guard<std::mutex> lock(g_hostmod_mutex);
+        if (!g_hostmod_enabled) return nullptr;
+        auto hit = g_hostmods.find(key);
+        if (hit != g_hostmods.end()) return hit->second;
+        auto running = g_hostmod_jobs.find(key);
+        if (running != g_hostmod_jobs.end()) job = running->second;
+        else {
+            const std::string cxx = host_compiler();
+            if (cxx.empty()) { g_hostmods[key] = nullptr; return nullptr; }
+            std::string dir = cache_dir();                                  // next to the device code objects, or a per-user temp dir
+            if (dir.empty()) dir = "/tmp/blinky_hip_hostmod." + std::to_string((long long)getuid());
+            char name[64];
+            snprintf(name, sizeof name, "/bk_host_%016llx.so", (unsigned long long)fnv1a64(cxx.data(), cxx.size(), key));
+            const std::string so = dir + name;
+            if (access(so.c_str(), R_OK) == 0) {
+                HostModuleP m = load_host_module(so);
+                if (m) { g_hostmods[key] = m; return m; }
+            }
+            make_dirs(dir);
+            job = std::async(std::launch::async, [source, cxx, so]() { return compile_host_module(source, cxx, so); }).share();
+            g_hostmod_jobs[key] = job;
+        }
+    }
+    if (!wait && job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return nullptr;
+    HostModuleP m = job.get();
+    std::lock_guard<std::mutex> lock(g_hostmod_mutex);
+    g_hostmods[key] = m;
+    g_hostmod_jobs.erase(key);
+    return m;
+}
+
 static std::string target_arch(bk_ctx *ctx)
 {
     hipDeviceProp_t prop;
@@ -983,21 +1147,23 @@ void sort_flagged(std::vector<uint32_t> &rec)
 template <typename Fn>
 void for_each_flagged(LensProgram *P, size_t n, Fn fn)
 {
-    HostEval main_eval{&P->interp, P->lens_inverse, P->lens_forward, P->globe_plate};
-    if (n < 256) {
-        for (size_t i = 0; i < n; ++i) fn(main_eval, i);
-        return;
-    }
-    FixupPool &pool = FixupPool::get();
-    const size_t nthreads = std::max<size_t>(1, std::min(pool.size(), n / 96));
+    // (never on the context's own interpreter: a callback that assigns script globals - fahey's `lat`, `lon` - would leave them
+    //  changed, the next build's generated source would carry different initial values for them, and the lens would go through
+    //  hiprtc again for nothing: the 490 ms second build of fahey in round 2's tables)
+    const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
+    FixupPool *pool_p = n >= 256 ? &FixupPool::get() : nullptr;
+    const size_t nthreads = pool_p ? std::max<size_t>(1, std::min(pool_p->size(), n / 96)) : 1;
     if (nthreads <= 1) {
-        for (size_t i = 0; i < n; ++i) fn(main_eval, i);
+        Values roots;
+        std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
+        HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
+        for (size_t i = 0; i < n; ++i) fn(ev, i);
         return;
     }
+    FixupPool &pool = *pool_p;
     const size_t run = std::max<size_t>(32, std::min<size_t>(2048, n / (nthreads * 6)));
     std::atomic<size_t> next{0};
     std::vector<std::string> errors(nthreads);
-    const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
     pool.run(nthreads, [&](size_t t) {
         try {
             // every worker copies the interpreter for itself (the original is only read meanwhile)
@@ -1014,7 +1180,35 @@ void for_each_flagged(LensProgram *P, size_t n, Fn fn)
     for (const std::string &e : errors) if (!e.empty()) throw LuaError(e);
 }
 
+/* call(first, count) over [0, n) in runs of consecutive entries, on a few pool workers: the compiled host module answers an
+ * entry in a fraction of a microsecond, so a handful of threads is plenty */
+template <typename Call>
+void hostmod_runs(size_t n, Call call)
+{
+    const size_t run = 512;
+    FixupPool &pool = FixupPool::get();
+    const size_t nthreads = n < 2 * run ? 1 : std::min<size_t>(std::min<size_t>(pool.size(), (n + run - 1) / run), 48);
+    if (nthreads <= 1) { if (n) call((size_t)0, n); return; }
+    std::atomic<size_t> next{0};
+    pool.run(nthreads, [&](size_t) {
+        for (;;) {
+            const size_t i0 = next.fetch_add(run, std::memory_order_relaxed);
+            if (i0 >= n) break;
+            call(i0, std::min(run, n - i0));
+        }
+    });
+}
+
 }  // namespace
+
+/* the compiled host module to re-derive flagged entries with, or nullptr: the interpreter does it (host math switched away
+ * from the platform libm, no compiler on this machine, still compiling, switched off) */
+static HostModuleP fixup_module(LensProgram *P, const std::string &source)
+{
+    if (bk::g_debug.host_module == 2) return nullptr;
+    if (P->interp.math != &math_platform()) return nullptr;
+    return host_module_for(source, bk::g_debug.host_module == 1);
+}
 
 // the flag list a kernel just filled: grows the list and reports `retry` when it overflowed
 static int read_flagged(bk_ctx *ctx, unsigned int count, std::vector<uint32_t> *list, bool *retry)
@@ -1060,6 +1254,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     ctx->last_build_ms = 0;
     ctx->last_host_eval_ms = ctx->last_kernel_wall_ms = 0;
     ctx->last_kernel_retries = 0;
+    ctx->last_fixup_compiled = false;
     ctx->last_flagged = ctx->last_changed = 0;
 
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
@@ -1125,7 +1320,12 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 std::vector<uint8_t> rtint(nfl);
                 std::vector<int> rshown(nfl), rerr(nfl, 0);
                 const auto th0 = std::chrono::steady_clock::now();
-                for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
+                const HostModuleP hm = nfl ? fixup_module(P, src) : nullptr;
+                ctx->last_fixup_compiled = hm != nullptr;
+                if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) {
+                    hm->inverse(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &roff[i0], &rtint[i0], &rshown[i0], &rerr[i0]);
+                });
+                else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
                     h_inverse_entry(E, bp, flagged[4 * i], &roff[i], &rtint[i], &rshown[i], &rerr[i]);
                 });
                 ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
@@ -1174,7 +1374,12 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 std::vector<int> rsx(nfl), rsy(nfl), rerr(nfl, 0);
                 std::vector<uint8_t> rok(nfl);
                 const auto th0 = std::chrono::steady_clock::now();
-                for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
+                const HostModuleP hm = nfl ? fixup_module(P, src) : nullptr;
+                ctx->last_fixup_compiled = hm != nullptr;
+                if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) {
+                    hm->corners(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &rsx[i0], &rsy[i0], &rok[i0], &rerr[i0]);
+                });
+                else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
                     h_corner_entry(ctx, E, bp, flagged[4 * i], &rsx[i], &rsy[i], &rok[i], &rerr[i]);
                 });
                 ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
@@ -1215,7 +1420,9 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                     std::vector<std::pair<uint32_t, uint32_t>> ans;
                     const size_t nfl = flagged.size() / 4;
                     std::vector<uint8_t> rown(nfl);
-                    for_each_flagged(P, nfl, [&](HostEval &E, size_t i) { rown[i] = h_texel_owns(ctx, E, bp, flagged[4 * i]) ? 1 : 0; });
+                    const HostModuleP hm = fixup_module(P, src);
+                    if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) { hm->texel_owns(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &rown[i0]); });
+                    else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) { rown[i] = h_texel_owns(ctx, E, bp, flagged[4 * i]) ? 1 : 0; });
                     for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
                         const bool own = rown[k / 4] != 0;
                         if ((own ? 1u : 0u) != flagged[k + 1]) { again = true; ++ctx->last_changed; }
@@ -1303,7 +1510,12 @@ extern "C" int bk_debug_host_entries(bk_ctx *ctx, const uint32_t *ids, size_t n,
     for (size_t i = 0; i < n; ++i) if (ids[i] >= px) return ctx->fail(BK_E_INVALID, "bk_debug_host_entries: index out of range");
     std::vector<int> shown(n), err(n, 0);
     try {
-        for_each_flagged(P, n, [&](HostEval &E, size_t i) { h_inverse_entry(E, bp, ids[i], &offsets[i], &tints[i], &shown[i], &err[i]); });
+        std::string src;
+        HostModuleP hm;
+        if (bk::g_debug.host_module != 2 && generate_source(ctx, P, &src) == BK_OK) hm = fixup_module(P, src);
+        if (bk::g_debug.host_module == 1 && !hm) return ctx->fail(BK_E_STATE, "bk_debug_host_entries: no host module (no C++ compiler, or host math is not the platform libm)");
+        if (hm) hostmod_runs(n, [&](size_t i0, size_t cnt) { hm->inverse(&bp, &ids[i0], 1, (unsigned long)cnt, &offsets[i0], &tints[i0], &shown[i0], &err[i0]); });
+        else for_each_flagged(P, n, [&](HostEval &E, size_t i) { h_inverse_entry(E, bp, ids[i], &offsets[i], &tints[i], &shown[i], &err[i]); });
     } catch (const LuaError &e) {
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }
@@ -1333,7 +1545,12 @@ extern "C" int bk_debug_host_corners(bk_ctx *ctx, const uint32_t *ids, size_t n,
     for (size_t i = 0; i < n; ++i) if (ids[i] >= total) return ctx->fail(BK_E_INVALID, "bk_debug_host_corners: index out of range");
     std::vector<int> err(n, 0), x(n), y(n);
     try {
-        for_each_flagged(P, n, [&](HostEval &E, size_t i) { h_corner_entry(ctx, E, bp, ids[i], &x[i], &y[i], &ok[i], &err[i]); });
+        std::string src;
+        HostModuleP hm;
+        if (bk::g_debug.host_module != 2 && generate_source(ctx, P, &src) == BK_OK) hm = fixup_module(P, src);
+        if (bk::g_debug.host_module == 1 && !hm) return ctx->fail(BK_E_STATE, "bk_debug_host_corners: no host module (no C++ compiler, or host math is not the platform libm)");
+        if (hm) hostmod_runs(n, [&](size_t i0, size_t cnt) { hm->corners(&bp, &ids[i0], 1, (unsigned long)cnt, &x[i0], &y[i0], &ok[i0], &err[i0]); });
+        else for_each_flagged(P, n, [&](HostEval &E, size_t i) { h_corner_entry(ctx, E, bp, ids[i], &x[i], &y[i], &ok[i], &err[i]); });
     } catch (const LuaError &e) {
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }
@@ -1351,10 +1568,23 @@ extern "C" int bk_debug_build_breakdown(const bk_ctx *ctx, double out[6])
     out[2] = (double)ctx->last_flagged;
     out[3] = (double)FixupPool::get().size();
     out[4] = ctx->last_kernel_wall_ms;
-    out[5] = (double)ctx->last_kernel_retries;
+    out[5] = (double)ctx->last_kernel_retries + (ctx->last_fixup_compiled ? 1000.0 : 0.0);
     return BK_OK;
 }
 #endif
+
+/* Is the compiled host module of the current lens + globe there (see bk_set_host_compile)?  wait != 0: compile it now if need
+ * be and wait for it.  1 = ready, 0 = not (still compiling, no compiler, switched off, host math not the platform libm). */
+extern "C" int bk_host_module_ready(bk_ctx *ctx, int wait)
+{
+    if (!ctx) return 0;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid || !ctx->globe_valid || P->info.map_type == BK_MAP_NONE) return 0;
+    if (P->interp.math != &math_platform()) return 0;
+    std::string src;
+    if (generate_source(ctx, P, &src) != BK_OK) return 0;
+    return host_module_for(src, wait != 0) ? 1 : 0;
+}
 
 extern "C" int bk_last_build_fixups(const bk_ctx *ctx, int *flagged, int *changed)
 {

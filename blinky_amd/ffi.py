@@ -79,6 +79,8 @@ _SIGS = {
     "bk_version": (C.c_char_p, []),
     "bk_set_apply_variant": (_i, [_vp, _i]),
     "bk_set_blockmap_tuning": (_i, [_vp, _i]),
+    "bk_set_host_compile": (_i, [_i]),
+    "bk_host_module_ready": (_i, [_vp, _i]),
     "bk_debug_module_from_cache": (_i, [_vp]),
     "bk_debug_set_option": (_i, [C.c_char_p, _i]),
     "bk_debug_build_breakdown": (_i, [_vp, C.POINTER(_d)]),
@@ -278,7 +280,8 @@ class Context:
     def build_breakdown(self):
         out = (_d * 6)()
         self._chk(lib.bk_debug_build_breakdown(self._h, out))
-        return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4], retries=int(out[5]))
+        return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4],
+                    retries=int(out[5]) % 1000, compiled_host_module=out[5] >= 1000)
 
     def last_build_ms(self):
         return lib.bk_last_build_ms(self._h)
@@ -339,6 +342,9 @@ class Context:
             pal = np.ascontiguousarray(pal, dtype=np.uint8)
         self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
                                       int(rubix_on), _ptr(pal)))
+
+    def host_module_ready(self, wait=False):
+        return bool(lib.bk_host_module_ready(self._h, int(wait)))
 
     def set_blockmap_tuning(self, measured):
         self._chk(lib.bk_set_blockmap_tuning(self._h, int(measured)))

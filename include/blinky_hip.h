@@ -281,6 +281,15 @@ int         bk_set_apply_variant(bk_ctx *ctx, int variant);
 int         bk_set_blockmap_tuning(bk_ctx *ctx, int measured);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */
 double      bk_last_build_ms(const bk_ctx *ctx);
+/* The entries a build flags (results that hinge on the platform libm's last bits) are re-derived on the host: by the script
+ * interpreter, or - when the machine has a C++ compiler - by the generated lens code itself compiled for the host and loaded
+ * with dlopen (a fraction of a microsecond per entry instead of 4-10 us).  The compiler ($BLINKY_HIP_HOSTCXX, else c++ / g++ /
+ * clang++ on $PATH, else ROCm's clang; "off" = none) runs on another thread, its output is cached beside the device code
+ * objects (bk_set_cache_dir); until it is there the interpreter answers - same results either way.
+ * bk_set_host_compile(0) switches the mechanism off for the process.  bk_host_module_ready: 1 when the current lens + globe's
+ * module is loaded; with wait != 0 it is compiled now if need be. */
+int         bk_set_host_compile(int on);
+int         bk_host_module_ready(bk_ctx *ctx, int wait);
 /* host-side script arithmetic (chunk execution, calc_zoom, globe loading, re-derivation of flagged pixels): 0 = the
  * platform libm, which is what the reference's Lua VM calls (default: scale, lens_width, plates bit-identical to the
  * reference on the same machine); 1 = the portable bkm.h functions the GPU kernels use.  (Values >= 2 select the

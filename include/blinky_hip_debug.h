@@ -19,6 +19,8 @@ extern "C" {
  *   "libm_rel_log2"      n in 8..52: generate the build kernels with the assumed libm discrepancy 2^-n instead of 2^-50
  *                        (paired with bk_set_host_math(ctx, n): the flag -> host fix-up path on thousands of pixels)
  *   "print_model"        != 0: the block-shape cost model prints its inputs to stderr, one line per candidate
+ *   "host_module"        1: flagged entries are re-derived by the compiled host module only (it is waited for; an error if
+ *                        there is none), 2: by the script interpreter only; 0: whichever is there (the default)
  * returns BK_E_INVALID for an unknown name */
 int         bk_debug_set_option(const char *name, int value);
 /* bk_debug_module_from_cache: 1 if the current module was loaded from the disk cache (test hook; BLINKY_HIP_NO_MEMCACHE
@@ -74,7 +76,8 @@ int         bk_debug_eval(bk_ctx *ctx, int which, const double *args, int nargs,
 int         bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, int nargs, int n, double *out, int *nout);
 /* where the last bk_build's time went: out = {bk_last_build_ms (HIP events around the whole build: kernels + host fix-up),
  * wall ms of the host re-evaluation of the flagged entries inside it, flagged entries, worker threads of the fix-up pool,
- * wall ms of the inverse kernel launch(es) + read-back and sorting of the flag list, kernel re-runs because the list grew} */
+ * wall ms of the inverse kernel launch(es) + read-back and sorting of the flag list, kernel re-runs because the list grew
+ * (+ 1000 when the compiled host module did the re-evaluation)} */
 int         bk_debug_build_breakdown(const bk_ctx *ctx, double out[6]);
 /* bk_set_host_math(ctx, n >= 2), test mode: the host interpreter's libm becomes bkm.h with every inexact result moved
  * pseudo-randomly by up to 2^-n relative, standing in for "another libm" when the tests check the exactness flags

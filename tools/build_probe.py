@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--host-entries", type=int, default=0)
+    ap.add_argument("--no-host-module", action="store_true", help="do not wait for the compiled host module: the interpreter re-derives")
     args = ap.parse_args()
     W, H = [int(v) for v in args.size.split("x")]
     for lens in args.lenses.split(","):
@@ -29,6 +30,9 @@ def main():
         t0 = time.time()
         ctx.build()
         first = (time.time() - t0) * 1e3
+        t0 = time.time()
+        have_module = ctx.host_module_ready(wait=not args.no_host_module)       # the compiled host module of the fix-up (bk_set_host_compile)
+        module_s = time.time() - t0
         walls, recs = [], []
         for _ in range(args.reps):
             t0 = time.time()
@@ -38,7 +42,7 @@ def main():
         best = min(range(args.reps), key=lambda i: walls[i])
         b = recs[best]
         flagged, changed = ctx.last_build_fixups()
-        print(f"{lens:14s} {W}x{H} first {first:8.1f} ms | wall best {walls[best]:7.3f} median {sorted(walls)[len(walls) // 2]:7.3f} ms | "
+        print(f"{lens:14s} {W}x{H} first {first:8.1f} ms (host module {'ready after %.2f s' % module_s if have_module else 'none'}, used: {b['compiled_host_module']}) | wall best {walls[best]:7.3f} median {sorted(walls)[len(walls) // 2]:7.3f} ms | "
               f"device+fixup events {b['build_ms']:7.3f} ms, host re-evaluation {b['host_eval_ms']:7.3f} ms of it | flagged {flagged} changed {changed} "
               f"| kernel + read-back wall {b['kernel_wall_ms']:7.3f} ms, {b['retries']} retries | pool threads {b['pool_threads']}", flush=True)
         if args.host_entries:
