@@ -123,6 +123,28 @@ def test_gpu_equals_portable_libm_oracle_exactly(bk, cfg):
     ctx.close()
 
 
+@pytest.mark.parametrize("globe,lens,W,H", [("cube", "quincuncial", 3840, 2160), ("cube", "eckert4", 800, 400), ("cube", "eckert5", 640, 480),
+                                             ("fast", "panini", 640, 400)])
+def test_flagged_entries_through_the_compiled_host_module(bk, globe, lens, W, H, request):
+    """the same goldens with the flagged entries re-derived by the compiled host module (forced and waited for) and by the
+    script interpreter alone: same table, same counts"""
+    import shutil
+    if not (shutil.which("c++") or shutil.which("g++") or shutil.which("clang++")):
+        pytest.skip("no host C++ compiler on this box")
+    rec = next(r for r in GOLD if (r["globe"], r["lens"], r["W"], r["H"]) == (globe, lens, W, H))
+    request.addfinalizer(lambda: bk.debug_set_option("host_module", 0))
+    counts = {}
+    for mode in (1, 2):
+        bk.debug_set_option("host_module", mode)
+        ctx, display, scale, off, tin = build(bk, globe, lens, rec["zoom"], W, H)
+        assert repr(scale) == rec["scale"] and display[: len(rec["display"])] == rec["display"]
+        assert O.fnv(off) == rec["fnv_offsets"] and O.fnv(tin) == rec["fnv_tints"]
+        counts[mode] = ctx.last_build_fixups()
+        assert ctx.build_breakdown()["compiled_host_module"] == (mode == 1 and counts[mode][0] > 0)
+        ctx.close()
+    assert counts[1] == counts[2]
+
+
 def test_exact_ties_are_resolved_on_the_platform_libm(bk):
     """cube/quincuncial at 3840x2160 (BASELINE.json configs[2]): at a few pixels 2*atan2(r,1) - pi/2 cancels to
     exactly 0 on glibc and to +-1 ulp on any other correct libm, which moves u*ps across an integer.  The device

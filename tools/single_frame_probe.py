@@ -23,21 +23,24 @@ def main():
     ap.add_argument("--shapes", default="0")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--frames", default="1,16")
+    ap.add_argument("--no-tuning", action="store_true", help="block height by the cost model alone (bk_set_blockmap_tuning 0)")
     args = ap.parse_args()
     W, H = [int(v) for v in args.size.split("x")]
     for lens in args.lenses.split(","):
         wl = bench.OneGpuWorkload(torch, blinky_amd, S, 0, "cube", lens, None if lens != "panini" else "f_fov 180", W, H, 16)
+        wl.ctx.set_blockmap_tuning(not args.no_tuning)
         for shape in [int(v) for v in args.shapes.split(",")]:
             wl.ctx.set_tile_shape(shape)
             for flags in [int(v) for v in args.flags.split(",")]:
                 wl.ctx.set_ablation(flags)
-                stats = wl.ctx.tile_stats()
-                line = f"{lens:14s} {W}x{H} shape {shape} flags {flags:4d} blocks {stats['tiles']} h {stats['tile_h'] % 1000} lds {stats['lds_bytes_per_wave']}"
+                line = f"{lens:14s} {W}x{H} shape {shape} flags {flags:4d}"
                 for nf in [int(v) for v in args.frames.split(",")]:
+                    wl.ctx.set_tile_shape(shape)                 # drops the block map: the next launch compiles (and tunes) it for nf frames
                     for i in range(3):
                         wl.launch(i, nf)
+                    stats = wl.ctx.tile_stats()
                     med, lo, hi = wl.kernel_ms(nframes=nf, launches=40, repeats=7)
-                    line += f" | x{nf}: {med * 1e3 / nf:7.3f} us/frame (min {lo * 1e3 / nf:.3f})"
+                    line += f" | x{nf}: {med * 1e3 / nf:7.3f} us/frame (min {lo * 1e3 / nf:.3f}) [128x{stats['tile_h'] % 1000} lds {stats['lds_bytes_per_wave'] // 1024}K]"
                 print(line, flush=True)
         wl.ctx.set_ablation(0)
         wl.close()
