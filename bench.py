@@ -225,6 +225,74 @@ def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, 
     return out
 
 
+def traffic_child(args):
+    """`bench.py --traffic-child`: what bench.py runs under `rocprofv3 --pmc <counter> --kernel-trace` to MEASURE the bytes the
+    dominant kernel moves (measure_traffic): the same context, lensmap, ring and batch launch as the timed run, 3 + 20 launches
+    on one stream, no timing, no JSON."""
+    import torch
+    import blinky_amd
+    import scripts as S
+    F, R = args.frames, max(args.ring, args.frames)
+    ctx = blinky_amd.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_frames(R)
+    S.configure(ctx, GLOBE, LENS, ZOOM, (W, H))
+    if args.variant >= 0:
+        ctx.set_apply_variant(args.variant)
+    if args.shape:
+        ctx.set_tile_shape(args.shape)                   # the block height the parent's (measured) tuning chose
+    ctx.build()
+    for f in range(R):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, f)
+    out = [torch.zeros((F, H, W), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for i in range(23):
+        ctx.apply_device(out[i % 4].data_ptr(), W, H * W, frame0=(i * F) % R, nframes=F)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(args, F, R, block_h):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under rocprofv3, one --pmc
+    counter each (FETCH_SIZE, WRITE_SIZE; counters only ever together with --kernel-trace), per MI355X_MICROARCH.md's HBM
+    section: values in KiB; on gfx950 FETCH_SIZE tallies the 128-byte TCC->EA read requests at 64 bytes, so reads are doubled
+    (cross-checked against TCC_EA0_RDREQ_* in profiles/).  Returns (bytes or None, provenance dict)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    vals, t0 = {}, time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bk_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
+               "--frames", str(F), "--ring", str(R), "--variant", str(args.variant), "--shape", str(block_h // 8)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, {"error": f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})", "stderr_tail": r.stderr[-300:]}
+            con = sqlite3.connect(dbs[0])
+            rows = list(con.execute("select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name = ? and "
+                                    "kernel_name like '%apply_%' group by kernel_name, grid_size order by grid_size desc", (counter,)))
+            con.close()
+            if not rows:
+                return None, {"error": f"no apply kernel in the {counter} pass"}
+            vals[counter] = rows[0]
+        except Exception as e:      # noqa: BLE001
+            return None, {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    return int(round((2 * f[3] + w[3]) * 1024)), {
+        "measured": "live, in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) around "
+                    "`bench.py --traffic-child` (the same launch, 20 of them); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies its 128-byte read requests at 64 bytes)",
+        "kernel": f[0][:80], "grid_work_items": f[1], "launches_profiled": f[2], "FETCH_SIZE_KiB_per_launch": round(f[3], 2),
+        "WRITE_SIZE_KiB_per_launch": round(w[3], 2), "seconds": round(time.time() - t0, 1)}
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` outside torchrun: one process per GPU, this node, RCCL"""
     s = socket.socket()
@@ -250,6 +318,10 @@ def main():
     ap.add_argument("--min-gpu-seconds", type=float, default=3.0,
                     help="with --repeats 0: total GPU-timed seconds the regions should add up to (a 50-step region is ~3 ms)")
     ap.add_argument("--no-extra", action="store_true", help="skip configs_extra (1080p C2) and predicted_stripe_complete")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two child runs under rocprofv3 --pmc); use the stamped record in profiles/ if it matches")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--shape", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps alternate between: the tail of a batch launch (its last, partly filled round of "
                          "workgroups) then overlaps the ramp of the next; 1 = every launch on one stream")
@@ -258,6 +330,8 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="after the timed region, compare every reassembled frame this rank owns with a full-frame warp")
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
@@ -569,7 +643,10 @@ def main():
         compulsory = compulsory_bytes(model, F)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "apply_traffic.json")
-        if os.path.exists(tpath) and world == 1:
+        if world == 1 and not args.no_live_traffic:
+            traffic, traffic_src = measure_traffic(args, F, R, int(model["block_height"]))
+        if traffic is None and os.path.exists(tpath) and world == 1:
+            live_error = traffic_src
             try:
                 rec = json.load(open(tpath))
                 want = f"{W}x{H} {GLOBE}/{LENS} x{F} ring{R}"
@@ -583,6 +660,8 @@ def main():
                                    "rerun tools/profile_bench.sh"}
             except Exception as e:      # noqa: BLE001
                 traffic_src = {"stale": True, "why": f"unreadable record: {e}"}
+            if live_error and traffic_src is not None:
+                traffic_src["live_measurement"] = live_error
         t_launch = k_med * 1e-3
         # calibration: a plain streaming kernel with the apply's read : write ratio (compulsory model), on this box, now
         stream_mix = None

@@ -967,13 +967,13 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     };
     // MEASURED choice (bk_set_blockmap_tuning, on by default): the cost model ranks the block heights, but its picks miss by
     // 10-17 % where the launch is small (1080p hammer / quincuncial: 128x8 beats the 128x16 it picks; which side wins also moves
-    // with how cold the globe ring is).  So the candidates the model puts within 30 % of its best are compiled in full and the very
+    // with how cold the globe ring is).  So the candidates the model puts within 20 % of its best are compiled in full and the very
     // launch the caller is about to make - same frame count, the context's own globe - is timed on each; the fastest stays.
     // A lensmap is built once per lens / zoom change and applied every frame: ~0.7 ms more here for up to 17 % per frame.
     int measured = 0;
     if (ctx->blockmap_tuning && !forced && nc > 1 && ctx->d_globe && !(ctx->apply_flags & (2 | 4))) {
         int keep = 1;
-        while (keep < nc && c_cost[keep] <= 1.3 * c_cost[0]) ++keep;
+        while (keep < nc && c_cost[keep] <= 1.2 * c_cost[0]) ++keep;
         if (keep > 1) {
             const int nf = launch_frames > 0 ? (launch_frames < 16 ? launch_frames : 16) : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
             uint8_t *scratch = nullptr;
@@ -983,21 +983,24 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             BK_HIP(ctx, hipEventCreate(&t1));
             int rc = BK_OK, win = 0;
             float best_ms = -1;
+            // every candidate: one warm-up launch, then a train of launches between two events - back to back, as a caller's
+            // steady state issues them; the globe frames advance through the context's ring from launch to launch, candidate
+            // after candidate, so that none of them is handed the cache state another one left behind
+            const int train = (double)nf * rows * ctx->W < 40e6 ? 5 : 2;
+            const int span = ctx->nframes > nf ? ctx->nframes - nf + 1 : 1;
+            int seq = 0;
             for (int i = 0; i < keep && rc == BK_OK; ++i) {
                 rc = compile_full(c_rg[i], c_kb[i]);
-                float ms_min = -1;
-                for (int rep = 0; rep < 3 && rc == BK_OK; ++rep) {            // one warm-up, two timed: the faster counts
-                    const int f0 = ctx->nframes > nf ? (rep * nf) % (ctx->nframes - nf + 1) : 0;
-                    if (hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
-                    if (rc == BK_OK) rc = launch_compiled(ctx, cm, f0, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
-                    float ms = 0;
-                    if (rc == BK_OK && (hipEventRecord(t1, ctx->stream) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
-                                        hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
-                        rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
-                    if (rep > 0 && (ms_min < 0 || ms < ms_min)) ms_min = ms;
-                }
-                if (g_debug.print_model) fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d: %.2f us\n", ctx->W, rows, nf, c_rg[i], c_kb[i], ms_min * 1e3);
-                if (rc == BK_OK && (best_ms < 0 || ms_min < best_ms)) { best_ms = ms_min; win = i; }
+                if (rc == BK_OK) rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
+                if (rc == BK_OK && hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
+                for (int rep = 0; rep < train && rc == BK_OK; ++rep)
+                    rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
+                float ms = 0;
+                if (rc == BK_OK && (hipEventRecord(t1, ctx->stream) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
+                                    hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
+                    rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
+                if (g_debug.print_model) fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], c_kb[i], ms * 1e3 / train);
+                if (rc == BK_OK && (best_ms < 0 || ms < best_ms)) { best_ms = ms; win = i; }
                 measured = i;
             }
             (void)hipEventDestroy(t0);

@@ -276,7 +276,7 @@ const char *bk_version(void);
 /* selects the apply kernel: 0 = direct gather, 2 = workgroup-cooperative LDS staging (default) */
 int         bk_set_apply_variant(bk_ctx *ctx, int variant);
 /* How the staged apply picks its block height (128x8 / 128x16 / 128x32 pixels) after a build: 1 (default) = the candidates
- * its cost model ranks within 30 % of the best are compiled and the caller's own first launch is TIMED on each (about
+ * its cost model ranks within 20 % of the best are compiled and the caller's own first launch is TIMED on each (about
  * 0.7 ms more per lensmap at 3840x2160, for up to 17 % per frame where the model misses); 0 = the cost model alone. */
 int         bk_set_blockmap_tuning(bk_ctx *ctx, int measured);
 /* milliseconds of the last bk_build's device work (HIP events on the context stream) */

@@ -2,8 +2,14 @@
  * oracle_cli.c -- CPU ORACLE command line (test infrastructure only).
  *   oracle_cli <globe> <lens> <zoomcmd|-> <W> <H> [apply_reps]
  * prints scale, display flags, non-NULL count, FNV-1a-64 of offsets / tints
- * (same conventions as SURVEY.md Appendix C) and, with apply_reps, the
- * best-of-N time of ok_apply on LCG globe faces plus the frame hash.
+ * (the hashing convention SURVEY.md Appendix C describes: little-endian uint32
+ * offsets = ptr - globe.pixels, 0xFFFFFFFF for NULL, row-major; tints as bytes)
+ * and, with apply_reps, the best-of-N time of ok_apply on LCG globe faces plus
+ * the frame hash.  NOTE: the hash VALUES printed in Appendix C are not
+ * reproduced by the unmodified reference compiled here (oracle/_ref) - scale,
+ * display flags and non-NULL counts are; the survey itself says "re-derive
+ * before trusting".  What pins this oracle is tests/golden/lensmaps.json,
+ * recorded from oracle/_ref by tests/golden/make_golden.py.
  */
 #include "oracle.h"
 #include <stdio.h>

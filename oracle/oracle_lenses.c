@@ -5,8 +5,13 @@
  * /root/reference/game/lua-scripts into C, preserving Lua 5.2's evaluation
  * order (all arithmetic in double, `^` = pow(), math.xxx = libm xxx).  They are
  * deliberately independent of the product's Lua front-end so that a front-end
- * bug cannot cancel out in a parity test.  Same method as the survey probe
- * (SURVEY.md Appendix C), whose reference-derived hashes pin these.
+ * bug cannot cancel out in a parity test.  Same METHOD as the survey probe
+ * (C transliterations driving the unmodified fisheye.c);
+ * what pins them is not the survey's table - its FNV values are not reproduced
+ * by the unmodified reference compiled here, only its scale / display /
+ * non-NULL columns are - but oracle/_ref itself: every configuration of
+ * tests/golden/lensmaps.json is the unmodified reference's output driven by
+ * these very callbacks (tests/test_oracle_golden.py, marker `ref`).
  */
 #include "oracle.h"
 
