@@ -986,7 +986,10 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             // every candidate: one warm-up launch, then a train of launches between two events - back to back, as a caller's
             // steady state issues them; the globe frames advance through the context's ring from launch to launch, candidate
             // after candidate, so that none of them is handed the cache state another one left behind
-            const int train = (double)nf * rows * ctx->W < 40e6 ? 5 : 2;
+            // (short launches - stripes, small frames - are timed on longer trains: at 10 us a launch the fixed costs and their
+            //  jitter are as large as the differences looked for)
+            const double work = (double)nf * rows * ctx->W;
+            const int train = work < 20e6 ? 12 : work < 40e6 ? 6 : 2;
             const int span = ctx->nframes > nf ? ctx->nframes - nf + 1 : 1;
             int seq = 0;
             for (int i = 0; i < keep && rc == BK_OK; ++i) {
@@ -1000,7 +1003,8 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                                     hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
                     rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
                 if (g_debug.print_model) fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], c_kb[i], ms * 1e3 / train);
-                if (rc == BK_OK && (best_ms < 0 || ms < best_ms)) { best_ms = ms; win = i; }
+                // candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
+                if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = i; }
                 measured = i;
             }
             (void)hipEventDestroy(t0);

@@ -63,6 +63,25 @@ __device__ __forceinline__ void bk_push_flagged(const BkBuildParams &P, unsigned
     }
 }
 
+/* The same for a whole wave at once (every lane that is still active calls it): the flagged lanes take CONSECUTIVE slots, in lane
+ * order - one atomic per wave instead of one per entry, and the list arrives in runs of ascending ids (a wave covers 64 consecutive
+ * pixels of a row / 64 consecutive corners), which is what keeps a script's per-row caches warm when the host walks it (eckert4). */
+__device__ __forceinline__ void bk_push_flagged_wave(const BkBuildParams &P, bool flag, unsigned int id, unsigned int a, unsigned int b, unsigned int c)
+{
+    const unsigned long long m = __ballot(flag);
+    if (!m) return;
+    const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(P.flag_count, (unsigned int)__popcll(m));
+    base = (unsigned int)__shfl((int)base, leader);
+    if (flag) {
+        const unsigned int k = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (k < P.flag_cap) {
+            P.flag_list[4 * k] = id; P.flag_list[4 * k + 1] = a; P.flag_list[4 * k + 2] = b; P.flag_list[4 * k + 3] = c;
+        }
+    }
+}
+
 __device__ __forceinline__ void bk_publish_flags(const int *s_disp, int *display, int serr, int *err)
 {
     /* per-block reduction of the display[] flags: at most 6 atomics per block, none once set */
@@ -128,20 +147,22 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
     const int lyl = blockIdx.y;                      /* row inside the owned stripe */
     const int ly = P.row0 + lyl;
     int err = 0;
+    bool flagged = false;
+    unsigned int off = 0xFFFFFFFFu;
+    unsigned char tint = 255;
+    const size_t o = (size_t)lyl * P.W + lx;
     if (lx < P.W) {
-        unsigned int off;
-        unsigned char tint;
         int plate;
         BkState S;
         bk_state_init(S, &P);
         bk_inverse_entry(P, S, lx, ly, &off, &tint, &plate);
         if (plate >= 0 && !S.flag) s_disp[plate] = 1;    /* (a flagged pixel's plate is the host's to say) */
         err = S.err;
-        const size_t o = (size_t)lyl * P.W + lx;
         P.offsets[o] = off;
         P.tints[o] = tint;
-        if (S.flag) bk_push_flagged(P, (unsigned int)o, off, tint, 0u);
+        flagged = S.flag != 0;
     }
+    bk_push_flagged_wave(P, flagged, (unsigned int)o, off, tint, 0u);
     __syncthreads();
     bk_publish_flags(s_disp, P.display, err, P.err);
 }
@@ -211,7 +232,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
     P.corner_xy[2 * id] = sx;
     P.corner_xy[2 * id + 1] = sy;
     P.corner_ok[id] = ok;
-    if (S.flag) bk_push_flagged(P, (unsigned int)id, (unsigned int)sx, (unsigned int)sy, ok);
+    bk_push_flagged_wave(P, S.flag != 0, (unsigned int)id, (unsigned int)sx, (unsigned int)sy, ok);
     if (S.err) atomicOr(P.err, S.err);
 }
 

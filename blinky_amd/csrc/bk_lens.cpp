@@ -1187,7 +1187,7 @@ void hostmod_runs(size_t n, Call call)
 {
     const size_t run = 512;
     FixupPool &pool = FixupPool::get();
-    const size_t nthreads = n < 2 * run ? 1 : std::min<size_t>(std::min<size_t>(pool.size(), (n + run - 1) / run), 48);
+    const size_t nthreads = n < 2 * run ? 1 : std::min<size_t>(std::min<size_t>(pool.size(), (n + run - 1) / run), n > 200000 ? 128 : 48);
     if (nthreads <= 1) { if (n) call((size_t)0, n); return; }
     std::atomic<size_t> next{0};
     pool.run(nthreads, [&](size_t) {
@@ -1229,7 +1229,10 @@ static int read_flagged(bk_ctx *ctx, unsigned int count, std::vector<uint32_t> *
     list->resize((size_t)count * 4);
     BK_HIP(ctx, hipMemcpyAsync(list->data(), ctx->d_flag_list, (size_t)count * 16, hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    sort_flagged(*list);
+    // The kernels append wave by wave: runs of up to 64 ascending ids.  A short list is put into the reference's scan order outright;
+    // a long one (eckert4 flags whole rows: 640 K entries) is left in its runs - sorting it cost more than the re-derivation, and a
+    // script's per-row cache is as warm within a run as within the sorted list.
+    if (count <= 131072) sort_flagged(*list);
     return BK_OK;
 }
 

@@ -17,4 +17,9 @@ static inline void __syncthreads() {}
 template <typename T> static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+/* one "thread" per block: a wave of one lane */
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
+static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
+static inline int __shfl(int v, int) { return v; }
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
