@@ -963,6 +963,10 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
         hipLaunchKernelGGL(coop_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, cm->d_cost, nb, cm->blocks_x, (nb + 7) / 8,
                            cm->d_order, cm->d_cum, cm->d_bands, cm->d_wgmap, cm->d_stats);
         BK_HIP(ctx, hipGetLastError());
+        // its statistics travel back asynchronously; whoever needs them (launch configuration, traffic model) folds them in
+        BK_HIP(ctx, hipMemcpyAsync(cm->h_stats, cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        BK_HIP(ctx, hipEventRecord(cm->stats_ready, ctx->stream));
+        cm->stats_pending = true;
         return BK_OK;
     };
     // MEASURED choice (bk_set_blockmap_tuning, on by default): the cost model ranks the block heights, but its picks miss by
@@ -994,6 +998,9 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             int seq = 0;
             for (int i = 0; i < keep && rc == BK_OK; ++i) {
                 rc = compile_full(c_rg[i], c_kb[i]);
+                // (timed in the configuration the caller's steady state runs in: with the block map's statistics there - live
+                //  blocks, uneven bands - the launch may take another form than in the first microseconds after a compile)
+                if (rc == BK_OK) rc = coop_stats_wait(ctx, cm);
                 if (rc == BK_OK) rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
                 if (rc == BK_OK && hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
                 for (int rep = 0; rep < train && rc == BK_OK; ++rep)
@@ -1019,10 +1026,6 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     }
     if (measured != -1)
         if (int r = compile_full(best_rg, best_kb)) return r;
-    BK_HIP(ctx, hipGetLastError());
-    BK_HIP(ctx, hipMemcpyAsync(cm->h_stats, cm->d_stats, 64 * BK_COOP_STATS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    BK_HIP(ctx, hipEventRecord(cm->stats_ready, ctx->stream));
-    cm->stats_pending = true;
     cm->valid = true;
     return BK_OK;
 }
