@@ -187,9 +187,39 @@ __global__ __launch_bounds__(256) void scatter_kernel(T *__restrict__ dst, const
     if (i < n) dst[idx[i]] = val[i];
 }
 
+// The reference stops building at the first malformed callback result (status -1, fisheye.c:2113-2115) and keeps what its scan -
+// rows from the bottom up, pixels left to right - had set by then.  The GPU build evaluates every pixel; this pass takes away
+// the entries the reference would not have reached (scan key <= the failing pixel's) and recounts the display flags.
+__global__ __launch_bounds__(256) void truncate_scan_kernel(uint32_t *__restrict__ off, uint8_t *__restrict__ tints, int W, int row0, size_t n,
+                                                            uint32_t bad_key, uint32_t plate_bytes, int *__restrict__ display)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int lyl = (int)(i / (size_t)W), lx = (int)(i - (size_t)lyl * W), ly = row0 + lyl;
+    const uint32_t key = (uint32_t)(ly * W + (W - 1 - lx)) + 1u;
+    if (key <= bad_key) { off[i] = BK_NULL_OFFSET; tints[i] = 255; return; }
+    const uint32_t o = off[i];
+    if (o != BK_NULL_OFFSET) {
+        const uint32_t plate = o / plate_bytes;
+        if (plate < (uint32_t)BK_MAX_PLATES && __hip_atomic_load(&display[plate], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&display[plate], 1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+int launch_truncate_scan(bk_ctx *ctx, unsigned int bad_key, int display_out[BK_MAX_PLATES])
+{
+    const size_t n = (size_t)ctx->W * ctx->rows();
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, BK_MAX_PLATES * sizeof(int), ctx->stream));
+    if (n) hipLaunchKernelGGL(truncate_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W,
+                              ctx->row0, n, bad_key, (uint32_t)ctx->plate_bytes(), ctx->d_display);
+    BK_HIP(ctx, hipGetLastError());
+    BK_HIP(ctx, hipMemcpyAsync(display_out, ctx->d_display, BK_MAX_PLATES * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
 // dst = address of pixel (0, row0) of frame 0, i.e. the first owned row
 int launch_apply(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int dst_pitch,
                  size_t frame_stride, int rubix_on)

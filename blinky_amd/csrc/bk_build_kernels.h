@@ -161,6 +161,8 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
         P.offsets[o] = off;
         P.tints[o] = tint;
         flagged = S.flag != 0;
+        /* status -1 (fisheye.c:2113-2115) ends the reference's scan there: remember the first such pixel in ITS order */
+        if ((err & BK_ERR_RESULT) && P.first_bad) atomicMax(P.first_bad, (unsigned int)(ly * P.W + (P.W - 1 - lx)) + 1u);
     }
     bk_push_flagged_wave(P, flagged, (unsigned int)o, off, tint, 0u);
     __syncthreads();

@@ -36,6 +36,9 @@ typedef struct {
      * texels the first pass flagged (globe_plate scripts): (texel id << 1 | answer), ascending */
     const unsigned int *ovr_list;
     unsigned int ovr_count;
+    /* inverse build: 1 + scan key of the FIRST pixel (in the reference's scan order: rows bottom-up, pixels left to right,
+     * fisheye.c:2093-2103) whose callback returned a malformed result - key = ly * W + (W - 1 - lx), max-reduced; 0 = none */
+    unsigned int *first_bad;
 } BkBuildParams;
 
 /* Device globe layout.  A plate is gp = round_up(ps,64) texels wide and ph = round_up(ps,8) high and is

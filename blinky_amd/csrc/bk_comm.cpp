@@ -597,13 +597,25 @@ extern "C" int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], doubl
     for (std::thread &t : pool) t.join();
     for (size_t i = 0; i < n; ++i) m->ctx[i]->async_compile = was_async[i] != 0;
     int all[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
+    // a malformed callback result somewhere: the reference's scan stopped at the FIRST such pixel of the whole frame - every
+    // stripe gives up what that scan had not reached (bk_build did so for the stripe's own first failing pixel only)
+    unsigned int bad_key = 0;
+    std::string bad_msg;
+    for (size_t i = 0; i < n; ++i)
+        if (rc[i] == BK_E_SCRIPT && bk_last_build_bad_key(m->ctx[i])) {
+            if (bad_msg.empty()) bad_msg = std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]);
+            bad_key = std::max(bad_key, bk_last_build_bad_key(m->ctx[i]));
+            rc[i] = BK_OK;
+        }
     for (size_t i = 0; i < n; ++i) {
         if (rc[i] != BK_OK) return m->fail(rc[i], std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]));
+        if (bad_key) if (int r = bk_truncate_build(m->ctx[i], bad_key, disp[i].data())) return m->fail(r, std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]));
         for (int p = 0; p < BK_MAX_PLATES; ++p) all[p] |= disp[i][(size_t)p];
     }
     for (size_t i = 0; i < n; ++i) for (int p = 0; p < BK_MAX_PLATES; ++p) m->ctx[i]->display[p] = all[p];
     if (display_out) for (int p = 0; p < BK_MAX_PLATES; ++p) display_out[p] = all[p];
     if (scale_out) *scale_out = scale[0];
+    if (bad_key) return m->fail(BK_E_SCRIPT, bad_msg);
     return BK_OK;
 }
 

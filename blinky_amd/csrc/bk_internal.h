@@ -75,7 +75,8 @@ struct bk_ctx {
     uint8_t *d_frame = nullptr;      // [row1-row0][W] staging for bk_apply (host dst)
     uint8_t *d_pal = nullptr;        // [6][256]
     uint64_t *d_mask = nullptr;      // mapped bits, 1 per pixel of the owned rows
-    int *d_display = nullptr;        // [6] display flags + [1] error bits + [1] flagged-entry count written by the build kernels
+    int *d_display = nullptr;        // [6] display flags + [1] error bits + [1] flagged-entry count + [1] first malformed result (scan key + 1) written by the build kernels
+    unsigned int last_bad_key = 0;   // of the last bk_build: 1 + scan key of the first pixel whose callback returned a malformed result (0 = none)
     uint32_t *d_flag_list = nullptr; // entries a build flagged for re-evaluation on the platform libm (bk_device_rt.h)
     size_t flag_cap = 0;
     int last_flagged = 0, last_changed = 0;   // of the last bk_build: entries re-evaluated on the host / entries that changed
@@ -141,6 +142,9 @@ int launch_convert_offsets(bk_ctx *ctx, uint32_t *buf, size_t n, int to_device);
 int launch_plate_retile(bk_ctx *ctx, uint8_t *plate_tiled, int to_tiled, uint8_t *rowmajor = nullptr);   // row-major staging (default d_plate_stage) <-> a plate of the globe
 int launch_scatter32(bk_ctx *ctx, uint32_t *dst, const uint32_t *h_idx, const uint32_t *h_val, size_t n);   // dst[idx[i]] = val[i]; synchronous
 int launch_scatter8(bk_ctx *ctx, uint8_t *dst, const uint32_t *h_idx, const uint8_t *h_val, size_t n);
+// the owned rows of the lensmap as the reference leaves them when its scan stops at the pixel with scan key bad_key - 1 (everything it
+// had not reached yet NULL) and the display flags of what is left; synchronous
+int launch_truncate_scan(bk_ctx *ctx, unsigned int bad_key, int display_out[BK_MAX_PLATES]);
 // bk_apply_coop.hip
 void coopmap_invalidate(bk_ctx *ctx);
 int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst_first_owned_row, int dst_pitch,

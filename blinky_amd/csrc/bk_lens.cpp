@@ -914,6 +914,7 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
     bp->display = ctx->d_display;
     bp->err = ctx->d_display + BK_MAX_PLATES;
     bp->flag_count = (unsigned int *)(ctx->d_display + BK_MAX_PLATES + 1);
+    bp->first_bad = (unsigned int *)(ctx->d_display + BK_MAX_PLATES + 2);
     bp->flag_list = ctx->d_flag_list;
     bp->flag_cap = (unsigned int)ctx->flag_cap;
 }
@@ -1249,8 +1250,9 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     // the lensmap stays valid-and-empty so that bk_apply draws nothing, as the reference does.
     BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
     BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
-    BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 2) * sizeof(int), ctx->stream));
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 3) * sizeof(int), ctx->stream));
     ctx->lensmap_valid = true;
+    ctx->last_bad_key = 0;
     ctx->spans_valid = false;
     bk::coopmap_invalidate(ctx);
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
@@ -1288,11 +1290,12 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     };
 #define BK_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = ctx->fail(BK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
 #define BK_RC_C(expr) do { rc = (expr); if (rc != BK_OK) { cleanup(); return rc; } } while (0)
-    int flags[BK_MAX_PLATES + 2];
+    int flags[BK_MAX_PLATES + 3];
+    unsigned int host_bad_key = 0;                     // (the same, among the entries the host re-derived)
     int host_display[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
     int host_err = 0;
     std::vector<uint32_t> flagged;
-    auto reset_counters = [&]() -> hipError_t { return hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 2) * sizeof(int), ctx->stream); };
+    auto reset_counters = [&]() -> hipError_t { return hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 3) * sizeof(int), ctx->stream); };
     auto read_counters = [&]() -> hipError_t {
         hipError_t e = hipMemcpyAsync(flags, ctx->d_display, sizeof flags, hipMemcpyDeviceToHost, ctx->stream);
         return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
@@ -1334,6 +1337,10 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
                 for (size_t i = 0; i < nfl; ++i) {
                     host_err |= rerr[i];
+                    if (rerr[i] & BK_ERR_RESULT) {
+                        const uint32_t o = flagged[4 * i], lyl = o / (uint32_t)ctx->W, lx = o - lyl * (uint32_t)ctx->W;
+                        host_bad_key = std::max(host_bad_key, (uint32_t)(((uint32_t)ctx->row0 + lyl) * (uint32_t)ctx->W + ((uint32_t)ctx->W - 1u - lx)) + 1u);
+                    }
                     if (rshown[i] >= 0) host_display[rshown[i]] = 1;
                     if (roff[i] != flagged[4 * i + 1] || rtint[i] != (uint8_t)flagged[4 * i + 2]) {
                         idx.push_back(flagged[4 * i]); voff.push_back(roff[i]); vtint.push_back(rtint[i]);
@@ -1463,10 +1470,21 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         if (display_out) display_out[i] = ctx->display[i];
     }
     const int errbits = flags[BK_MAX_PLATES] | host_err;
+    if (errbits == BK_ERR_RESULT && P->info.map_type == BK_MAP_INVERSE) {
+        // A malformed callback result (status -1) ends the reference's scan at that pixel and KEEPS what it had set by then
+        // (fisheye.c:2113-2117; rows from the bottom up, pixels left to right; run to completion, no time slicing).  The GPU
+        // build has evaluated every pixel: take away what the reference had not reached, recount the display flags, and
+        // report the error with that table in place.  (A stripe context knows only its own rows: bk_multi_build / the host
+        // of a bk_comm group hands every stripe the group's first failing pixel - bk_truncate_build.)
+        ctx->last_bad_key = std::max((unsigned int)flags[BK_MAX_PLATES + 2], host_bad_key);
+        int disp[BK_MAX_PLATES];
+        if (int r = bk::launch_truncate_scan(ctx, ctx->last_bad_key, disp)) return r;
+        for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
+        return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
+    }
     if (errbits) {
-        // The reference aborts the build at the first malformed callback result and keeps the rows done so far
-        // (fisheye.c:2113-2117); which rows those are depends on its scan order and time slicing.  Here a failed
-        // build leaves an EMPTY map (nothing is drawn) and reports the error.
+        // Any other per-pixel error is a Lua runtime error, which the reference does not survive (lua_call is unprotected:
+        // fisheye.c:1551); here the build leaves an EMPTY map (nothing is drawn) and reports it.
         BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
         BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
         BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1587,6 +1605,24 @@ extern "C" int bk_host_module_ready(bk_ctx *ctx, int wait)
     std::string src;
     if (generate_source(ctx, P, &src) != BK_OK) return 0;
     return host_module_for(src, wait != 0) ? 1 : 0;
+}
+
+/* Multi-GPU companion of bk_build's handling of a malformed callback result: `bad_key` = the group's first failing pixel
+ * (max over the stripes of bk_last_build_bad_key); this stripe gives up what the reference's scan had not reached by then. */
+extern "C" unsigned int bk_last_build_bad_key(const bk_ctx *ctx) { return ctx ? ctx->last_bad_key : 0u; }
+extern "C" int bk_truncate_build(bk_ctx *ctx, unsigned int bad_key, int display_out[BK_MAX_PLATES])
+{
+    if (!ctx) return BK_E_INVALID;
+    if (!ctx->lensmap_valid || !ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_truncate_build: no lensmap");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    int disp[BK_MAX_PLATES];
+    if (bad_key == 0) return BK_OK;
+    if (int r = bk::launch_truncate_scan(ctx, bad_key, disp)) return r;
+    ctx->last_bad_key = bad_key;
+    ctx->spans_valid = false;
+    bk::coopmap_invalidate(ctx);
+    for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
+    return BK_OK;
 }
 
 extern "C" int bk_last_build_fixups(const bk_ctx *ctx, int *flagged, int *changed)

@@ -62,6 +62,8 @@ _SIGS = {
     "bk_build": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
     "bk_calc_zoom": (_i, [_vp, C.POINTER(_d)]),
     "bk_last_build_fixups": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "bk_last_build_bad_key": (C.c_uint, [_vp]),
+    "bk_truncate_build": (_i, [_vp, C.c_uint, C.POINTER(_i)]),
     "bk_set_cache_dir": (_i, [C.c_char_p]),
     "bk_set_async_compile": (_i, [_vp, _i]),
     "bk_set_lensmap": (_i, [_vp, _vp, _vp]),
@@ -282,6 +284,14 @@ class Context:
         self._chk(lib.bk_debug_build_breakdown(self._h, out))
         return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4],
                     retries=int(out[5]) % 1000, compiled_host_module=out[5] >= 1000)
+
+    def last_build_bad_key(self):
+        return int(lib.bk_last_build_bad_key(self._h))
+
+    def truncate_build(self, bad_key):
+        out = (_i * MAX_PLATES)()
+        self._chk(lib.bk_truncate_build(self._h, bad_key, out))
+        return list(out)
 
     def last_build_ms(self):
         return lib.bk_last_build_ms(self._h)

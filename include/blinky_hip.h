@@ -106,12 +106,22 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * (2084-2124) or resume_lensmap_forward (2126-2217), run to completion on the GPU,
  * including the NULL/255 clears of F_RenderView (731-732).
  * display_out (nullable) receives globe.plates[i].display; scale_out lens.scale.
- * A callback that fails at run time (malformed result, arithmetic on nil, runaway loop) makes bk_build return
- * BK_E_SCRIPT and leaves an EMPTY lensmap (the reference keeps the rows built before the failing pixel).
+ * A lens_inverse that returns a MALFORMED RESULT (status -1, fisheye.c:1565-1584) ends the reference's scan at that pixel and keeps
+ * what it had set by then (2113-2115; rows from the bottom up, pixels left to right): bk_build returns BK_E_SCRIPT with exactly
+ * that table in place - the entries the reference's scan had not reached are NULL - and the display flags of what is left.
+ * (Stripes: a context knows only its rows; bk_multi_build hands every stripe the group's first failing pixel, a bk_comm host
+ * does the same with bk_last_build_bad_key (max over the ranks) and bk_truncate_build.)  Any other run-time failure (arithmetic
+ * on nil, a runaway loop - Lua errors the reference's unprotected lua_call does not survive; a malformed lens_forward result)
+ * returns BK_E_SCRIPT and leaves an EMPTY lensmap.
  * Script globals that lens_inverse / lens_forward / globe_plate ASSIGN are per-pixel state on the GPU, initialised
  * from their value after the chunk ran: fine for scratch variables and pure caches (all bundled scripts), but a
  * script that accumulates state from one pixel to the next does not behave as in the reference's sequential scan. */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
+/* after a bk_build that returned BK_E_SCRIPT for a malformed result: 1 + scan key (ly * W + (W - 1 - lx)) of the first failing
+ * pixel in the reference's scan order, 0 if none; bk_truncate_build NULLs everything the reference's scan would not have reached
+ * before the pixel with that key (a no-op for key 0) and recounts display_out (nullable) */
+unsigned int bk_last_build_bad_key(const bk_ctx *ctx);
+int bk_truncate_build(bk_ctx *ctx, unsigned int bad_key, int display_out[BK_MAX_PLATES]);
 int bk_calc_zoom(bk_ctx *ctx, double *scale_out);                                   /* calc_zoom only */
 /* Lens modules are compiled with hiprtc on first use (0.2-1.1 s per lens) and kept (a) in the process and (b) on disk:
  * bk_set_cache_dir(dir) / $BLINKY_HIP_CACHE / $XDG_CACHE_HOME/blinky_hip / $HOME/.cache/blinky_hip, in that order

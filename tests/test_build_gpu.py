@@ -145,6 +145,67 @@ def test_flagged_entries_through_the_compiled_host_module(bk, globe, lens, W, H,
     assert counts[1] == counts[2]
 
 
+MALFORMED = """
+local good = lens_inverse
+function lens_inverse(x, y)
+   if x > 0.3 and y > 0.2 then
+      return x, y            -- two values: LUAtoC_lens_inverse's status -1 (fisheye.c:1579-1584)
+   end
+   return good(x, y)
+end
+"""
+
+
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_malformed_result_keeps_what_the_reference_scan_had_set(bk, ranks):
+    """A lens_inverse that returns a malformed result ends the reference's scan - rows from the bottom up, pixels left to right
+    (fisheye.c:2093-2103) - at that pixel and keeps what it had set (2113-2115).  bk_build / bk_multi_build report BK_E_SCRIPT
+    and leave exactly that table: the oracle's panini table up to the first failing pixel of the scan, NULL from there on, and
+    the display flags of what is left."""
+    W, H = 320, 200
+    lm = O.lensmap("cube", "panini", "f_fov 180", W, H)
+    ly, lx = np.divmod(np.arange(W * H), W)
+    x = (lx - W // 2) * lm.scale
+    y = -(ly - H // 2) * lm.scale
+    bad = (x > 0.3) & (y > 0.2)
+    key = ly * W + (W - 1 - lx)                     # larger = earlier in the reference's scan
+    first = key[bad].max()
+    want_off = np.where(key > first, lm.offsets, O.NULL).astype(np.uint32)
+    want_tin = np.where(key > first, lm.tints, 255).astype(np.uint8)
+    kept_plates = sorted(set((want_off[want_off != O.NULL] // (lm.ps * lm.ps)).tolist()))
+    src = S.script("lenses", "panini") + MALFORMED
+    if ranks == 1:
+        ctx = bk.Context()
+        ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+        ctx.load_lens(src, "panini_malformed.lua")
+        ctx.set_zoom(bk.ffi.ZOOM_FOV, 180)
+        ctx.resize(W, H)
+        with pytest.raises(bk.BlinkyError, match="malformed result"):
+            ctx.build()
+        assert ctx.last_build_bad_key() == first + 1
+        off, tin = ctx.read_lensmap()
+        frame = ctx.apply(np.zeros((H, W), np.uint8))          # the partial table is a valid lensmap: it can be applied
+        assert (frame.reshape(-1)[want_off == O.NULL] == 0).all()
+        ctx.close()
+    else:
+        m = bk.Multi([0] * ranks)
+        m.load_globe(S.script("globes", "cube"), "cube.lua")
+        m.load_lens(src, "panini_malformed.lua")
+        m.set_zoom(bk.ffi.ZOOM_FOV, 180)
+        m.resize(W, H)
+        with pytest.raises(bk.BlinkyError, match="malformed result"):
+            m.build()
+        parts = [m.ctx(r).read_lensmap() for r in range(ranks)]
+        off, tin = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        # (bk_truncate_build is idempotent: asking again with the same pixel returns each stripe's display flags)
+        shown = sorted(set(i for r in range(ranks) for i, d in enumerate(m.ctx(r).truncate_build(int(first) + 1)) if d))
+        assert shown == kept_plates
+        m.close()
+    np.testing.assert_array_equal(off, want_off)
+    np.testing.assert_array_equal(tin, want_tin)
+    assert 0 < int((off != O.NULL).sum()) < lm.nonnull
+
+
 def test_exact_ties_are_resolved_on_the_platform_libm(bk):
     """cube/quincuncial at 3840x2160 (BASELINE.json configs[2]): at a few pixels 2*atan2(r,1) - pi/2 cancels to
     exactly 0 on glibc and to +-1 ulp on any other correct libm, which moves u*ps across an integer.  The device
