@@ -82,7 +82,16 @@ def test_module_equals_the_platform_oracle_on_whole_tables(bk, cfg):
 
 def test_module_is_cached_on_disk_and_optional(bk, tmp_path, monkeypatch):
     monkeypatch.setenv("BLINKY_HIP_CACHE", str(tmp_path))
-    ctx, _ = host_ctx(bk, "cube", "gumby", None, 320, 200)
+
+    def variant(lens, tag):                      # a source no other test of this process has compiled (line numbers move)
+        ctx = bk.Context(bk.ffi.DEVICE_NONE)
+        ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+        ctx.load_lens("\n" * tag + "-- (variant)\n" + S.script("lenses", lens), lens + "_variant.lua")
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN)
+        ctx.resize(320, 200)
+        ctx.calc_zoom()
+        return ctx
+    ctx = variant("gumby", 3)
     assert ctx.host_module_ready(wait=True)
     files = [f.name for f in tmp_path.iterdir()]
     assert any(f.startswith("bk_host_") and f.endswith(".so") for f in files), files
@@ -93,12 +102,7 @@ def test_module_is_cached_on_disk_and_optional(bk, tmp_path, monkeypatch):
     ctx.close()
     # no compiler: the interpreter answers, nothing fails
     monkeypatch.setenv("BLINKY_HIP_HOSTCXX", "off")
-    ctx = bk.Context(bk.ffi.DEVICE_NONE)
-    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
-    ctx.load_lens("\n\n-- (a variant no other test has compiled)\n" + S.script("lenses", "fahey"), "fahey_variant.lua")
-    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN)
-    ctx.resize(320, 200)
-    ctx.calc_zoom()
+    ctx = variant("fahey", 5)
     assert not ctx.host_module_ready(wait=True)
     off, tin = ctx.host_entries(np.arange(1000, dtype=np.uint32))
     assert off.shape == (1000,)
