@@ -276,7 +276,7 @@ def measure_traffic(args, F, R, block_h):
                 return None, {"error": f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})", "stderr_tail": r.stderr[-300:]}
             con = sqlite3.connect(dbs[0])
             rows = list(con.execute("select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name = ? and "
-                                    "kernel_name like '%apply_%' group by kernel_name, grid_size order by grid_size desc", (counter,)))
+                                    "kernel_name like '%apply_%' group by kernel_name, grid_size order by count(*) * grid_size desc", (counter,)))
             con.close()
             if not rows:
                 return None, {"error": f"no apply kernel in the {counter} pass"}

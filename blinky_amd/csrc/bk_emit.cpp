@@ -670,6 +670,126 @@ struct Emitter {
 
 }  // namespace
 
+
+namespace {
+
+// definite-assignment walk for callbacks_carry_state
+struct StateScan {
+    Interp &I;
+    const std::set<std::string> &mut;
+    std::string culprit;
+    std::set<const FuncProto *> active;
+    using Set = std::set<std::string>;
+
+    void read_global(const std::string &name, const Set &def)
+    {
+        if (culprit.empty() && mut.count(name) && !def.count(name)) culprit = name;
+    }
+    void expr(const Expr *e, const Closure *cl, Set &def)
+    {
+        if (!e) return;
+        if (e->kind == Expr::Name && e->var == VarKind::Global) { read_global(e->str, def); return; }
+        if (e->kind == Expr::Function) return;                       // (creating a closure reads nothing; the emitter rejects calling it)
+        expr(e->a.get(), cl, def);
+        expr(e->b.get(), cl, def);
+        for (auto &x : e->args) expr(x.get(), cl, def);
+        for (auto &x : e->fields) { expr(x.first.get(), cl, def); expr(x.second.get(), cl, def); }
+        if (e->kind == Expr::Call) {
+            Value callee;
+            bool known = false;
+            if (e->a->kind == Expr::Name && e->a->var == VarKind::Global && !mut.count(e->a->str)) { callee = I.get_global(e->a->str); known = true; }
+            else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) { callee = *cl->upvals[e->a->slot]; known = true; }
+            if (known && callee.t == Value::FUNC && !active.count(callee.fn()->proto)) {
+                active.insert(callee.fn()->proto);
+                Set inner = def;                                     // the callee sees what is assigned so far; its own assignments stay its own
+                block(callee.fn()->proto->body, callee.fn(), inner);
+                active.erase(callee.fn()->proto);
+            }
+        }
+    }
+    // returns whether control can fall out of the end of the block
+    bool block(const Block &b, const Closure *cl, Set &def)
+    {
+        for (const StmtP &sp : b) {
+            const Stmt &s = *sp;
+            switch (s.kind) {
+            case Stmt::Return:
+                for (auto &x : s.exprs) expr(x.get(), cl, def);
+                return false;
+            case Stmt::Break: return false;
+            case Stmt::If: {
+                Set meet;
+                bool any = false, has_else = false;
+                for (auto &c : s.clauses) {
+                    if (c.first) expr(c.first.get(), cl, def); else has_else = true;
+                    Set d = def;
+                    if (block(c.second, cl, d)) { meet = any ? intersect(meet, d) : d; any = true; }
+                }
+                if (!has_else) { meet = any ? intersect(meet, def) : def; any = true; }
+                if (!any) return false;                               // every branch returned
+                def = meet;
+                break;
+            }
+            case Stmt::While: case Stmt::NumFor: case Stmt::GenFor: {
+                expr(s.cond.get(), cl, def);
+                for (auto &x : s.exprs) expr(x.get(), cl, def);
+                Set d = def;
+                block(s.body, cl, d);                                 // may run zero times: nothing it assigns is definite afterwards
+                break;
+            }
+            case Stmt::Repeat: {
+                Set d = def;
+                const bool falls = block(s.body, cl, d);
+                expr(s.cond.get(), cl, d);
+                if (falls) def = d;                                   // the body runs at least once
+                break;
+            }
+            case Stmt::Do: if (!block(s.body, cl, def)) return false; break;
+            default:
+                for (auto &x : s.exprs) expr(x.get(), cl, def);       // right-hand sides first ...
+                expr(s.call.get(), cl, def);
+                for (auto &t : s.targets) {
+                    if (t->kind == Expr::Name && t->var == VarKind::Global) def.insert(t->str);      // ... then the assignment
+                    else if (t->kind == Expr::Index) { expr(t->a.get(), cl, def); expr(t->b.get(), cl, def); }
+                }
+                break;
+            }
+        }
+        return true;
+    }
+    static Set intersect(const Set &a, const Set &b)
+    {
+        Set o;
+        for (const std::string &x : a) if (b.count(x)) o.insert(x);
+        return o;
+    }
+};
+
+}  // namespace
+
+bool callbacks_carry_state(const EmitRequest &req, std::string *which)
+{
+    Emitter em(*req.interp);
+    std::set<const FuncProto *> seen;
+    const Value *roots[3] = {&req.lens_inverse, &req.lens_forward, &req.globe_plate};
+    for (const Value *v : roots)
+        if (v->t == Value::FUNC && !seen.count(v->fn()->proto)) {
+            seen.insert(v->fn()->proto);
+            em.scan_block(v->fn()->proto->body, v->fn(), seen);
+        }
+    if (em.mutable_globals.empty()) return false;
+    StateScan sc{*req.interp, em.mutable_globals, std::string(), {}};
+    for (const Value *v : roots)
+        if (v->t == Value::FUNC) {
+            StateScan::Set def;
+            sc.active.insert(v->fn()->proto);
+            sc.block(v->fn()->proto->body, v->fn(), def);
+            sc.active.erase(v->fn()->proto);
+        }
+    if (which) *which = sc.culprit;
+    return !sc.culprit.empty();
+}
+
 std::string emit_build_source(const EmitRequest &req)
 {
     Emitter em(*req.interp);

@@ -19,6 +19,12 @@ struct EmitRequest {
 // naming the construct when a script uses something the device compiler does not support.
 std::string emit_build_source(const EmitRequest &req);
 
+// Does a callback READ a script global that callbacks assign before assigning it itself on that path - i.e. can a value travel
+// from one pixel's evaluation to the next (eckert4's per-row cache; a counter)?  Conservative definite-assignment walk over the
+// callbacks and the script functions they call (assignments inside callees are not credited to the caller).  `which` (nullable)
+// names the first such global.  The parallel GPU build gives every pixel the post-load value instead (include/blinky_hip.h: bk_build).
+bool callbacks_carry_state(const EmitRequest &req, std::string *which);
+
 // headers the generated unit #includes, embedded at build time (bk_embed.inc) and handed to
 // hiprtcCreateProgram: bkm.h, bkm_tables.h, bk_build_params.h, bk_device_rt.h, bk_build_kernels.h
 struct EmbeddedHeader { const char *name; const char *text; };

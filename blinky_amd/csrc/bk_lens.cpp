@@ -567,6 +567,7 @@ struct HostModule {
     void (*inverse)(const BkBuildParams *, const unsigned int *, int, unsigned long, unsigned int *, unsigned char *, int *, int *) = nullptr;
     void (*corners)(const BkBuildParams *, const unsigned int *, int, unsigned long, int *, int *, unsigned char *, int *) = nullptr;
     void (*texel_owns)(const BkBuildParams *, const unsigned int *, int, unsigned long, unsigned char *) = nullptr;
+    int (*inverse_scan)(const BkBuildParams *, unsigned int *, unsigned char *, int *) = nullptr;
     ~HostModule() { if (dl) dlclose(dl); }
 };
 using HostModuleP = std::shared_ptr<HostModule>;
@@ -625,7 +626,8 @@ static HostModuleP load_host_module(const std::string &so)
     m->inverse = (decltype(m->inverse))dlsym(dl, "bk_hostmod_inverse");
     m->corners = (decltype(m->corners))dlsym(dl, "bk_hostmod_corners");
     m->texel_owns = (decltype(m->texel_owns))dlsym(dl, "bk_hostmod_texel_owns");
-    if (!abi || abi() != 3 + (int)sizeof(BkBuildParams) * 16 || !m->inverse || !m->corners || !m->texel_owns) return nullptr;
+    m->inverse_scan = (decltype(m->inverse_scan))dlsym(dl, "bk_hostmod_inverse_scan");
+    if (!abi || abi() != 4 + (int)sizeof(BkBuildParams) * 16 || !m->inverse || !m->corners || !m->texel_owns || !m->inverse_scan) return nullptr;
     return m;
 }
 
@@ -1237,6 +1239,79 @@ static int read_flagged(bk_ctx *ctx, unsigned int count, std::vector<uint32_t> *
     return BK_OK;
 }
 
+// The inverse build as ONE sequential scan on the host (bk_set_sequential_build): what the reference does (fisheye.c:2084-2124) -
+// one evaluator whose script globals travel from pixel to pixel, rows from the bottom up, pixels left to right, stopping at the
+// first malformed result - by the compiled host module on the platform libm (waited for), else by the script interpreter.  For
+// scripts that accumulate state across pixels, which the parallel GPU build cannot reproduce.  A stripe context scans its own rows
+// with a fresh state: use a single full-height context for such scripts.
+static int build_sequential(bk_ctx *ctx, LensProgram *P, const std::string &source, const BkBuildParams &bp, int display_out[BK_MAX_PLATES])
+{
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    std::vector<uint32_t> off(px, BK_NULL_OFFSET);
+    std::vector<uint8_t> tint(px, 255);
+    int disp[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
+    int errbits = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    HostModuleP hm = P->interp.math == &math_platform() && bk::g_debug.host_module != 2 ? host_module_for(source, true) : nullptr;
+    ctx->last_fixup_compiled = hm != nullptr;
+    try {
+        if (hm) errbits = hm->inverse_scan(&bp, off.data(), tint.data(), disp);
+        else {
+            const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
+            Values roots;
+            std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
+            HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
+            for (int lyl = ctx->rows() - 1; lyl >= 0 && !errbits; --lyl)
+                for (int lx = 0; lx < ctx->W && !errbits; ++lx) {
+                    const size_t o = (size_t)lyl * ctx->W + lx;
+                    int shown = -1;
+                    h_inverse_entry(ev, bp, (uint32_t)o, &off[o], &tint[o], &shown, &errbits);
+                    if (errbits) { off[o] = BK_NULL_OFFSET; tint[o] = 255; }
+                    else if (shown >= 0) disp[shown] = 1;
+                }
+        }
+    } catch (const LuaError &e) {
+        return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", e.what());
+    }
+    ctx->last_host_eval_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->last_build_ms = ctx->last_host_eval_ms;
+    ctx->last_flagged = ctx->last_changed = 0;
+    if (errbits & ~BK_ERR_RESULT) {                              // a Lua runtime error: nothing is drawn (see bk_build)
+        std::fill(off.begin(), off.end(), BK_NULL_OFFSET);
+        std::fill(tint.begin(), tint.end(), (uint8_t)255);
+        for (int &d : disp) d = 0;
+    }
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, off.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tint.data(), px, hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
+    if (errbits) return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
+    return BK_OK;
+}
+
+extern "C" int bk_set_sequential_build(bk_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return BK_E_INVALID;
+    ctx->sequential_build = mode;
+    return BK_OK;
+}
+
+/* 1 if a callback of the current lens / globe reads a script global that callbacks assign before assigning it itself (state can
+ * travel from pixel to pixel), 0 if not, negative on error; `global_name` (nullable) receives the first such global */
+extern "C" int bk_lens_carries_state(bk_ctx *ctx, char *global_name, size_t cap)
+{
+    if (!ctx) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");
+    bk::EmitRequest rq;
+    rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
+    std::string which;
+    bool carries = false;
+    try { carries = bk::callbacks_carry_state(rq, &which); } catch (const LuaError &e) { return ctx->fail(BK_E_SCRIPT, "%s", e.what()); }
+    if (global_name && cap) snprintf(global_name, cap, "%s", which.c_str());
+    return carries ? 1 : 0;
+}
+
 extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out)
 {
     if (!ctx) return BK_E_INVALID;
@@ -1277,6 +1352,14 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
 
     BkBuildParams bp;
     fill_params(ctx, &bp);
+    // bk_set_sequential_build: a lens whose callbacks carry state from pixel to pixel (or every lens, mode 2) is built the way the
+    // reference builds it - one evaluator, its scan order - on the host
+    if (P->info.map_type == BK_MAP_INVERSE && ctx->sequential_build) {
+        bk::EmitRequest rq;
+        rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
+        std::string which;
+        if (ctx->sequential_build >= 2 || bk::callbacks_carry_state(rq, &which)) return build_sequential(ctx, P, src, bp, display_out);
+    }
     void *args[] = {&bp};
     hipEvent_t e0, e1;
     BK_HIP(ctx, hipEventCreate(&e0));

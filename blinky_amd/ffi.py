@@ -63,6 +63,8 @@ _SIGS = {
     "bk_calc_zoom": (_i, [_vp, C.POINTER(_d)]),
     "bk_last_build_fixups": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "bk_last_build_bad_key": (C.c_uint, [_vp]),
+    "bk_set_sequential_build": (_i, [_vp, _i]),
+    "bk_lens_carries_state": (_i, [_vp, C.c_char_p, _sz]),
     "bk_truncate_build": (_i, [_vp, C.c_uint, C.POINTER(_i)]),
     "bk_set_cache_dir": (_i, [C.c_char_p]),
     "bk_set_async_compile": (_i, [_vp, _i]),
@@ -284,6 +286,17 @@ class Context:
         self._chk(lib.bk_debug_build_breakdown(self._h, out))
         return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4],
                     retries=int(out[5]) % 1000, compiled_host_module=out[5] >= 1000)
+
+    def set_sequential_build(self, mode):
+        self._chk(lib.bk_set_sequential_build(self._h, int(mode)))
+
+    def lens_carries_state(self):
+        """(bool, name of the first script global a callback reads before assigning it)"""
+        buf = C.create_string_buffer(128)
+        rc = lib.bk_lens_carries_state(self._h, buf, 128)
+        if rc < 0:
+            self._chk(rc)
+        return bool(rc), buf.value.decode()
 
     def last_build_bad_key(self):
         return int(lib.bk_last_build_bad_key(self._h))

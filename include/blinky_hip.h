@@ -115,8 +115,14 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * returns BK_E_SCRIPT and leaves an EMPTY lensmap.
  * Script globals that lens_inverse / lens_forward / globe_plate ASSIGN are per-pixel state on the GPU, initialised
  * from their value after the chunk ran: fine for scratch variables and pure caches (all bundled scripts), but a
- * script that accumulates state from one pixel to the next does not behave as in the reference's sequential scan. */
+ * script that accumulates state from one pixel to the next does not behave as in the reference's sequential scan -
+ * unless bk_set_sequential_build asks for that scan: mode 1 = an inverse-map lens whose callbacks read a script global before
+ * assigning it (bk_lens_carries_state: eckert4's per-row cache counts, a pixel counter certainly does) is built as ONE sequential
+ * scan on the host, in the reference's order, by the compiled host module (else the script interpreter) - seconds instead of
+ * milliseconds at 4K, the reference's result for any script; mode 2 = every inverse-map lens; 0 (default) = never. */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
+int bk_set_sequential_build(bk_ctx *ctx, int mode);
+int bk_lens_carries_state(bk_ctx *ctx, char *global_name /* nullable */, size_t cap);
 /* after a bk_build that returned BK_E_SCRIPT for a malformed result: 1 + scan key (ly * W + (W - 1 - lx)) of the first failing
  * pixel in the reference's scan order, 0 if none; bk_truncate_build NULLs everything the reference's scan would not have reached
  * before the pixel with that key (a no-op for key 0) and recounts display_out (nullable) */

@@ -206,6 +206,65 @@ def test_malformed_result_keeps_what_the_reference_scan_had_set(bk, ranks):
     assert 0 < int((off != O.NULL).sum()) < lm.nonnull
 
 
+COUNTER = """
+count = 0
+local good = lens_inverse
+function lens_inverse(x, y)
+   count = count + 1
+   if count % 7 == 0 then return nil end
+   return good(x, y)
+end
+"""
+
+
+@pytest.mark.parametrize("host_module", [0, 2], ids=["compiled", "interpreter"])
+def test_sequential_build_reproduces_a_script_that_counts_pixels(bk, host_module, request):
+    """bk_set_sequential_build(1): a lens whose callback carries state from pixel to pixel - here a counter that drops every 7th
+    pixel it is asked for - is built as ONE scan in the reference's order (rows from the bottom up, pixels left to right,
+    fisheye.c:2093-2103) on the host.  Expected: the oracle's panini table with the entry of the k-th scanned pixel gone where
+    k % 7 == 0.  The parallel GPU build (the default) gives every pixel count = 1 instead: documented, and shown here."""
+    W, H = 200, 120
+    lm = O.lensmap("cube", "panini", "f_fov 180", W, H)
+    ly, lx = np.divmod(np.arange(W * H), W)
+    k = (H - 1 - ly) * W + lx + 1                       # the reference's scan reaches this pixel k-th
+    want = np.where(k % 7 == 0, O.NULL, lm.offsets).astype(np.uint32)
+    request.addfinalizer(lambda: bk.debug_set_option("host_module", 0))
+    bk.debug_set_option("host_module", host_module)
+    ctx = bk.Context()
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(S.script("lenses", "panini") + COUNTER, "counter.lua")
+    ctx.set_zoom(bk.ffi.ZOOM_FOV, 180)
+    ctx.resize(W, H)
+    assert ctx.lens_carries_state() == (True, "count")
+    ctx.build()                                         # default: parallel, per-pixel state -> every pixel sees count == 1
+    off, _ = ctx.read_lensmap()
+    np.testing.assert_array_equal(off, lm.offsets)
+    ctx.set_sequential_build(1)
+    display, scale = ctx.build()
+    off, tin = ctx.read_lensmap()
+    np.testing.assert_array_equal(off, want)
+    np.testing.assert_array_equal(tin, np.where(k % 7 == 0, 255, lm.tints).astype(np.uint8))
+    assert scale == lm.scale and display[: lm.numplates] == lm.display
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [("cube", "eckert4", None, 800, 400), ("cube", "quincuncial", None, 640, 480), ("fast", "panini", "f_fov 200", 640, 400)])
+def test_sequential_build_equals_the_reference_goldens(bk, cfg):
+    """mode 2: every inverse lens through the one-scan host build - eckert4's per-row cache carried exactly as the reference
+    carries it - gives the golden tables"""
+    globe, lens, zoom, W, H = cfg
+    rec = next(r for r in GOLD if (r["globe"], r["lens"], r["zoom"], r["W"], r["H"]) == cfg)
+    ctx = bk.Context()
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    ctx.set_sequential_build(2)
+    display, scale = ctx.build()
+    off, tin = ctx.read_lensmap()
+    assert repr(scale) == rec["scale"] and display[: len(rec["display"])] == rec["display"]
+    assert O.fnv(off) == rec["fnv_offsets"] and O.fnv(tin) == rec["fnv_tints"]
+    assert ctx.last_build_fixups() == (0, 0)            # nothing to flag: the platform libm computed every entry
+    ctx.close()
+
+
 def test_exact_ties_are_resolved_on_the_platform_libm(bk):
     """cube/quincuncial at 3840x2160 (BASELINE.json configs[2]): at a few pixels 2*atan2(r,1) - pi/2 cancels to
     exactly 0 on glibc and to +-1 ulp on any other correct libm, which moves u*ps across an integer.  The device

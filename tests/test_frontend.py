@@ -355,3 +355,42 @@ def test_generic_for_over_an_unknown_iterator_is_rejected_with_a_message(bk):
     ctx.resize(64, 48)
     with pytest.raises(bk.BlinkyError, match="generic 'for ... in' other than ipairs"):
         ctx.kernel_source()
+
+
+def test_which_scripts_carry_state_from_pixel_to_pixel(bk):
+    """bk_lens_carries_state: a conservative definite-assignment walk - does a callback read a script global that callbacks assign
+    before assigning it itself?  Of the 31 shipped lenses only eckert4 does (its per-row cache: `if y ~= lasty`); scratch globals
+    (fahey's lat / lon, quincuncial's longd / latp, winkeltripel's) are assigned first on every path."""
+    carrying = {}
+    for lens in S.LENSES:
+        ctx = host_ctx(bk)
+        S.configure(ctx, "cube", lens, None, (320, 200))
+        yes, which = ctx.lens_carries_state()
+        if yes:
+            carrying[lens] = which
+    assert carrying == {"eckert4": "lasty"}
+    counter = S.script("lenses", "panini") + """
+count = 0
+local good = lens_inverse
+function lens_inverse(x, y)
+   count = count + 1
+   if count % 7 == 0 then return nil end
+   return good(x, y)
+end
+"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(counter, "counter.lua")
+    assert ctx.lens_carries_state() == (True, "count")
+    scratch = S.script("lenses", "panini") + """
+local good = lens_inverse
+function lens_inverse(x, y)
+   if x > 0 then tmp = x else tmp = -x end      -- assigned on every path before it is read
+   if tmp > 100 then return nil end
+   return good(x, y)
+end
+"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(scratch, "scratch.lua")
+    assert ctx.lens_carries_state() == (False, "")

@@ -61,14 +61,14 @@ def traffic_record(out_json, profile_name, bench_log, kt_db, fetch_db, write_db,
     def dominant(db, counter):
         con = sqlite3.connect(db)
         q = ("select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name = ? and "
-             "kernel_name like '%apply_%' group by kernel_name, grid_size order by grid_size desc")
+             "kernel_name like '%apply_%' group by kernel_name, grid_size order by count(*) * grid_size desc")     # (not the largest grid alone: the block-height tuning times a few launches of other shapes)
         rows = list(con.execute(q, (counter,)))
         return rows[0] if rows else None
     f, w = dominant(fetch_db, "FETCH_SIZE"), dominant(write_db, "WRITE_SIZE")
     req = {c: dominant(rdreq_db, c) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")}
     con = sqlite3.connect(kt_db)
     krow = list(con.execute("select name, grid_x * grid_y, count(*), avg(duration)/1e3 from kernels where name like '%apply_%' "
-                            "group by name, grid_x, grid_y order by grid_x * grid_y desc"))[0]
+                            "group by name, grid_x, grid_y order by count(*) * grid_x * grid_y desc"))[0]
     bench = None
     for line in open(bench_log):
         if line.startswith("{") and '"metric"' in line:
