@@ -247,6 +247,16 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
 // ---------------------------------------------------------------------------------------------
 // apply
 // ---------------------------------------------------------------------------------------------
+// The staging buffer's two barriers order LDS traffic only - chunks written / gather done.  __syncthreads() is a workgroup-scope FENCE as
+// well: hipcc puts an s_waitcnt vmcnt(0) at it, which makes every wave wait there for the frame stores it has just issued and for the
+// next frame's globe loads it has just put in flight - the very latency the pipelining is meant to hide.  No wave of this kernel reads global
+// memory another wave wrote, so the raw barrier with the LDS counter alone is enough (ablation bit 2048 restores __syncthreads()).
+#define BK_LDS_BARRIER()                                                           \
+    do {                                                                           \
+        if (kflags & 2048) __syncthreads();                                        \
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    } while (0)
+
 template <int RG>
 struct CoopIdx {              // a lane's LDS addresses (two 16-bit per dword) and tints, per row group
     uint2 iw[RG];
@@ -436,11 +446,12 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                 if (m3) *reinterpret_cast<uint4 *>(md + 12288) = q3;
             }
         }
-        __syncthreads();                      // the block's chunks are in `buf`
+        if (DMA) __syncthreads();             // (the LDS-DMA form needs the fence's vmcnt(0): its loads ARE the LDS writes)
+        else BK_LDS_BARRIER();                // the block's chunks are in `buf`
         if (!DMA && pipe && f + 1 < f_end) BK_COOP_LOADS(f + 1);
-        if (tile_empty) { __syncthreads(); continue; }
+        if (tile_empty) { BK_LDS_BARRIER(); continue; }
         coop_gather_store<RUBIX, RG>(buf, ix, fast_store, pal_s, dst, frame_stride, dst_pitch, f, row0, x, kflags);
-        __syncthreads();                      // every wave is done with `buf`
+        BK_LDS_BARRIER();                     // every wave is done with `buf`
     }
 }
 
@@ -738,7 +749,7 @@ __device__ __forceinline__ void coop_block_pipe(CoopPrefetch<RG> &cur, int blk, 
         if (threadIdx.x + 256u < nchunks) *reinterpret_cast<uint4 *>(mine + 4096) = pre.q1;
         if (threadIdx.x + 512u < nchunks) *reinterpret_cast<uint4 *>(mine + 8192) = pre.q2;
         if (threadIdx.x + 768u < nchunks) *reinterpret_cast<uint4 *>(mine + 12288) = pre.q3;
-        __syncthreads();                      // the block's chunks are in LDS
+        BK_LDS_BARRIER();                     // the block's chunks are in LDS
         if (f + 1 < f_end) BK_PIPE_LOADS(cur.c, nchunks, f + 1);
         else {
             if (next_simple) {                // the workgroup's next block: its first frame's chunks and its pixel addresses
@@ -749,7 +760,7 @@ __device__ __forceinline__ void coop_block_pipe(CoopPrefetch<RG> &cur, int blk, 
             if (has_nn) cur = coop_fetch<RUBIX, RG>(hdr, list, blk_nn);      // ... and the header and list head of the one after it
         }
         if (!tile_empty) coop_gather_store<RUBIX, RG>(smem, ix, fast_store, pal_s, dst, frame_stride, dst_pitch, f, row0, x, kflags);
-        __syncthreads();                      // every wave is done with the buffer
+        BK_LDS_BARRIER();                     // every wave is done with the buffer
     }
 }
 #undef BK_PIPE_LOADS

@@ -234,7 +234,7 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
         # (128: non-temporal globe loads; 256: LDS-DMA staging in single-frame launches - results must not change)
         # (1024: the strided walk without cross-block pipelining; knob 702 = with it for batch launches too, 32 = strided walk always)
         for wgs, abl, pipe in ((1, 0, 700), (1, 64, 700), (2, 0, 700), (16, 0, 700), (16, 64, 700), (16, 32, 700), (16, 16, 700), (16, 128, 700),
-                               (16, 256, 700), (16, 384, 700), (1, 256 + 64, 700), (1, 1024, 700), (1, 0, 702), (2, 32, 702), (16, 32, 702), (16, 32 + 1024, 702)):
+                               (16, 256, 700), (16, 384, 700), (1, 256 + 64, 700), (1, 1024, 700), (1, 0, 702), (2, 32, 702), (16, 32, 702), (16, 32 + 1024, 702), (16, 2048, 700), (1, 2048 + 32, 702)):
             ctx.set_tile_shape(100 + wgs)
             ctx.set_tile_shape(pipe)
             ctx.set_ablation(abl)
