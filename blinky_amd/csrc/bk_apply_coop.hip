@@ -676,134 +676,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// persistent form with CROSS-BLOCK pipelining (round 3)
-// ---------------------------------------------------------------------------------------------
-// The persistent form above hides a block's header / list behind the previous block, but a block's first globe loads - and its
-// pixel addresses - are only issued when the block starts: one exposed trip to memory per block visit.  With 8 frames per visit that
-// is a small part of the visit; with ONE frame per visit (the engine's launches) it is most of it, and the whole-globe lenses with
-// large staging buffers (3-5 workgroups per CU, two rounds of blocks) sit 20-30 % above what their bytes cost.  Here the last frame of
-// a block issues the first frame's loads of the workgroup's NEXT block (and its pixel addresses) before its own gather, so that a
-// workgroup always has a frame's worth of chunks in flight.  Headers and list heads are fetched two blocks ahead.  Only for block maps
-// without blocks of more than 1024 chunks, multi-pass or direct-gather blocks (the launcher checks the compile's statistics).
-template <int RG>
-struct CoopPre {                 // what the previous block left in flight for this one
-    uint4 q0, q1, q2, q3;
-    CoopIdx<RG> ix;
-    bool valid;
-};
-
-#define BK_PIPE_LD(Q, PTR)                                                                                 \
-    do {                                                                                                   \
-        if (nt_globe) {                                                                                    \
-            const bk_v4u t_ = __builtin_nontemporal_load(reinterpret_cast<const bk_v4u *>(PTR));           \
-            Q = make_uint4(t_.x, t_.y, t_.z, t_.w);                                                        \
-        } else {                                                                                           \
-            Q = *reinterpret_cast<const uint4 *>(PTR);                                                     \
-        }                                                                                                  \
-    } while (0)
-// a frame's chunks of the block whose list head is C (entries of this thread), NCH chunks in all, into pre.q*
-#define BK_PIPE_LOADS(C, NCH, F)                                                                           \
-    do {                                                                                                   \
-        const uint8_t *gl_ = globe + (size_t)((frame0 + (F)) % globe_frames) * globe_stride;              \
-        if (threadIdx.x < (NCH)) BK_PIPE_LD(pre.q0, gl_ + (C)[0]);                                         \
-        if (threadIdx.x + 256u < (NCH)) BK_PIPE_LD(pre.q1, gl_ + (C)[1]);                                  \
-        if (threadIdx.x + 512u < (NCH)) BK_PIPE_LD(pre.q2, gl_ + (C)[2]);                                  \
-        if (threadIdx.x + 768u < (NCH)) BK_PIPE_LD(pre.q3, gl_ + (C)[3]);                                  \
-    } while (0)
-
-template <bool RUBIX, int RG>
-__device__ __forceinline__ void coop_block_pipe(CoopPrefetch<RG> &cur, int blk, const CoopPrefetch<RG> *nxt, int blk_next, bool has_nn, int blk_nn,
-                                                CoopPre<RG> &pre, const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list,
-                                                const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
-                                                const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
-                                                int globe_frames, int frame0, int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch,
-                                                size_t frame_stride, int W, int rows, int blocks_x, uint8_t *smem, int lds_buf,
-                                                const uint8_t *pal_s, bool aligned, int ry, int cx, int wave, int kflags)
-{
-    // On return `cur` holds the header and list head of the block AFTER next (blk_nn, if has_nn): this block's own are dead once
-    // its last frame's loads - or the next block's first - have been issued, and their registers take the new fetch.
-    typedef uint32_t bk_v4u __attribute__((ext_vector_type(4)));
-    const bool nt_globe = (kflags & 128) != 0;
-    // (the launcher takes this kernel only for block maps in which EVERY live block has a chunk list of at most 1024 entries that
-    //  fits the staging buffer - the exact statistics of the compile say so; anything else walks with apply_coop_kernel)
-    (void)lmap; (void)W; (void)rows; (void)lds_buf;
-    const uint32_t nchunks = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.x);
-    const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.y);
-    const int by = blk / blocks_x, bx = blk - by * blocks_x;
-    const int row0 = by * 8 * RG + ry, x = bx * 128 + cx * 4 * RG;
-    const bool tile_all = (flags >> wave) & 1u, tile_empty = (flags >> (4 + wave)) & 1u;
-    const bool fast_store = tile_all && aligned;
-    CoopIdx<RG> ix;
-    if (pre.valid) ix = pre.ix;
-    else {
-        ix = coop_load_idx<RUBIX, RG>(idx, tint_t, blk, wave, lane_of());
-        BK_PIPE_LOADS(cur.c, nchunks, f_begin);
-    }
-    const bool next_simple = nxt != nullptr;
-    const uint32_t nchunks_n = next_simple ? (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt->h.x) : 0u;
-    pre.valid = false;
-    uint8_t *mine = smem + threadIdx.x * 16u;
-    for (int f = f_begin; f < f_end; ++f) {
-        if (threadIdx.x < nchunks) *reinterpret_cast<uint4 *>(mine) = pre.q0;
-        if (threadIdx.x + 256u < nchunks) *reinterpret_cast<uint4 *>(mine + 4096) = pre.q1;
-        if (threadIdx.x + 512u < nchunks) *reinterpret_cast<uint4 *>(mine + 8192) = pre.q2;
-        if (threadIdx.x + 768u < nchunks) *reinterpret_cast<uint4 *>(mine + 12288) = pre.q3;
-        BK_LDS_BARRIER();                     // the block's chunks are in LDS
-        if (f + 1 < f_end) BK_PIPE_LOADS(cur.c, nchunks, f + 1);
-        else {
-            if (next_simple) {                // the workgroup's next block: its first frame's chunks and its pixel addresses
-                BK_PIPE_LOADS(nxt->c, nchunks_n, f_begin);
-                pre.ix = coop_load_idx<RUBIX, RG>(idx, tint_t, blk_next, wave, lane_of());
-                pre.valid = true;
-            }
-            if (has_nn) cur = coop_fetch<RUBIX, RG>(hdr, list, blk_nn);      // ... and the header and list head of the one after it
-        }
-        if (!tile_empty) coop_gather_store<RUBIX, RG>(smem, ix, fast_store, pal_s, dst, frame_stride, dst_pitch, f, row0, x, kflags);
-        BK_LDS_BARRIER();                     // every wave is done with the buffer
-    }
-}
-#undef BK_PIPE_LOADS
-#undef BK_PIPE_LD
-
-template <bool RUBIX, int RG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_pipe_kernel(BK_COOP_KERNEL_ARGS)
-{
-    BK_COOP_PROLOGUE;
-    (void)wgmap; (void)l_end;
-    l = (int)bands[band] + wg_in_band;
-    const int l_hi = (int)bands[band + 1];
-    if (l >= l_hi) return;
-    int b_cur = (int)order[l];
-    int l_next = l + wgs_per_band;
-    bool has_next = l_next < l_hi;
-    int b_next = has_next ? (int)order[l_next] : 0;
-    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, b_cur);
-    CoopPrefetch<RG> nxt = cur;
-    if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, b_next);
-    CoopPre<RG> pre;
-    pre.q0 = pre.q1 = pre.q2 = pre.q3 = make_uint4(0, 0, 0, 0);
-    pre.valid = false;
-    for (;;) {
-        const int l_nn = l_next + wgs_per_band;
-        const bool has_nn = has_next && l_nn < l_hi;
-        const int b_nn = has_nn ? (int)order[l_nn] : 0;
-        coop_block_pipe<RUBIX, RG>(cur, b_cur, has_next ? &nxt : nullptr, b_next, has_nn, b_nn, pre, hdr, list, idx, tint_t, lmap, globe,
-                                   globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, W, rows, blocks_x, smem,
-                                   lds_buf, pal_s, aligned, ry, cx, wave, kflags);
-        if (!has_next) break;
-        {                                      // `cur` now holds the block after next: rotate (cur, nxt) <- (nxt, cur)
-            const CoopPrefetch<RG> t = cur;
-            cur = nxt;
-            nxt = t;
-        }
-        b_cur = b_next;
-        b_next = b_nn;
-        l_next = l_nn;
-        has_next = has_nn;
-    }
-}
-
 // one block per workgroup (launches short enough that the whole grid is resident at once, e.g. the engine's
 // single frames): no next-block state, fewer registers, more workgroups per CU - every block starts at once
 // (8 waves per SIMD = 8 workgroups per CU: the 128x32 form would take 67 VGPRs and 7; at 4K that is 1792 places for 2040
@@ -1243,9 +1115,11 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     // crosses the fabric, not by the staging instructions - it stays a developer bit.  Bit 512 leaves both to the caller.
     if (fchunk == 1 && !(kflags & 512)) kflags |= 128;
     const bool dma = fchunk == 1 && (kflags & 256) != 0;
-    // the strided walk with cross-block pipelining (bit 1024: without; it needs the balanced walk's order list)
-    const bool all_simple = !cm->stats_pending && cm->stats[1] == 0 && cm->stats[0] <= 1024u && (int)(cm->stats[0] * 16u) <= lds_buf;
-    const bool pipe_blocks = !once && !rubix_on && all_simple && (kflags & (16 | 64 | 1024)) == 0 && (ctx->apply_pipe_blocks < 0 ? fchunk == 1 : ctx->apply_pipe_blocks != 0);
+    // (Tried in round 3 and removed: a strided walk in which a block's last frame issues the NEXT block's first globe loads and pixel
+    //  addresses - apply_coop_pipe_kernel, git history.  Where it applied (block maps without blocks of more than 1024 chunks) it was
+    //  slower - 4K panini at 128x16: 12.0 -> 18.3 us single frame, 4.5 -> 6.4 us/frame x16: 77-96 VGPRs against 67 - and the
+    //  whole-globe lenses it was meant for have larger blocks.  What separates mercator's 16.5 us from hammer's 11.5 is not per-block
+    //  latency but the quantisation of rounds: 4050 live blocks on 1792 resident places are 2.26 rounds and take 3.)
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
@@ -1254,8 +1128,7 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
-#define BK_APPLY(RBX, N) do { if (once && dma) BK_APPLY_KD(RBX, N); else if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N);       \
-                              else if (pipe_blocks && !RBX) BK_APPLY_K(apply_coop_pipe_kernel, false, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
+#define BK_APPLY(RBX, N) do { if (once && dma) BK_APPLY_KD(RBX, N); else if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
     if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
     else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
 #undef BK_APPLY_K

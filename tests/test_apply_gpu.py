@@ -232,11 +232,10 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
         if bal["live_blocks"] >= 64:
             assert max(cost) <= 1.15 * (sum(cost) / 8), cost                # level to a block or two
         # (128: non-temporal globe loads; 256: LDS-DMA staging in single-frame launches - results must not change)
-        # (1024: the strided walk without cross-block pipelining; knob 702 = with it for batch launches too, 32 = strided walk always)
-        for wgs, abl, pipe in ((1, 0, 700), (1, 64, 700), (2, 0, 700), (16, 0, 700), (16, 64, 700), (16, 32, 700), (16, 16, 700), (16, 128, 700),
-                               (16, 256, 700), (16, 384, 700), (1, 256 + 64, 700), (1, 1024, 700), (1, 0, 702), (2, 32, 702), (16, 32, 702), (16, 32 + 1024, 702), (16, 2048, 700), (1, 2048 + 32, 702)):
+        # (2048: __syncthreads() instead of the raw LDS barriers; 32 = strided walk always)
+        for wgs, abl in ((1, 0), (1, 64), (2, 0), (16, 0), (16, 64), (16, 32), (16, 16), (16, 128), (16, 256), (16, 384), (1, 256 + 64),
+                         (16, 2048), (1, 2048 + 32)):
             ctx.set_tile_shape(100 + wgs)
-            ctx.set_tile_shape(pipe)
             ctx.set_ablation(abl)
             for nf in (1, F):
                 out = torch.full((nf, H, W), 9, dtype=torch.uint8, device="cuda")
@@ -246,7 +245,6 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
                 for f in range(nf):
                     np.testing.assert_array_equal(got[f], want[f], err_msg=f"{lens} shape {shape} wgs/cu {wgs} ablation {abl} frames {nf} frame {f}")
     ctx.set_ablation(0)
-    ctx.set_tile_shape(700)
     ctx.close()
 
 
