@@ -75,6 +75,8 @@ struct CoopMap {
     int rg = 4;
     int lds_bytes = 0;              // bytes of the staging buffer of the apply launch
     int tuned_frames = 0;           // frames per launch the block height was measured with (0 = cost model alone)
+    int single_form = 0;            // single-frame launches: 0 = the launcher's rule, 1 = one block per workgroup, 2 = strided walk (measured)
+    bool lds_fixed = false;         // the staging buffer size was measured: the exact statistics do not re-choose it
     uint32_t stats[BK_COOP_STATS] = {0};
     uint32_t *h_stats = nullptr;    // pinned [64][BK_COOP_STATS]: the full compile's statistics land here asynchronously ...
     hipEvent_t stats_ready = nullptr;   // ... and are folded into `stats` when somebody asks (coopmap_stats / traffic model)
@@ -831,7 +833,7 @@ static int coop_stats_wait(bk_ctx *ctx, CoopMap *cm)
     fold_stats(cm->h_stats, cm->stats, 1);
     // the buffer size was chosen on a survey (every 2nd / 8th row of blocks); now that the exact histogram is here, let the
     // model look again - the buffer is a launch parameter, nothing in the block map depends on it
-    if (ctx->apply_lds_kb <= 0 && (int)(cm->stats[0] * 16u) > cm->lds_bytes) {
+    if (ctx->apply_lds_kb <= 0 && !cm->lds_fixed && (int)(cm->stats[0] * 16u) > cm->lds_bytes) {
         double c = 0;
         const int kb = coop_choose_buffer(cm, cm->rg, (double)ctx->W * ctx->rows(), ctx->num_cus, &c);
         if (kb * 1024 > cm->lds_bytes) cm->lds_bytes = kb * 1024;
@@ -995,17 +997,37 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     // launch the caller is about to make - same frame count, the context's own globe - is timed on each; the fastest stays.
     // A lensmap is built once per lens / zoom change and applied every frame: ~0.7 ms more here for up to 17 % per frame.
     int measured = 0;
-    if (ctx->blockmap_tuning && !forced && nc > 1 && ctx->d_globe && !(ctx->apply_flags & (2 | 4))) {
+    cm->single_form = 0;
+    cm->lds_fixed = false;
+    if (ctx->blockmap_tuning && !forced && nc > 0 && ctx->d_globe && !(ctx->apply_flags & (2 | 4 | 32))) {
         int keep = 1;
         while (keep < nc && c_cost[keep] <= 1.2 * c_cost[0]) ++keep;
-        if (keep > 1) {
-            const int nf = launch_frames > 0 ? (launch_frames < 16 ? launch_frames : 16) : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
+        const int nf = launch_frames > 0 ? (launch_frames < 16 ? launch_frames : 16) : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
+        // Single-frame launches have two more things worth measuring per height.  (a) The form: one block per workgroup (dealt out by
+        // the hardware as places free up) or the strided walk (prefetch, but a static split) - the launcher's rule of thumb is right
+        // for most maps and 10-20 % off for some.  (b) The staging buffer: a launch is a whole number of ROUNDS of blocks - 4050 live
+        // blocks on 7 x 256 places are 2.26 rounds and take 3 (4K mercator: 16.5 us where its bytes cost 12.8) - and a buffer of 20 KiB
+        // instead of the 21-26 KiB that hold every block lets 8 workgroups share a CU: 1.98 rounds, with the few larger blocks going
+        // through the buffer in two passes.  The buffer is a launch parameter, so (b) costs no compile.
+        struct Variant { int form, kb; };
+        auto variants_of = [&](int kb, Variant *v) {
+            int n = 0;
+            v[n++] = {0, kb};
+            if (nf == 1 && ctx->apply_wgs_per_cu == 16) {
+                v[n++] = {1, kb};
+                if (ctx->apply_lds_kb <= 0 && kb > 20 && kb <= 28) v[n++] = {1, 20};
+            }
+            return n;
+        };
+        Variant vtmp[3];
+        if (keep > 1 || variants_of(c_kb[0], vtmp) > 1) {
             uint8_t *scratch = nullptr;
             hipEvent_t t0, t1;
             BK_HIP(ctx, hipMallocAsync((void **)&scratch, (size_t)nf * rows * ctx->W, ctx->stream));
             BK_HIP(ctx, hipEventCreate(&t0));
             BK_HIP(ctx, hipEventCreate(&t1));
             int rc = BK_OK, win = 0;
+            Variant win_v = {0, c_kb[0]};
             float best_ms = -1;
             // every candidate: one warm-up launch, then a train of launches between two events - back to back, as a caller's
             // steady state issues them; the globe frames advance through the context's ring from launch to launch, candidate
@@ -1021,27 +1043,40 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                 // (timed in the configuration the caller's steady state runs in: with the block map's statistics there - live
                 //  blocks, uneven bands - the launch may take another form than in the first microseconds after a compile)
                 if (rc == BK_OK) rc = coop_stats_wait(ctx, cm);
-                if (rc == BK_OK) rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
-                if (rc == BK_OK && hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
-                for (int rep = 0; rep < train && rc == BK_OK; ++rep)
+                Variant vs[3];
+                const int nv = variants_of(cm->lds_bytes / 1024, vs);
+                for (int k = 0; k < nv && rc == BK_OK; ++k) {
+                    cm->single_form = vs[k].form;
+                    cm->lds_bytes = clamp_kb(vs[k].kb) * 1024;
                     rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
-                float ms = 0;
-                if (rc == BK_OK && (hipEventRecord(t1, ctx->stream) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
-                                    hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
-                    rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
-                if (g_debug.print_model) fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], c_kb[i], ms * 1e3 / train);
-                // candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
-                if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = i; }
+                    if (rc == BK_OK && hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
+                    for (int rep = 0; rep < train && rc == BK_OK; ++rep)
+                        rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
+                    float ms = 0;
+                    if (rc == BK_OK && (hipEventRecord(t1, ctx->stream) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
+                                        hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
+                        rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
+                    if (g_debug.print_model)
+                        fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d form %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], vs[k].kb, vs[k].form, ms * 1e3 / train);
+                    // the first variant of candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
+                    if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = i; win_v = vs[k]; }
+                }
                 measured = i;
             }
             (void)hipEventDestroy(t0);
             (void)hipEventDestroy(t1);
             (void)hipFreeAsync(scratch, ctx->stream);
             if (rc != BK_OK) return rc;
-            best_rg = c_rg[win]; best_kb = c_kb[win];
+            best_rg = c_rg[win]; best_kb = win_v.kb;
             cm->tuned_frames = nf;
             if (win == measured) measured = -1;           // the winner is what is compiled right now
             else measured = 0;
+            if (measured != -1)
+                if (int r = compile_full(best_rg, best_kb)) return r;
+            measured = -1;
+            cm->single_form = win_v.form;
+            cm->lds_bytes = clamp_kb(win_v.kb) * 1024;
+            cm->lds_fixed = true;
         }
     }
     if (measured != -1)
@@ -1091,8 +1126,9 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
         const int by_regs = 8;                              // (one-block form: <= 64 VGPRs)
         per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
         const int live = cm->stats_pending ? nblocks : nblocks - (int)cm->stats[2];
-        // (up to 1.5 x what is resident the one-block form still wins: 4K panini, 2040 blocks on 1792 places, 9.0 against 9.3 us)
-        if (2 * live <= 3 * ctx->num_cus * per_cu) per_cu = 1 << 20;         // one block each
+        // (up to 1.5 x what is resident the one-block form still wins: 4K panini, 2040 blocks on 1792 places, 9.0 against 9.3 us;
+        //  the measured tuning may have settled the form for this block map: CoopMap::single_form)
+        if (cm->single_form == 1 || (cm->single_form == 0 && 2 * live <= 3 * ctx->num_cus * per_cu)) per_cu = 1 << 20;         // one block each
     }
     {
         const long long resident_per_band = (long long)ctx->num_cus * per_cu / 8;
