@@ -270,7 +270,7 @@ def measure_traffic(args, F, R, block_h):
         cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
                "--frames", str(F), "--ring", str(R), "--variant", str(args.variant), "--shape", str(block_h // 8)]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, {"error": f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})", "stderr_tail": r.stderr[-300:]}

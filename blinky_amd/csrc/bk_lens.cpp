@@ -692,8 +692,16 @@ static HostModuleP host_module_for(const std::string &source, bool wait)
         else {
             const std::string cxx = host_compiler();
             if (cxx.empty()) { g_hostmods[key] = nullptr; return nullptr; }
-            std::string dir = cache_dir();                                  // next to the device code objects, or a per-user temp dir
-            if (dir.empty()) dir = "/tmp/blinky_hip_hostmod." + std::to_string((long long)getuid());
+            std::string dir = cache_dir();                                  // next to the device code objects, or a private temp dir
+            if (dir.empty()) {                                              // (disk cache off: a directory only this process can have made)
+                static std::string private_dir;
+                if (private_dir.empty()) {
+                    char tmpl[] = "/tmp/blinky_hip_hostmod.XXXXXX";
+                    if (!mkdtemp(tmpl)) { g_hostmods[key] = nullptr; return nullptr; }
+                    private_dir = tmpl;
+                }
+                dir = private_dir;
+            }
             char name[64];
             snprintf(name, sizeof name, "/bk_host_%016llx.so", (unsigned long long)fnv1a64(cxx.data(), cxx.size(), key));
             const std::string so = dir + name;
