@@ -294,7 +294,6 @@ extern "C" int bk_debug_set_ablation(bk_ctx *ctx, int bits)
 extern "C" int bk_debug_set_tile_shape(bk_ctx *ctx, int lw)
 {
     if (!ctx) return BK_E_INVALID;
-    if (lw >= 800) { ctx->apply_list_form = lw - 800; bk::coopmap_invalidate(ctx); return BK_OK; }                          // 800 measured, 801 chunks, 802 lines
     if (lw >= 600) { ctx->apply_block_cost = lw == 600 ? -1 : lw - 601; bk::coopmap_invalidate(ctx); return BK_OK; }   // 600 default, 601+n = n
     if (lw >= 400) { ctx->apply_lds_kb = lw - 400; bk::coopmap_invalidate(ctx); return BK_OK; }
     if (lw >= 300) { ctx->apply_fchunk = lw - 300; return BK_OK; }

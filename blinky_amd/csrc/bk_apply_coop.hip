@@ -44,8 +44,6 @@ constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's r
 constexpr uint32_t CF_SLOW = 0x100, CF_EMPTY = 0x200;  // direct-gather block / nothing mapped in the block
 constexpr uint32_t BK_COOP_BINS = 65;                  // LDS-need histogram: 1 KiB bins, 0..64 KiB
 constexpr int BK_COOP_STATS = 208;                     // words per stats replica
-constexpr int BK_KF_LINES = 1 << 29;                   // kflags (set by the launcher): the block map is in LINE form (CoopMap::line_form)
-constexpr uint32_t BK_COOP_MAX_LINES = 511;            // line form: 16-bit LDS addresses = line slot * 128 + byte
 constexpr int BK_KF_WGMAP = 1 << 30;                   // kflags (set by the launcher): one-block form reads CoopMap::d_wgmap
 constexpr int BK_COOP_BLOCK_COST = 4;                  // what a block costs beyond its lines and pixels, in lines (barriers, header)
 
@@ -77,9 +75,6 @@ struct CoopMap {
     int rg = 4;
     int lds_bytes = 0;              // bytes of the staging buffer of the apply launch
     int tuned_frames = 0;           // frames per launch the block height was measured with (0 = cost model alone)
-    bool line_form = false;         // the chunk list names whole 128-byte globe LINES (one entry per line, all 8 chunks staged) instead of
-                                    // the exact 16-byte chunks: an eighth of the list bytes for 1.1-1.2 x the staging buffer - worth it
-                                    // where the list is read once per frame (single-frame launches)
     int single_form = 0;            // single-frame launches: 0 = the launcher's rule, 1 = one block per workgroup, 2 = strided walk (measured)
     bool lds_fixed = false;         // the staging buffer size was measured: the exact statistics do not re-choose it
     uint32_t stats[BK_COOP_STATS] = {0};
@@ -100,11 +95,8 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
                                                            CoopHdr *__restrict__ hdr, uint32_t *__restrict__ list,
                                                            uint16_t *__restrict__ idx, uint8_t *__restrict__ tint_t,
                                                            uint32_t *__restrict__ stats, int row_stride, uint32_t *__restrict__ cost,
-                                                           int block_cost, int line_form)
+                                                           int block_cost)
 {
-    // line_form: the keys are 128-byte LINE numbers, the list holds one entry per line and a pixel's LDS address is line slot * 128 +
-    // its byte within the line; hdr.nchunks stays "16-byte chunks to stage" (8 per line)
-    const int kshift = line_form ? 7 : 4;
     // row_stride > 1: a SURVEY pass for the cost model - only every row_stride-th row of blocks is looked at and nothing
     // but the statistics is written (ensure_coopmap scales them up); row_stride == 1: the real block map
     constexpr int NP = 4 * RG, N = 256 * NP;      // pixels per thread / per block
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         const bool in = row < rows && x < W;
         o[i] = in ? lmap[(size_t)row * W + x] : BK_NULL_OFFSET;
         tn[i] = in ? tints[(size_t)row * W + x] : 255;
-        key[threadIdx.x * NP + i] = o[i] == BK_NULL_OFFSET ? 0xFFFFFFFFu : o[i] >> kshift;
+        key[threadIdx.x * NP + i] = o[i] == BK_NULL_OFFSET ? 0xFFFFFFFFu : o[i] >> 4;
         all_l = all_l && o[i] != BK_NULL_OFFSET;
         any_l = any_l || o[i] != BK_NULL_OFFSET;
         npx += o[i] != BK_NULL_OFFSET ? 1u : 0u;
@@ -165,7 +157,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         const uint32_t v = key[p], prev = p > 0 ? key[p - 1] : 0xFFFFFFFFu;
         const bool first = v != 0xFFFFFFFFu && (p == 0 || v != prev);
         cnt += first ? 1u : 0u;
-        lcnt += (first && (line_form || p == 0 || (v >> 3) != (prev >> 3))) ? 1u : 0u;       // a new 128-byte line
+        lcnt += (first && (p == 0 || (v >> 3) != (prev >> 3))) ? 1u : 0u;       // a new 128-byte line
     }
     uint32_t incl = cnt, lsum = lcnt;
     for (int m = 1; m < 64; m <<= 1) {
@@ -178,12 +170,10 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     __syncthreads();
     uint32_t base = incl - cnt;
     for (int w = 0; w < wave; ++w) base += s_wsum[w];
-    const uint32_t nuniq = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];       // list entries: chunks, or lines
-    const uint32_t nchunks = line_form ? nuniq * 8u : nuniq;                    // 16-byte chunks the block stages
+    const uint32_t nchunks = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     const uint32_t lines = s_wlines[0] + s_wlines[1] + s_wlines[2] + s_wlines[3];
     const uint32_t mapped = s_wpx[0] + s_wpx[1] + s_wpx[2] + s_wpx[3];
-    // (no list: only a 128x32 block whose 4096 pixels all read different chunks - or, in line form, a block that touches more than 511 lines)
-    const bool slow = line_form ? nuniq > BK_COOP_MAX_LINES : nuniq > BK_COOP_MAX_CHUNKS;
+    const bool slow = nchunks > BK_COOP_MAX_CHUNKS;        // (only a 128x32 block whose 4096 pixels all read different chunks)
     {
         uint32_t k = base;
 #pragma unroll
@@ -192,7 +182,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
             const uint32_t v = key[p];
             if (v != 0xFFFFFFFFu && (p == 0 || v != key[p - 1])) {
                 uniq[k] = v;
-                if (!slow && !survey) list[(size_t)blk * N + k] = v << kshift;
+                if (!slow && !survey) list[(size_t)blk * N + k] = v << 4;
                 ++k;
             }
         }
@@ -214,13 +204,13 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
             if (o[i] != BK_NULL_OFFSET) {
                 a[k] = 0;
                 if (!slow) {
-                    const uint32_t c = o[i] >> kshift;
-                    uint32_t lo = 0, hi = nuniq;                // first slot with uniq[slot] >= c
+                    const uint32_t c = o[i] >> 4;
+                    uint32_t lo = 0, hi = nchunks;              // first slot with uniq[slot] >= c
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi) >> 1;
                         if (uniq[mid] < c) lo = mid + 1; else hi = mid;
                     }
-                    a[k] = line_form ? lo * 128u + (o[i] & 127u) : lo * 16u + (o[i] & 15u);
+                    a[k] = lo * 16u + (o[i] & 15u);
                 }
             }
             tw |= (uint32_t)tn[i] << (8 * k);
@@ -232,7 +222,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     }
     if (threadIdx.x == 0) {
         const uint32_t wflags = s_flags;
-        const bool any_blk = nuniq != 0;
+        const bool any_blk = nchunks != 0;
         CoopHdr h;
         h.nchunks = slow ? 0u : nchunks;
         h.flags = wflags | (slow ? CF_SLOW : 0u) | (any_blk ? 0u : CF_EMPTY);
@@ -302,21 +292,17 @@ __device__ __forceinline__ int bk_block_at(int l, int blocks_x, int nblocks, int
     return (srow * PH + row) * blocks_x + col;
 }
 
-// globe byte offset of the block's i-th staged chunk: list entry i, or - line form - entry i / 8 plus the chunk's place in its line
-#define BK_LIST_AT(BL, I, LINES) ((LINES) ? (BL)[(I) >> 3] + (((I)&7u) << 4) : (BL)[(I)])
-
 template <bool RUBIX, int RG>
-__device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list, int blk, int kflags)
+__device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict__ hdr, const uint32_t *__restrict__ list, int blk)
 {
     constexpr int N = 1024 * RG;
     CoopPrefetch<RG> p;
     int bv;
     asm volatile("v_mov_b32 %0, %1" : "=v"(bv) : "s"(blk));     // make the address a VGPR: vector load
     p.h = *(reinterpret_cast<const uint2 *>(hdr) + (size_t)bv);
-    const uint32_t *lp = list + (size_t)blk * N;
-    const bool lines_ = (kflags & BK_KF_LINES) != 0;
+    const uint32_t *lp = list + (size_t)blk * N + threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p.c[j] = 256 * j < N ? BK_LIST_AT(lp, threadIdx.x + 256u * j, lines_) : 0u;
+    for (int j = 0; j < 4; ++j) p.c[j] = 256 * j < N ? lp[256 * j] : 0u;
     return p;
 }
 
@@ -396,7 +382,6 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
 {
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;     // (scalars, not an array: they must stay in VGPRs)
     const bool pipe = (kflags & 8) == 0;      // issue frame f+1's loads before frame f's gather (ablation bit 8 turns it off)
-    const bool lines_ = (kflags & BK_KF_LINES) != 0;
     typedef uint32_t bk_v4u __attribute__((ext_vector_type(4)));
     // kflags bit 128: the globe chunks are fetched with the non-temporal hint (streamed through L2, evicted first), so that
     // what L2 keeps from one launch to the next is the block map - headers, chunk lists, pixel addresses: the same bytes every
@@ -436,7 +421,7 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
             if (NQ > 3) {
                 for (uint32_t c0 = 1024; c0 < nchunks; c0 += 256) {
                     const uint32_t c = c0 + threadIdx.x;
-                    if (c < nchunks) BK_COOP_DMA(gl + BK_LIST_AT(blist, c, lines_), c0);
+                    if (c < nchunks) BK_COOP_DMA(gl + blist[c], c0);
                 }
             }
         } else {
@@ -450,8 +435,8 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
             for (uint32_t c0 = 1024; c0 < nchunks; c0 += 1024) {      // blocks above 16 KiB: rounds of four loads
                 const uint32_t c = c0 + threadIdx.x;
                 const bool m0 = c < nchunks, m1 = c + 256u < nchunks, m2 = c + 512u < nchunks, m3 = c + 768u < nchunks;
-                const uint32_t a0 = m0 ? BK_LIST_AT(blist, c, lines_) : 0u, a1 = m1 ? BK_LIST_AT(blist, c + 256u, lines_) : 0u,
-                               a2 = m2 ? BK_LIST_AT(blist, c + 512u, lines_) : 0u, a3 = m3 ? BK_LIST_AT(blist, c + 768u, lines_) : 0u;
+                const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
+                               a3 = m3 ? blist[c + 768u] : 0u;
                 BK_COOP_LD(q0, gl + a0);
                 BK_COOP_LD(q1, gl + a1);
                 BK_COOP_LD(q2, gl + a2);
@@ -484,7 +469,7 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                                                    int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
                                                    uint8_t *buf, uint32_t lds_buf, const uint32_t *__restrict__ blist,
                                                    uint32_t nchunks, const CoopIdx<RG> ix, bool fast_store, bool tile_empty,
-                                                   const uint8_t *pal_s, int row0, int x, bool lines_)
+                                                   const uint8_t *pal_s, int row0, int x)
 {
     const uint32_t cpb = lds_buf >> 4;                       // chunks per pass
     for (int f = f_begin; f < f_end; ++f) {
@@ -497,8 +482,8 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
             for (uint32_t c0 = base; c0 < end; c0 += 1024) {
                 const uint32_t c = c0 + threadIdx.x;
                 const bool m0 = c < end, m1 = c + 256u < end, m2 = c + 512u < end, m3 = c + 768u < end;
-                const uint32_t a0 = m0 ? BK_LIST_AT(blist, c, lines_) : 0u, a1 = m1 ? BK_LIST_AT(blist, c + 256u, lines_) : 0u,
-                               a2 = m2 ? BK_LIST_AT(blist, c + 512u, lines_) : 0u, a3 = m3 ? BK_LIST_AT(blist, c + 768u, lines_) : 0u;
+                const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
+                               a3 = m3 ? blist[c + 768u] : 0u;
                 const uint4 q0 = *reinterpret_cast<const uint4 *>(gl + a0), q1 = *reinterpret_cast<const uint4 *>(gl + a1),
                             q2 = *reinterpret_cast<const uint4 *>(gl + a2), q3 = *reinterpret_cast<const uint4 *>(gl + a3);
                 uint8_t *md = buf + (size_t)(c - base) * 16u;
@@ -608,7 +593,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
         // a chunk list larger than this launch's staging buffer goes through it in passes
         coop_frames_multipass<RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
                                          smem, (uint32_t)lds_buf, list + (size_t)l * N, nchunks, ix, tile_all && aligned,
-                                         tile_empty, pal_s, row0, x, (kflags & BK_KF_LINES) != 0);
+                                         tile_empty, pal_s, row0, x);
     } else {
         const bool k0 = threadIdx.x < nchunks, k1 = threadIdx.x + 256u < nchunks, k2 = threadIdx.x + 512u < nchunks,
                    k3 = threadIdx.x + 768u < nchunks;
@@ -673,10 +658,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     int l_next = l + wgs_per_band;
     bool has_next = l_next < l_hi;
     int b_next = has_next ? BK_BLOCK_OF(l_next) : 0;
-    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, b_cur, kflags);
+    CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, b_cur);
     for (;;) {
         CoopPrefetch<RG> nxt = cur;
-        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, b_next, kflags);
+        if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, b_next);
         const int l_nn = l_next + wgs_per_band;                    // two ahead: its block number is here before it is needed
         const bool has_nn = has_next && l_nn < l_hi;
         const int b_nn = has_nn ? BK_BLOCK_OF(l_nn) : 0;
@@ -711,7 +696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (l >= l_end) return;
         blk = bk_block_at(l, blocks_x, nblocks, kflags);
     }
-    const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, blk, kflags);
+    const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, blk);
     coop_block<RUBIX, RG, DMA>(cur, blk, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
                                dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
 }
@@ -821,7 +806,7 @@ static void fold_stats(const uint32_t *rep, uint32_t *out, uint32_t scale)
 
 // one pass of coop_compile_kernel over the owned rows with block height 8*rg; row_stride > 1 = survey pass into statistics
 // set `set` of d_stats (nothing else written)
-static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride, int set, bool line_form = false)
+static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride, int set)
 {
     const int rows = ctx->rows();
     const int bx = (ctx->W + 127) / 128, by = (rows + 8 * rg - 1) / (8 * rg);
@@ -830,7 +815,7 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
     BK_HIP(ctx, hipMemsetAsync(st, 0, 64 * BK_COOP_STATS * sizeof(uint32_t), ctx->stream));
     const dim3 grid((unsigned)(bx * sampled_rows)), block(256);
 #define BK_COMPILE(N) hipLaunchKernelGGL((coop_compile_kernel<N>), grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
-                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride, cm->d_cost, ctx->apply_block_cost >= 0 ? ctx->apply_block_cost : BK_COOP_BLOCK_COST, line_form ? 1 : 0)
+                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride, cm->d_cost, ctx->apply_block_cost >= 0 ? ctx->apply_block_cost : BK_COOP_BLOCK_COST)
     if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
 #undef BK_COMPILE
     BK_HIP(ctx, hipGetLastError());
@@ -990,13 +975,12 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
         if (ctx->apply_lds_kb > 0) kb = ctx->apply_lds_kb > BK_COOP_LDS_CAP / 1024 ? BK_COOP_LDS_CAP / 1024 : ctx->apply_lds_kb;   // developer knob
         return kb < 1 ? 1 : kb;
     };
-    auto compile_full = [&](int rg, int kb, bool lines = false) -> int {
+    auto compile_full = [&](int rg, int kb) -> int {
         cm->rg = rg;
-        cm->line_form = lines;
         cm->blocks_x = (ctx->W + 127) / 128;
         cm->blocks_y = (rows + 8 * rg - 1) / (8 * rg);
         cm->lds_bytes = clamp_kb(kb) * 1024;
-        if (int r = coop_compile_launch(ctx, cm, rg, 1, 0, lines)) return r;
+        if (int r = coop_compile_launch(ctx, cm, rg, 1, 0)) return r;
         const int nb = cm->blocks_x * cm->blocks_y;
         hipLaunchKernelGGL(coop_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, cm->d_cost, nb, cm->blocks_x, (nb + 7) / 8,
                            cm->d_order, cm->d_cum, cm->d_bands, cm->d_wgmap, cm->d_stats);
@@ -1054,15 +1038,8 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             const int train = work < 20e6 ? 12 : work < 40e6 ? 6 : 2;
             const int span = ctx->nframes > nf ? ctx->nframes - nf + 1 : 1;
             int seq = 0;
-            // single-frame launches read the chunk list once per frame (a batch launch once per 8): the model's pick is also tried in
-            // LINE form - one list entry per 128-byte globe line, all 8 chunks of it staged: an eighth of the list, 1.1-1.2 x the buffer
-            const bool try_lines = nf == 1 && ctx->apply_list_form == 0;
-            bool win_lines = ctx->apply_list_form == 2;
-            const int ncand = keep + (try_lines ? 1 : 0);
-            for (int ci = 0; ci < ncand && rc == BK_OK; ++ci) {
-                const int i = ci < keep ? ci : 0;
-                const bool lines = ci >= keep || ctx->apply_list_form == 2;
-                rc = compile_full(c_rg[i], c_kb[i], lines);
+            for (int i = 0; i < keep && rc == BK_OK; ++i) {
+                rc = compile_full(c_rg[i], c_kb[i]);
                 // (timed in the configuration the caller's steady state runs in: with the block map's statistics there - live
                 //  blocks, uneven bands - the launch may take another form than in the first microseconds after a compile)
                 if (rc == BK_OK) rc = coop_stats_wait(ctx, cm);
@@ -1080,23 +1057,22 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                                         hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
                         rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
                     if (g_debug.print_model)
-                        fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d form %d %s: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], vs[k].kb, vs[k].form,
-                                lines ? "lines" : "chunks", ms * 1e3 / train);
+                        fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d form %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], vs[k].kb, vs[k].form, ms * 1e3 / train);
                     // the first variant of candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
-                    if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = ci; win_v = vs[k]; win_lines = lines; }
+                    if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = i; win_v = vs[k]; }
                 }
-                measured = ci;
+                measured = i;
             }
             (void)hipEventDestroy(t0);
             (void)hipEventDestroy(t1);
             (void)hipFreeAsync(scratch, ctx->stream);
             if (rc != BK_OK) return rc;
-            best_rg = c_rg[win < keep ? win : 0]; best_kb = win_v.kb;
+            best_rg = c_rg[win]; best_kb = win_v.kb;
             cm->tuned_frames = nf;
             if (win == measured) measured = -1;           // the winner is what is compiled right now
             else measured = 0;
             if (measured != -1)
-                if (int r = compile_full(best_rg, best_kb, win_lines)) return r;
+                if (int r = compile_full(best_rg, best_kb)) return r;
             measured = -1;
             cm->single_form = win_v.form;
             cm->lds_bytes = clamp_kb(win_v.kb) * 1024;
@@ -1104,7 +1080,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
         }
     }
     if (measured != -1)
-        if (int r = compile_full(best_rg, best_kb, ctx->apply_list_form == 2)) return r;
+        if (int r = compile_full(best_rg, best_kb)) return r;
     cm->valid = true;
     return BK_OK;
 }
@@ -1167,7 +1143,7 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     const bool once = wgs_per_band == per && !(ctx->apply_flags & 32);     // every workgroup has exactly one block (ablation bit 32: persistent form anyway)
     // one-block form: take the cost-balanced workgroup -> block map if bands of equal block count are known to be uneven
     // (the block map's statistics arrive asynchronously: until they are here, the direct mapping)
-    int kflags = (ctx->apply_flags & ~(BK_KF_WGMAP | BK_KF_LINES)) | (cm->line_form ? BK_KF_LINES : 0);
+    int kflags = ctx->apply_flags & ~BK_KF_WGMAP;
     if (once && !(kflags & (16 | 64)) && !cm->stats_pending && cm->stats[7]) kflags |= BK_KF_WGMAP;
     // Single-frame launches fetch the globe chunks non-temporally: between two of them it is the block map L2 should keep
     // (4K hammer 12.4 -> 11.6 us, quincuncial 12.8 -> 11.8, panini 8.4 -> 8.2); batch launches lose 3-10 % that way.
@@ -1255,7 +1231,7 @@ int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8])
     out[0] = h[1];
     out[1] = cm->stats[3];
     out[2] = cm->stats[4];
-    out[3] = nblocks * sizeof(CoopHdr) + (uint64_t)(cm->line_form ? cm->stats[3] : cm->stats[4]) * 4u + live * (uint64_t)(1024 * cm->rg) * 2u;
+    out[3] = nblocks * sizeof(CoopHdr) + (uint64_t)cm->stats[4] * 4u + live * (uint64_t)(1024 * cm->rg) * 2u;
     out[4] = h[0];
     out[5] = 8;
     out[6] = nblocks;

@@ -96,7 +96,6 @@ struct bk_ctx {
     int apply_flags = 0;             // developer ablations of the coop apply (bk_debug_set_ablation): 2 no globe loads, 4 no stores, 8 no load pipelining
     int apply_block_cost = -1;       // coop apply: constant term of a block's cost in the band balance (-1 = default; knob 600+n)
     int apply_lds_kb = 0;            // coop apply: force the staging buffer size in KiB (0 = cost model; knob 400+n)
-    int apply_list_form = 0;         // coop apply, chunk list: 0 = measured for single-frame launches, 1 = chunks always, 2 = lines always (knob 800+n)
     int apply_fchunk = 0;            // frames a workgroup keeps a block for (0 = default 8; knob 300+n)
     int apply_wgs_per_cu = 16;       // persistent apply grid: workgroups per CU (tunable, bk_debug_set_tile_shape)
     bool blockmap_tuning = true;     // bk_set_blockmap_tuning: block height of the staged apply chosen by timing the candidates

@@ -54,8 +54,7 @@ int         bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int write
 int         bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups);
 /* developer knobs: 0 = block height by the cost model, 1 / 2 / 4 = force 128x8 / 128x16 / 128x32 pixel blocks;
  * 100+n = n workgroups per CU in the persistent grid; 300+n = frames per block visit; 400+n = staging buffer KiB;
- * 600 / 601+n = default / n as the constant term of a block's cost in the band balance;
- * 800 / 801 / 802 = chunk list form: measured for single-frame launches / exact chunks always / whole lines always */
+ * 600 / 601+n = default / n as the constant term of a block's cost in the band balance */
 int         bk_debug_set_tile_shape(bk_ctx *ctx, int lw);
 /* the HIP translation unit generated for the current lens + globe scripts (needed = strlen+1);
  * compile != 0 also runs it through hiprtc (works on a BK_DEVICE_NONE context) */

@@ -221,8 +221,7 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
         w[r1:] = 9
     if rows:
         uneven = False                                      # (the stripe cuts the ellipse's caps off: may or may not be uneven)
-    for shape, lform in ((1, 801), (2, 801), (4, 801), (2, 802), (4, 802)):
-        ctx.set_tile_shape(lform)
+    for shape in (1, 2, 4):
         ctx.set_tile_shape(shape)
         st = ctx.tile_stats()                              # (waits for the block map's statistics: the balance is known from here on)
         bal = ctx.band_balance()
@@ -246,7 +245,6 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
                 for f in range(nf):
                     np.testing.assert_array_equal(got[f], want[f], err_msg=f"{lens} shape {shape} wgs/cu {wgs} ablation {abl} frames {nf} frame {f}")
     ctx.set_ablation(0)
-    ctx.set_tile_shape(800)
     ctx.close()
 
 
@@ -425,9 +423,8 @@ def _scrambled_lensmap(W, H, ps, kind, seed):
 
 
 @pytest.mark.parametrize("kind", ["random", "rows", "columns"])
-@pytest.mark.parametrize("lines", [801, 802], ids=["chunks", "lines"])
 @pytest.mark.parametrize("shape,ldskb", [(0, 0), (1, 0), (1, 48), (2, 48), (4, 48), (4, 8), (2, 1)])
-def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb, lines):
+def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb):
     """Variant 2 on arbitrary tables, with the block height and staging buffer forced so that blocks take the
     register plan (<= 1024 chunks), the extra rounds (> 1024 chunks), and the direct-gather fallback (list larger
     than the buffer); rubix on and off, unaligned pitch/origin, a batch longer than one frame chunk."""
@@ -441,7 +438,6 @@ def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb, lines):
     ctx.set_apply_variant(2)
     ctx.set_tile_shape(shape)
     ctx.set_tile_shape(400 + ldskb)
-    ctx.set_tile_shape(lines)                 # the chunk list as exact 16-byte chunks, or as whole 128-byte lines
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     globes = [O.lcg_globe(ps, 6, f) for f in range(F)]
     for f in range(F):
@@ -471,8 +467,6 @@ def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb, lines):
     ctx.set_ablation(0)
     if kind == "random" and (shape, ldskb) == (2, 1):
         assert stats["slow"] > 0            # 2048 chunks per block against a 1 KiB buffer: the fallback ran
-    if kind == "random" and lines == 802 and shape in (2, 4):
-        assert stats["slow"] > 0            # a block of random texels touches more than 511 lines: no list in line form
     ctx.close()
 
 

@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--shapes", default="0")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--frames", default="1,16")
-    ap.add_argument("--list-form", default="800", help="chunk list form knob(s): 800 measured (single frames), 801 chunks, 802 lines")
     ap.add_argument("--no-tuning", action="store_true", help="block height by the cost model alone (bk_set_blockmap_tuning 0)")
     args = ap.parse_args()
     W, H = [int(v) for v in args.size.split("x")]
@@ -32,10 +31,9 @@ def main():
         wl.ctx.set_blockmap_tuning(not args.no_tuning)
         for shape in [int(v) for v in args.shapes.split(",")]:
             wl.ctx.set_tile_shape(shape)
-            for flags, lform in [(int(v), int(q)) for v in args.flags.split(",") for q in args.list_form.split(",")]:
+            for flags in [int(v) for v in args.flags.split(",")]:
                 wl.ctx.set_ablation(flags)
-                wl.ctx.set_tile_shape(lform)
-                line = f"{lens:14s} {W}x{H} shape {shape} flags {flags:4d} list {lform}"
+                line = f"{lens:14s} {W}x{H} shape {shape} flags {flags:4d}"
                 for nf in [int(v) for v in args.frames.split(",")]:
                     wl.ctx.set_tile_shape(shape)                 # drops the block map: the next launch compiles (and tunes) it for nf frames
                     for i in range(3):
