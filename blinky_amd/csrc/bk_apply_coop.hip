@@ -1023,7 +1023,12 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
         if (keep > 1 || variants_of(c_kb[0], vtmp) > 1) {
             uint8_t *scratch = nullptr;
             hipEvent_t t0, t1;
-            BK_HIP(ctx, hipMallocAsync((void **)&scratch, (size_t)nf * rows * ctx->W, ctx->stream));
+            bool pooled = true;                    // (stream-ordered allocation where the device has a memory pool, plain otherwise)
+            if (hipMallocAsync((void **)&scratch, (size_t)nf * rows * ctx->W, ctx->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                pooled = false;
+                BK_HIP(ctx, hipMalloc((void **)&scratch, (size_t)nf * rows * ctx->W));
+            }
             BK_HIP(ctx, hipEventCreate(&t0));
             BK_HIP(ctx, hipEventCreate(&t1));
             int rc = BK_OK, win = 0;
@@ -1065,7 +1070,8 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             }
             (void)hipEventDestroy(t0);
             (void)hipEventDestroy(t1);
-            (void)hipFreeAsync(scratch, ctx->stream);
+            if (pooled) (void)hipFreeAsync(scratch, ctx->stream);
+            else { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(scratch); }
             if (rc != BK_OK) return rc;
             best_rg = c_rg[win]; best_kb = win_v.kb;
             cm->tuned_frames = nf;
