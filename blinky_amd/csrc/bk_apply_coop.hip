@@ -376,11 +376,15 @@ template <int NQ, bool RUBIX, int RG, bool DMA>
 __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, size_t globe_stride, int globe_frames, int frame0,
                                             int f_begin, int f_end, uint8_t *__restrict__ dst, int dst_pitch, size_t frame_stride,
                                             uint8_t *buf, const uint32_t *__restrict__ blist,
-                                            uint32_t nchunks, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
-                                            bool k0, bool k1, bool k2, bool k3, const CoopIdx<RG> ix, bool fast_store,
+                                            uint32_t nchunks, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, uint32_t s5,
+                                            bool k0, bool k1, bool k2, bool k3, bool k4, bool k5, const CoopIdx<RG> ix, bool fast_store,
                                             bool tile_empty, const uint8_t *pal_s, int row0, int x, int kflags)
 {
-    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;     // (scalars, not an array: they must stay in VGPRs)
+    // NQ = 5, 6 (strided walk only): a thread's fifth and sixth chunk ride in registers too - blocks of up to 24 KiB (the whole-globe
+    // lenses have them: 9 % of 4K hammer's blocks are above 16 KiB) stay inside the frame pipeline instead of fetching the rest of
+    // their list and chunks synchronously every frame, two dependent trips to memory that doubled those blocks' frames
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;     // (scalars, not an array: they must stay in VGPRs)
+    constexpr uint32_t REG_CHUNKS = NQ > 4 ? 1536u : 1024u;           // chunks the register plan covers before the extra rounds
     const bool pipe = (kflags & 8) == 0;      // issue frame f+1's loads before frame f's gather (ablation bit 8 turns it off)
     typedef uint32_t bk_v4u __attribute__((ext_vector_type(4)));
     // kflags bit 128: the globe chunks are fetched with the non-temporal hint (streamed through L2, evicted first), so that
@@ -403,6 +407,8 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
         if (NQ > 1) BK_COOP_LD(q1, gl_ + s1);                                                              \
         if (NQ > 2) BK_COOP_LD(q2, gl_ + s2);                                                              \
         if (NQ > 3) BK_COOP_LD(q3, gl_ + s3);                                                              \
+        if (NQ > 4) BK_COOP_LD(q4, gl_ + s4);                                                              \
+        if (NQ > 5) BK_COOP_LD(q5, gl_ + s5);                                                              \
     } while (0)
     // DMA form (single-frame launches): the chunks go HBM -> LDS directly (global_load_lds_dwordx4: a wave-uniform LDS base
     // + lane * 16 - exactly "list entry i -> slot i"), no staging registers, no ds_write pass; the barrier's fence waits for them
@@ -430,9 +436,11 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
         if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(mine + 4096) = q1;
         if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(mine + 8192) = q2;
         if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(mine + 12288) = q3;
+        if (NQ > 4 && k4) *reinterpret_cast<uint4 *>(mine + 16384) = q4;
+        if (NQ > 5 && k5) *reinterpret_cast<uint4 *>(mine + 20480) = q5;
         }
-        if (!DMA && NQ > 3) {
-            for (uint32_t c0 = 1024; c0 < nchunks; c0 += 1024) {      // blocks above 16 KiB: rounds of four loads
+        if (!DMA && (NQ == 4 || NQ == 6)) {
+            for (uint32_t c0 = REG_CHUNKS; c0 < nchunks; c0 += 1024) {      // blocks above what the registers hold: rounds of four loads
                 const uint32_t c = c0 + threadIdx.x;
                 const bool m0 = c < nchunks, m1 = c + 256u < nchunks, m2 = c + 512u < nchunks, m3 = c + 768u < nchunks;
                 const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
@@ -568,7 +576,7 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
 __device__ __forceinline__ int lane_of() { return (int)(threadIdx.x & 63u); }
 
 // everything a workgroup does for one block: `cur` holds the block's header and list head
-template <bool RUBIX, int RG, bool DMA = false>
+template <bool RUBIX, int RG, bool DMA = false, int MAXQ = 4>
 __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, const uint32_t *__restrict__ list,
                                            const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t,
                                            const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
@@ -598,15 +606,21 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
         const bool k0 = threadIdx.x < nchunks, k1 = threadIdx.x + 256u < nchunks, k2 = threadIdx.x + 512u < nchunks,
                    k3 = threadIdx.x + 768u < nchunks;
         const uint32_t s0 = k0 ? cur.c[0] : 0u, s1 = k1 ? cur.c[1] : 0u, s2 = k2 ? cur.c[2] : 0u, s3 = k3 ? cur.c[3] : 0u;
+        // (MAXQ = 6, the strided walk: list entries five and six of the thread, once per block visit)
+        const bool k4 = MAXQ > 4 && threadIdx.x + 1024u < nchunks, k5 = MAXQ > 4 && threadIdx.x + 1280u < nchunks;
+        const uint32_t *bl = list + (size_t)l * N;
+        const uint32_t s4 = k4 ? bl[threadIdx.x + 1024u] : 0u, s5 = k5 ? bl[threadIdx.x + 1280u] : 0u;
         const bool fast_store = tile_all && aligned;
         const uint32_t nq = (nchunks + 255u) >> 8;
 #define BK_COOP(NQ_) coop_frames<NQ_, RUBIX, RG, DMA>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride, smem, \
-                                                list + (size_t)l * N, nchunks, s0, s1, s2, s3, k0, k1, k2, k3,                    \
+                                                bl, nchunks, s0, s1, s2, s3, s4, s5, k0, k1, k2, k3, k4, k5,                       \
                                                 ix, fast_store, tile_empty, pal_s, row0, x, kflags)
         if (nq <= 1) BK_COOP(1);
         else if (nq == 2) BK_COOP(2);
         else if (nq == 3) BK_COOP(3);
-        else BK_COOP(4);
+        else if (MAXQ <= 4 || nq == 4) BK_COOP(4);
+        else if (nq == 5) BK_COOP(5);
+        else BK_COOP(6);
 #undef BK_COOP
     }
 }
@@ -641,7 +655,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
 // persistent form: a workgroup walks a strided list of blocks and prefetches the next one.  By default the list is the
 // XCD's band of the LIVE blocks in walk order, the bands cut at equal cost (CoopMap::d_order / d_bands; ablation bit 64:
 // bands of equal block count over all blocks, empty ones included, as in rounds 1 and 2a).
-template <bool RUBIX, int RG>
+template <bool RUBIX, int RG, int MAXQ = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
@@ -665,8 +679,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const int l_nn = l_next + wgs_per_band;                    // two ahead: its block number is here before it is needed
         const bool has_nn = has_next && l_nn < l_hi;
         const int b_nn = has_nn ? BK_BLOCK_OF(l_nn) : 0;
-        coop_block<RUBIX, RG>(cur, b_cur, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
-                              dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
+        coop_block<RUBIX, RG, false, MAXQ>(cur, b_cur, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
+                                        dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
         if (!has_next) break;
         l_next = l_nn;
         b_cur = b_next;
@@ -1157,6 +1171,10 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     // crosses the fabric, not by the staging instructions - it stays a developer bit.  Bit 512 leaves both to the caller.
     if (fchunk == 1 && !(kflags & 512)) kflags |= 128;
     const bool dma = fchunk == 1 && (kflags & 256) != 0;
+    // the strided walk with six chunks per thread in registers (82 instead of 64-67 VGPRs: 6 instead of 7 workgroups per CU) only for
+    // block maps that have blocks above 16 KiB - the whole-globe lenses, whose staging buffers allow 6 per CU or fewer anyway -
+    // and for batch launches, where the frame pipeline is what it keeps those blocks in (ablation bit 4096: never)
+    const bool wideq = !once && !rubix_on && fchunk > 1 && !cm->stats_pending && cm->stats[0] > 1024u && !(kflags & 4096);
     // (Tried in round 3 and removed: a strided walk in which a block's last frame issues the NEXT block's first globe loads and pixel
     //  addresses - apply_coop_pipe_kernel, git history.  Where it applied (block maps without blocks of more than 1024 chunks) it was
     //  slower - 4K panini at 128x16: 12.0 -> 18.3 us single frame, 4.5 -> 6.4 us/frame x16: 77-96 VGPRs against 67 - and the
@@ -1170,11 +1188,17 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
                                            cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
-#define BK_APPLY(RBX, N) do { if (once && dma) BK_APPLY_KD(RBX, N); else if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
+#define BK_APPLY_KW(N) hipLaunchKernelGGL((apply_coop_kernel<false, N, 6>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
+                                           cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
+                                           dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
+                                           ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
+#define BK_APPLY(RBX, N) do { if (once && dma) BK_APPLY_KD(RBX, N); else if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N);        \
+                              else if (wideq && !RBX) BK_APPLY_KW(N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
     if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
     else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
 #undef BK_APPLY_K
 #undef BK_APPLY_KD
+#undef BK_APPLY_KW
 #undef BK_APPLY
     BK_HIP(ctx, hipGetLastError());
     return BK_OK;

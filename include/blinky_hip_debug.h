@@ -29,7 +29,8 @@ int         bk_debug_module_from_cache(const bk_ctx *ctx);
 /* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
  * pipelining; 16 row-major block walk, 32 persistent form always, 64 XCD bands of equal block count instead of equal
  * cost, 128 non-temporal globe loads, 256 LDS-DMA staging (global_load_lds) in single-frame launches of the one-block form,
- * 512 no automatic choice of 128 / 256 for single-frame launches - results stay exact for 8..512); results are wrong while
+ * 512 no automatic choice of 128 / 256 for single-frame launches, 2048 __syncthreads() instead of the raw LDS barriers, 4096 never
+ * the six-chunks-per-thread register plan of the strided walk - results stay exact for 8..4096); results are wrong while
  * bits 2/4 are set.  0 restores normal operation. */
 int         bk_debug_set_ablation(bk_ctx *ctx, int bits);
 /* staged apply statistics of the current lensmap: out = {blocks, blocks on the direct-gather fallback,

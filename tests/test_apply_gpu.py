@@ -234,7 +234,7 @@ def test_xcd_bands_of_equal_cost(bk, lens, uneven, rows):
         # (128: non-temporal globe loads; 256: LDS-DMA staging in single-frame launches - results must not change)
         # (2048: __syncthreads() instead of the raw LDS barriers; 32 = strided walk always)
         for wgs, abl in ((1, 0), (1, 64), (2, 0), (16, 0), (16, 64), (16, 32), (16, 16), (16, 128), (16, 256), (16, 384), (1, 256 + 64),
-                         (16, 2048), (1, 2048 + 32)):
+                         (16, 2048), (1, 2048 + 32), (1, 4096 + 32), (2, 4096)):
             ctx.set_tile_shape(100 + wgs)
             ctx.set_ablation(abl)
             for nf in (1, F):
@@ -454,6 +454,17 @@ def test_coop_apply_any_table_every_staging_path(bk, kind, shape, ldskb):
                 want = np.full((H + 4, pitch), 77, np.uint8)
                 O.apply(off, tints, W, H, globes[(1 + f) % F], want, pitch, x0, y0, rubix, pal)
                 np.testing.assert_array_equal(got[f], want, err_msg=f"{kind} shape {shape} ldskb {ldskb} rubix {rubix} frame {f} stats {stats}")
+    # the strided walk forced (32), with and without the six-chunk register plan (4096): batch launches over blocks above 16 KiB
+    for abl in (32, 32 + 4096):
+        ctx.set_ablation(abl)
+        out = torch.full((F, H, W), 77, dtype=torch.uint8, device="cuda")
+        ctx.apply_device(out.data_ptr(), W, H * W, frame0=0, nframes=F)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for f in range(F):
+            want = np.full((H, W), 77, np.uint8)
+            O.apply(off, tints, W, H, globes[f], want, W, 0, 0, False, pal)
+            np.testing.assert_array_equal(got[f], want, err_msg=f"{kind} shape {shape} ldskb {ldskb} strided walk, ablation {abl}, frame {f}")
     # single-frame launches (the engine's call), also with the non-temporal globe loads (128) and the LDS-DMA staging (256)
     for abl in (0, 128, 256, 384, 512):
         ctx.set_ablation(abl)
