@@ -1174,7 +1174,9 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     // the strided walk with six chunks per thread in registers (82 instead of 64-67 VGPRs: 6 instead of 7 workgroups per CU) only for
     // block maps that have blocks above 16 KiB - the whole-globe lenses, whose staging buffers allow 6 per CU or fewer anyway -
     // and for batch launches, where the frame pipeline is what it keeps those blocks in (ablation bit 4096: never)
-    const bool wideq = !once && !rubix_on && fchunk > 1 && !cm->stats_pending && cm->stats[0] > 1024u && !(kflags & 4096);
+    // (4K hammer x16 7.39 -> 7.07 us/frame; mercator, whose 21 KiB buffers let 7 workgroups share a CU, lost 7 % to the registers and keeps
+    //  the narrow plan: only where the staging buffer already limits a CU to 6)
+    const bool wideq = !once && !rubix_on && fchunk > 1 && !cm->stats_pending && cm->stats[0] > 1024u && shmem * 7 > 160u * 1024u && !(kflags & 4096);
     // (Tried in round 3 and removed: a strided walk in which a block's last frame issues the NEXT block's first globe loads and pixel
     //  addresses - apply_coop_pipe_kernel, git history.  Where it applied (block maps without blocks of more than 1024 chunks) it was
     //  slower - 4K panini at 128x16: 12.0 -> 18.3 us single frame, 4.5 -> 6.4 us/frame x16: 77-96 VGPRs against 67 - and the
