@@ -1309,6 +1309,41 @@ int coopmap_band_balance(bk_ctx *ctx, uint32_t out[18])
     return BK_OK;
 }
 
+// What a row costs the staged apply, for a multi-GPU stripe split (bk_row_costs_device): every block's cost - the one the XCD
+// bands are balanced with: lines staged + a share per mapped pixel + a constant - spread over the block's rows, x16 to keep
+// integer resolution.  Mapped pixels alone miss by up to 30 % on whole-globe lenses: 8K hammer's rows at 35-55 degrees of
+// latitude cross the cube's corners, where a pixel touches up to five times the globe lines it touches at a face's centre.
+__global__ __launch_bounds__(256) void coop_row_cost_kernel(const uint32_t *__restrict__ cost, int blocks_x, int block_rows, int rows,
+                                                            uint32_t *__restrict__ out)
+{
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    if (y >= rows) return;
+    const int by = y / block_rows, here = min(block_rows, rows - by * block_rows);
+    uint32_t s = 0;
+    for (int bx = 0; bx < blocks_x; ++bx) s += cost[by * blocks_x + bx];
+    out[y] = (s * 16u + (uint32_t)here / 2u) / (uint32_t)here + 16u;          // (+ a line's worth: empty rows are dealt out too)
+}
+
+// rows_out: device uint32 [ctx->rows()], on the context stream.  The block map is compiled by the cost model alone if there is
+// none yet (no timed candidates: the stripe is about to change and with it the map).
+int coopmap_row_costs(bk_ctx *ctx, uint32_t *rows_out)
+{
+    const int tuning = ctx->blockmap_tuning;
+    const bool had_map = ctx->coopmap && ctx->coopmap->valid;
+    ctx->blockmap_tuning = 0;
+    const int r = ensure_coopmap(ctx);
+    ctx->blockmap_tuning = tuning;
+    if (r) return r;
+    CoopMap *cm = ctx->coopmap;
+    if (!had_map && tuning) cm->valid = false;      // (should the stripe stay as it is, the next apply compiles the measured map)
+    if (ctx->rows() > 0) {
+        hipLaunchKernelGGL(coop_row_cost_kernel, dim3((unsigned)((ctx->rows() + 255) / 256)), dim3(256), 0, ctx->stream,
+                           cm->d_cost, cm->blocks_x, 8 * cm->rg, ctx->rows(), rows_out);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    return BK_OK;
+}
+
 int coopmap_stats(bk_ctx *ctx, int out[6])
 {
     if (int r = ensure_coopmap(ctx)) return r;

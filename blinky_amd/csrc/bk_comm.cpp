@@ -335,15 +335,18 @@ extern "C" int bk_comm_exchange_rotating(bk_comm *c, const void *stripe_dev, int
 
 // Stripes of equal WORK instead of equal height.  A lens that leaves part of the screen unmapped (hammer's ellipse,
 // quincuncial under f_contain) gives the ranks that own the top and the bottom of the screen a fraction of the middle
-// ranks' pixels; the frame is done when the slowest stripe is.  Row cost = mapped pixels + W/32 (so that empty rows are
-// still dealt out), bounds at equal shares of the prefix sum, multiples of 8 rows (the apply's smallest block height),
-// at least 8 rows each.  Deterministic: every rank computes the same bounds from the same sums.
-static std::vector<int> bounds_from_costs(const std::vector<uint32_t> &cost, int W, int nranks)
+// ranks' pixels; the frame is done when the slowest stripe is.  Row cost (bk_row_costs_device): for the staged apply the
+// cost of the row's blocks in the block map - globe lines staged, mapped pixels, a constant per block: rows of equal
+// mapped pixels differ by up to 5x in the lines they touch (cube corners against face centres) - and for the direct
+// gather mapped pixels + W/32; either way > 0 for an empty row, so that those are dealt out too.  Bounds at equal shares
+// of the prefix sum, multiples of 8 rows (the apply's smallest block height), at least 8 rows each.  Deterministic:
+// every rank computes the same bounds from the same sums.
+static std::vector<int> bounds_from_costs(const std::vector<uint32_t> &cost, int nranks)
 {
     const int H = (int)cost.size();
     std::vector<uint64_t> pre((size_t)H + 1, 0);
-    const uint64_t base = (uint64_t)std::max(1, W / 32);
-    for (int y = 0; y < H; ++y) pre[(size_t)y + 1] = pre[(size_t)y] + cost[(size_t)y] + base;
+    for (int y = 0; y < H; ++y) pre[(size_t)y + 1] = pre[(size_t)y] + cost[(size_t)y];
+    if (pre[(size_t)H] == 0) for (int y = 0; y <= H; ++y) pre[(size_t)y] = (uint64_t)y;       // nothing to do anywhere: equal heights
     std::vector<int> b((size_t)nranks + 1, 0);
     b[(size_t)nranks] = H;
     const int q = H >= 16 * nranks ? 8 : 1;                 // (tiny frames: any row)
@@ -361,8 +364,10 @@ static std::vector<int> bounds_from_costs(const std::vector<uint32_t> &cost, int
 /* test hook (no device needed): the stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs */
 extern "C" int bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, int nranks, int *bounds_out)
 {
-    if (!row_cost || !bounds_out || H < 1 || W < 1 || nranks < 1 || nranks > H) return BK_E_INVALID;
-    const std::vector<int> b = bounds_from_costs(std::vector<uint32_t>(row_cost, row_cost + H), W, nranks);
+    if (!row_cost || !bounds_out || H < 1 || W < 0 || nranks < 1 || nranks > H) return BK_E_INVALID;
+    std::vector<uint32_t> cost(row_cost, row_cost + H);
+    if (W > 0) for (uint32_t &c : cost) c += (uint32_t)std::max(1, W / 32);     // (as row_cost_kernel prices a row of mapped pixels)
+    const std::vector<int> b = bounds_from_costs(cost, nranks);
     for (int i = 0; i <= nranks; ++i) bounds_out[i] = b[(size_t)i];
     return BK_OK;
 }
@@ -388,7 +393,7 @@ extern "C" int bk_comm_rebalance(bk_comm *c)
     (void)hipFree(d);
     if (nr != ncclSuccess) return c->fail(BK_E_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
     if (e != hipSuccess) return c->fail(BK_E_HIP, std::string("bk_comm_rebalance: ") + hipGetErrorString(e));
-    c->bounds = bounds_from_costs(cost, ctx->W, c->nranks);
+    c->bounds = bounds_from_costs(cost, c->nranks);
     if (int r = bk_set_rows(ctx, c->row0(c->rank), c->row0(c->rank + 1))) return c->fail(r, bk_last_error(ctx));
     return BK_OK;
 }
@@ -546,7 +551,7 @@ extern "C" int bk_multi_lensmap_valid(const bk_multi *m)
 extern "C" int bk_multi_rebalance(bk_multi *m, int *bounds_out)
 {
     if (!m || m->ctx.empty() || !m->comm[0]) return BK_E_INVALID;
-    const int n = (int)m->ctx.size(), H = m->ctx[0]->H, W = m->ctx[0]->W;
+    const int n = (int)m->ctx.size(), H = m->ctx[0]->H;
     std::vector<uint32_t> cost((size_t)H, 0), part((size_t)H);
     for (int i = 0; i < n; ++i) {
         bk_ctx *c = m->ctx[(size_t)i];
@@ -561,7 +566,7 @@ extern "C" int bk_multi_rebalance(bk_multi *m, int *bounds_out)
         if (e != hipSuccess) return m->fail(BK_E_HIP, std::string("bk_multi_rebalance: ") + hipGetErrorString(e));
         for (int y = 0; y < H; ++y) cost[(size_t)y] += part[(size_t)y];
     }
-    const std::vector<int> b = bounds_from_costs(cost, W, n);
+    const std::vector<int> b = bounds_from_costs(cost, n);
     for (int i = 0; i < n; ++i) {
         m->comm[(size_t)i]->bounds = b;
         if (int r = bk_set_rows(m->ctx[(size_t)i], b[(size_t)i], b[(size_t)i + 1])) return m->fail(r, bk_last_error(m->ctx[(size_t)i]));

@@ -154,8 +154,9 @@ int coopmap_stats(bk_ctx *ctx, int out[6]);   // blocks, direct-gather blocks, e
 int coopmap_traffic_model(bk_ctx *ctx, uint64_t out[8]);
 int coopmap_xcd_probe(bk_ctx *ctx, int *out, int nwg);
 int coopmap_band_balance(bk_ctx *ctx, uint32_t out[18]);
+int coopmap_row_costs(bk_ctx *ctx, uint32_t *rows_out);      // device uint32 [rows()]: block costs spread over their rows, x16
 }
-int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev);     // bk_probe.hip: mapped pixels per owned row into a device uint32 [H]
+int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev);     // bk_probe.hip: what every owned row costs the apply, into a device uint32 [H]
 namespace bk {
 void coopmap_free(CoopMap *);
 

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void stream_mix_kernel(const uint4 *__restrict
     if (acc == 0x12345679u) *sink = acc;
 }
 
-// mapped pixels of every owned row (the cost of a row in a multi-GPU stripe split, bk_comm_rebalance)
+// mapped pixels of every owned row + W/32: the cost of a row in a multi-GPU stripe split (bk_comm_rebalance) for the
+// direct-gather apply; the staged apply prices rows from its block map instead (coopmap_row_costs)
 __global__ __launch_bounds__(256) void row_cost_kernel(const uint32_t *__restrict__ lmap, int W, uint32_t *__restrict__ cost)
 {
     __shared__ uint32_t s_sum[4];
@@ -32,17 +33,19 @@ __global__ __launch_bounds__(256) void row_cost_kernel(const uint32_t *__restric
     for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = n;
     __syncthreads();
-    if (threadIdx.x == 0) cost[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (threadIdx.x == 0) cost[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3] + (uint32_t)max(1, W / 32);
 }
 
 }  // namespace bk
 
-// cost_dev: device uint32 [H]; the owned rows get their mapped-pixel counts, every other row 0 (on the context stream)
+// cost_dev: device uint32 [H]; the owned rows get what they cost the context's apply variant, every other row 0 (on the
+// context stream).  The two variants price in different units: the ranks of a job all run the same one.
 int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev)
 {
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "row costs: no lensmap (call bk_build first)");
     BK_HIP(ctx, hipSetDevice(ctx->device));
     BK_HIP(ctx, hipMemsetAsync(cost_dev, 0, (size_t)ctx->H * sizeof(uint32_t), ctx->stream));
+    if (ctx->apply_variant != 0) return bk::coopmap_row_costs(ctx, cost_dev + ctx->row0);
     if (ctx->rows() > 0) {
         hipLaunchKernelGGL(bk::row_cost_kernel, dim3((unsigned)ctx->rows()), dim3(256), 0, ctx->stream, ctx->d_offsets, ctx->W, cost_dev + ctx->row0);
         BK_HIP(ctx, hipGetLastError());
@@ -51,6 +54,23 @@ int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev)
 }
 
 #if BK_DEBUG_API
+// the row costs bk_comm_rebalance / bk_multi_rebalance would sum over the ranks, for this context's stripe (host uint32 [H])
+extern "C" int bk_debug_row_costs(bk_ctx *ctx, uint32_t *host_out)
+{
+    if (!ctx || !host_out) return BK_E_INVALID;
+    if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_debug_row_costs: this context has no device");
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *d = nullptr;
+    BK_HIP(ctx, hipMalloc((void **)&d, (size_t)ctx->H * sizeof(uint32_t)));
+    const int rc = bk_row_costs_device(ctx, d);
+    hipError_t e = rc == BK_OK ? hipMemcpyAsync(host_out, d, (size_t)ctx->H * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (rc != BK_OK) return rc;
+    if (e != hipSuccess) return ctx->fail(BK_E_HIP, "bk_debug_row_costs: %s", hipGetErrorString(e));
+    return BK_OK;
+}
+
 // best of 5 passes over `bytes` read, writes / period of it written; *gbps = (bytes read + bytes written) / time
 extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps)
 {

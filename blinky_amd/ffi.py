@@ -122,6 +122,7 @@ _SIGS = {
     "bk_comm_restripe": (_i, [_vp]),
     "bk_comm_rebalance": (_i, [_vp]),
     "bk_debug_stripe_bounds": (_i, [C.POINTER(C.c_uint32), _i, _i, _i, C.POINTER(_i)]),
+    "bk_debug_row_costs": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "bk_multi_rebalance": (_i, [_vp, C.POINTER(_i)]),
     "bk_comm_or_display": (_i, [_vp, C.POINTER(_i)]),
     "bk_comm_gather": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i]),
@@ -379,6 +380,13 @@ class Context:
         out = (_i * 6)()
         self._chk(lib.bk_debug_tile_stats(self._h, out))
         return dict(tiles=out[0], slow=out[1], empty=out[2], lds_bytes_per_wave=out[3], tile_h=out[4], lines=out[5])
+
+    def row_costs(self):
+        """what every row of this stripe costs the apply (uint32 [H], other stripes' rows 0): the input of the rebalance"""
+        _, H = self.size()[:2]
+        out = np.zeros(H, np.uint32)
+        self._chk(lib.bk_debug_row_costs(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
 
     def build_params(self):
         """raw BkBuildParams bytes (tests/hostemu)"""
@@ -665,7 +673,8 @@ class Multi:
 
 
 def stripe_bounds_from_costs(row_cost, W, nranks):
-    """the stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs (host logic, no device)"""
+    """the stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs (host logic, no device); W = 0: the
+    costs are complete (Context.row_costs()), W >= 1: mapped pixels per row, priced like the direct-gather apply's rows"""
     row_cost = np.ascontiguousarray(row_cost, dtype=np.uint32)
     out = (_i * (nranks + 1))()
     rc = lib.bk_debug_stripe_bounds(row_cost.ctypes.data_as(C.POINTER(C.c_uint32)), len(row_cost), W, nranks, out)

@@ -83,9 +83,13 @@ int         bk_debug_build_breakdown(const bk_ctx *ctx, double out[6]);
 /* bk_set_host_math(ctx, n >= 2), test mode: the host interpreter's libm becomes bkm.h with every inexact result moved
  * pseudo-randomly by up to 2^-n relative, standing in for "another libm" when the tests check the exactness flags
  * (tests/test_exactness_cpu.py); + 64 moves every result up by that amount instead, + 128 down. */
-/* test hook, no device needed: the N+1 stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs
- * (mapped pixels of each of H rows) */
+/* test hook, no device needed: the N+1 stripe bounds bk_comm_rebalance / bk_multi_rebalance derive from per-row costs.
+ * W >= 1: row_cost holds the mapped pixels of each of H rows and is priced as the direct-gather apply's rows are
+ * (+ W/32 per row); W == 0: row_cost is taken as it is (bk_debug_row_costs' output). */
 int         bk_debug_stripe_bounds(const uint32_t *row_cost, int H, int W, int nranks, int *bounds_out);
+/* what bk_comm_rebalance / bk_multi_rebalance sum over the ranks: the cost of every row of this context's stripe to its apply
+ * variant (host uint32 [H], rows of other stripes 0); needs a built lensmap */
+int         bk_debug_row_costs(bk_ctx *ctx, uint32_t *host_out);
 
 #ifdef __cplusplus
 }

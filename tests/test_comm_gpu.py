@@ -145,7 +145,7 @@ def test_c4_eight_stripes_full_size(bk):
 
 def test_stripes_of_equal_work(bk):
     """bk_multi_rebalance: hammer's ellipse leaves the top and bottom stripes of an equal-height split nearly empty; cut by
-    mapped pixels instead, every stripe gets its share, and the reassembled frames are still the oracle's."""
+    what the rows cost the apply instead (its block map's costs), every stripe gets its share, and the reassembled frames are still the oracle's."""
     import torch
     globe, lens, W, H, F, N = "cube", "hammer", 640, 400, 4, 4
     m = bk.Multi([0] * N)
@@ -160,10 +160,16 @@ def test_stripes_of_equal_work(bk):
     equal = [H * r // N for r in range(N + 1)]
     share_eq = [mapped[equal[r]:equal[r + 1]].sum() for r in range(N)]
     assert max(share_eq) > 1.25 * (mapped.sum() / N)                      # the reason to do it
+    cost = sum(m.ctx(r).row_costs().astype(np.int64) for r in range(N))   # every stripe prices its own rows from its block map
+    assert (cost > 0).all()                                               # (empty rows too: they are dealt out as well)
+    cost_eq = [cost[equal[r]:equal[r + 1]].sum() for r in range(N)]
     bounds = m.rebalance()
     assert bounds[0] == 0 and bounds[-1] == H and bounds == sorted(bounds) and all(b % 8 == 0 for b in bounds[1:-1])
-    share = [mapped[bounds[r]:bounds[r + 1]].sum() + (bounds[r + 1] - bounds[r]) * (W // 32) for r in range(N)]
-    assert max(share) < 1.12 * (sum(share) / N), (bounds, share)
+    assert bounds == bk.ffi.stripe_bounds_from_costs(cost.astype(np.uint32), 0, N)
+    share = [cost[bounds[r]:bounds[r + 1]].sum() for r in range(N)]
+    assert max(share) < 1.12 * (sum(share) / N) and max(share) < max(cost_eq), (bounds, share, cost_eq)
+    px = [mapped[bounds[r]:bounds[r + 1]].sum() for r in range(N)]
+    assert max(px) < max(share_eq), (px, share_eq)                        # and nobody holds as many pixels as the fullest equal stripe did
     with pytest.raises(bk.BlinkyError):                                   # the stripes' lensmaps are gone: build again
         m.apply(np.zeros((H, W), np.uint8))
     m.build()

@@ -40,3 +40,11 @@ def test_degenerate_inputs(ffi):
     assert b[0] == 0 and b[-1] == 100 and b == sorted(b) and all(y1 - y0 >= 8 for y0, y1 in zip(b, b[1:]))   # all the work in the last rows
     with pytest.raises(ffi.BlinkyError):
         ffi.stripe_bounds_from_costs(np.ones(4, np.uint32), 64, 5)                                     # more ranks than rows
+
+
+def test_complete_costs_are_taken_as_they_are(ffi):
+    """W = 0: the costs already hold everything (the staged apply's block-map costs) - no per-row base is added"""
+    cost = np.r_[np.full(64, 10, np.uint32), np.full(64, 30, np.uint32)]
+    assert ffi.stripe_bounds_from_costs(cost, 0, 2) == [0, 88, 128]           # 640 + 24 * 30 = 1360 of 2560: the nearest multiple of 8 rows to the half
+    assert ffi.stripe_bounds_from_costs(cost, 32 * 1000, 2) == [0, 64, 128]   # a base of 1000 a row drowns the difference
+    assert ffi.stripe_bounds_from_costs(np.zeros(64, np.uint32), 0, 4) == [0, 16, 32, 48, 64]

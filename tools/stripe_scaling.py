@@ -8,7 +8,7 @@ step of the N-GPU job lasts as long as its slowest rank, so
     predicted stripe_complete speed-up(N) = t(N=1) / max_r t(rank r of N)
 
 Stripes: equal heights (bench.py) and, for lenses that leave part of the screen unmapped, the bounds bk_comm_rebalance /
-bk_multi_rebalance would pick (equal mapped pixels, multiples of 8 rows).  Nothing is exchanged: this is the number the
+bk_multi_rebalance would pick (equal block-map cost, multiples of 8 rows).  Nothing is exchanged: this is the number the
 >= 6x target of BASELINE.json can be held against; the reassembled-frame rate is bounded by xGMI instead.
 
 usage: python tools/stripe_scaling.py [--configs panini4k,hammer4k,c5] [--single]     (prints a table; run on the GPU box)"""
@@ -38,6 +38,7 @@ CONFIGS = {
 }
 
 
+MAPPED_ONLY = False
 SHAPE = 0          # --shape: force the block height (1 / 2 / 4 = 128x8 / 128x16 / 128x32), 0 = the cost model
 
 
@@ -61,10 +62,14 @@ def balanced_bounds(globe, lens, zoom, W, H, n):
     ctx = blinky_amd.Context(0)
     S.configure(ctx, globe, lens, zoom, (W, H))
     ctx.build()
-    off, _ = ctx.read_lensmap()
+    if MAPPED_ONLY:                 # round 3's first rule: rows of equal mapped pixels
+        off, _ = ctx.read_lensmap()
+        ctx.close()
+        cost = (off.reshape(H, W) != 0xFFFFFFFF).sum(axis=1).astype(np.uint32)
+        return ffi.stripe_bounds_from_costs(cost, W, n)
+    cost = ctx.row_costs()          # what the rebalance sums over the ranks: the block map's costs, row by row
     ctx.close()
-    cost = (off.reshape(H, W) != 0xFFFFFFFF).sum(axis=1).astype(np.uint32)
-    return ffi.stripe_bounds_from_costs(cost, W, n)
+    return ffi.stripe_bounds_from_costs(cost, 0, n)
 
 
 def main():
@@ -73,9 +78,11 @@ def main():
     ap.add_argument("--single", action="store_true", help="also time single-frame launches of every stripe")
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--mapped-only", action="store_true", help="balanced = equal mapped pixels (the rule before the block-map costs)")
     args = ap.parse_args()
-    global SHAPE
+    global SHAPE, MAPPED_ONLY
     SHAPE = args.shape
+    MAPPED_ONLY = args.mapped_only
     print(f"# {torch.cuda.get_device_name(0)}; one GPU; every rank's stripe timed in turn; us per launch (HIP events, median of 5)")
     for name in args.configs.split(","):
         globe, lens, zoom, W, H, F, unmapped = CONFIGS[name]
