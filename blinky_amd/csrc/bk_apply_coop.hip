@@ -193,7 +193,11 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     if (!survey) {
     // (Tried: storing a u16 base per lane or per 4 pixels plus u8 offsets, 1.1-1.5 instead of 2 bytes per pixel.  Slots
     //  follow chunk numbers, so a row segment that crosses a tile-row boundary jumps by the whole staged tile row
-    //  (> 1 KiB): 3 of 510 panini blocks at 1080p could use the compact form.  Removed again.)
+    //  (> 1 KiB): 3 of 510 panini blocks at 1080p could use the compact form.  Removed again.
+    //  Round 3: one byte per pixel of chained DIFFERENCES along the row, a 16-bit exception list for such jumps (4K panini 1.08,
+    //  hammer 1.20 bytes per pixel), decoded once per block visit - parity-green, and slower everywhere: the ~130 VALU instructions
+    //  of the decode run in every workgroup of a round at the same moment, exactly where the raw form has its addresses waiting in
+    //  registers (4K panini single frame 8.5 -> 10.7 us, x16 +3-5 %; profiles/r03_barrier_and_pipelining_experiments.txt (5)).)
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
         uint32_t a[4], tw = 0;
