@@ -181,8 +181,9 @@ class OneGpuWorkload:
         self.out = None
 
 
-def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W, H, F, steps):
-    """one more BASELINE.json configuration, driver-timed beside the headline (N = 1 only)"""
+def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W, H, F, steps, args=None):
+    """one more BASELINE.json configuration, driver-timed beside the headline (N = 1 only); with `args`, its HBM traffic is measured
+    the way the headline's is (measure_traffic: two rocprofv3 --pmc child runs of the same launch)"""
     wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F)
     for i in range(5):
         wl.launch(i)
@@ -202,7 +203,13 @@ def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W,
            "single_frame": {"us": round(s_med * 1e3, 3),
                             "algorithmic_frac": round(ALGO_BYTES_PER_PX * W * H / (s_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
            "lensmap_build_ms": round(wl.build_ms, 3), "tile_stats": wl.tile_stats, "lens_scale": wl.scale}
+    ring, block_h = wl.R, int(wl.tile_stats["tile_h"]) % 1000
     wl.close()
+    if args is not None and not args.no_live_traffic:
+        traffic, src = measure_traffic(args, F, ring, block_h, config=f"{W}x{H}:{globe}:{lens}:{zoom or ''}")
+        rec["traffic"] = traffic
+        rec["traffic_source"] = src
+        rec["frac_traffic"] = round(traffic / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
     return rec
 
 
@@ -233,10 +240,15 @@ def traffic_child(args):
     import blinky_amd
     import scripts as S
     F, R = args.frames, max(args.ring, args.frames)
+    W, H, globe, lens, zoom = globals()["W"], globals()["H"], GLOBE, LENS, ZOOM
+    if args.child_config:                                   # "WxH:globe:lens:zoom" - configs_extra
+        size, globe, lens, zoom = args.child_config.split(":")
+        W, H = [int(v) for v in size.split("x")]
+        zoom = zoom or None
     ctx = blinky_amd.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_frames(R)
-    S.configure(ctx, GLOBE, LENS, ZOOM, (W, H))
+    S.configure(ctx, globe, lens, zoom, (W, H))
     if args.variant >= 0:
         ctx.set_apply_variant(args.variant)
     if args.shape:
@@ -252,7 +264,7 @@ def traffic_child(args):
     torch.cuda.synchronize()
 
 
-def measure_traffic(args, F, R, block_h):
+def measure_traffic(args, F, R, block_h, config=None):
     """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under rocprofv3, one --pmc
     counter each (FETCH_SIZE, WRITE_SIZE; counters only ever together with --kernel-trace), per MI355X_MICROARCH.md's HBM
     section: values in KiB; on gfx950 FETCH_SIZE tallies the 128-byte TCC->EA read requests at 64 bytes, so reads are doubled
@@ -269,6 +281,8 @@ def measure_traffic(args, F, R, block_h):
         d = tempfile.mkdtemp(prefix="bk_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
                "--frames", str(F), "--ring", str(R), "--variant", str(args.variant), "--shape", str(block_h // 8)]
+        if config:
+            cmd += ["--child-config", config]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -321,6 +335,7 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic live (two child runs under rocprofv3 --pmc); use the stamped record in profiles/ if it matches")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--child-config", default="", help=argparse.SUPPRESS)
     ap.add_argument("--shape", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps alternate between: the tail of a batch launch (its last, partly filled round of "
@@ -746,7 +761,7 @@ def main():
         if world == 1 and not args.no_extra:
             try:
                 out["configs_extra"] = [extra_config(torch, blinky_amd, S, local_rank, "C2 (BASELINE.json configs[1])", "cube", "stereographic",
-                                                     None, 1920, 1080, F, args.steps)]
+                                                     None, 1920, 1080, F, args.steps, args)]
             except Exception as e:      # noqa: BLE001
                 out["configs_extra"] = [{"error": f"{type(e).__name__}: {e}"}]
             try:

@@ -56,6 +56,10 @@ def test_bench_line_and_check_single_gpu():
     assert "error" not in c2, c2
     assert c2["workload"].startswith("1920x1080 cube/stereographic") and c2["value"] > 0 and c2["kernel_us_per_launch"] > 0
     assert 0 < c2["frac_compulsory"] <= 1.0 and 0 < c2["single_frame"]["algorithmic_frac"] <= 1.0
+    # ... and its HBM bytes counted the way the headline's are (FETCH_SIZE / WRITE_SIZE under rocprofv3): at least what 16 frames
+    # of output weigh, and no more than 1.5x the compulsory model
+    assert "traffic" in c2 and (c2["traffic"] is None or 1920 * 1080 * 16 < c2["traffic"] < 1.5 * c2["compulsory_bytes_per_launch"]), c2
+    assert c2["traffic"] is None or 0 < c2["frac_traffic"] <= 1.0
     # the scaling curve predicted on one GPU: rank r's stripe for N = 2 / 4 / 8, slowest rank
     ps = out["predicted_stripe_complete"]
     assert "error" not in ps, ps
