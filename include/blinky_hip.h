@@ -219,11 +219,13 @@ void        bk_comm_destroy(bk_comm *c);
 const char *bk_comm_last_error(const bk_comm *c);                                  /* c may be NULL: last failed create */
 int         bk_comm_stripe(const bk_comm *c, int rank, int *row0, int *row1);      /* any rank's rows */
 int         bk_comm_restripe(bk_comm *c);                                          /* after a later bk_resize */
-/* stripes of equal WORK instead of equal height (collective: every rank calls it after a bk_build): the mapped pixels of
- * every row are summed over the ranks (ncclAllReduce), the rows are cut into shares of equal cost (multiples of 8 rows)
- * and this rank's context gets its new stripe (bk_set_rows).  Build again afterwards; bk_comm_stripe tells the new
- * stripes.  For lenses that leave part of the screen unmapped (hammer's ellipse): with equal heights the ranks that own
- * the top and the bottom of the screen have a fraction of the middle ranks' pixels. */
+/* stripes of equal WORK instead of equal height (collective: every rank calls it after a bk_build): what every row costs
+ * the apply - for the default (staged) apply the costs of the row's blocks in this rank's block map: globe lines staged,
+ * mapped pixels, a constant per block; for the direct-gather variant its mapped pixels - is summed over the ranks
+ * (ncclAllReduce), the rows are cut into shares of equal cost (multiples of 8 rows) and this rank's context gets its new
+ * stripe (bk_set_rows).  Build again afterwards; bk_comm_stripe tells the new stripes.  For lenses that leave part of the
+ * screen unmapped or sample the globe unevenly (hammer's ellipse: with equal heights the ranks that own the top and the
+ * bottom of the screen have a fraction of the middle ranks' work).  Every rank must run the same apply variant. */
 int         bk_comm_rebalance(bk_comm *c);
 /* display[] |= every other rank's (which plates the WHOLE frame reads, fisheye.c:1976): ncclAllReduce(MAX); synchronous */
 int         bk_comm_or_display(bk_comm *c, int display[BK_MAX_PLATES]);
