@@ -28,6 +28,27 @@ __global__ __launch_bounds__(256) void probe_write_nt(uint4 *__restrict__ a, siz
         __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(a) + i);
     }
 }
+// the apply's STORE pattern alone: a [frames][H][W] byte image written in tiles of TW bytes x TH rows, one tile per workgroup step, 16 bytes
+// per lane, TW/16 lanes side by side (the staged apply: TW = 128 - 8 lanes write one 128-byte piece of a row, a wave 8 rows of a 3840-byte
+// pitch, a workgroup 32); wider tiles write longer contiguous pieces.  Tiles in row-major order within a frame, grid-stride.
+__global__ __launch_bounds__(256) void probe_write_tiles(uint8_t *__restrict__ img, int W, int H, int frames, int TW, int nt)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const int lpr = TW / 16, rows_per_wg = 256 / lpr;               // lanes per row piece, rows a workgroup covers
+    const int tx_n = (W + TW - 1) / TW, ty_n = (H + rows_per_wg - 1) / rows_per_wg;
+    const size_t tiles = (size_t)tx_n * ty_n * frames;
+    const int lx = threadIdx.x % lpr, ly = threadIdx.x / lpr;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int f = (int)(t / ((size_t)tx_n * ty_n));
+        const int r = (int)(t - (size_t)f * tx_n * ty_n), ty = r / tx_n, tx = r - ty * tx_n;
+        const int y = ty * rows_per_wg + ly, x = tx * TW + lx * 16;
+        if (y >= H || x >= W) continue;
+        uint8_t *o = img + ((size_t)f * H + y) * W + x;
+        v4u v = {(uint32_t)t, 1, 2, 3};
+        if (nt) __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o));
+        else *reinterpret_cast<v4u *>(o) = v;
+    }
+}
 // the apply's mix, streaming: read 13 bytes for every 8 written (non-temporal stores)
 __global__ __launch_bounds__(256) void probe_mix_nt(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n, uint32_t *sink)
 {
@@ -116,6 +137,24 @@ int main(int argc, char **argv)
             }
             const double moved = k == 0 ? (double)bytes : bytes * (1.0 + 8.0 / 13.0);
             printf("%-8s grid %5d: %8.3f ms  %7.2f TB/s (bytes moved %.0f MiB)\n", k == 0 ? "write-nt" : "mix-nt", g, best, moved / best / 1e9, moved / 1048576.0);
+        }
+    }
+    // the apply's store pattern: 3840 x 2160 frames (as many as fit `bytes`), tiles of 128 .. 3840 bytes per row piece
+    {
+        const int W = 3840, H = 2160, frames = (int)(bytes / ((size_t)W * H));
+        for (int g : {256 * 8, 256 * 16}) {
+            for (int TW : {64, 128, 256, 512, 1024, 4096}) for (int nt = 0; nt < 2; ++nt) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 5; ++rep) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(probe_write_tiles, dim3(g), dim3(256), 0, 0, reinterpret_cast<uint8_t *>(b), W, H, frames, TW, nt);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                const double moved = (double)W * H * frames;
+                printf("%s tiles of %4d B x %3d rows, grid %5d: %8.3f ms  %7.2f TB/s (%.0f MiB)\n", nt ? "write-nt" : "write   ", TW, 256 / (TW / 16), g, best, moved / best / 1e9, moved / 1048576.0);
+            }
         }
     }
     // random-line gather: 2 GiB of distinct lines (beyond the 256 MiB Infinity Cache), runs of 1..64 lines
