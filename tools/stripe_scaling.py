@@ -39,6 +39,8 @@ CONFIGS = {
 
 
 MAPPED_ONLY = False
+JOB = False           # --job: also the wall clock per step of the two-stream job (what bench.py's `value` times), host launch cost included
+LAST_JOB_US = None
 SHAPE = 0          # --shape: force the block height (1 / 2 / 4 = 128x8 / 128x16 / 128x32), 0 = the cost model
 
 
@@ -53,6 +55,8 @@ def time_stripe(globe, lens, zoom, W, H, F, rows, single):
     launches = 30 if W < 4000 else 6
     t = wl.kernel_ms(launches=launches, repeats=5)[0]
     t1 = wl.kernel_ms(nframes=1, launches=launches, repeats=5)[0] if single else None
+    global LAST_JOB_US
+    LAST_JOB_US = wl.job_seconds_per_step(steps=50, repeats=9, nstreams=2) * 1e6 if JOB else None
     stats = wl.tile_stats
     wl.close()
     return t, t1, stats
@@ -78,9 +82,11 @@ def main():
     ap.add_argument("--single", action="store_true", help="also time single-frame launches of every stripe")
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--job", action="store_true", help="also the two-stream job's wall clock per step on every stripe (host launch cost included)")
     ap.add_argument("--mapped-only", action="store_true", help="balanced = equal mapped pixels (the rule before the block-map costs)")
     args = ap.parse_args()
-    global SHAPE, MAPPED_ONLY
+    global SHAPE, MAPPED_ONLY, JOB
+    JOB = args.job
     SHAPE = args.shape
     MAPPED_ONLY = args.mapped_only
     print(f"# {torch.cuda.get_device_name(0)}; one GPU; every rank's stripe timed in turn; us per launch (HIP events, median of 5)")
@@ -92,11 +98,12 @@ def main():
                 if mode == "balanced" and n == 1:
                     continue
                 bounds = [H * r // n for r in range(n + 1)] if mode == "equal" else balanced_bounds(globe, lens, zoom, W, H, n)
-                ts, t1s, shapes = [], [], []
+                ts, t1s, shapes, jobs = [], [], [], []
                 for r in range(n):
                     t, t1, stats = time_stripe(globe, lens, zoom, W, H, F, (bounds[r], bounds[r + 1]), args.single)
                     ts.append(t * 1e3)
                     t1s.append(t1 * 1e3 if t1 else 0.0)
+                    jobs.append(LAST_JOB_US)
                     shapes.append(f"128x{stats['tile_h'] % 1000}/{stats['lds_bytes_per_wave'] // 1024}K/{stats['tiles']}blk")
                 if base is None:
                     base = ts[0] * n if n > 1 else ts[0]
@@ -106,6 +113,8 @@ def main():
                         + " ".join(f"{t:.1f}" for t in ts))
                 if args.single:
                     line += "  single-frame us: " + " ".join(f"{t:.2f}" for t in t1s)
+                if JOB:
+                    line += "  two-stream job, wall us per step: " + " ".join(f"{t:.1f}" for t in jobs) + f" -> {W * H * F / max(jobs):9.1f} Mpx/s"
                 print(line, flush=True)
                 if os.environ.get("BK_VERBOSE"):
                     print("    bounds", bounds, "block shape / staging buffer per rank:", shapes)
