@@ -143,6 +143,36 @@ def test_c4_eight_stripes_full_size(bk):
     m.close()
 
 
+def test_row_costs_of_both_apply_variants(bk):
+    """what the rebalance sums over the ranks: the direct-gather apply prices a row by its mapped pixels (+ W/32), the staged apply by
+    the costs of the row's blocks in its block map - zero for no row, larger where the row touches more of the globe; rows of other
+    stripes are 0"""
+    globe, lens, W, H = "cube", "hammer", 640, 400
+    lm = O.lensmap(globe, lens, None, W, H)
+    mapped = (lm.offsets.reshape(H, W) != 0xFFFFFFFF).sum(axis=1)
+    ctx = bk.Context()
+    S.configure(ctx, globe, lens, None, (W, H))
+    ctx.set_rows(96, 304)
+    ctx.build()
+    ctx.set_apply_variant(0)
+    c0 = ctx.row_costs()
+    np.testing.assert_array_equal(c0[96:304], mapped[96:304] + W // 32)
+    assert not c0[:96].any() and not c0[304:].any()
+    ctx.set_apply_variant(2)
+    c2 = ctx.row_costs().astype(np.int64)
+    assert (c2[96:304] > 0).all() and not c2[:96].any() and not c2[304:].any()
+    # rows of one block row share their blocks' cost: constant over runs of 8 rows at least
+    assert all(len(set(c2[y:y + 8])) == 1 for y in range(96, 304, 8))
+    # and the staged apply still warps the stripe after its block map was compiled for the costs alone
+    for p in range(6):
+        ctx.fill_plate_lcg(0, p, 5)
+    want = O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, 6, 5), np.zeros((H, W), np.uint8))
+    got = ctx.apply(np.zeros((H, W), np.uint8))
+    np.testing.assert_array_equal(got[96:304], want[96:304])
+    assert not got[:96].any() and not got[304:].any()
+    ctx.close()
+
+
 def test_stripes_of_equal_work(bk):
     """bk_multi_rebalance: hammer's ellipse leaves the top and bottom stripes of an equal-height split nearly empty; cut by
     what the rows cost the apply instead (its block map's costs), every stripe gets its share, and the reassembled frames are still the oracle's."""

@@ -4,6 +4,8 @@ lens_forward must be bit-identical (values, NaNs, nil vs numbers, count of resul
 exercise the constructs their authors happened to use; this walks the emitter through operator precedence,
 short-circuit and/or, script functions with upvalues, numeric for / while / repeat loops, local array tables,
 multiple assignment and multiple returns."""
+import os
+
 import numpy as np
 import pytest
 
@@ -154,7 +156,16 @@ class Gen:
         ])
 
 
-@pytest.mark.parametrize("seed", range(60))
+def _seeds(default, env):
+    """the committed seed range, or (developer campaigns) `lo:hi` from the environment"""
+    v = os.environ.get(env)
+    if not v:
+        return range(default)
+    lo, hi = [int(x) for x in v.split(":")]
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _seeds(60, "BLINKY_FUZZ_EVAL_SEEDS"))
 def test_random_scripts_device_equals_host_interpreter(seed):
     import blinky_amd
     forward = seed % 3 == 2
@@ -182,7 +193,7 @@ def test_random_scripts_device_equals_host_interpreter(seed):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(18))
+@pytest.mark.parametrize("seed", _seeds(18, "BLINKY_FUZZ_BUILD_SEEDS"))
 def test_random_scripts_build_the_oracle_table(seed):
     """The whole build on random scripts: the GPU lensmap (inverse map for inverse scripts, the forward scatter for
     forward scripts - whose garbage projections push draw_quad through NaNs, huge coordinates and degenerate quads)
