@@ -101,73 +101,86 @@ static qboolean load_globe(void)
 
 /* ---- console commands (fisheye.c:916-1176) -------------------------------------------------------- */
 
-static void clear_zoom(void)                        /* fisheye.c:1273-1278 */
+/* The four zoom commands set one piece of state; the same table prints it ("Zoom currently: ...") and writes it to the config
+ * (names, argument meaning and console text: fisheye.c:955-965, 1032-1058, 1273-1291, 683-696). */
+static const struct zoom_cmd { int type; const char *name; const char *usage; } zoom_cmds[] = {
+    {BK_ZOOM_FOV, "f_fov", "f_fov <degrees>: set horizontal FOV\n"},
+    {BK_ZOOM_VFOV, "f_vfov", "f_vfov <degrees>: set vertical FOV\n"},
+    {BK_ZOOM_COVER, "f_cover", NULL},             /* (no argument: no usage line) */
+    {BK_ZOOM_CONTAIN, "f_contain", NULL},
+};
+
+/* the current zoom as the command that would set it ("f_vfov 100", "f_cover"), "" if none */
+static void zoom_as_command(char *out, size_t n)
 {
-    zoom.type = BK_ZOOM_NONE;
-    zoom.fov = 0;
+    size_t i;
+    out[0] = 0;
+    for (i = 0; i < sizeof zoom_cmds / sizeof zoom_cmds[0]; ++i) {
+        if (zoom_cmds[i].type != zoom.type) continue;
+        if (zoom_cmds[i].usage) snprintf(out, n, "%s %d", zoom_cmds[i].name, zoom.fov);
+        else snprintf(out, n, "%s", zoom_cmds[i].name);
+    }
+}
+
+static void zoom_command(const struct zoom_cmd *z)
+{
+    char now[32];
+    if (z->usage && Cmd_Argc() < 2) {             /* a degrees command without degrees: say what it does and where the zoom stands */
+        zoom_as_command(now, sizeof now);
+        Con_Printf("%s", z->usage);
+        Con_Printf("Zoom currently: %s\n", now[0] ? now : "none");
+        return;
+    }
+    zoom.type = z->type;
+    zoom.fov = z->usage ? (int)Q_atof(Cmd_Argv(1)) : 0;
     zoom.changed = true;
 }
+static void con_fov(void) { zoom_command(&zoom_cmds[0]); }
+static void con_vfov(void) { zoom_command(&zoom_cmds[1]); }
+static void con_cover(void) { zoom_command(&zoom_cmds[2]); }
+static void con_contain(void) { zoom_command(&zoom_cmds[3]); }
 
-static void print_zoom(void)                        /* fisheye.c:1280-1291 */
+static void con_dumppal(void)                       /* fisheye.c:916-931: the base palette as "r, g, b," lines in ./palette */
 {
-    Con_Printf("Zoom currently: ");
-    switch (zoom.type) {
-    case BK_ZOOM_FOV: Con_Printf("f_fov %d", zoom.fov); break;
-    case BK_ZOOM_VFOV: Con_Printf("f_vfov %d", zoom.fov); break;
-    case BK_ZOOM_COVER: Con_Printf("f_cover"); break;
-    case BK_ZOOM_CONTAIN: Con_Printf("f_contain"); break;
-    default: Con_Printf("none");
-    }
-    Con_Printf("\n");
-}
-
-static void cmd_dumppal(void)                       /* fisheye.c:916-931 */
-{
-    int i;
-    byte *pal = host_basepal;
+    int c;
     FILE *f = fopen("palette", "w");
     if (!f) { Con_Printf("could not open \"palette\" for writing\n"); return; }
-    for (i = 0; i < 256; ++i, pal += 3) fprintf(f, "%d, %d, %d,\n", pal[0], pal[1], pal[2]);
+    for (c = 0; c < 3 * 256; c += 3) fprintf(f, "%d, %d, %d,\n", host_basepal[c], host_basepal[c + 1], host_basepal[c + 2]);
     fclose(f);
 }
 
-static void cmd_rubix(void)                         /* fisheye.c:933-937 */
+static void con_rubix(void)                         /* fisheye.c:933-937 */
 {
     rubix.enabled = !rubix.enabled;
     Con_Printf("Rubix is %s\n", rubix.enabled ? "ON" : "OFF");
 }
 
-static void cmd_rubixgrid(void)                     /* fisheye.c:939-953 */
+static void con_rubixgrid(void)                     /* fisheye.c:939-953 */
 {
-    if (Cmd_Argc() == 4) {
-        rubix.numcells = (int)Q_atof(Cmd_Argv(1));
-        rubix.cell_size = Q_atof(Cmd_Argv(2));
-        rubix.pad_size = Q_atof(Cmd_Argv(3));
-        lens.changed = true;                        /* need to recompute lens to update grid */
-    } else {
-        Con_Printf("RubixGrid <numcells> <cellsize> <padsize>\n");
-        Con_Printf("   numcells (default 10) = %d\n", rubix.numcells);
-        Con_Printf("   cellsize (default  4) = %f\n", rubix.cell_size);
-        Con_Printf("   padsize  (default  1) = %f\n", rubix.pad_size);
-    }
-}
-
-static void cmd_cover(void) { clear_zoom(); zoom.type = BK_ZOOM_COVER; }       /* fisheye.c:955-959 */
-static void cmd_contain(void) { clear_zoom(); zoom.type = BK_ZOOM_CONTAIN; }   /* fisheye.c:961-965 */
-
-static void cmd_fisheye(void)                       /* fisheye.c:967-977 */
-{
-    if (Cmd_Argc() < 2) {
-        Con_Printf("Currently: ");
-        Con_Printf("fisheye %d\n", fisheye_enabled);
-        Con_Printf("\nTry F_HELP for more options and commands.\n");
+    if (Cmd_Argc() != 4) {
+        Con_Printf("RubixGrid <numcells> <cellsize> <padsize>\n"
+                   "   numcells (default 10) = %d\n"
+                   "   cellsize (default  4) = %f\n"
+                   "   padsize  (default  1) = %f\n", rubix.numcells, rubix.cell_size, rubix.pad_size);
         return;
     }
-    fisheye_enabled = Q_atoi(Cmd_Argv(1)) ? true : false;
-    vid.recalc_refdef = true;
+    rubix.numcells = (int)Q_atof(Cmd_Argv(1));
+    rubix.cell_size = Q_atof(Cmd_Argv(2));
+    rubix.pad_size = Q_atof(Cmd_Argv(3));
+    lens.changed = true;                            /* the grid is baked into the lensmap's tints: build again */
 }
 
-static void cmd_shortcutkeys(void)                  /* fisheye.c:979-1016 */
+static void con_fisheye(void)                       /* fisheye.c:967-977 */
+{
+    if (Cmd_Argc() >= 2) {
+        fisheye_enabled = Q_atoi(Cmd_Argv(1)) != 0;
+        vid.recalc_refdef = true;
+        return;
+    }
+    Con_Printf("Currently: fisheye %d\n\nTry F_HELP for more options and commands.\n", fisheye_enabled);
+}
+
+static void con_shortcutkeys(void)                  /* fisheye.c:979-1016 */
 {
     static const char *lens_keys[9] = {"panini", "stereographic", "hammer", "winkeltripel", "fisheye1",
                                        "mercator", "quincuncial", "cube", "debug"};
@@ -199,45 +212,18 @@ static void cmd_shortcutkeys(void)                  /* fisheye.c:979-1016 */
     }
 }
 
-static void cmd_help(void)                          /* fisheye.c:1018-1030 */
+static void con_help(void)                          /* fisheye.c:1018-1030 */
 {
-    Con_Printf("-----------------------------\n");
-    Con_Printf("Welcome to the FISHEYE ADDON!\n");
-    Con_Printf("-> fisheye 1    (ENABLE)\n");
-    Con_Printf("-> fisheye 0    (DISABLE)\n");
-    Con_Printf("\n");
-    Con_Printf("-> f_lens <tab>    (CHANGE LENS)\n");
-    Con_Printf("-> f_fov <degrees> (SET FOV)\n");
-    Con_Printf("\n");
-    Con_Printf("-> f_<tab>         (MORE COMMANDS)\n");
-    Con_Printf("-----------------------------\n");
+    static const char *const lines[] = {
+        "-----------------------------", "Welcome to the FISHEYE ADDON!", "-> fisheye 1    (ENABLE)", "-> fisheye 0    (DISABLE)", "",
+        "-> f_lens <tab>    (CHANGE LENS)", "-> f_fov <degrees> (SET FOV)", "", "-> f_<tab>         (MORE COMMANDS)",
+        "-----------------------------",
+    };
+    size_t i;
+    for (i = 0; i < sizeof lines / sizeof lines[0]; ++i) Con_Printf("%s\n", lines[i]);
 }
 
-static void cmd_fov(void)                           /* fisheye.c:1032-1044 */
-{
-    if (Cmd_Argc() < 2) {
-        Con_Printf("f_fov <degrees>: set horizontal FOV\n");
-        print_zoom();
-        return;
-    }
-    clear_zoom();
-    zoom.type = BK_ZOOM_FOV;
-    zoom.fov = (int)Q_atof(Cmd_Argv(1));
-}
-
-static void cmd_vfov(void)                          /* fisheye.c:1046-1058 */
-{
-    if (Cmd_Argc() < 2) {
-        Con_Printf("f_vfov <degrees>: set vertical FOV\n");
-        print_zoom();
-        return;
-    }
-    clear_zoom();
-    zoom.type = BK_ZOOM_VFOV;
-    zoom.fov = (int)Q_atof(Cmd_Argv(1));
-}
-
-static void cmd_lens(void)                          /* fisheye.c:1061-1103 */
+static void con_lens(void)                          /* fisheye.c:1061-1103 */
 {
     bk_lens_info info;
     if (Cmd_Argc() < 2) {
@@ -264,7 +250,7 @@ static void cmd_lens(void)                          /* fisheye.c:1061-1103 */
 
 static struct { qboolean should; int with_margins; char name[32]; } save;       /* globe.save, fisheye.c:370-375 */
 
-static void cmd_saveglobe(void)                     /* fisheye.c:1120-1136 */
+static void con_saveglobe(void)                     /* fisheye.c:1120-1136 */
 {
     if (Cmd_Argc() < 2) {
         Con_Printf("f_saveglobe <name> [full flag=0]: screenshot the globe plates\n");
@@ -338,7 +324,7 @@ static void save_globe(int numplates)                /* fisheye.c:1467-1484 */
     D_DisableBackBufferAccess();
 }
 
-static void cmd_globe(void)                         /* fisheye.c:1138-1161 */
+static void con_globe(void)                         /* fisheye.c:1138-1161 */
 {
     if (Cmd_Argc() < 2) {
         Con_Printf("f_globe <name>: use a new globe\n");
@@ -399,21 +385,21 @@ void F_Init(void)                                   /* fisheye.c:642-676 */
         else bk_set_async_compile(bk, 1);
     }
 
-    Cmd_AddCommand("fisheye", cmd_fisheye);
-    Cmd_AddCommand("f_help", cmd_help);
-    Cmd_AddCommand("f_dumppal", cmd_dumppal);
-    Cmd_AddCommand("f_rubix", cmd_rubix);
-    Cmd_AddCommand("f_rubixgrid", cmd_rubixgrid);
-    Cmd_AddCommand("f_cover", cmd_cover);
-    Cmd_AddCommand("f_contain", cmd_contain);
-    Cmd_AddCommand("f_fov", cmd_fov);
-    Cmd_AddCommand("f_vfov", cmd_vfov);
-    Cmd_AddCommand("f_lens", cmd_lens);
+    Cmd_AddCommand("fisheye", con_fisheye);
+    Cmd_AddCommand("f_help", con_help);
+    Cmd_AddCommand("f_dumppal", con_dumppal);
+    Cmd_AddCommand("f_rubix", con_rubix);
+    Cmd_AddCommand("f_rubixgrid", con_rubixgrid);
+    Cmd_AddCommand("f_cover", con_cover);
+    Cmd_AddCommand("f_contain", con_contain);
+    Cmd_AddCommand("f_fov", con_fov);
+    Cmd_AddCommand("f_vfov", con_vfov);
+    Cmd_AddCommand("f_lens", con_lens);
     Cmd_SetCompletion("f_lens", cmdarg_lens);                        /* fisheye.c:661 */
-    Cmd_AddCommand("f_globe", cmd_globe);
+    Cmd_AddCommand("f_globe", con_globe);
     Cmd_SetCompletion("f_globe", cmdarg_globe);                      /* fisheye.c:663 */
-    Cmd_AddCommand("f_saveglobe", cmd_saveglobe);
-    Cmd_AddCommand("f_shortcutkeys", cmd_shortcutkeys);
+    Cmd_AddCommand("f_saveglobe", con_saveglobe);
+    Cmd_AddCommand("f_shortcutkeys", con_shortcutkeys);
 
     /* defaults */
     Cmd_ExecuteString("fisheye 1", src_command);
@@ -435,17 +421,11 @@ void F_Shutdown(void)                               /* fisheye.c:678-681 */
 
 void F_WriteConfig(FILE *f)                         /* fisheye.c:683-696 */
 {
-    fprintf(f, "fisheye %d\n", fisheye_enabled);
-    fprintf(f, "f_lens \"%s\"\n", lens.name);
-    fprintf(f, "f_globe \"%s\"\n", globe.name);
+    char z[32];
+    zoom_as_command(z, sizeof z);
+    fprintf(f, "fisheye %d\nf_lens \"%s\"\nf_globe \"%s\"\n", fisheye_enabled, lens.name, globe.name);
     fprintf(f, "f_rubixgrid %d %f %f\n", rubix.numcells, rubix.cell_size, rubix.pad_size);
-    switch (zoom.type) {
-    case BK_ZOOM_FOV: fprintf(f, "f_fov %d\n", zoom.fov); break;
-    case BK_ZOOM_VFOV: fprintf(f, "f_vfov %d\n", zoom.fov); break;
-    case BK_ZOOM_COVER: fprintf(f, "f_cover\n"); break;
-    case BK_ZOOM_CONTAIN: fprintf(f, "f_contain\n"); break;
-    default: break;
-    }
+    if (z[0]) fprintf(f, "%s\n", z);
 }
 
 /* render_plate (fisheye.c:2427-2450): the engine renders the view, its rows go to the GPU */
