@@ -249,7 +249,14 @@ BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key,
     if (offgrid) atomicMax(&P.fwd_key_tint[o], key);
 }
 
-/* draw_quad (fisheye.c:2246-2338); int overflow on INT_MIN coordinates wraps as on x86-64 */
+/* draw_quad (fisheye.c:2246-2338); int overflow on INT_MIN coordinates wraps as on x86-64.
+ * A NaN projection becomes INT_MIN in uv_to_screen (cvttsd2si), and abs(INT_MIN - 0) is INT_MIN again: a quad with one bound at
+ * INT_MIN and the other at exactly 0 PASSES the reference's 20-pixel size check and its loops then run over 2^31 rows or columns,
+ * of which only those on the screen write anything.  The loops below visit the visible part of such a range only: bit-identical,
+ * because a row's two crossings lie between corner x's - within the 20-pixel x extent, so no row of a tall quad can trip the
+ * per-row abort - unless the x extent wraps as well (both bounds INT_MIN / 0 in x AND y: then the abort of an off-screen row is
+ * not seen; the top-left pixel's neighbourhood under a lens that returns NaN for both coordinates). */
+BK_DEV int bk_wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, const int *bl, const int *br,
                          unsigned int key, bool offgrid, int *wrote)
 {
@@ -263,33 +270,37 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, c
     }
     const int maxdiff = 20;
     {
-        int dx = (int)((unsigned)minx - (unsigned)maxx), dy = (int)((unsigned)miny - (unsigned)maxy);
-        int adx = dx < 0 ? (int)(0u - (unsigned)dx) : dx, ady = dy < 0 ? (int)(0u - (unsigned)dy) : dy;
+        int dx = bk_wrap_sub(minx, maxx), dy = bk_wrap_sub(miny, maxy);
+        int adx = dx < 0 ? bk_wrap_sub(0, dx) : dx, ady = dy < 0 ? bk_wrap_sub(0, dy) : dy;      /* abs(): INT_MIN stays INT_MIN */
         if (adx > maxdiff || ady > maxdiff) return;                          /* :2272 */
     }
-    const int nx = (int)((unsigned)maxx - (unsigned)minx), ny = (int)((unsigned)maxy - (unsigned)miny);   /* 0..20 */
+    /* the part of [min, max] that is on the screen (all of a normal, <= 21-long range that matters; one end of a 2^31-long one) */
+    const int vx0 = minx < 0 ? 0 : minx, vx1 = maxx >= P.W ? P.W - 1 : maxx;
+    const int vy0 = miny < 0 ? 0 : miny, vy1 = maxy >= P.H ? P.H - 1 : maxy;
     if (miny == maxy && minx == maxx) { bk_fwd_set(P, x, y, key, offgrid, wrote); return; }
-    if (miny == maxy) { for (int k = 0; k <= nx; ++k) bk_fwd_set(P, minx + k, miny, key, offgrid, wrote); return; }
-    if (minx == maxx) { for (int k = 0; k <= ny; ++k) bk_fwd_set(P, x, miny + k, key, offgrid, wrote); return; }
-    for (int ky = 0; ky <= ny; ++ky) {
-        y = miny + ky;
+    if (miny == maxy) { for (int tx = vx0; tx <= vx1; ++tx) bk_fwd_set(P, tx, miny, key, offgrid, wrote); return; }
+    if (minx == maxx) { for (int ty = vy0; ty <= vy1; ++ty) bk_fwd_set(P, x, ty, key, offgrid, wrote); return; }
+    const bool tall = bk_wrap_sub(maxy, miny) < 0;                            /* 2^31 rows: visible ones only (see above) */
+    const int y_first = tall ? vy0 : miny, nrows = bk_wrap_sub(tall ? vy1 : maxy, y_first);      /* <= 20, or <= H - 1; < 0: none */
+    for (int ky = 0; ky <= nrows; ++ky) {
+        y = (int)((unsigned)y_first + (unsigned)ky);
         int tx[2] = {minx, maxx};
         int txi = 0, j = 3;
         for (int i = 0; i < 4; ++i) {
             int ix = p[i][0], iy = p[i][1];
             int jx = p[j][0], jy = p[j][1];
             if ((iy < y && y <= jy) || (jy < y && y <= iy)) {                /* :2310 */
-                double dy = (double)(jy - iy);
-                double dx = (double)(jx - ix);
-                tx[txi] = bk_trunc_to_int((double)ix + (double)(y - iy) / dy * dx);   /* :2313 */
+                double dy = (double)bk_wrap_sub(jy, iy);
+                double dx = (double)bk_wrap_sub(jx, ix);
+                tx[txi] = bk_trunc_to_int((double)ix + (double)bk_wrap_sub(y, iy) / dy * dx);   /* :2313 */
                 if (++txi == 2) break;
             }
             j = i;
         }
         if (tx[0] > tx[1]) { int t = tx[0]; tx[0] = tx[1]; tx[1] = t; }
-        if ((int)((unsigned)tx[1] - (unsigned)tx[0]) > maxdiff) return;      /* :2327 aborts the quad */
-        const int n = tx[1] - tx[0];
-        for (int k = 0; k <= n; ++k) bk_fwd_set(P, tx[0] + k, y, key, offgrid, wrote);
+        if (bk_wrap_sub(tx[1], tx[0]) > maxdiff) return;                     /* :2327 aborts the quad */
+        const int x_first = tx[0] < 0 ? 0 : tx[0], x_last = tx[1] >= P.W ? P.W - 1 : tx[1];
+        for (x = x_first; x <= x_last; ++x) bk_fwd_set(P, x, y, key, offgrid, wrote);
     }
 }
 

@@ -156,11 +156,18 @@ class Gen:
         ])
 
 
-def _seeds(default, env):
+# found by a campaign over build seeds 138..938 (round 3): forward scripts whose NaN projections give a quad one bound at INT_MIN
+# and the other at exactly 0 - it passes the reference's size check (abs(INT_MIN) == INT_MIN) and is scanned over 2^31 rows.
+# The oracle does scan them (tens of seconds per such quad on one core), so only the two cheapest stay in the suite; the others -
+# 242, 383, 608, 917 - pass as well (BLINKY_FUZZ_BUILD_SEEDS=242:243 ...).
+EXTRA_BUILD_SEEDS = [368, 605]
+
+
+def _seeds(default, env, extra=()):
     """the committed seed range, or (developer campaigns) `lo:hi` from the environment"""
     v = os.environ.get(env)
     if not v:
-        return range(default)
+        return list(range(default)) + list(extra)
     lo, hi = [int(x) for x in v.split(":")]
     return range(lo, hi)
 
@@ -193,7 +200,7 @@ def test_random_scripts_device_equals_host_interpreter(seed):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", _seeds(18, "BLINKY_FUZZ_BUILD_SEEDS"))
+@pytest.mark.parametrize("seed", _seeds(18, "BLINKY_FUZZ_BUILD_SEEDS", EXTRA_BUILD_SEEDS))
 def test_random_scripts_build_the_oracle_table(seed):
     """The whole build on random scripts: the GPU lensmap (inverse map for inverse scripts, the forward scatter for
     forward scripts - whose garbage projections push draw_quad through NaNs, huge coordinates and degenerate quads)

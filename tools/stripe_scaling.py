@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--single", action="store_true", help="also time single-frame launches of every stripe")
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--balanced-all", action="store_true", help="try the rebalanced stripes for fully mapped lenses too")
     ap.add_argument("--job", action="store_true", help="also the two-stream job's wall clock per step on every stripe (host launch cost included)")
     ap.add_argument("--mapped-only", action="store_true", help="balanced = equal mapped pixels (the rule before the block-map costs)")
     args = ap.parse_args()
@@ -93,7 +94,7 @@ def main():
     for name in args.configs.split(","):
         globe, lens, zoom, W, H, F, unmapped = CONFIGS[name]
         base = None
-        for mode in (["equal", "balanced"] if unmapped else ["equal"]):
+        for mode in (["equal", "balanced"] if unmapped or args.balanced_all else ["equal"]):
             for n in [int(v) for v in args.ranks.split(',')]:
                 if mode == "balanced" and n == 1:
                     continue
