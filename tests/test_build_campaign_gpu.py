@@ -34,6 +34,8 @@ def test_random_build_configuration(seed):
         W, H = int(rng.integers(8, 640)), int(rng.integers(8, 420))
     else:
         W, H = [(320, 200), (640, 480), (400, 300), (512, 512), (300, 500), (854, 480), (333, 217)][int(rng.integers(0, 7))]
+    if os.environ.get("BLINKY_BUILD_CAMPAIGN_SIZES") == "big":      # developer campaign at BASELINE's frame sizes (the oracle takes seconds)
+        W, H = [(1920, 1080), (2560, 1440), (3840, 2160), (1080, 1920), (3440, 1440)][int(rng.integers(0, 5))]
     grid = (10, 4.0, 1.0) if rng.random() < 0.5 else (int(rng.integers(1, 24)), float(rng.choice([0.5, 1, 2, 4, 7.5])), float(rng.choice([0, 0.25, 1, 3])))
     r0, r1 = 0, H
     if rng.random() < 0.35:
