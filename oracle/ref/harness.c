@@ -172,7 +172,8 @@ int ref_run(const char *globe_name, const char *lens_name, const char *zoomcmd, 
 
     lens.scale = -1;
     F_RenderView();                             /* build (to completion) + stub plates + apply */
-    built = lens.valid && globe.valid && lens.scale > 0 && !lens_builder.working;
+    /* calc_zoom's own verdict (fisheye.c:1378: it fails on "scale <= 0" - a NaN scale passes and builds an all-NULL table) */
+    built = lens.valid && globe.valid && !(lens.scale <= 0) && !lens_builder.working;
 
     for (i = 0; i < area; ++i)
         offsets[i] = lens.pixels[i] ? (uint32_t)(lens.pixels[i] - globe.pixels) : 0xFFFFFFFFu;

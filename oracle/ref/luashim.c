@@ -29,15 +29,15 @@ struct Table { int n, cap; Value *arr; };
 
 #define STACK_MAX 1024
 #define GLOBALS_MAX 256
-#define REG_MAX 256
 
 struct lua_State {
     Value stack[STACK_MAX];
     int top, base;          /* absolute indices; frame-relative index 1 == stack[base] */
     struct { const char *name; Value v; } globals[GLOBALS_MAX];
     int nglobals;
-    Value registry[REG_MAX];
-    int nreg;
+    Value *registry;        /* grows: the reference never gives a reference back (no luaL_unref in fisheye.c), and a harness
+                             * process may load thousands of lenses */
+    int nreg, regcap;
 };
 
 static void die(const char *msg) { fprintf(stderr, "luashim: %s\n", msg); abort(); }
@@ -183,8 +183,12 @@ void lua_setglobal(lua_State *L, const char *name)
 int luaL_ref(lua_State *L, int t)
 {
     if (t != LUA_REGISTRYINDEX) die("luaL_ref: registry only");
-    if (L->nreg >= REG_MAX) L->nreg = 1;   /* test tool: recycle (refs are re-taken on every load) */
     if (L->nreg == 0) L->nreg = 1;         /* ref 0 unused, like real Lua */
+    if (L->nreg >= L->regcap) {
+        L->regcap = L->regcap ? 2 * L->regcap : 256;
+        L->registry = (Value *)realloc(L->registry, (size_t)L->regcap * sizeof(Value));
+        if (!L->registry) die("luaL_ref: out of memory");
+    }
     L->registry[L->nreg] = L->stack[--L->top];
     return L->nreg++;
 }
