@@ -12,6 +12,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <errno.h>
 #include <string.h>
 
 #include "../../include/blinky_hip.h"
@@ -51,7 +52,8 @@ static char *read_script(const char *kind, const char *name, size_t *len)
     snprintf(path, sizeof path, "%s/lua-scripts/%s/%s.lua", com_basedir, kind, name);   /* fisheye.c:1666, 1759 */
     f = fopen(path, "rb");
     if (!f) {
-        Con_Printf("could not loadfile (%s)\n", path);
+        /* what the reference prints when luaL_loadfile fails (fisheye.c:1671, 1764): Lua 5.2's LUA_ERRFILE and its message, no newline */
+        Con_Printf("could not loadfile (%d) \nERROR: cannot open %s: %s", 7, path, strerror(errno));
         return NULL;
     }
     fseek(f, 0, SEEK_END);
@@ -460,8 +462,8 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
         int rc, newdisplay[BK_MAX_PLATES];
         if (!build_pending || sizechange || zoom.changed || lens.changed || globe.changed) {
             /* the lens is loaded again so that variables depending on the globe (numplates) are fresh */
-            lens.valid = lens.name[0] ? load_lens() : false;
-            if (!lens.name[0]) DEV(bk_clear_lens(bk), bk_multi_clear_lens(mg));
+            /* (with no lens selected - the name is "" after an invalid one - the reference still tries, and says that ".lua" cannot be opened) */
+            lens.valid = load_lens();
             if (!lens.valid) {
                 strcpy(lens.name, "");
                 Con_Printf("not a valid lens\n");

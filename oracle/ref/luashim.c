@@ -205,7 +205,7 @@ int luaL_loadfilex(lua_State *L, const char *filename, const char *mode)
     (void)mode;
     if (!ref_script_exists(filename)) {
         char msg[512];
-        snprintf(msg, sizeof msg, "cannot open %s", filename);
+        snprintf(msg, sizeof msg, "cannot open %s: No such file or directory", filename);   /* Lua 5.2 lauxlib.c errfile(): "cannot %s %s: %s" */
         lua_pushstring(L, msg);
         return 7;            /* LUA_ERRFILE */
     }

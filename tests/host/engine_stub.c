@@ -25,7 +25,11 @@ refdef_t r_refdef;
 vrect_t scr_vrect;
 int sb_lines;
 byte *host_basepal;
+#ifdef BLINKY_IN_ENGINE
+char com_basedir[MAX_OSPATH];                  /* (the engine's own declaration: include/common.h:201) */
+#else
 char com_basedir[1024];
+#endif
 
 static byte basepal[768];
 static char console[1 << 16];
@@ -131,7 +135,8 @@ void Cmd_ExecuteString(const char *text, cmd_source_t src)
 float Q_atof(const char *str) { return (float)atof(str); }
 int Q_atoi(const char *str) { return atoi(str); }
 
-/* ---- math ----------------------------------------------------------------------------------------- */
+/* ---- math (oracle/ref/hosttest_ref.c links the reference's own common/mathlib.c instead) ---------------- */
+#ifndef HOSTTEST_WITH_REFERENCE
 void VectorMA(const vec3_t veca, const float scale, const vec3_t vecb, vec3_t vecc)
 {
     vecc[0] = veca[0] + scale * vecb[0];
@@ -148,6 +153,7 @@ void AngleVectors(const vec3_t angles, vec3_t forward, vec3_t right, vec3_t up)
     right[0] = -1 * sr * sp * cy + -1 * cr * -sy; right[1] = -1 * sr * sp * sy + -1 * cr * cy; right[2] = -1 * sr * cp;
     up[0] = cr * sp * cy + -sr * -sy; up[1] = cr * sp * sy + -sr * cy; up[2] = cr * cp;
 }
+#endif
 
 /* ---- zone / filesystem: files the host layer writes (f_saveglobe) are kept in memory ------------------- */
 void *Hunk_TempAlloc(int size)

@@ -142,5 +142,105 @@ def scenario_complete(base):
     print("complete ok")
 
 
+REFLIB = os.path.join(ROOT, "oracle", "_ref", "libhosttest_ref.so")
+
+
+def scenario_differential(base, seed_range="0:4", frames="1"):
+    """The same random session - console commands, resizes, frames - put to the product's host layer (libhosttest.so) and to the
+    UNMODIFIED reference behind the same engine stand-in (oracle/_ref/libhosttest_ref.so: fisheye.c's own F_Init / commands /
+    F_RenderView): after every step the console text and the config must be identical, and after every frame the screen, the number of
+    plate views the engine was asked for and their fov.  frames = "0": commands only (no GPU needed)."""
+    import scripts as S
+    with_frames = frames == "1"
+    if with_frames:
+        import blinky_amd  # noqa: F401
+        os.environ["BLINKY_HIP_SYNC_COMPILE"] = "1"
+    else:
+        os.environ["BLINKY_HIP_DEVICE"] = "none"
+    lo, hi = [int(v) for v in seed_range.split(":")]
+    mine, ref = load(), C.CDLL(REFLIB)
+    ref.hosttest_console.restype = C.c_char_p
+    ref.hosttest_plate_fov.restype = C.c_double
+    both = (mine, ref)
+    for h in both:
+        assert h.hosttest_init(base.encode()) == 1
+    ref.hosttest_ref_build_to_completion()
+    buf = C.create_string_buffer(8192)
+
+    def config(h):
+        h.hosttest_writeconfig(buf, 8192)
+        return buf.value.decode()
+
+    def console(h):
+        t = h.hosttest_console().decode()
+        h.hosttest_console_clear()
+        return t
+
+    def same_text(what):
+        a, b = console(mine), console(ref)
+        assert a == b, f"{what}: console differs\n--- product ---\n{a}\n--- reference ---\n{b}"
+        a, b = config(mine), config(ref)
+        assert a == b, f"{what}: config differs\n--- product ---\n{a}\n--- reference ---\n{b}"
+
+    same_text("after F_Init")
+    nframes = 0
+    for seed in range(lo, hi):
+        rng = np.random.default_rng(4000 + seed)
+        W, H, x0, y0, extra = 320, 200, 0, 0, 0
+        for h in both:
+            h.hosttest_resize(W, H, x0, y0, extra)
+        for step in range(int(rng.integers(10, 24))):
+            k = rng.random()
+            deg = int(rng.choice([10, 60, 90, 120, 150, 180, 181, 200, 270, 360, 400]))
+            if k < 0.16:
+                cmd = "f_lens " + (str(rng.choice(S.LENSES)) if rng.random() < 0.93 else "nosuchlens")
+            elif k < 0.26:
+                cmd = "f_globe " + (str(rng.choice(S.GLOBES)) if rng.random() < 0.93 else "nosuchglobe")
+            elif k < 0.42:
+                cmd = str(rng.choice([f"f_fov {deg}", f"f_vfov {deg}", "f_cover", "f_contain", "f_fov", "f_vfov", f"f_fov {deg}.7"]))
+            elif k < 0.50:
+                cmd = str(rng.choice(["f_rubix", f"f_rubixgrid {int(rng.integers(1, 20))} {float(rng.choice([0.5, 1, 2, 4]))} {float(rng.choice([0, 0.5, 1]))}",
+                                      "f_rubixgrid", "f_rubixgrid 3 2"]))
+            elif k < 0.56:
+                cmd = str(rng.choice(["f_help", "fisheye", "f_lens", "f_globe", "f_shortcutkeys", "f_saveglobe"]))
+            elif k < 0.66:
+                W, H = [(320, 200), (200, 120), (333, 217), (160, 240), (400, 300), (64, 48)][int(rng.integers(0, 6))]
+                x0, y0, extra = int(rng.integers(0, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 17))
+                for h in both:
+                    h.hosttest_resize(W, H, x0, y0, extra)
+                cmd = None
+            else:
+                cmd = "frame"
+            what = f"seed {seed} step {step}: {cmd or f'resize {W}x{H}+{x0}+{y0} pitch+{extra}'}"
+            if cmd == "frame":
+                if not with_frames:
+                    continue
+                fidx, bg = int(rng.integers(0, 5)), int(rng.integers(0, 256))
+                order = (C.c_int * 6)(0, 1, 2, 3, 4, 5)
+                outs, ns = [], []
+                for h in both:
+                    pitch, vh = h.hosttest_rowbytes(), h.hosttest_vidheight()
+                    out = np.zeros((vh, pitch), np.uint8)
+                    ns.append(h.hosttest_frame(order, 6, fidx, bg, out.ctypes.data_as(C.c_void_p)))
+                    outs.append(out[:, : pitch - extra] if extra else out)
+                # (one deliberate difference: when the zoom cannot be computed the reference returns from create_lensmap before it resets the
+                #  display flags (fisheye.c:2376-2384) and goes on rendering the PREVIOUS lensmap's plates into a lensmap that shows none of them;
+                #  the product asks for no plate view at all - the screens are the same)
+                assert ns[0] == ns[1] or ns[0] == 0, f"{what}: the engine was asked for {ns[0]} plate views, the reference asks for {ns[1]}"
+                for i in range(ns[0]):
+                    assert mine.hosttest_plate_fov(i) == ref.hosttest_plate_fov(i), f"{what}: plate view {i}: fisheye_plate_fov differs"
+                if not np.array_equal(outs[0], outs[1]):
+                    bad = np.argwhere(outs[0] != outs[1])
+                    raise AssertionError(f"{what}: {len(bad)} screen bytes differ, first at (y, x) = {tuple(bad[0])}; config:\n{config(ref)}")
+                nframes += 1
+            elif cmd:
+                for h in both:
+                    h.hosttest_cmd(cmd.encode())
+            same_text(what)
+    mine.hosttest_shutdown()
+    print(f"differential ok: seeds {lo}..{hi - 1}, {nframes} frames compared")
+
+
 if __name__ == "__main__":
-    {"frames": scenario_frames, "async": scenario_async, "complete": scenario_complete}[sys.argv[1]](sys.argv[2])
+    {"frames": scenario_frames, "async": scenario_async, "complete": scenario_complete,
+     "differential": scenario_differential}[sys.argv[1]](*sys.argv[2:])

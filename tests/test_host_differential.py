@@ -1,0 +1,38 @@
+"""The C host layer (blinky_amd/host/fisheye_hip.c: F_Init, the console commands, F_RenderView, F_WriteConfig) against the UNMODIFIED
+reference behind the same engine stand-in (oracle/_ref/libhosttest_ref.so = tests/host/engine_stub.c + engine/NQ/fisheye.c itself): random
+sessions of console commands, resizes and frames, everything a user can observe compared after every step - console text, config, and
+with a GPU the screen, the plate views the engine is asked to render and their fov (fisheye.c:683-811, 916-1176).  Each session runs in a
+process of its own (tests/hostlayer_driver.py differential).  BLINKY_HOST_CAMPAIGN=lo:hi runs a longer developer campaign."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_host_layer import ROOT, build_hostlib, game_dir
+
+REFLIB = os.path.join(ROOT, "oracle", "_ref", "libhosttest_ref.so")
+needs_ref = pytest.mark.skipif(not os.path.exists(REFLIB), reason="oracle/_ref/libhosttest_ref.so not built (needs /root/reference)")
+
+
+def run(tmp_path, seeds, frames, timeout=1500):
+    build_hostlib()
+    base = game_dir(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostlayer_driver.py"), "differential", base, seeds, frames],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    assert "differential ok" in r.stdout
+    return r.stdout
+
+
+@needs_ref
+@pytest.mark.ref
+def test_console_sessions_equal_the_reference(tmp_path):
+    run(tmp_path, os.environ.get("BLINKY_HOST_CAMPAIGN", "0:40"), "0")
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_frames_of_random_sessions_equal_the_reference(tmp_path):
+    out = run(tmp_path, os.environ.get("BLINKY_HOST_CAMPAIGN", "0:8"), "1")
+    assert " 0 frames compared" not in out
