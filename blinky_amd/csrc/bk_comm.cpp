@@ -462,7 +462,8 @@ extern "C" int bk_multi_uses_rccl(const bk_multi *m) { return m && !m->copy_tran
     do {                                                                                             \
         for (size_t i_ = 0; i_ < (m)->ctx.size(); ++i_) {                                            \
             bk_ctx *c = (m)->ctx[i_];                                                                \
-            if (int r_ = (call)) return (m)->fail(r_, std::string("device ") + std::to_string(c->device) + ": " + bk_last_error(c)); \
+            if (int r_ = (call))  /* (script / zoom verdicts are the same on every device: their text goes out as it is) */ \
+                return (m)->fail(r_, (r_ == BK_E_SCRIPT || r_ == BK_E_ZOOM ? std::string() : std::string("device ") + std::to_string(c->device) + ": ") + bk_last_error(c)); \
         }                                                                                            \
     } while (0)
 
@@ -608,11 +609,13 @@ extern "C" int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], doubl
     std::string bad_msg;
     for (size_t i = 0; i < n; ++i)
         if (rc[i] == BK_E_SCRIPT && bk_last_build_bad_key(m->ctx[i])) {
-            if (bad_msg.empty()) bad_msg = std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]);
+            if (bad_msg.empty()) bad_msg = bk_last_error(m->ctx[i]);
             bad_key = std::max(bad_key, bk_last_build_bad_key(m->ctx[i]));
             rc[i] = BK_OK;
         }
     for (size_t i = 0; i < n; ++i) {
+        // (a zoom or script verdict is the same on every stripe and its text is the reference's console text: no device in front)
+        if (rc[i] == BK_E_ZOOM || rc[i] == BK_E_SCRIPT) return m->fail(rc[i], bk_last_error(m->ctx[i]));
         if (rc[i] != BK_OK) return m->fail(rc[i], std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]));
         if (bad_key) if (int r = bk_truncate_build(m->ctx[i], bad_key, disp[i].data())) return m->fail(r, std::string("device ") + std::to_string(m->ctx[i]->device) + ": " + bk_last_error(m->ctx[i]));
         for (int p = 0; p < BK_MAX_PLATES; ++p) all[p] |= disp[i][(size_t)p];

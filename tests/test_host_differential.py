@@ -15,11 +15,14 @@ REFLIB = os.path.join(ROOT, "oracle", "_ref", "libhosttest_ref.so")
 needs_ref = pytest.mark.skipif(not os.path.exists(REFLIB), reason="oracle/_ref/libhosttest_ref.so not built (needs /root/reference)")
 
 
-def run(tmp_path, seeds, frames, timeout=1500):
+def run(tmp_path, seeds, frames, timeout=1500, devices=None):
     build_hostlib()
     base = game_dir(tmp_path)
+    env = dict(os.environ)
+    if devices:
+        env["BLINKY_HIP_DEVICES"] = devices          # several stripe contexts (bk_multi): rows split, rebalanced, reassembled
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostlayer_driver.py"), "differential", base, seeds, frames],
-                       capture_output=True, text=True, timeout=timeout)
+                       capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     assert "differential ok" in r.stdout
     return r.stdout
@@ -33,6 +36,7 @@ def test_console_sessions_equal_the_reference(tmp_path):
 
 @needs_ref
 @pytest.mark.gpu
-def test_frames_of_random_sessions_equal_the_reference(tmp_path):
-    out = run(tmp_path, os.environ.get("BLINKY_HOST_CAMPAIGN", "0:8"), "1")
+@pytest.mark.parametrize("devices", [None, "0,0,0"], ids=["one-context", "three-stripes"])
+def test_frames_of_random_sessions_equal_the_reference(tmp_path, devices):
+    out = run(tmp_path, os.environ.get("BLINKY_HOST_CAMPAIGN", "0:8"), "1", devices=devices or os.environ.get("BLINKY_HIP_DEVICES"))
     assert " 0 frames compared" not in out
