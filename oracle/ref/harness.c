@@ -247,3 +247,15 @@ void ref_palettes(uint8_t out[6][256])
     int p;
     for (p = 0; p < MAX_PLATES; ++p) memcpy(out[p], globe.plates[p].palette, 256);
 }
+
+/* the same for any base palette: the reference's own create_palmap (fisheye.c:835-908) on `pal` (768 bytes) */
+void ref_palettes_of(const uint8_t *pal, uint8_t out[6][256])
+{
+    byte *saved = host_basepal;
+    int p;
+    host_basepal = (byte *)pal;
+    create_palmap();
+    for (p = 0; p < MAX_PLATES; ++p) memcpy(out[p], globe.plates[p].palette, 256);
+    host_basepal = saved;
+    create_palmap();
+}

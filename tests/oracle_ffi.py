@@ -146,6 +146,16 @@ def ref_palettes():
     return out
 
 
+def ref_palettes_of(basepal):
+    """the unmodified reference's create_palmap on any 768-byte base palette"""
+    global _r
+    if _r is None:
+        _r = C.CDLL(REF_SO)
+    out = np.empty((6, 256), np.uint8)
+    _r.ref_palettes_of(_p(np.ascontiguousarray(basepal, np.uint8)), _p(out))
+    return out
+
+
 def ref_saveglobe(name, with_margins, frame_index, plate, ps):
     """the reference's own f_saveglobe (cmd_saveglobe + save_globe + WritePCXplate) on the state the last
     ref_run left behind, plates = LCG(frame_index): (file name, file bytes) of plate `plate`"""

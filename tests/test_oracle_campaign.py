@@ -57,3 +57,26 @@ def test_oracle_equals_unmodified_reference_on_a_random_configuration(seed):
     frame = np.zeros((H, W), np.uint8)
     O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, lm.numplates, 0), frame, rubix_on=True, pal=O.palmap(O.synthetic_basepal()))
     np.testing.assert_array_equal(frame, frame_ref, err_msg=cfg)
+
+
+@ref
+@pytest.mark.ref
+def test_rubix_palettes_of_random_base_palettes():
+    """create_palmap / find_closest_pal_index (fisheye.c:835-908) on base palettes built to tie: greys, a few levels, repeated colours -
+    the unmodified reference, the oracle's restatement and the product's bk_create_palmap give the same six look-up tables"""
+    import blinky_amd
+    O.ref_run("cube", "panini", None, 64, 48, want_frame=False)           # F_Init
+    rng = np.random.default_rng(5)
+    for i in range(80):
+        kind = i % 4
+        if kind == 0:
+            pal = rng.integers(0, 256, 768, dtype=np.uint8)
+        elif kind == 1:
+            pal = np.repeat(rng.integers(0, 256, 256, dtype=np.uint8), 3)
+        elif kind == 2:
+            pal = (rng.integers(0, 4, 768) * 85).astype(np.uint8)
+        else:
+            pal = np.tile(rng.integers(0, 256, 48, dtype=np.uint8), 16)
+        want = O.ref_palettes_of(pal)
+        np.testing.assert_array_equal(O.palmap(pal), want, err_msg=f"oracle, palette {i}")
+        np.testing.assert_array_equal(blinky_amd.ffi.create_palmap(pal), want, err_msg=f"bk_create_palmap, palette {i}")
