@@ -202,7 +202,8 @@ def scenario_differential(base, seed_range="0:4", frames="1"):
                 cmd = str(rng.choice(["f_rubix", f"f_rubixgrid {int(rng.integers(1, 20))} {float(rng.choice([0.5, 1, 2, 4]))} {float(rng.choice([0, 0.5, 1]))}",
                                       "f_rubixgrid", "f_rubixgrid 3 2"]))
             elif k < 0.56:
-                cmd = str(rng.choice(["f_help", "fisheye", "f_lens", "f_globe", "f_shortcutkeys", "f_saveglobe"]))
+                cmd = str(rng.choice(["f_help", "fisheye", "f_lens", "f_globe", "f_shortcutkeys", "f_saveglobe", f"f_saveglobe shot{step}",
+                                      f"f_saveglobe full{step} 1"]))
             elif k < 0.66:
                 W, H = [(320, 200), (200, 120), (333, 217), (160, 240), (400, 300), (64, 48)][int(rng.integers(0, 6))]
                 x0, y0, extra = int(rng.integers(0, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 17))
@@ -232,6 +233,27 @@ def scenario_differential(base, seed_range="0:4", frames="1"):
                 if not np.array_equal(outs[0], outs[1]):
                     bad = np.argwhere(outs[0] != outs[1])
                     raise AssertionError(f"{what}: {len(bad)} screen bytes differ, first at (y, x) = {tuple(bad[0])}; config:\n{config(ref)}")
+                # the globe screenshots a pending f_saveglobe wrote during this frame (WritePCXplate, fisheye.c:1396-1484)
+                nf = [h.hosttest_num_files() for h in both]
+                assert nf[0] == nf[1], f"{what}: {nf[0]} files written, the reference writes {nf[1]}"
+                for i in range(nf[0]):
+                    got = []
+                    for h in both:
+                        name, data = C.create_string_buffer(128), np.zeros(1 << 20, np.uint8)
+                        n = h.hosttest_file(i, name, data.ctypes.data_as(C.c_void_p), data.size)
+                        got.append((name.value, bytes(data[:n])))
+                    # (a plate the lensmap does not show is not rendered, and its pixels in a screenshot are whatever the globe buffer held: in the
+                    #  reference uninitialised memory after a resize - compared only when every plate was rendered this frame)
+                    if got[0][0] != got[1][0]:
+                        raise AssertionError(f"{what}: file {i} is called {got[0][0]}, the reference's {got[1][0]}")
+                    if got[0] != got[1] and ns[0] == nf[0]:
+                        a, b = np.frombuffer(got[0][1], np.uint8), np.frombuffer(got[1][1], np.uint8)
+                        m = min(a.size, b.size)
+                        d = np.flatnonzero(a[:m] != b[:m])
+                        raise AssertionError(f"{what}: file {i} ({got[0][0]} / {got[1][0]}) differs: {a.size} / {b.size} bytes, {d.size} of the common "
+                                             f"{m} differ, first at {d[:5]}: {a[d[:5]]} vs {b[d[:5]]}; {W}x{H}; config:\n{config(ref)}")
+                for h in both:
+                    h.hosttest_clear_files()
                 nframes += 1
             elif cmd:
                 for h in both:
