@@ -487,7 +487,10 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
         }
         build_pending = rc == BK_PENDING;
         if (!build_pending) {                    /* (while the new lens compiles the previous lensmap and its plates stay) */
-            for (i = 0; i < BK_MAX_PLATES; ++i) display[i] = newdisplay[i];
+            /* the reference clears the display flags only once calc_zoom has succeeded (fisheye.c:2376-2385): after a zoom it cannot
+             * compute, or with no valid lens / globe, the plates of the previous lensmap go on being rendered (into a lensmap that shows
+             * none of them) - kept, so that the engine sees the same R_RenderView calls */
+            if (rc == BK_OK) for (i = 0; i < numplates; ++i) display[i] = newdisplay[i];     /* (only the current globe's plates are reset) */
             lensmap_ok = rc == BK_OK;
             if (rc != BK_OK && lens.valid && globe.valid) Con_Printf("%s\n", dev_error());
         }
