@@ -33,6 +33,8 @@ def configuration(seed):
         W, H = int(rng.integers(8, 400)), int(rng.integers(8, 300))
     else:
         W, H = [(320, 200), (640, 480), (400, 300), (256, 256), (300, 500), (333, 217)][int(rng.integers(0, 6))]
+    if os.environ.get("BLINKY_ORACLE_CAMPAIGN_SIZES") == "big":      # developer campaign at HD sizes (seconds per configuration)
+        W, H = [(1280, 720), (1920, 1080), (1080, 1920), (1600, 1200), (2040, 1200)][int(rng.integers(0, 5))]
     grid = None if rng.random() < 0.5 else (int(rng.integers(1, 24)), float(rng.choice([0.5, 1, 2, 4, 7.5])), float(rng.choice([0, 0.25, 1, 3])))
     return globe, lens, zoom, W, H, grid
 
