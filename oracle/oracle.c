@@ -407,6 +407,24 @@ static void draw_quad(ok_state *s, const int *tl, const int *tr, const int *bl, 
     }
 }
 
+/* TEST HOOK: draw_quad alone on an empty W x H table (one 8 x 8 plate, texel (0,0)): mask[y * W + x] = 1 where it wrote.
+ * corners = tl.x, tl.y, tr.x, tr.y, bl.x, bl.y, br.x, br.y (tests/test_exactness_cpu.py pins the INT_MIN cases with it). */
+void ok_test_draw_quad(int W, int H, const int corners[8], unsigned char *mask)
+{
+    ok_state s;
+    size_t area = (size_t)W * (size_t)H, i;
+    memset(&s, 0, sizeof s);
+    s.width_px = W; s.height_px = H; s.platesize = 8; s.numplates = 1;
+    s.rubix_numcells = 10; s.rubix_cell = 4; s.rubix_pad = 1;
+    s.offsets = (uint32_t *)malloc(area * sizeof(uint32_t));
+    s.tints = (uint8_t *)malloc(area);
+    for (i = 0; i < area; ++i) s.offsets[i] = OK_NULL_OFFSET;
+    memset(s.tints, 255, area);
+    draw_quad(&s, corners + 0, corners + 2, corners + 4, corners + 6, 0, 0, 0);
+    for (i = 0; i < area; ++i) mask[i] = s.offsets[i] != OK_NULL_OFFSET;
+    free(s.offsets); free(s.tints);
+}
+
 /* fisheye.c:2126-2217 with seconds_per_frame = infinity.
  * Defined behaviour for a nil corner (the reference reads a stale / uninitialised
  * entry there; no shipped forward lens returns nil): the quads touching that

@@ -161,3 +161,14 @@ def forward_values(ctx, rays, defines=()):
     lib.emu_forward_values(bp, n, C.c_void_p(rays.ctypes.data),
                            *[C.c_void_p(out[k].ctypes.data) for k in ("nret", "val", "bound", "tag", "flag", "err")])
     return out
+
+
+def draw_quad(ctx, corners, defines=()):
+    """the generated code's bk_draw_quad alone on an empty W x H table (ctx: a configured FORWARD-lens context): uint8 mask [H, W]"""
+    lib = compile_source(ctx.kernel_source(), defines)
+    bp = ctx.build_params()
+    W, H, ps, r0, r1 = ctx.size()
+    keys = np.zeros(W * H, np.uint32)
+    c = np.ascontiguousarray(corners, np.int32)
+    lib.emu_draw_quad(bp, C.c_void_p(c.ctypes.data), C.c_void_p(keys.ctypes.data))
+    return (keys != 0).astype(np.uint8).reshape(H, W)

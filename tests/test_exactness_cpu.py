@@ -325,3 +325,32 @@ def test_forward_corner_flags_cover_an_adversarial_libm(lens):
     print(f"{lens}: {len(differs)} of {n} corners differ, {len(flagged)} flagged")
     assert len(missed) == 0, (len(differs), len(flagged), missed[:10])
     assert len(flagged) < n                                    # (and the flags are not simply everything)
+
+
+def test_draw_quad_with_int_min_corners_scans_like_the_reference():
+    """draw_quad (fisheye.c:2246-2338) on quads a NaN projection produces: a corner at INT_MIN.  With the opposite bound at exactly 0 the
+    reference's size check passes (abs(INT_MIN) is INT_MIN) and it scans 2^31 rows / columns; the generated code visits the visible part.
+    The oracle really scans them (about ten seconds per such quad on one core: three of them here)."""
+    import ctypes as C
+    import blinky_amd
+    IMIN = -2 ** 31
+    W, H = 40, 24
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    S.configure(ctx, "cube", "eckert5", None, (W, H))
+    quads = [
+        (21, -2, 24, IMIN, 22, 0, 24, IMIN),          # the campaign's case: tall (y from INT_MIN to 0), row 0 visible
+        (IMIN, 3, 0, 3, IMIN, 5, 0, 6),               # wide: x from INT_MIN to 0, rows 3..6
+        (IMIN, 4, 0, 4, -7, 4, 0, 4),                 # a horizontal line from INT_MIN to 0
+        (3, 2, 9, 2, 3, 8, 10, 9),                    # an ordinary quad
+        (3, 2, 30, 2, 3, 8, 10, 9),                   # too wide: rejected
+        (IMIN, IMIN, IMIN, IMIN, IMIN, IMIN, IMIN, IMIN),   # a single off-screen point
+        (5, -5, 9, IMIN, 6, -1, 9, IMIN),             # tall, the other bound at -1: rejected by the size check
+    ]
+    O._o.ok_test_draw_quad.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for q in quads:
+        c = np.array(q, np.int32)
+        want = np.zeros((H, W), np.uint8)
+        O._o.ok_test_draw_quad(W, H, c.ctypes.data, want.ctypes.data)
+        got = emu.draw_quad(ctx, c)
+        np.testing.assert_array_equal(got, want, err_msg=str(q))
+    ctx.close()
