@@ -15,9 +15,26 @@ REFLIB = os.path.join(ROOT, "oracle", "_ref", "libhosttest_ref.so")
 needs_ref = pytest.mark.skipif(not os.path.exists(REFLIB), reason="oracle/_ref/libhosttest_ref.so not built (needs /root/reference)")
 
 
+request_cleanup = []
+
+
+@pytest.fixture(autouse=True)
+def _cleanup():
+    yield
+    while request_cleanup:
+        request_cleanup.pop()()
+
+
 def run(tmp_path, seeds, frames, timeout=1500, devices=None):
     build_hostlib()
-    base = game_dir(tmp_path)
+    # (the reference formats script paths into fixed 100-byte buffers, fisheye.c:1665, 1758: the game directory has to be short - pytest's
+    #  own tmp_path under xdist is not)
+    import pathlib
+    import shutil
+    import tempfile
+    short = pathlib.Path(tempfile.mkdtemp(prefix="bk", dir="/tmp"))
+    request_cleanup.append(lambda: shutil.rmtree(short, ignore_errors=True))
+    base = game_dir(short)
     env = dict(os.environ)
     if devices:
         env["BLINKY_HIP_DEVICES"] = devices          # several stripe contexts (bk_multi): rows split, rebalanced, reassembled
