@@ -114,7 +114,10 @@ def test_interpreter_inverse_bit_equals_hand_c(bk, lens):
     ctx = host_ctx(bk)
     S.configure(ctx, "cube", lens)
     rng = np.random.default_rng(11)
-    for x, y in rng.uniform(-3, 3, (1500, 2)):
+    # (and where scripts branch: zeros of either sign, the axes, pi and its fractions, one ulp around 1, tiny, huge, infinite)
+    special = [0.0, -0.0, 1.0, -1.0, 0.5, 2.0, np.pi, -np.pi, np.pi / 2, np.pi / 4, 1e-10, 1e-300, 1e10, 0.9999999999999999, 1.0000000000000002,
+               np.inf, -np.inf]
+    for x, y in [(x, y) for x in special for y in special] + [tuple(p) for p in rng.uniform(-3, 3, (1500, 2))]:
         a, b = ctx.eval_host(0, x, y), O.eval_lens(lens, 0, x, y)
         assert (a is None) == (b is None)
         if a is not None:
