@@ -1,0 +1,146 @@
+"""The drop-in inside the engine it is a drop-in for.  oracle/_ref/engine holds the reference's TyrQuake engine (NQ client, software
+renderer) built headless twice from the sources where they lie (oracle/Makefile, target _ref): `tq_ref` with the UNMODIFIED
+engine/NQ/fisheye.c, `tq_hip` with blinky_amd/host/fisheye_hip.c + libblinkyhip.so in its place - every other object file is the same, down
+to the display-less video driver (oracle/ref/engine/headless.c) that logs a hash of every frame the engine presents.  Both run the same
+console script on a generated game directory (oracle/ref/engine/mkgame.py: one textured, lit room; the real id1/pak0.pak is not in the
+reference tree) and everything a player could see is compared: every presented frame (the real R_RenderView renders the plates, the real
+screen / status bar / console code draws around and over the warped view), the console text, the files written (config.cfg, screenshots,
+f_saveglobe's plate images).
+
+Without a GPU: that both engines link with nothing unresolved, and console sessions (no map, so no frame is warped)."""
+import os
+import pathlib
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENGINE = os.path.join(ROOT, "oracle", "_ref", "engine")
+TQ_REF = os.path.join(ENGINE, "tq_ref")
+TQ_HIP = os.path.join(ENGINE, "tq_hip")
+GAME = os.path.join(ENGINE, "game")
+needs_engines = pytest.mark.skipif(not (os.path.exists(TQ_REF) and os.path.exists(TQ_HIP) and os.path.isdir(GAME)),
+                                   reason="oracle/_ref/engine not built (needs /root/reference: make -C oracle _ref)")
+
+CONNECT = ["host_framerate 0.05",      # every frame advances the game by the same 50 ms whatever the wall clock says
+           "scr_conspeed 1000000",      # the console leaves the screen at once instead of scrolling out by wall-clock time
+           "con_notifytime -1",         # no notify lines: they expire by wall-clock time
+           "map box"] + ["wait"] * 8
+
+
+def run_engine(binary, script, size=None, env_extra=None, timeout=600):
+    """-> (stdout, [frame log lines], {file name: bytes of what the engine wrote into its game directory})"""
+    # the reference formats script paths into fixed 100-byte buffers (fisheye.c:1665, 1758): a short game directory
+    base = pathlib.Path(tempfile.mkdtemp(prefix="bq", dir="/tmp"))
+    try:
+        shutil.copytree(GAME, base / "g")
+        game = base / "g"
+        (game / "id1" / "session.cfg").write_text("\n".join(script) + "\n")
+        # the engine writes (config.cfg, screenshots, plate images) into $HOME/.blinky/<game> (common/common.c:2045)
+        env = dict(os.environ, HOME=str(base), BLINKY_HEADLESS_LOG=str(base / "frames.log"), BLINKY_HEADLESS_FRAMES="2000", BLINKY_HIP_SYNC_COMPILE="1")
+        env.pop("BLINKY_HIP_DEVICES", None)
+        if size:
+            env["BLINKY_HEADLESS_SIZE"] = size
+        env.update(env_extra or {})
+        r = subprocess.run([binary, "-basedir", ".", "-noconinput", "+exec", "session.cfg"], cwd=game, env=env, capture_output=True,
+                           timeout=timeout)
+        assert r.returncode == 0, (binary, r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+        frames = (base / "frames.log").read_text().splitlines() if (base / "frames.log").exists() else []
+        out_dir = base / ".blinky" / "id1"
+        written = {p.name: p.read_bytes() for p in out_dir.iterdir() if p.is_file()} if out_dir.is_dir() else {}
+        return r.stdout.decode("latin-1"), frames, written
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+def console_text(stdout):
+    """what the engine printed, without the build stamp and without the product's 'no device' notes of the CPU sessions"""
+    keep = []
+    for line in stdout.splitlines():
+        if line.startswith("Exe: ") or "this context has no device" in line:
+            continue
+        keep.append(line)
+    return keep
+
+
+@needs_engines
+@pytest.mark.ref
+def test_both_engines_link_and_the_drop_in_resolves_everything_from_the_engine():
+    """tq_hip = the reference's engine objects + fisheye_hip.o + libblinkyhip.so, nothing unresolved, no Lua library (engine/Makefile:818,
+    838-840 link one for fisheye.c); the only dynamic symbols beyond libc / libm are the C ABI's"""
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", TQ_HIP], capture_output=True, text=True, check=True).stdout.split("\n")
+    names = [line.split()[-1].split("@")[0] for line in undefined if line.strip()]
+    abi = sorted(n for n in names if n.startswith("bk_"))
+    assert abi and all(n.startswith("bk_") for n in abi)
+    assert not [n for n in names if n.startswith("lua")]
+    header = open(os.path.join(ROOT, "include", "blinky_hip.h")).read()
+    assert all(n + "(" in header for n in abi), [n for n in abi if n + "(" not in header]       # only the PUBLIC header's entry points
+    needed = subprocess.run(["readelf", "-d", TQ_HIP], capture_output=True, text=True, check=True).stdout
+    libs = sorted(line.split("[")[1].split("]")[0] for line in needed.splitlines() if "(NEEDED)" in line)
+    assert libs == ["libblinkyhip.so", "libc.so.6", "libm.so.6"], libs
+    defined = subprocess.run(["nm", TQ_HIP], capture_output=True, text=True, check=True).stdout
+    for sym in ("F_Init", "F_Shutdown", "F_RenderView", "F_WriteConfig", "fisheye_enabled", "fisheye_plate_fov"):   # engine/include/fisheye.h:4-9
+        assert any(line.split()[-1] == sym and line.split()[-2] in "TBD" for line in defined.splitlines() if len(line.split()) >= 3), sym
+
+
+CONSOLE_SESSION = [
+    "f_help", "fisheye", "f_lens", "f_globe", "f_fov", "f_vfov", "f_rubixgrid", "f_rubix", "f_rubix",
+    "f_lens hammer", "f_lens", "f_fov", "f_lens quincuncial", "f_vfov", "f_lens eckert5", "f_lens nosuchlens", "f_lens", "f_lens panini",
+    "f_globe trism", "f_globe", "f_globe nosuchglobe", "f_globe", "f_globe tetra", "f_fov 120", "f_fov", "f_vfov 75.9", "f_vfov", "f_cover",
+    "f_fov", "f_contain", "f_vfov", "f_rubixgrid 4 8.5 2", "f_rubixgrid", "f_rubixgrid 1 2", "f_saveglobe", "f_shortcutkeys", "bind 3",
+    "bind y", "f_shortcutkeys", "bind 3", "bind 9", "fisheye 0", "fisheye", "fisheye 1", "f_lens stereographic", "f_globe cube",
+    "toggleconsole", "quit",
+]
+
+
+@needs_engines
+@pytest.mark.ref
+def test_console_sessions_in_the_real_engine_equal_the_reference():
+    """the 13 fisheye commands through the engine's own Cmd_* / Cbuf / key binding code, and the config the engine writes on quit"""
+    ref_out, _, ref_files = run_engine(TQ_REF, CONSOLE_SESSION)
+    hip_out, _, hip_files = run_engine(TQ_HIP, CONSOLE_SESSION, env_extra={"BLINKY_HIP_DEVICE": "none"})
+    assert "f_lens hammer; f_contain" in ref_out and "not a valid lens" in ref_out and "Enabled Fisheye shortcut keys" in ref_out
+    assert console_text(hip_out) == console_text(ref_out)
+    assert "config.cfg" in ref_files and b"f_lens \"stereographic\"" in ref_files["config.cfg"]
+    assert hip_files.keys() == ref_files.keys()
+    assert hip_files["config.cfg"] == ref_files["config.cfg"]
+
+
+FRAME_SESSION = CONNECT + [
+    "wait", "f_lens hammer", "wait", "wait", "f_globe trism", "wait", "f_fov 120", "wait", "f_vfov 90", "wait", "f_cover", "wait",
+    "f_lens quincuncial", "wait", "f_rubix", "wait", "f_rubixgrid 4 8 2", "wait", "f_rubix", "wait",
+    "viewsize 120", "wait", "wait", "viewsize 60", "wait", "wait", "viewsize 100", "wait",
+    "f_globe cube_edge", "f_lens stereographic", "wait", "+left", "wait", "wait", "wait", "-left", "+lookup", "wait", "wait", "-lookup",
+    "f_lens eckert5", "wait", "f_lens nosuchlens", "wait", "wait", "f_lens panini", "wait", "f_globe nosuchglobe", "wait", "f_globe tetra",
+    "wait", "f_fov 400", "wait", "f_globe fast", "f_lens fisheye1", "wait", "f_globe cube", "f_lens winkeltripel", "wait",
+    "f_saveglobe plate", "wait", "f_saveglobe full 1", "wait", "screenshot", "wait",
+    "fisheye 0", "wait", "wait", "fisheye 1", "wait", "wait", "toggleconsole", "wait", "quit",
+]
+
+
+@needs_engines
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", ["320x200", "640x480", "1024x600"])
+def test_every_frame_of_a_session_in_the_real_engine_equals_the_reference(size):
+    ref_out, ref_frames, ref_files = run_engine(TQ_REF, FRAME_SESSION, size)
+    hip_out, hip_frames, hip_files = run_engine(TQ_HIP, FRAME_SESSION, size)
+    assert len(ref_frames) > 60 and len(set(ref_frames[i].split()[-1] for i in range(len(ref_frames)))) > 25      # the session does show things
+    assert len(hip_frames) == len(ref_frames)
+    different = [(a, b) for a, b in zip(ref_frames, hip_frames) if a != b]
+    assert not different, different[:5]
+    assert console_text(hip_out) == console_text(ref_out)
+    assert sorted(hip_files) == sorted(ref_files) and len([n for n in ref_files if n.endswith(".pcx")]) >= 13
+    for name in ref_files:
+        assert hip_files[name] == ref_files[name], name
+
+
+@needs_engines
+@pytest.mark.gpu
+def test_the_engine_session_with_the_warp_spread_over_three_stripe_contexts():
+    ref_out, ref_frames, ref_files = run_engine(TQ_REF, FRAME_SESSION, "640x480")
+    hip_out, hip_frames, hip_files = run_engine(TQ_HIP, FRAME_SESSION, "640x480", env_extra={"BLINKY_HIP_DEVICES": "0,0,0"})
+    assert hip_frames == ref_frames
+    assert console_text(hip_out) == console_text(ref_out)
+    assert {n: hip_files[n] for n in ref_files} == ref_files
