@@ -41,6 +41,7 @@ def run_engine(binary, script, size=None, env_extra=None, timeout=600):
         # the engine writes (config.cfg, screenshots, plate images) into $HOME/.blinky/<game> (common/common.c:2045)
         env = dict(os.environ, HOME=str(base), BLINKY_HEADLESS_LOG=str(base / "frames.log"), BLINKY_HEADLESS_FRAMES="2000", BLINKY_HIP_SYNC_COMPILE="1")
         env.pop("BLINKY_HIP_DEVICES", None)
+        env.setdefault("BLINKY_HIP_CACHE", os.path.join(tempfile.gettempdir(), "bq_hipcache"))     # compiled lenses shared by the sessions
         if size:
             env["BLINKY_HEADLESS_SIZE"] = size
         env.update(env_extra or {})
@@ -126,7 +127,7 @@ FRAME_SESSION = CONNECT + [
 def test_every_frame_of_a_session_in_the_real_engine_equals_the_reference(size):
     ref_out, ref_frames, ref_files = run_engine(TQ_REF, FRAME_SESSION, size)
     hip_out, hip_frames, hip_files = run_engine(TQ_HIP, FRAME_SESSION, size)
-    assert len(ref_frames) > 60 and len(set(ref_frames[i].split()[-1] for i in range(len(ref_frames)))) > 25      # the session does show things
+    assert len(ref_frames) > 40 and len(set(ref_frames[i].split()[-1] for i in range(len(ref_frames)))) > 25      # the session does show things
     assert len(hip_frames) == len(ref_frames)
     different = [(a, b) for a, b in zip(ref_frames, hip_frames) if a != b]
     assert not different, different[:5]
