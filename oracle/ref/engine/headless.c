@@ -11,6 +11,7 @@
  *   BLINKY_HEADLESS_SIZE=WxH    frame size (default 320x200, the engine's base size)
  *   BLINKY_HEADLESS_LOG=path    per-frame hashes (appended)
  *   BLINKY_HEADLESS_DUMP=dir    also write every presented frame as dir/frame%04d.raw (W*H bytes)
+ *   BLINKY_HEADLESS_TIMES=path  wall-clock milliseconds each presented frame took, one per line (tools/engine_fps.py)
  *   BLINKY_HEADLESS_FRAMES=N    leave through Sys_Quit after N presented frames (a script that never reaches "quit" still ends)
  *
  * Interfaces implemented: include/vid.h:104-146 (VID_*), include/input.h:42-61 (IN_*), include/sys.h:73,
@@ -20,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #include "quakedef.h"
 #include "d_local.h"
@@ -38,6 +40,7 @@ static byte *frame_buffer;
 static short *z_buffer;
 static byte *surface_cache;
 static int frames_presented;
+static struct timespec frame_started;
 
 static void set_size(int width, int height)
 {
@@ -110,6 +113,20 @@ void VID_Update(vrect_t *rects)
             fclose(f);
         }
     }
+    {
+        /* the engine runs at most 72 frames a second (Host_FilterTime, NQ/host.c:518): what a frame COSTS is the time from its first
+         * call into a driver - Sys_SendKeyEvents, right after the filter let it through (NQ/host.c, _Host_Frame) - to its presentation */
+        const char *times = getenv("BLINKY_HEADLESS_TIMES");
+        struct timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        if (times && frame_started.tv_sec) {
+            FILE *f = fopen(times, "a");
+            if (f) {
+                fprintf(f, "%.3f\n", (now.tv_sec - frame_started.tv_sec) * 1e3 + (now.tv_nsec - frame_started.tv_nsec) * 1e-6);
+                fclose(f);
+            }
+        }
+    }
     ++frames_presented;
     {
         const char *limit = getenv("BLINKY_HEADLESS_FRAMES");
@@ -121,7 +138,7 @@ void D_BeginDirectRect(int x, int y, const byte *pbitmap, int width, int height)
 void D_EndDirectRect(int x, int y, int width, int height) { (void)x; (void)y; (void)width; (void)height; }
 
 /* no keyboard, no mouse: the console script (quake.rc, +commands) is the only input */
-void Sys_SendKeyEvents(void) {}
+void Sys_SendKeyEvents(void) { clock_gettime(CLOCK_MONOTONIC, &frame_started); }
 void IN_Init(void) {}
 void IN_Shutdown(void) {}
 void IN_Commands(void) {}

@@ -146,3 +146,69 @@ def test_the_engine_session_with_the_warp_spread_over_three_stripe_contexts():
     assert hip_frames == ref_frames
     assert console_text(hip_out) == console_text(ref_out)
     assert {n: hip_files[n] for n in ref_files} == ref_files
+
+
+# ---- random sessions -----------------------------------------------------------------------------------------------------------
+
+def random_session(seed):
+    """a seed is a whole session in the engine: frame size, and a script of console commands with frames in between"""
+    import random
+    sys_path_scripts = __import__("scripts")
+    rng = random.Random(seed)
+    size = rng.choice(["320x200", "400x300", "512x384", "640x400", "640x480", "800x600", "854x480", "1024x600", "1280x720"])
+    lenses, globes = sys_path_scripts.LENSES, sys_path_scripts.GLOBES
+    script = list(CONNECT)
+    held = set()
+    for _ in range(rng.randint(12, 28)):
+        kind = rng.random()
+        if kind < 0.25:
+            script.append("f_lens " + rng.choice(lenses))
+        elif kind < 0.35:
+            script.append("f_globe " + rng.choice(globes))
+        elif kind < 0.50:
+            script.append(rng.choice(["f_fov %d" % rng.choice([30, 90, 120, 150, 180, 200, 270, 359, 400]),
+                                      "f_vfov %d" % rng.choice([45, 90, 120, 170, 181]), "f_cover", "f_contain"]))
+        elif kind < 0.58:
+            script.append("viewsize %d" % rng.choice([30, 50, 70, 90, 100, 110, 120]))
+        elif kind < 0.64:
+            script.append("f_rubix")
+        elif kind < 0.68:
+            script.append("f_rubixgrid %d %g %g" % (rng.randint(1, 12), rng.choice([1, 2.5, 4, 8]), rng.choice([0.5, 1, 2])))
+        elif kind < 0.78:
+            key = rng.choice(["left", "right", "lookup", "lookdown"])
+            script.append(("-" if key in held else "+") + key)
+            held.symmetric_difference_update({key})
+        elif kind < 0.82:
+            script.append("fisheye %d" % rng.randint(0, 1))
+        elif kind < 0.86:
+            script.append("f_saveglobe s%d %d" % (len(script), rng.randint(0, 1)))
+        elif kind < 0.89:
+            script.append("screenshot")
+        elif kind < 0.92:
+            script.append("f_lens no_such_lens" if rng.random() < 0.5 else "f_globe no_such_globe")
+        script.extend(["wait"] * rng.randint(1, 3))
+    script.extend("-" + k for k in sorted(held))
+    script.extend(["wait", "toggleconsole", "quit"])
+    return size, script
+
+
+def _seeds(default):
+    lo, hi = os.environ.get("BLINKY_ENGINE_CAMPAIGN", default).split(":")
+    return range(int(lo), int(hi))
+
+
+@needs_engines
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(_seeds("0:6")))
+def test_random_sessions_in_the_real_engine_equal_the_reference(seed):
+    """BLINKY_ENGINE_CAMPAIGN=lo:hi runs a longer developer campaign"""
+    size, script = random_session(seed)
+    devices = {"BLINKY_HIP_DEVICES": "0,0"} if seed % 3 == 2 else None
+    ref_out, ref_frames, ref_files = run_engine(TQ_REF, script, size)
+    hip_out, hip_frames, hip_files = run_engine(TQ_HIP, script, size, env_extra=devices)
+    assert console_text(hip_out) == console_text(ref_out), (seed, size)
+    different = [(a, b) for a, b in zip(ref_frames, hip_frames) if a != b]
+    assert len(hip_frames) == len(ref_frames) and not different, (seed, size, different[:3])
+    assert sorted(hip_files) == sorted(ref_files), (seed, size)
+    for name in ref_files:
+        assert hip_files[name] == ref_files[name], (seed, size, name)
