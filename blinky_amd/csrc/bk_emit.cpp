@@ -72,14 +72,52 @@ struct Emitter {
     explicit Emitter(Interp &i) : I(i) {}
 
     // ---- per-function state --------------------------------------------------------------
-    struct Fn {
-        const FuncProto *proto;
-        const Closure *cl;
+    // a function being walked: a script function known when the code is generated (cl: its closure, upvalues are the chunk's
+    // cells) or a function defined inside one (cl null: its upvalues are locals of `parent`, or what `parent` sees)
+    struct Scope {
+        const FuncProto *proto = nullptr;
+        const Closure *cl = nullptr;
+        const Scope *parent = nullptr;
+    };
+    struct Fn : Scope {
         std::ostringstream out;
         int indent = 1;
         std::map<int, int> array_slots;               // local slot -> capacity (array tables)
+        std::map<int, std::string> fn_slots;          // local slot -> the lambda a `local function` / `local f = function` became
+        std::set<int> fn_open;                        // ... whose body is being emitted right now (a call from inside is recursion)
+        std::string lp = "l", ap = "A";               // names of locals / local arrays (functions defined inside others get their own)
         std::string chunk;
     };
+    // what upvalue `idx` of `s` is: a local of an enclosing function being emitted (*owner, *slot), or (returned) a chunk cell
+    static const Value *upvalue_of(const Scope *s, int idx, const Scope **owner, int *slot)
+    {
+        while (!s->cl) {
+            const UpvalDesc &d = s->proto->upvals[(size_t)idx];
+            if (d.from_parent_local) { *owner = s->parent; *slot = d.index; return nullptr; }
+            idx = d.index;
+            s = s->parent;
+        }
+        *owner = nullptr;
+        return s->cl->upvals[(size_t)idx].get();
+    }
+    // is `e` the name of a local variable of f or of a function around it?  -> that function, the slot
+    static Fn *local_of(Fn &f, const Expr &e, int *slot)
+    {
+        if (e.kind != Expr::Name) return nullptr;
+        if (e.var == VarKind::Local) { *slot = e.slot; return &f; }
+        if (e.var == VarKind::Upvalue) {
+            const Scope *owner = nullptr;
+            if (!upvalue_of(&f, e.slot, &owner, slot)) return const_cast<Fn *>(static_cast<const Fn *>(owner));
+        }
+        return nullptr;
+    }
+    // chunk cells that device code assigns: per-thread state like the assigned globals (cell -> field of BkState)
+    std::vector<std::pair<const Value *, std::string>> mutable_cells;
+    const std::string *cell_field(const Value *cell) const
+    {
+        for (auto &c : mutable_cells) if (c.first == cell) return &c.second;
+        return nullptr;
+    }
     std::string tmp(const char *p = "t") { return std::string(p) + std::to_string(++uid); }
     static void line(Fn &f, const std::string &s) { f.out << std::string((size_t)f.indent * 4, ' ') << s << "\n"; }
 
@@ -93,7 +131,14 @@ struct Emitter {
                 *v = I.get_global(e.str);
                 return true;
             }
-            if (e.var == VarKind::Upvalue) { *v = *f.cl->upvals[e.slot]; return true; }
+            if (e.var == VarKind::Upvalue) {
+                const Scope *owner = nullptr;
+                int slot = 0;
+                const Value *cell = upvalue_of(&f, e.slot, &owner, &slot);
+                if (!cell || cell_field(cell)) return false;
+                *v = *cell;
+                return true;
+            }
             return false;
         }
         if (e.kind == Expr::Index && e.b->kind == Expr::String) {
@@ -104,39 +149,62 @@ struct Emitter {
     }
 
     // ---- pre-pass: which globals does device code assign? ------------------------------------
-    void scan_block(const Block &b, const Closure *cl, std::set<const FuncProto *> &seen)
+    void scan_closure(const Closure *cl, std::set<const FuncProto *> &seen)
     {
-        for (const StmtP &s : b) scan_stmt(*s, cl, seen);
+        Scope sc;
+        sc.proto = cl->proto;
+        sc.cl = cl;
+        scan_block(cl->proto->body, sc, seen);
     }
-    void scan_expr(const Expr *e, const Closure *cl, std::set<const FuncProto *> &seen)
+    void scan_block(const Block &b, const Scope &sc, std::set<const FuncProto *> &seen)
+    {
+        for (const StmtP &s : b) scan_stmt(*s, sc, seen);
+    }
+    void scan_expr(const Expr *e, const Scope &sc, std::set<const FuncProto *> &seen)
     {
         if (!e) return;
         if (e->kind == Expr::Call) {
             Value callee;
             bool known = false;
             if (e->a->kind == Expr::Name && e->a->var == VarKind::Global) { callee = I.get_global(e->a->str); known = true; }
-            else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) { callee = *cl->upvals[e->a->slot]; known = true; }
+            else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) {
+                const Scope *owner = nullptr;
+                int slot = 0;
+                if (const Value *cell = upvalue_of(&sc, e->a->slot, &owner, &slot)) { callee = *cell; known = true; }
+            }
             if (known && callee.t == Value::FUNC && !seen.count(callee.fn()->proto)) {
                 seen.insert(callee.fn()->proto);
-                scan_block(callee.fn()->proto->body, callee.fn(), seen);
+                scan_closure(callee.fn(), seen);
             }
         }
-        scan_expr(e->a.get(), cl, seen);
-        scan_expr(e->b.get(), cl, seen);
-        for (auto &x : e->args) scan_expr(x.get(), cl, seen);
-        for (auto &x : e->fields) { scan_expr(x.first.get(), cl, seen); scan_expr(x.second.get(), cl, seen); }
+        if (e->kind == Expr::Function && e->proto) {                  // a function defined inside device code: its body is device code
+            Scope inner;
+            inner.proto = e->proto;
+            inner.parent = &sc;
+            scan_block(e->proto->body, inner, seen);
+        }
+        scan_expr(e->a.get(), sc, seen);
+        scan_expr(e->b.get(), sc, seen);
+        for (auto &x : e->args) scan_expr(x.get(), sc, seen);
+        for (auto &x : e->fields) { scan_expr(x.first.get(), sc, seen); scan_expr(x.second.get(), sc, seen); }
     }
-    void scan_stmt(const Stmt &s, const Closure *cl, std::set<const FuncProto *> &seen)
+    void scan_stmt(const Stmt &s, const Scope &sc, std::set<const FuncProto *> &seen)
     {
         for (auto &t : s.targets) {
             if (t->kind == Expr::Name && t->var == VarKind::Global) mutable_globals.insert(t->str);
-            scan_expr(t.get(), cl, seen);
+            if (t->kind == Expr::Name && t->var == VarKind::Upvalue) {
+                const Scope *owner = nullptr;
+                int slot = 0;
+                const Value *cell = upvalue_of(&sc, t->slot, &owner, &slot);
+                if (cell && !cell_field(cell)) mutable_cells.emplace_back(cell, "u" + std::to_string(mutable_cells.size() + 1) + "_" + sanitize(t->str));
+            }
+            scan_expr(t.get(), sc, seen);
         }
-        for (auto &x : s.exprs) scan_expr(x.get(), cl, seen);
-        scan_expr(s.call.get(), cl, seen);
-        scan_expr(s.cond.get(), cl, seen);
-        scan_block(s.body, cl, seen);
-        for (auto &c : s.clauses) { scan_expr(c.first.get(), cl, seen); scan_block(c.second, cl, seen); }
+        for (auto &x : s.exprs) scan_expr(x.get(), sc, seen);
+        scan_expr(s.call.get(), sc, seen);
+        scan_expr(s.cond.get(), sc, seen);
+        scan_block(s.body, sc, seen);
+        for (auto &c : s.clauses) { scan_expr(c.first.get(), sc, seen); scan_block(c.second, sc, seen); }
     }
 
     // ---- constant (never assigned) global / upvalue tables -----------------------------------
@@ -194,21 +262,30 @@ struct Emitter {
         case Expr::Vararg: unsupported(f.chunk, e.line, "'...'");
         case Expr::Function: unsupported(f.chunk, e.line, "function values / closures");
         case Expr::Table: unsupported(f.chunk, e.line, "table constructors other than 'local t = {a, b, ...}'");
-        case Expr::Name:
-            if (e.var == VarKind::Local) {
-                if (f.array_slots.count(e.slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
-                return "l" + std::to_string(e.slot);
+        case Expr::Name: {
+            int slot = 0;
+            if (Fn *o = local_of(f, e, &slot)) {
+                if (o->array_slots.count(slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
+                if (o->fn_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (a function defined inside a callback can only be called)");
+                return o->lp + std::to_string(slot);
             }
             if (e.var == VarKind::Global && mutable_globals.count(e.str)) return "S.g_" + sanitize(e.str);
+            if (e.var == VarKind::Upvalue) {
+                const Scope *owner = nullptr;
+                if (const std::string *field = cell_field(upvalue_of(&f, e.slot, &owner, &slot))) return "S." + *field;
+            }
             {
                 Value v;
                 static_value(f, e, &v);
                 return const_value(f, e, v, "'" + e.str + "'");
             }
+        }
         case Expr::Index: {
-            if (e.a->kind == Expr::Name && e.a->var == VarKind::Local && f.array_slots.count(e.a->slot)) {
+            int aslot = 0;
+            Fn *ao = local_of(f, *e.a, &aslot);
+            if (ao && ao->array_slots.count(aslot)) {
                 std::string k = emit_expr(f, *e.b), t = tmp();
-                line(f, "bkv " + t + " = bk_aget(S, A" + std::to_string(e.a->slot) + ", " + std::to_string(f.array_slots[e.a->slot]) + ", " + k + ");");
+                line(f, "bkv " + t + " = bk_aget(S, " + ao->ap + std::to_string(aslot) + ", " + std::to_string(ao->array_slots[aslot]) + ", " + k + ");");
                 return t;
             }
             Value sv;
@@ -232,8 +309,9 @@ struct Emitter {
         case Expr::Unop: {
             if (e.str == "()") return emit_expr(f, *e.a);
             if (e.str == "#") {
-                if (e.a->kind == Expr::Name && e.a->var == VarKind::Local && f.array_slots.count(e.a->slot))
-                    return num_literal((double)f.array_slots[e.a->slot]);
+                int aslot = 0;
+                Fn *ao = local_of(f, *e.a, &aslot);
+                if (ao && ao->array_slots.count(aslot)) return num_literal((double)ao->array_slots[aslot]);
                 unsupported(f.chunk, e.line, "the length operator on this expression");
             }
             std::string a = emit_expr(f, *e.a), t = tmp();
@@ -336,6 +414,20 @@ struct Emitter {
     void emit_call(Fn &f, const Expr &e, std::string *arr, std::string *cnt)
     {
         Value callee;
+        {
+            int slot = 0;
+            Fn *o = local_of(f, *e.a, &slot);
+            if (o && o->fn_slots.count(slot)) {                      // a function defined inside this callback: a lambda of the enclosing C++ function
+                if (o->fn_open.count(slot)) unsupported(f.chunk, e.line, "recursion ('" + e.a->str + "')");
+                *arr = tmp("r");
+                *cnt = tmp("n");
+                Args a = emit_args(f, e.args);
+                auto packed = pack(f, a, 1);
+                line(f, "bkv " + *arr + "[BK_MAXRET];");
+                line(f, "const int " + *cnt + " = " + o->fn_slots[slot] + "(" + packed.first + ", " + packed.second + ", " + *arr + ");");
+                return;
+            }
+        }
         if (!static_value(f, *e.a, &callee)) {
             std::string n = e.a->kind == Expr::Name ? "'" + e.a->str + "'" : "this expression";
             unsupported(f.chunk, e.line, "calling " + n + " (callee must be a script function or builtin known at build time)");
@@ -435,27 +527,86 @@ struct Emitter {
 
     void store(Fn &f, const Expr &target, const std::string &val)
     {
+        int slot = 0;
         if (target.kind == Expr::Name) {
-            if (target.var == VarKind::Local) {
-                if (f.array_slots.count(target.slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
-                line(f, "l" + std::to_string(target.slot) + " = " + val + ";");
+            if (Fn *o = local_of(f, target, &slot)) {
+                if (o->array_slots.count(slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
+                if (o->fn_slots.count(slot)) unsupported(f.chunk, target.line, "re-assigning function '" + target.str + "'");
+                line(f, o->lp + std::to_string(slot) + " = " + val + ";");
             } else if (target.var == VarKind::Global) {
                 line(f, "S.g_" + sanitize(target.str) + " = " + val + ";");
-            } else unsupported(f.chunk, target.line, "assigning to the enclosing function's local '" + target.str + "'");
+            } else {
+                const Scope *owner = nullptr;
+                const std::string *field = cell_field(upvalue_of(&f, target.slot, &owner, &slot));
+                if (!field) unsupported(f.chunk, target.line, "assigning to the enclosing function's local '" + target.str + "'");
+                line(f, "S." + *field + " = " + val + ";");
+            }
             return;
         }
-        if (target.a->kind == Expr::Name && target.a->var == VarKind::Local && f.array_slots.count(target.a->slot)) {
+        Fn *ao = local_of(f, *target.a, &slot);
+        if (ao && ao->array_slots.count(slot)) {
             std::string k = emit_expr(f, *target.b);
-            line(f, "bk_aset(S, A" + std::to_string(target.a->slot) + ", " + std::to_string(f.array_slots[target.a->slot]) + ", " + k + ", " + val + ");");
+            line(f, "bk_aset(S, " + ao->ap + std::to_string(slot) + ", " + std::to_string(ao->array_slots[slot]) + ", " + k + ", " + val + ");");
             return;
         }
         unsupported(f.chunk, target.line, "storing into this table (only tables created by 'local t = {..}' in the same function are writable)");
+    }
+
+    // the local variables of a function: parameters from the argument array, tables as arrays, everything else nil
+    static void declare_locals(std::ostream &o, const Fn &f, const std::string &pad)
+    {
+        const FuncProto *p = f.proto;
+        for (int i = 0; i < p->nslots; ++i) {
+            if (f.fn_slots.count(i)) continue;                          // (a function defined inside: declared where it is defined)
+            if (f.array_slots.count(i)) {
+                o << pad << "bkv " << f.ap << i << "[" << f.array_slots.at(i) + 1 << "];   /* " << p->slot_names[i] << " */\n";
+                o << pad << "for (int q = 0; q <= " << f.array_slots.at(i) << "; ++q) " << f.ap << i << "[q] = bk_nil();\n";
+            } else if (i < p->nparams) {
+                o << pad << "bkv " << f.lp << i << " = na > " << i << " ? a[" << i << "] : bk_nil();   /* " << p->slot_names[i] << " */\n";
+            } else {
+                o << pad << "bkv " << f.lp << i << " = bk_nil();   /* " << p->slot_names[i] << " */\n";
+            }
+        }
+    }
+
+    // `local function g(..) .. end` / `local g = function(..) .. end` inside device code: a lambda of the C++ function the
+    // enclosing script function became, capturing by reference - which is what a Lua closure does with the locals it refers to.
+    // It can be called (from the enclosing function and from functions defined after it); it is not a value.
+    void emit_local_function(Fn &f, const Stmt &s)
+    {
+        const FuncProto *p = s.exprs[0]->proto;
+        const int slot = s.slots[0];
+        if (p->is_vararg) unsupported(f.chunk, s.line, "vararg functions");
+        if (f.fn_slots.count(slot) || f.array_slots.count(slot)) unsupported(f.chunk, s.line, "re-declaring '" + s.names[0] + "'");
+        const std::string id = std::to_string(++uid);
+        Fn g;
+        g.proto = p;
+        g.parent = &f;
+        g.chunk = f.chunk;
+        g.lp = "n" + id + "_l";
+        g.ap = "n" + id + "_A";
+        g.indent = f.indent + 1;
+        const std::string name = "NF" + id + "_" + sanitize(s.names[0]);
+        f.fn_slots[slot] = name;
+        f.fn_open.insert(slot);
+        emit_block(g, p->body);
+        f.fn_open.erase(slot);
+        line(f, "/* " + f.chunk + ":" + std::to_string(p->line) + "  function " + s.names[0] + " */");
+        line(f, "auto " + name + " = [&](const bkv *a, int na, bkv *r) -> int {");
+        std::ostringstream decl;
+        declare_locals(decl, g, std::string((size_t)(f.indent + 1) * 4, ' '));
+        f.out << decl.str();
+        line(f, "    (void)a; (void)na; (void)r;");
+        f.out << g.out.str();
+        line(f, "    return 0;");
+        line(f, "};");
     }
 
     void emit_stmt(Fn &f, const Stmt &s)
     {
         switch (s.kind) {
         case Stmt::Local: {
+            if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Function) { emit_local_function(f, s); return; }
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table) {
                 const Expr &t = *s.exprs[0];
                 if (!t.fields.empty()) unsupported(f.chunk, s.line, "table constructors with named fields");
@@ -468,14 +619,14 @@ struct Emitter {
                 int n = (int)vals.size();
                 if (f.array_slots.count(s.slots[0]) && f.array_slots[s.slots[0]] != n) unsupported(f.chunk, s.line, "re-declaring a table with a different size");
                 f.array_slots[s.slots[0]] = n;
-                for (int i = 0; i < n; ++i) line(f, "A" + std::to_string(s.slots[0]) + "[" + std::to_string(i + 1) + "] = " + vals[i] + ";");
+                for (int i = 0; i < n; ++i) line(f, f.ap + std::to_string(s.slots[0]) + "[" + std::to_string(i + 1) + "] = " + vals[i] + ";");
                 return;
             }
             auto v = emit_values(f, s.exprs, s.slots.size());
-            for (size_t i = 0; i < s.slots.size(); ++i) line(f, "l" + std::to_string(s.slots[i]) + " = " + v[i] + ";");
+            for (size_t i = 0; i < s.slots.size(); ++i) line(f, f.lp + std::to_string(s.slots[i]) + " = " + v[i] + ";");
             return;
         }
-        case Stmt::LocalFunction: unsupported(f.chunk, s.line, "nested function definitions");
+        case Stmt::LocalFunction: emit_local_function(f, s); return;
         case Stmt::Assign: {
             auto v = emit_values(f, s.exprs, s.targets.size());
             for (size_t i = 0; i < s.targets.size(); ++i) store(f, *s.targets[i], v[i]);
@@ -554,7 +705,7 @@ struct Emitter {
             line(f, idx + " = " + idx + " + " + st + ";");                                     // OP_FORLOOP
             line(f, "if (!(0 < " + st + " ? " + idx + " <= " + lim + " : " + lim + " <= " + idx + ")) break;");
             line(f, "if (!bk_tick(S)) break;");
-            line(f, "l" + std::to_string(s.slots[0]) + " = bk_num(" + idx + ");");
+            line(f, f.lp + std::to_string(s.slots[0]) + " = bk_num(" + idx + ");");
             emit_block(f, s.body);
             f.indent--;
             line(f, "}");
@@ -572,9 +723,11 @@ struct Emitter {
             const Expr &targ = *call->args[0];
             std::string arr;
             int n = 0;
-            if (targ.kind == Expr::Name && targ.var == VarKind::Local && f.array_slots.count(targ.slot)) {
-                arr = "A" + std::to_string(targ.slot);
-                n = f.array_slots[targ.slot];
+            int tslot = 0;
+            Fn *to = local_of(f, targ, &tslot);
+            if (to && to->array_slots.count(tslot)) {
+                arr = to->ap + std::to_string(tslot);
+                n = to->array_slots[tslot];
             } else {
                 Value tv;
                 if (!static_value(f, targ, &tv) || tv.t != Value::TABLE) unsupported(f.chunk, s.line, "iterating a table that is not known when the kernel is generated");
@@ -589,7 +742,7 @@ struct Emitter {
             line(f, "const bkv " + gv + " = " + arr + "[" + gi + "];");
             line(f, std::string("if (") + gv + ".t == BK_TNIL) " + (is_ipairs ? "break;" : "continue;"));   // ipairs stops at the first nil, pairs skips it
             for (size_t i = 0; i < s.slots.size(); ++i)
-                line(f, "l" + std::to_string(s.slots[i]) + " = " + (i == 0 ? "bk_num((double)" + gi + ")" : i == 1 ? gv : std::string("bk_nil()")) + ";");
+                line(f, f.lp + std::to_string(s.slots[i]) + " = " + (i == 0 ? "bk_num((double)" + gi + ")" : i == 1 ? gv : std::string("bk_nil()")) + ";");
             emit_block(f, s.body);
             f.indent--;
             line(f, "}");
@@ -648,16 +801,7 @@ struct Emitter {
         std::ostringstream o;
         o << "/* " << f.chunk << ":" << cl->proto->line << "  function " << cl->proto->name << " */\n";
         o << "BK_DEV int " << fi.cname << "(BkState &S, const bkv *a, int na, bkv *r)\n{\n";
-        for (int i = 0; i < cl->proto->nslots; ++i) {
-            if (f.array_slots.count(i)) {
-                o << "    bkv A" << i << "[" << f.array_slots[i] + 1 << "];   /* " << cl->proto->slot_names[i] << " */\n";
-                o << "    for (int q = 0; q <= " << f.array_slots[i] << "; ++q) A" << i << "[q] = bk_nil();\n";
-            } else if (i < cl->proto->nparams) {
-                o << "    bkv l" << i << " = na > " << i << " ? a[" << i << "] : bk_nil();   /* " << cl->proto->slot_names[i] << " */\n";
-            } else {
-                o << "    bkv l" << i << " = bk_nil();   /* " << cl->proto->slot_names[i] << " */\n";
-            }
-        }
+        declare_locals(o, f, "    ");
         o << "    (void)a; (void)na; (void)r;\n";
         o << f.out.str();
         o << "    return 0;\n}\n\n";
@@ -685,45 +829,63 @@ struct StateScan {
     {
         if (culprit.empty() && mut.count(name) && !def.count(name)) culprit = name;
     }
-    void expr(const Expr *e, const Closure *cl, Set &def)
+    void expr(const Expr *e, const Emitter::Scope *sc, Set &def)
     {
         if (!e) return;
         if (e->kind == Expr::Name && e->var == VarKind::Global) { read_global(e->str, def); return; }
-        if (e->kind == Expr::Function) return;                       // (creating a closure reads nothing; the emitter rejects calling it)
-        expr(e->a.get(), cl, def);
-        expr(e->b.get(), cl, def);
-        for (auto &x : e->args) expr(x.get(), cl, def);
-        for (auto &x : e->fields) { expr(x.first.get(), cl, def); expr(x.second.get(), cl, def); }
+        if (e->kind == Expr::Function) {
+            // a function defined inside device code can only be called after this point, where at least as much is assigned as here:
+            // its body is walked once, now, as if it were called here (its own assignments stay its own)
+            if (e->proto) {
+                Emitter::Scope inner_scope;
+                inner_scope.proto = e->proto;
+                inner_scope.parent = sc;
+                Set inner = def;
+                block(e->proto->body, &inner_scope, inner);
+            }
+            return;
+        }
+        expr(e->a.get(), sc, def);
+        expr(e->b.get(), sc, def);
+        for (auto &x : e->args) expr(x.get(), sc, def);
+        for (auto &x : e->fields) { expr(x.first.get(), sc, def); expr(x.second.get(), sc, def); }
         if (e->kind == Expr::Call) {
             Value callee;
             bool known = false;
             if (e->a->kind == Expr::Name && e->a->var == VarKind::Global && !mut.count(e->a->str)) { callee = I.get_global(e->a->str); known = true; }
-            else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) { callee = *cl->upvals[e->a->slot]; known = true; }
+            else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) {
+                const Emitter::Scope *owner = nullptr;
+                int slot = 0;
+                if (const Value *cell = Emitter::upvalue_of(sc, e->a->slot, &owner, &slot)) { callee = *cell; known = true; }
+            }
             if (known && callee.t == Value::FUNC && !active.count(callee.fn()->proto)) {
                 active.insert(callee.fn()->proto);
                 Set inner = def;                                     // the callee sees what is assigned so far; its own assignments stay its own
-                block(callee.fn()->proto->body, callee.fn(), inner);
+                Emitter::Scope callee_scope;
+                callee_scope.proto = callee.fn()->proto;
+                callee_scope.cl = callee.fn();
+                block(callee.fn()->proto->body, &callee_scope, inner);
                 active.erase(callee.fn()->proto);
             }
         }
     }
     // returns whether control can fall out of the end of the block
-    bool block(const Block &b, const Closure *cl, Set &def)
+    bool block(const Block &b, const Emitter::Scope *sc, Set &def)
     {
         for (const StmtP &sp : b) {
             const Stmt &s = *sp;
             switch (s.kind) {
             case Stmt::Return:
-                for (auto &x : s.exprs) expr(x.get(), cl, def);
+                for (auto &x : s.exprs) expr(x.get(), sc, def);
                 return false;
             case Stmt::Break: return false;
             case Stmt::If: {
                 Set meet;
                 bool any = false, has_else = false;
                 for (auto &c : s.clauses) {
-                    if (c.first) expr(c.first.get(), cl, def); else has_else = true;
+                    if (c.first) expr(c.first.get(), sc, def); else has_else = true;
                     Set d = def;
-                    if (block(c.second, cl, d)) { meet = any ? intersect(meet, d) : d; any = true; }
+                    if (block(c.second, sc, d)) { meet = any ? intersect(meet, d) : d; any = true; }
                 }
                 if (!has_else) { meet = any ? intersect(meet, def) : def; any = true; }
                 if (!any) return false;                               // every branch returned
@@ -731,26 +893,26 @@ struct StateScan {
                 break;
             }
             case Stmt::While: case Stmt::NumFor: case Stmt::GenFor: {
-                expr(s.cond.get(), cl, def);
-                for (auto &x : s.exprs) expr(x.get(), cl, def);
+                expr(s.cond.get(), sc, def);
+                for (auto &x : s.exprs) expr(x.get(), sc, def);
                 Set d = def;
-                block(s.body, cl, d);                                 // may run zero times: nothing it assigns is definite afterwards
+                block(s.body, sc, d);                                 // may run zero times: nothing it assigns is definite afterwards
                 break;
             }
             case Stmt::Repeat: {
                 Set d = def;
-                const bool falls = block(s.body, cl, d);
-                expr(s.cond.get(), cl, d);
+                const bool falls = block(s.body, sc, d);
+                expr(s.cond.get(), sc, d);
                 if (falls) def = d;                                   // the body runs at least once
                 break;
             }
-            case Stmt::Do: if (!block(s.body, cl, def)) return false; break;
+            case Stmt::Do: if (!block(s.body, sc, def)) return false; break;
             default:
-                for (auto &x : s.exprs) expr(x.get(), cl, def);       // right-hand sides first ...
-                expr(s.call.get(), cl, def);
+                for (auto &x : s.exprs) expr(x.get(), sc, def);       // right-hand sides first ...
+                expr(s.call.get(), sc, def);
                 for (auto &t : s.targets) {
                     if (t->kind == Expr::Name && t->var == VarKind::Global) def.insert(t->str);      // ... then the assignment
-                    else if (t->kind == Expr::Index) { expr(t->a.get(), cl, def); expr(t->b.get(), cl, def); }
+                    else if (t->kind == Expr::Index) { expr(t->a.get(), sc, def); expr(t->b.get(), sc, def); }
                 }
                 break;
             }
@@ -775,15 +937,23 @@ bool callbacks_carry_state(const EmitRequest &req, std::string *which)
     for (const Value *v : roots)
         if (v->t == Value::FUNC && !seen.count(v->fn()->proto)) {
             seen.insert(v->fn()->proto);
-            em.scan_block(v->fn()->proto->body, v->fn(), seen);
+            em.scan_closure(v->fn(), seen);
         }
+    if (!em.mutable_cells.empty()) {
+        // a local of the script that callbacks assign: not followed path by path like the globals - taken to carry state
+        if (which) *which = em.mutable_cells[0].second.substr(em.mutable_cells[0].second.find('_') + 1);
+        return true;
+    }
     if (em.mutable_globals.empty()) return false;
     StateScan sc{*req.interp, em.mutable_globals, std::string(), {}};
     for (const Value *v : roots)
         if (v->t == Value::FUNC) {
             StateScan::Set def;
+            Emitter::Scope root;
+            root.proto = v->fn()->proto;
+            root.cl = v->fn();
             sc.active.insert(v->fn()->proto);
-            sc.block(v->fn()->proto->body, v->fn(), def);
+            sc.block(v->fn()->proto->body, &root, def);
             sc.active.erase(v->fn()->proto);
         }
     if (which) *which = sc.culprit;
@@ -798,7 +968,7 @@ std::string emit_build_source(const EmitRequest &req)
     for (const Value *v : roots)
         if (v->t == Value::FUNC && !seen.count(v->fn()->proto)) {
             seen.insert(v->fn()->proto);
-            em.scan_block(v->fn()->proto->body, v->fn(), seen);
+            em.scan_closure(v->fn(), seen);
         }
     for (const Value *v : roots)
         if (v->t != Value::NIL && v->t != Value::FUNC)
@@ -812,6 +982,7 @@ std::string emit_build_source(const EmitRequest &req)
     src << "/* generated by libblinkyhip (bk_emit.cpp) */\n";
     src << "#define BK_MUTABLE_GLOBALS";
     for (const std::string &g : em.mutable_globals) src << " bkv g_" << sanitize(g) << ";";
+    for (auto &c : em.mutable_cells) src << " bkv " << c.second << ";";
     src << "\n";
     src << "#include \"bkm.h\"\n#include \"bk_build_params.h\"\n#include \"bk_device_rt.h\"\n\n";
     src << em.table_code.str() << "\n";
@@ -830,6 +1001,20 @@ std::string emit_build_source(const EmitRequest &req)
                            " when the lensmap build starts; only nil / boolean / number / string globals can be per-pixel state");
         }
         src << " (S).g_" << sanitize(g) << " = " << init << ";";
+    }
+    for (auto &c : em.mutable_cells) {                               // chunk locals the callbacks assign: the same per-thread treatment
+        const Value &v = *c.first;
+        std::string init;
+        switch (v.t) {
+        case Value::NIL: init = "bk_nil()"; break;
+        case Value::BOOL: init = v.b ? "bk_bool(true)" : "bk_bool(false)"; break;
+        case Value::NUM: init = num_literal(v.n); break;
+        case Value::STR: init = em.str_literal(v.str()); break;
+        default:
+            throw LuaError("local '" + c.second.substr(c.second.find('_') + 1) + "' of the script is assigned inside a GPU callback but holds a " +
+                           v.type_name() + " when the lensmap build starts; only nil / boolean / number / string values can be per-pixel state");
+        }
+        src << " (S)." << c.second << " = " << init << ";";
     }
     src << "\n";
     if (!names[0].empty()) src << "#define BK_HAS_INVERSE 1\n#define LF_lens_inverse " << names[0] << "\n";

@@ -217,8 +217,24 @@ end
 """
 
 
+# the same counter kept in a LOCAL of the script and advanced by a function defined inside the callback
+COUNTER_LOCAL = """
+local count = 0
+local good = lens_inverse
+function lens_inverse(x, y)
+   local function dropped()
+      count = count + 1
+      return count % 7 == 0
+   end
+   if dropped() then return nil end
+   return good(x, y)
+end
+"""
+
+
 @pytest.mark.parametrize("host_module", [0, 2], ids=["compiled", "interpreter"])
-def test_sequential_build_reproduces_a_script_that_counts_pixels(bk, host_module, request):
+@pytest.mark.parametrize("counter", ["global", "local"])
+def test_sequential_build_reproduces_a_script_that_counts_pixels(bk, host_module, counter, request):
     """bk_set_sequential_build(1): a lens whose callback carries state from pixel to pixel - here a counter that drops every 7th
     pixel it is asked for - is built as ONE scan in the reference's order (rows from the bottom up, pixels left to right,
     fisheye.c:2093-2103) on the host.  Expected: the oracle's panini table with the entry of the k-th scanned pixel gone where
@@ -232,7 +248,7 @@ def test_sequential_build_reproduces_a_script_that_counts_pixels(bk, host_module
     bk.debug_set_option("host_module", host_module)
     ctx = bk.Context()
     ctx.load_globe(S.script("globes", "cube"), "cube.lua")
-    ctx.load_lens(S.script("lenses", "panini") + COUNTER, "counter.lua")
+    ctx.load_lens(S.script("lenses", "panini") + (COUNTER if counter == "global" else COUNTER_LOCAL), "counter.lua")
     ctx.set_zoom(bk.ffi.ZOOM_FOV, 180)
     ctx.resize(W, H)
     assert ctx.lens_carries_state() == (True, "count")
@@ -523,3 +539,25 @@ def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monk
     print(f"{lens}: 2^-30 kernels flagged {flagged} changed {changed}; 2^-50 kernels flagged {f2} changed {c2}, entries that differ between the two tables {int((off != off2).sum())}")
     ctx.close()
     ctx2.close()
+
+
+def test_functions_defined_inside_a_callback_build_the_same_table_on_the_gpu(bk):
+    """tests/test_frontend.py's pair of scripts - the same arithmetic written plainly and with local functions / closures / chunk
+    locals as scratch - through the GPU build, and the second one through the one-scan host build as well"""
+    from test_frontend import NESTED_LENS, PLAIN_LENS
+    tables = []
+    for body, sequential in ((PLAIN_LENS, 0), (NESTED_LENS, 0), (NESTED_LENS, 1)):
+        ctx = bk.Context()
+        ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+        ctx.load_lens(body, "nested.lua")
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(640, 400)
+        ctx.set_sequential_build(sequential)
+        display, scale = ctx.build()
+        tables.append(ctx.read_lensmap() + (display, scale))
+        ctx.close()
+    assert (tables[0][0] != O.NULL).sum() > 150000 and sum(tables[0][2]) == 6
+    for t in tables[1:]:
+        np.testing.assert_array_equal(t[0], tables[0][0])
+        np.testing.assert_array_equal(t[1], tables[0][1])
+        assert t[2:] == tables[0][2:]

@@ -397,3 +397,107 @@ end
     ctx.load_globe(S.script("globes", "cube"), "cube.lua")
     ctx.load_lens(scratch, "scratch.lua")
     assert ctx.lens_carries_state() == (False, "")
+
+
+# ---- functions defined inside callbacks, chunk locals as per-pixel state ---------------------------------------------------------
+
+PLAIN_LENS = '''
+max_fov = 360
+max_vfov = 180
+onload = "f_contain"
+lens_width = 2*pi
+lens_height = pi
+local k = 0.5
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local lon = x
+   local lat = y
+   local s = sin(lat) * k + sin(lat) * (1 - k)
+   local c = cos(lat)
+   local t = {c * sin(lon), s, c * cos(lon)}
+   local n = sqrt(t[1]*t[1] + t[2]*t[2] + t[3]*t[3])
+   return t[1]/n, t[2]/n, t[3]/n
+end
+'''
+# the same arithmetic in the same order, written with functions defined inside the callback (closing over its parameters, locals and
+# a table, one inside another, `local function` and `local f = function`) and with chunk locals the callback assigns
+NESTED_LENS = '''
+max_fov = 360
+max_vfov = 180
+onload = "f_contain"
+lens_width = 2*pi
+lens_height = pi
+local k = 0.5
+local scratch = 0
+local calls = 0
+function lens_inverse(x, y)
+   local function outside() return abs(x) > pi or abs(y) > pi/2 end
+   if outside() then return nil end
+   local lon, lat = x, y
+   local blend = function(v, w) return v * w + v * (1 - w) end
+   scratch = blend(sin(lat), k)
+   local c = cos(lat)
+   local t = {0, 0, 0}
+   local function fill()
+      t[1] = c * sin(lon)
+      t[2] = scratch
+      t[3] = c * cos(lon)
+      local function norm2()
+         local acc = 0
+         for i = 1, #t do acc = acc + t[i]*t[i] end
+         return acc
+      end
+      return sqrt(norm2())
+   end
+   local n = fill()
+   calls = calls + 1
+   return t[1]/n, t[2]/n, t[3]/n
+end
+'''
+
+
+def test_functions_defined_inside_a_callback_translate_to_the_same_table(bk):
+    """the generated code of both scripts, run on the host (tests/hostemu), builds the same lensmap; the device compiler takes it"""
+    from hostemu import emu
+    tables = []
+    for body in (PLAIN_LENS, NESTED_LENS):
+        ctx = lens_ctx(bk, body)
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(160, 100)
+        off, tin, flagged, err = emu.build_inverse(ctx)
+        assert err == 0
+        tables.append((off, tin))
+        for x, y in ((0.3, 0.2), (-2.0, 1.0), (3.0, -1.5)):
+            assert ctx.eval_host(0, x, y) == lens_ctx(bk, PLAIN_LENS).eval_host(0, x, y)       # the interpreter agrees as well
+    assert (tables[0][0] != 0xFFFFFFFF).sum() > 10000
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
+    ctx = lens_ctx(bk, NESTED_LENS)
+    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+    ctx.resize(160, 100)
+    src = ctx.kernel_source(compile=True)                       # hiprtc for gfx950 (no GPU needed to compile)
+    assert "auto NF" in src and "S.u1_scratch" in src and "S.u2_calls" in src
+    # a chunk local that callbacks assign is taken to carry state from pixel to pixel (`calls` does): bk_set_sequential_build's business
+    assert ctx.lens_carries_state() == (True, "scratch")
+    assert lens_ctx(bk, PLAIN_LENS).lens_carries_state() == (False, "")
+
+
+@pytest.mark.parametrize("body,message", [
+    ("function lens_inverse(x,y) local function f(n) if n <= 0 then return 0 end return 1 + f(n - 1) end return x, y, f(3) end", "recursion"),
+    ("function lens_inverse(x,y) local function f(a) return a end local g = f return x, y, g(1) end", "used as a value"),
+    ("function lens_inverse(x,y) local function f(a) return a end f = nil return x, y, 1 end", "re-assigning function"),
+    ("function lens_inverse(x,y) local function f(...) return 1 end return x, y, f(1) end", "vararg"),
+    ("local t = {1}\nfunction lens_inverse(x,y) t = {2} return x, y, 1 end", "table constructors"),
+])
+def test_function_constructs_the_device_cannot_take_are_named(bk, body, message):
+    ctx = lens_ctx(bk, body)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match=message):
+        ctx.kernel_source(compile=False)
+
+
+def test_a_global_assigned_inside_a_nested_function_is_per_pixel_state(bk):
+    ctx = lens_ctx(bk, "acc = 1\nfunction lens_inverse(x,y) local function bump() acc = acc + 1 end bump() return x, y, acc end")
+    ctx.resize(64, 48)
+    src = ctx.kernel_source(compile=False)
+    assert "S.g_acc" in src and ctx.lens_carries_state() == (True, "acc")
