@@ -9,6 +9,7 @@
  * ("frame <n> <width> <height> <fnv-1a-64 of the visible rows>").
  *
  *   BLINKY_HEADLESS_SIZE=WxH    frame size (default 320x200, the engine's base size)
+ *   console command             headless_size <width> <height>: a resize while the engine runs
  *   BLINKY_HEADLESS_LOG=path    per-frame hashes (appended)
  *   BLINKY_HEADLESS_DUMP=dir    also write every presented frame as dir/frame%04d.raw (W*H bytes)
  *   BLINKY_HEADLESS_TIMES=path  wall-clock milliseconds each presented frame took, one per line (tools/engine_fps.py)
@@ -24,6 +25,8 @@
 #include <time.h>
 
 #include "quakedef.h"
+#include "cmd.h"
+#include "console.h"
 #include "d_local.h"
 #include "host.h"
 #include "input.h"
@@ -66,6 +69,17 @@ static void set_size(int width, int height)
     D_InitCaches(surface_cache, cache_bytes);
 }
 
+/* "headless_size <width> <height>": what a window resize or a video mode change is to the engine - new buffers, vid.recalc_refdef */
+static void headless_size_f(void)
+{
+    int width, height;
+    if (Cmd_Argc() != 3) { Con_Printf("headless_size <width> <height>\n"); return; }
+    width = atoi(Cmd_Argv(1));
+    height = atoi(Cmd_Argv(2));
+    if (width < 320 || height < 200 || width > MAXWIDTH || height > MAXHEIGHT) { Con_Printf("headless_size: out of range\n"); return; }
+    set_size(width, height);
+}
+
 void VID_Init(const byte *palette)
 {
     int width = 320, height = 200;
@@ -77,6 +91,7 @@ void VID_Init(const byte *palette)
     vid.fullbright = 256 - LittleLong(*((int *)vid.colormap + 2048));
     set_size(width, height);
     VID_SetPalette(palette);
+    Cmd_AddCommand("headless_size", headless_size_f);
 }
 
 void VID_Shutdown(void) {}

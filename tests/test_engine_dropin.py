@@ -51,6 +51,8 @@ def run_engine(binary, script, size=None, env_extra=None, timeout=600):
         frames = (base / "frames.log").read_text().splitlines() if (base / "frames.log").exists() else []
         out_dir = base / ".blinky" / "id1"
         written = {p.name: p.read_bytes() for p in out_dir.iterdir() if p.is_file()} if out_dir.is_dir() else {}
+        if (game / "palette").exists():                                    # f_dumppal writes into the working directory (fisheye.c:916-931)
+            written["palette"] = (game / "palette").read_bytes()
         return r.stdout.decode("latin-1"), frames, written
     finally:
         shutil.rmtree(base, ignore_errors=True)
@@ -91,7 +93,7 @@ CONSOLE_SESSION = [
     "f_lens hammer", "f_lens", "f_fov", "f_lens quincuncial", "f_vfov", "f_lens eckert5", "f_lens nosuchlens", "f_lens", "f_lens panini",
     "f_globe trism", "f_globe", "f_globe nosuchglobe", "f_globe", "f_globe tetra", "f_fov 120", "f_fov", "f_vfov 75.9", "f_vfov", "f_cover",
     "f_fov", "f_contain", "f_vfov", "f_rubixgrid 4 8.5 2", "f_rubixgrid", "f_rubixgrid 1 2", "f_saveglobe", "f_shortcutkeys", "bind 3",
-    "bind y", "f_shortcutkeys", "bind 3", "bind 9", "fisheye 0", "fisheye", "fisheye 1", "f_lens stereographic", "f_globe cube",
+    "bind y", "f_shortcutkeys", "bind 3", "bind 9", "f_dumppal", "fisheye 0", "fisheye", "fisheye 1", "f_lens stereographic", "f_globe cube",
     "toggleconsole", "quit",
 ]
 
@@ -107,6 +109,7 @@ def test_console_sessions_in_the_real_engine_equal_the_reference():
     assert "config.cfg" in ref_files and b"f_lens \"stereographic\"" in ref_files["config.cfg"]
     assert hip_files.keys() == ref_files.keys()
     assert hip_files["config.cfg"] == ref_files["config.cfg"]
+    assert len(ref_files["palette"].splitlines()) == 256 and hip_files["palette"] == ref_files["palette"]
 
 
 FRAME_SESSION = CONNECT + [
@@ -116,6 +119,8 @@ FRAME_SESSION = CONNECT + [
     "f_globe cube_edge", "f_lens stereographic", "wait", "+left", "wait", "wait", "wait", "-left", "+lookup", "wait", "wait", "-lookup",
     "f_lens eckert5", "wait", "f_lens nosuchlens", "wait", "wait", "f_lens panini", "wait", "f_globe nosuchglobe", "wait", "f_globe tetra",
     "wait", "f_fov 400", "wait", "f_globe fast", "f_lens fisheye1", "wait", "f_globe cube", "f_lens winkeltripel", "wait",
+    "headless_size 512 384", "wait", "wait", "f_lens hammer", "wait", "headless_size 700 300", "wait", "f_saveglobe small", "wait",
+    "headless_size 640 480", "wait",
     "f_saveglobe plate", "wait", "f_saveglobe full 1", "wait", "screenshot", "wait",
     "fisheye 0", "wait", "wait", "fisheye 1", "wait", "wait",
     "toggleconsole", "quit",            # (no frame with the console down: its input cursor blinks by wall-clock time, console.c)
@@ -181,11 +186,16 @@ def random_session(seed):
         elif kind < 0.82:
             script.append("fisheye %d" % rng.randint(0, 1))
         elif kind < 0.86:
-            script.append("f_saveglobe s%d %d" % (len(script), rng.randint(0, 1)))
+            # (after a resize the reference's plate memory is a fresh malloc: what f_saveglobe writes for a plate the lensmap does not
+            #  show is then uninitialised memory, fisheye.c:712-727 - only asked for while the first, zero-filled allocation is in use)
+            if not any(c.startswith("headless_size") for c in script):
+                script.append("f_saveglobe s%d %d" % (len(script), rng.randint(0, 1)))
         elif kind < 0.89:
             script.append("screenshot")
         elif kind < 0.92:
             script.append("f_lens no_such_lens" if rng.random() < 0.5 else "f_globe no_such_globe")
+        elif kind < 0.96:
+            script.append("headless_size %d %d" % rng.choice([(320, 200), (400, 300), (640, 360), (512, 512), (800, 450), (333, 241)]))
         script.extend(["wait"] * rng.randint(1, 3))
     script.extend("-" + k for k in sorted(held))
     script.extend(["wait", "toggleconsole", "quit"])
