@@ -163,7 +163,7 @@ struct Emitter {
     void scan_expr(const Expr *e, const Scope &sc, std::set<const FuncProto *> &seen)
     {
         if (!e) return;
-        if (e->kind == Expr::Call) {
+        if (e->kind == Expr::Call && e->str.empty()) {
             Value callee;
             bool known = false;
             if (e->a->kind == Expr::Name && e->a->var == VarKind::Global) { callee = I.get_global(e->a->str); known = true; }
@@ -405,7 +405,7 @@ struct Emitter {
     bool single_valued_call(Fn &f, const Expr &e)
     {
         Value callee;
-        if (e.kind != Expr::Call || !static_value(f, *e.a, &callee) || callee.t != Value::BUILTIN) return false;
+        if (e.kind != Expr::Call || !e.str.empty() || !static_value(f, *e.a, &callee) || callee.t != Value::BUILTIN) return false;
         const std::string &bn = callee.bi()->name;
         return bn.compare(0, 5, "math.") == 0 && bn != "math.modf" && bn != "math.frexp";
     }
@@ -413,6 +413,7 @@ struct Emitter {
     // a call in multi-value context: results land in *arr (bkv[BK_MAXRET]) with count *cnt
     void emit_call(Fn &f, const Expr &e, std::string *arr, std::string *cnt)
     {
+        if (!e.str.empty()) unsupported(f.chunk, e.line, "method calls (a:" + e.str + "(..))");
         Value callee;
         {
             int slot = 0;
@@ -849,7 +850,7 @@ struct StateScan {
         expr(e->b.get(), sc, def);
         for (auto &x : e->args) expr(x.get(), sc, def);
         for (auto &x : e->fields) { expr(x.first.get(), sc, def); expr(x.second.get(), sc, def); }
-        if (e->kind == Expr::Call) {
+        if (e->kind == Expr::Call && e->str.empty()) {
             Value callee;
             bool known = false;
             if (e->a->kind == Expr::Name && e->a->var == VarKind::Global && !mut.count(e->a->str)) { callee = I.get_global(e->a->str); known = true; }

@@ -339,13 +339,14 @@ struct Parser {
         f->id = (int)chunk->protos.size() - 1;
         return f;
     }
-    ExprP function_body(const std::string &name, int line)
+    ExprP function_body(const std::string &name, int line, bool method = false)
     {
         FuncProto *f = new_proto(name, line);
         f->parent = fs ? fs->f : nullptr;
         FuncState nfs{f, fs, {}};
         fs = &nfs;
         open_scope();
+        if (method) { declare_local("self"); f->nparams++; }      // function a:b(..) is a.b = function(self, ..)
         expect_char('(', "(");
         if (!is_char(')')) {
             do {
@@ -460,8 +461,13 @@ struct Parser {
                 i->b = expr();
                 expect_char(']', "]");
                 e = std::move(i);
-            } else if (is_char(':')) {
-                error("method call syntax (a:b()) is not supported");
+            } else if (is_char(':')) {                       // a:b(args): Call with the method's name in `str`; `a` is evaluated once
+                advance();
+                ExprP c = mk(Expr::Call);
+                c->str = expect_name();
+                c->a = std::move(e);
+                c->args = call_args();
+                e = std::move(c);
             } else if (is_char('(') || is_char('{') || tok.t == T_STRING) {
                 ExprP c = mk(Expr::Call);
                 c->a = std::move(e);
@@ -707,11 +713,21 @@ struct Parser {
                 i->b = std::move(k);
                 target = std::move(i);
             }
-            if (is_char(':')) error("method definitions (function a:b()) are not supported");
+            bool method = false;
+            if (accept_char(':')) {
+                method = true;
+                ExprP k = mk(Expr::String);
+                k->str = expect_name();
+                full += ":" + k->str;
+                ExprP i = mk(Expr::Index);
+                i->a = std::move(target);
+                i->b = std::move(k);
+                target = std::move(i);
+            }
             StmtP s = mks(Stmt::Assign);
             s->line = line;
             s->targets.push_back(std::move(target));
-            s->exprs.push_back(function_body(full, line));
+            s->exprs.push_back(function_body(full, line, method));
             return s;
         }
         case T_LOCAL: {
@@ -918,6 +934,10 @@ struct Exec {
     Value index(Frame &f, const Expr &e, const Value &obj, const Value &key)
     {
         if (obj.t == Value::TABLE) return obj.tab()->get(key);
+        if (obj.t == Value::STR) {                               // strings index the string library (("x"):len(), s:sub(1, 2))
+            Value lib = I.get_global("string");
+            if (lib.t == Value::TABLE) return lib.tab()->get(key);
+        }
         std::string what = e.a && e.a->kind == Expr::Name ? " (" + std::string(e.a->var == VarKind::Global ? "global" : "local") + " '" + e.a->str + "')" : "";
         error(e.line, chunk_of(f), std::string("attempt to index a ") + obj.type_name() + " value" + what);
     }
@@ -1095,9 +1115,24 @@ struct Exec {
         --I.depth;
         return true;
     }
+    void note_call_site(Frame &f, const Expr &e) { I.call_site = chunk_of(f) + ":" + std::to_string(e.line) + ":"; }
+    // a:b(args): the function is a.b, its first argument a
+    Values method_call(Frame &f, const Expr &e)
+    {
+        Value obj = eval(f, *e.a);
+        Value fn = index(f, e, obj, Value::string(e.str));
+        if (!fn.is_function()) error(e.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value (method '" + e.str + "')");
+        Values args;
+        args.push_back(std::move(obj));
+        Values rest = eval_list(f, e.args);
+        args.append(rest.begin(), rest.end());
+        if (fn.t == Value::BUILTIN) note_call_site(f, e);
+        return I.call(fn, args);
+    }
     // a call of which only the first result is wanted
     Value eval_call1(Frame &f, const Expr &e)
     {
+        if (!e.str.empty()) { Values r = method_call(f, e); return r.empty() ? Value() : std::move(r[0]); }
         Value fn = eval(f, *e.a);
         Value out;
         Values args;
@@ -1108,6 +1143,7 @@ struct Exec {
         }
         if (args.empty()) args = eval_list(f, e.args);
         if (!fn.is_function()) not_callable(f, e, fn);
+        if (fn.t == Value::BUILTIN) note_call_site(f, e);
         Values r = I.call(fn, args);
         return r.empty() ? Value() : std::move(r[0]);
     }
@@ -1116,6 +1152,7 @@ struct Exec {
     {
         if (e.kind == Expr::Vararg) return f.varargs;
         if (e.kind != Expr::Call) return Values{eval(f, e)};
+        if (!e.str.empty()) return method_call(f, e);
         Value fn = eval(f, *e.a);
         Value out;
         Values args;
@@ -1126,6 +1163,7 @@ struct Exec {
         }
         if (args.empty()) args = eval_list(f, e.args);
         if (!fn.is_function()) not_callable(f, e, fn);
+        if (fn.t == Value::BUILTIN) note_call_site(f, e);
         return I.call(fn, args);
     }
 
@@ -1495,13 +1533,251 @@ Interp::Interp(const MathLib &m) : math(&m)
         if (a.empty() || !a[0].truthy()) throw LuaError(a.size() > 1 ? I.tostring(a[1]) : "assertion failed!");
         r = a;
     });
-    register_builtin("error", [](Interp &I, const Values &a, Values &) { throw LuaError(a.empty() ? "nil" : I.tostring(a[0])); });
+    // luaB_error: a string message gets the position of the call in front (level 1, the default; level 0 = none)
+    register_builtin("error", [](Interp &I, const Values &a, Values &) {
+        if (a.empty()) throw LuaError("nil");
+        const bool positioned = a[0].t == Value::STR && !(a.size() > 1 && a[1].t == Value::NUM && a[1].n == 0) && !I.call_site.empty();
+        throw LuaError((positioned ? I.call_site + " " : std::string()) + I.tostring(a[0]));
+    });
     register_builtin("select", [](Interp &, const Values &a, Values &r) {
         if (!a.empty() && a[0].t == Value::STR && a[0].str() == "#") { r.push_back(Value::number((double)a.size() - 1)); return; }
         double n = argnum(a, 0, "select");
         if (n < 1) throw LuaError("bad argument #1 to 'select' (index out of range)");
         for (size_t i = (size_t)n; i < a.size(); ++i) r.push_back(a[i]);
     });
+    // pcall(f, ...): true + results, or false + the error message (lua_pcall; messages carry no traceback here either)
+    register_builtin("pcall", [](Interp &I, const Values &a, Values &r) {
+        if (a.empty()) throw LuaError("bad argument #1 to 'pcall' (value expected)");
+        Values args;
+        args.append(a.begin() + 1, a.end());
+        const int depth = I.depth;
+        try {
+            Values out = I.call(a[0], args);
+            r.push_back(Value::boolean(true));
+            r.append(out.begin(), out.end());
+        } catch (const LuaError &e) {
+            I.depth = depth;
+            r.clear();
+            r.push_back(Value::boolean(false));
+            r.push_back(Value::string(e.what()));
+        }
+    });
+    register_builtin("rawget", [](Interp &, const Values &a, Values &r) {
+        if (a.size() < 2 || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'rawget' (table expected)");
+        r.push_back(a[0].tab()->get(a[1]));
+    });
+    register_builtin("rawset", [](Interp &, const Values &a, Values &r) {
+        if (a.size() < 3 || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'rawset' (table expected)");
+        a[0].tab()->set(a[1], a[2]);
+        r.push_back(a[0]);
+    });
+    register_builtin("rawequal", [](Interp &, const Values &a, Values &r) {
+        if (a.size() < 2) throw LuaError("bad argument #2 to 'rawequal' (value expected)");
+        r.push_back(Value::boolean(Exec::raw_equal(a[0], a[1])));
+    });
+    register_builtin("rawlen", [](Interp &, const Values &a, Values &r) {
+        if (!a.empty() && a[0].t == Value::TABLE) r.push_back(Value::number((double)a[0].tab()->length()));
+        else if (!a.empty() && a[0].t == Value::STR) r.push_back(Value::number((double)a[0].str().size()));
+        else throw LuaError("table or string expected");
+    });
+    // ---- string library (lstrlib.c), without patterns: find takes plain strings only -------------------------------------------
+    auto argstr = [](const Values &a, size_t i, const char *fn) -> std::string {
+        if (i < a.size() && a[i].t == Value::STR) return a[i].str();
+        if (i < a.size() && a[i].t == Value::NUM) { char b[64]; snprintf(b, sizeof b, "%.14g", a[i].n); return b; }
+        throw LuaError(std::string("bad argument #") + std::to_string(i + 1) + " to '" + fn + "' (string expected, got " +
+                       (i < a.size() ? a[i].type_name() : "no value") + ")");
+    };
+    // str_sub's positions: negative counts from the end, clipped to [1, len]
+    auto posrelat = [](double pos, size_t len) -> long {
+        long p = (long)pos;
+        if (p >= 0) return p;
+        if ((size_t)-p > len) return 0;
+        return (long)len + p + 1;
+    };
+    register_builtin("string.len", [argstr](Interp &, const Values &a, Values &r) { r.push_back(Value::number((double)argstr(a, 0, "len").size())); });
+    register_builtin("string.sub", [argstr, posrelat](Interp &, const Values &a, Values &r) {
+        const std::string s = argstr(a, 0, "sub");
+        long i = posrelat(argnum(a, 1, "sub"), s.size()), j = posrelat(a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "sub") : -1, s.size());
+        if (i < 1) i = 1;
+        if (j > (long)s.size()) j = (long)s.size();
+        r.push_back(Value::string(i <= j ? s.substr((size_t)i - 1, (size_t)(j - i + 1)) : std::string()));
+    });
+    register_builtin("string.upper", [argstr](Interp &, const Values &a, Values &r) {
+        std::string s = argstr(a, 0, "upper");
+        for (char &c : s) c = (char)toupper((unsigned char)c);
+        r.push_back(Value::string(s));
+    });
+    register_builtin("string.lower", [argstr](Interp &, const Values &a, Values &r) {
+        std::string s = argstr(a, 0, "lower");
+        for (char &c : s) c = (char)tolower((unsigned char)c);
+        r.push_back(Value::string(s));
+    });
+    register_builtin("string.reverse", [argstr](Interp &, const Values &a, Values &r) {
+        std::string s = argstr(a, 0, "reverse");
+        r.push_back(Value::string(std::string(s.rbegin(), s.rend())));
+    });
+    register_builtin("string.rep", [argstr](Interp &, const Values &a, Values &r) {
+        const std::string s = argstr(a, 0, "rep"), sep = a.size() > 2 ? argstr(a, 2, "rep") : std::string();
+        const long n = (long)argnum(a, 1, "rep");
+        std::string out;
+        if (n > 0 && (s.size() + sep.size()) * (size_t)n > (size_t)1 << 24) throw LuaError("resulting string too large");
+        for (long i = 0; i < n; ++i) { out += s; if (i + 1 < n) out += sep; }
+        r.push_back(Value::string(out));
+    });
+    register_builtin("string.byte", [argstr, posrelat](Interp &, const Values &a, Values &r) {
+        const std::string s = argstr(a, 0, "byte");
+        long i = posrelat(a.size() > 1 && a[1].t != Value::NIL ? argnum(a, 1, "byte") : 1, s.size());
+        long j = posrelat(a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "byte") : (double)i, s.size());
+        if (i < 1) i = 1;
+        if (j > (long)s.size()) j = (long)s.size();
+        for (long k = i; k <= j; ++k) r.push_back(Value::number((double)(unsigned char)s[(size_t)k - 1]));
+    });
+    register_builtin("string.char", [](Interp &, const Values &a, Values &r) {
+        std::string out;
+        for (size_t i = 0; i < a.size(); ++i) {
+            const double c = argnum(a, i, "char");
+            if (c < 0 || c > 255 || c != std::floor(c)) throw LuaError("bad argument #" + std::to_string(i + 1) + " to 'char' (value out of range)");
+            out += (char)(unsigned char)c;
+        }
+        r.push_back(Value::string(out));
+    });
+    register_builtin("string.find", [argstr, posrelat](Interp &, const Values &a, Values &r) {
+        const std::string s = argstr(a, 0, "find"), pat = argstr(a, 1, "find");
+        long init = posrelat(a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "find") : 1, s.size());
+        const bool plain = a.size() > 3 && a[3].truthy();
+        if (!plain && pat.find_first_of("^$*+?.([%-") != std::string::npos)
+            throw LuaError("string.find: patterns are not supported by this interpreter (pass plain = true for a substring search)");
+        if (init < 1) init = 1;
+        if ((size_t)init > s.size() + 1) { r.push_back(Value()); return; }
+        const size_t at = s.find(pat, (size_t)init - 1);
+        if (at == std::string::npos) { r.push_back(Value()); return; }
+        r.push_back(Value::number((double)at + 1));
+        r.push_back(Value::number((double)(at + pat.size())));
+    });
+    // str_format: one C conversion per directive, flags / width / precision as given (lstrlib.c:scanformat)
+    register_builtin("string.format", [argstr](Interp &I, const Values &a, Values &r) {
+        const std::string fmt = argstr(a, 0, "format");
+        std::string out;
+        size_t arg = 0;
+        for (size_t i = 0; i < fmt.size(); ++i) {
+            if (fmt[i] != '%') { out += fmt[i]; continue; }
+            if (++i >= fmt.size()) throw LuaError("invalid option '%' to 'format'");
+            if (fmt[i] == '%') { out += '%'; continue; }
+            std::string spec = "%";
+            while (i < fmt.size() && strchr("-+ #0", fmt[i])) spec += fmt[i++];
+            while (i < fmt.size() && isdigit((unsigned char)fmt[i])) spec += fmt[i++];
+            if (i < fmt.size() && fmt[i] == '.') { spec += fmt[i++]; while (i < fmt.size() && isdigit((unsigned char)fmt[i])) spec += fmt[i++]; }
+            if (i >= fmt.size() || spec.size() > 20) throw LuaError("invalid format (width or precision too long)");
+            const char conv = fmt[i];
+            ++arg;
+            char buf[512];
+            switch (conv) {
+            case 'c': out += (char)(int)argnum(a, arg, "format"); break;
+            case 'd': case 'i':
+                snprintf(buf, sizeof buf, (spec + "lld").c_str(), (long long)argnum(a, arg, "format"));
+                out += buf;
+                break;
+            case 'o': case 'u': case 'x': case 'X':
+                snprintf(buf, sizeof buf, (spec + "ll" + conv).c_str(), (unsigned long long)(long long)argnum(a, arg, "format"));
+                out += buf;
+                break;
+            case 'e': case 'E': case 'f': case 'g': case 'G': case 'a': case 'A':
+                snprintf(buf, sizeof buf, (spec + conv).c_str(), argnum(a, arg, "format"));
+                out += buf;
+                break;
+            case 'q': {
+                const std::string v = argstr(a, arg, "format");
+                out += '"';
+                for (char c : v) {
+                    if (c == '"' || c == '\\' || c == '\n') { out += '\\'; out += c; }
+                    else if (c == '\r') out += "\\r";
+                    else if (c == '\0') out += "\\0";
+                    else out += c;
+                }
+                out += '"';
+                break;
+            }
+            case 's': {
+                if (arg >= a.size()) throw LuaError("bad argument #" + std::to_string(arg + 1) + " to 'format' (no value)");
+                const std::string v = I.tostring(a[arg]);                      // luaL_tolstring: any value
+                if (spec == "%") out += v;
+                else {
+                    std::vector<char> big(v.size() + 64);
+                    snprintf(big.data(), big.size(), (spec + "s").c_str(), v.c_str());
+                    out += big.data();
+                }
+                break;
+            }
+            default: throw LuaError(std::string("invalid option '%") + conv + "' to 'format'");
+            }
+        }
+        r.push_back(Value::string(out));
+    });
+    // ---- more of the table library ----------------------------------------------------------------------------------------------
+    register_builtin("table.concat", [](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'concat' (table expected)");
+        const Table &t = *a[0].tab();
+        const std::string sep = a.size() > 1 && a[1].t != Value::NIL ? I.tostring(a[1]) : std::string();
+        const long i0 = a.size() > 2 && a[2].t != Value::NIL ? (long)argnum(a, 2, "concat") : 1;
+        const long i1 = a.size() > 3 && a[3].t != Value::NIL ? (long)argnum(a, 3, "concat") : (long)t.length();
+        std::string out;
+        for (long i = i0; i <= i1; ++i) {
+            const Value v = t.get(Value::number((double)i));
+            if (v.t != Value::STR && v.t != Value::NUM) throw LuaError("invalid value (at index " + std::to_string(i) + ") in table for 'concat'");
+            out += I.tostring(v);
+            if (i < i1) out += sep;
+        }
+        r.push_back(Value::string(out));
+    });
+    register_builtin("table.remove", [](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'remove' (table expected)");
+        Table &t = *a[0].tab();
+        const size_t n = t.length();
+        size_t pos = a.size() > 1 && a[1].t != Value::NIL ? (size_t)argnum(a, 1, "remove") : n;
+        if (n == 0 && (a.size() < 2 || pos == 0 || pos == n)) { r.push_back(Value()); return; }
+        if (pos < 1 || pos > n + 1) throw LuaError("bad argument #2 to 'remove' (position out of bounds)");
+        if (pos == n + 1) { r.push_back(Value()); return; }
+        r.push_back(t.arr[pos - 1]);
+        t.arr.erase(t.arr.begin() + (long)(pos - 1));
+    });
+    register_builtin("table.sort", [](Interp &I, const Values &a, Values &) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'sort' (table expected)");
+        Table &t = *a[0].tab();
+        const bool custom = a.size() > 1 && a[1].t != Value::NIL;
+        if (custom && !a[1].is_function()) throw LuaError("bad argument #2 to 'sort' (function expected)");
+        const Value cmp = custom ? a[1] : Value();
+        auto less = [&](const Value &x, const Value &y) {
+            if (custom) { Values r = I.call(cmp, Values{x, y}); return !r.empty() && r[0].truthy(); }
+            if (x.t == Value::NUM && y.t == Value::NUM) return x.n < y.n;
+            if (x.t == Value::STR && y.t == Value::STR) return x.str() < y.str();
+            throw LuaError(std::string("attempt to compare ") + x.type_name() + " with " + y.type_name());
+        };
+        // insertion by binary search: well defined for any comparison function, and lens scripts sort a handful of values
+        std::vector<Value> out;
+        for (const Value &v : t.arr) {
+            size_t lo = 0, hi = out.size();
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (less(v, out[mid])) hi = mid; else lo = mid + 1; }
+            out.insert(out.begin() + (long)lo, v);
+        }
+        t.arr.swap(out);
+    });
+    // ---- the rest of lmathlib.c that is plain arithmetic ------------------------------------------------------------------------
+    register_builtin("math.ldexp", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(std::ldexp(argnum(a, 0, "ldexp"), (int)argnum(a, 1, "ldexp")))); });
+    register_builtin("math.frexp", [](Interp &, const Values &a, Values &r) {
+        int e = 0;
+        r.push_back(Value::number(std::frexp(argnum(a, 0, "frexp"), &e)));
+        r.push_back(Value::number((double)e));
+    });
+    // math.random / math.randomseed as lmathlib.c has them, over the C library's rand() - the sequence the reference's VM would draw
+    // on this platform.  Host only: the GPU build rejects them (every pixel would need the draws of all pixels before it).
+    register_builtin("math.random", [](Interp &, const Values &a, Values &r) {
+        const double x = (double)(rand() % RAND_MAX) / (double)RAND_MAX;
+        if (a.empty()) { r.push_back(Value::number(x)); return; }
+        const double lo = a.size() > 1 ? argnum(a, 0, "random") : 1.0, hi = argnum(a, a.size() > 1 ? 1 : 0, "random");
+        if (lo > hi) throw LuaError("bad argument #" + std::to_string(a.size() > 1 ? 2 : 1) + " to 'random' (interval is empty)");
+        r.push_back(Value::number(std::floor(x * (hi - lo + 1)) + lo));
+    });
+    register_builtin("math.randomseed", [](Interp &, const Values &a, Values &) { srand((unsigned)argnum(a, 0, "randomseed")); (void)rand(); });
     register_builtin("next", [](Interp &, const Values &a, Values &r) {
         if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'next' (table expected)");
         const Table &t = *a[0].tab();

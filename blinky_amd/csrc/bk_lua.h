@@ -236,6 +236,7 @@ struct Interp {
         return *p;
     }
     long steps = 0, max_steps = 200000000;  // runaway-script guard
+    std::string call_site;                  // "chunk:line:" of the builtin call being made (error() puts it in front of its message)
     int depth = 0;
     std::function<void(const std::string &)> print_sink;   // `print` output (Con_Printf)
 

@@ -501,3 +501,98 @@ def test_a_global_assigned_inside_a_nested_function_is_per_pixel_state(bk):
     ctx.resize(64, 48)
     src = ctx.kernel_source(compile=False)
     assert "S.g_acc" in src and ctx.lens_carries_state() == (True, "acc")
+
+
+# ---- more of the language and library for the part of a script that runs on the host -----------------------------------------------
+
+HOST_LIBRARY = r'''
+print(string.format("%d|%5d|%-5d|%05d|%x|%X|%o", 42, 42, 42, 42, 255, 255, 8))
+print(string.format("%.3f|%10.2f|%e|%g|%g", 3.14159, 2.5, 12345.678, 0.0001, 1e20))
+print(string.format("%s|%10s|%-10s|%q|%%|%c", "ab", "cd", "ef", 'q"x', 65))
+print(string.format("%s %s %s", 1.5, true, nil))
+print(("hello"):upper(), ("HeLLo"):lower(), ("abc"):len(), #"abcd", ("abc"):rep(3, "-"), ("abc"):reverse())
+local s = "hello world"
+print(s:sub(1, 5), s:sub(-5), s:sub(7, -1), s:sub(0), s:sub(20), s:sub(-100, 3), s:sub(3, 2))
+print(s:byte(1), s:byte(-1), s:byte(1, 3), string.char(72, 105))
+print(s:find("world", 1, true), s:find("xyz", 1, true), s:find("o", 6, true), string.find(s, "lo"))
+print(pcall(function() error("boom") end))
+print(pcall(function() error("plain", 0) end))
+print(pcall(function(a, b) return a + b, "x" end, 1, 2))
+print(select("#", 1, 2, 3), select(2, "a", "b", "c"))
+local t = {5, 2, 8, 1}
+table.sort(t) print(table.concat(t, ","))
+table.sort(t, function(a, b) return a > b end) print(table.concat(t, ",", 2, 3))
+print(table.remove(t), table.remove(t, 1), #t, table.concat(t, "-"))
+local words = {"pear", "apple", "fig"} table.sort(words) print(table.concat(words, " "))
+print(math.ldexp(0.75, 4), math.frexp(12), math.frexp(0))
+local Vec = {}
+function Vec.new(x, y) return {x = x, y = y, dot = Vec.dot, scaled = Vec.scaled} end
+function Vec:dot(o) return self.x * o.x + self.y * o.y end
+function Vec:scaled(k) return Vec.new(self.x * k, self.y * k) end
+local a, b = Vec.new(1, 2), Vec.new(3, 4)
+print(a:dot(b), a:scaled(2):dot(b), rawget(a, "x"), rawequal(a, a), rawlen({1, 2, 3}), rawlen("ab"))
+local geo = {r = 2}
+function geo.area(self) return self.r * self.r * 3 end
+function geo:grow(d) self.r = self.r + d return self end
+print(geo:area(), geo:grow(1):area(), geo.area(geo))
+math.randomseed(42) local r1 = math.random() math.randomseed(42) print(r1 == math.random(), math.random(10) <= 10, math.random(5, 6) >= 5)
+max_fov = geo:area()
+function lens_inverse(x, y) return x, y, 1 end
+'''
+HOST_LIBRARY_OUTPUT = '''42|   42|42   |00042|ff|FF|10
+3.142|      2.50|1.234568e+04|0.0001|1e+20
+ab|        cd|ef        |"q\\"x"|%|A
+1.5 true nil
+HELLO\thello\t3\t4\tabc-abc-abc\tcba
+hello\tworld\tworld\thello world\t\thel\t
+104\t100\t104\tHi
+7\tnil\t8\t4\t5
+false\tlib.lua:11: boom
+false\tplain
+true\t3\tx
+3\tb\tc
+1,2,5,8
+5,2
+1\t8\t2\t5-2
+apple fig pear
+12\t0.75\t0\t0
+11\t22\t1\ttrue\t3\t2
+12\t27\t27
+true\ttrue\ttrue
+'''
+
+
+def test_host_side_library_and_method_syntax(bk):
+    """what a script may use while it LOADS (chunks run on the host interpreter; the reference links the whole Lua 5.2 library,
+    engine/Makefile:818): string.format / sub / byte / char / find (plain) / rep / upper / lower / reverse, method definitions and calls
+    (also on strings), pcall / error with positions, rawget / rawset / rawequal / rawlen, table.sort / concat / remove, math.ldexp / frexp /
+    random / randomseed - outputs as the Lua 5.2 manual defines them"""
+    ctx2 = host_ctx(bk)
+    ctx2.load_globe(S.script("globes", "cube"), "cube")
+    ctx2.load_lens(HOST_LIBRARY, "lib.lua")
+    assert ctx2.console() == HOST_LIBRARY_OUTPUT
+    assert ctx2.lens_info().max_fov == 27
+
+
+def test_first_math_random_is_the_c_librarys_first_draw(bk):
+    """math.random is rand() % RAND_MAX / RAND_MAX (lmathlib.c): in a fresh process the value every Lua 5.2 on glibc prints first"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import blinky_amd as bk, scripts as S\n"
+            "c = bk.Context(bk.ffi.DEVICE_NONE); c.load_globe(S.script('globes', 'cube'), 'cube')\n"
+            "c.load_lens('print(math.random())\\nfunction lens_inverse(x, y) return x, y, 1 end', 'r.lua'); print(c.console())") % (
+                os.path.dirname(HERE), HERE)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    assert out.split()[0] == "0.84018771715471"       # (%.14g of 0.840187717154710...)
+
+
+@pytest.mark.parametrize("body,message", [
+    ("local o = {k = 2}\nfunction o:f(x) return x * self.k end\nfunction lens_inverse(x,y) return o:f(x), y, 1 end", "method calls"),
+    ("function lens_inverse(x,y) return x, y, math.random() end", "math.random"),
+    ("function lens_inverse(x,y) local s = string.format('%d', x) return x, y, 1 end", "string.format"),
+])
+def test_host_only_library_is_named_when_a_gpu_callback_uses_it(bk, body, message):
+    ctx = lens_ctx(bk, body)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match=message):
+        ctx.kernel_source(compile=False)
