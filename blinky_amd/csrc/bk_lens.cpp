@@ -40,6 +40,14 @@ struct CodeResult {
 
 static void park_compile(std::shared_future<::CodeResult> &f);      // (below, next to the code caches)
 
+/* (int)double as the reference's x86-64 build converts it (cvttsd2si): NaN and out-of-range values become INT_MIN - where the
+ * reference assigns a Lua number to an int (fisheye.c:1522, 1734, 1738) the C language leaves that case undefined */
+static int h_trunc_to_int(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
 namespace bk {
 
 struct LensProgram {
@@ -91,6 +99,7 @@ static void h_ray_to_latlon(const MathLib &M, const float *ray, double *lat, dou
     *lon = M.atan2((double)ray[0], (double)ray[2]);
     *lat = M.atan2((double)ray[1], M.sqrt((double)(ray[0] * ray[0] + ray[2] * ray[2])));
 }
+
 static void h_plate_uv_to_ray(const bk_plate &p, double u, double v, float *ray)
 {
     u -= 0.5;
@@ -122,7 +131,7 @@ static double need_num(const Values &a, size_t i, const char *fn)
 // to the portable bkm.h functions (= what the GPU kernels use) for platform-independent results.
 LensProgram::LensProgram(bk_ctx *ctx) : interp(math_platform())
 {
-    interp.print_sink = [this](const std::string &s) { console += s + "\n"; };
+    interp.print_sink = [this](const std::string &s) { console += s; };          // (print's lines with their newline, io.write's text as it is)
     // the aliases init_lua installs (fisheye.c:1230-1248): cos = math.cos ... tau = math.pi*2
     static const char *alias[] = {"cos", "sin", "tan", "asin", "acos", "atan", "atan2", "sinh", "cosh", "tanh",
                                   "log", "log10", "abs", "sqrt", "exp", "pow"};
@@ -145,7 +154,7 @@ LensProgram::LensProgram(bk_ctx *ctx) : interp(math_platform())
         r.push_back(Value::number(lon));
     });
     interp.register_builtin("plate_to_ray", [ctx](Interp &, const Values &a, Values &r) {
-        int pi = (int)need_num(a, 0, "plate_to_ray");
+        int pi = h_trunc_to_int(need_num(a, 0, "plate_to_ray"));
         double u = need_num(a, 1, "plate_to_ray"), v = need_num(a, 2, "plate_to_ray");
         if (pi < 0 || pi >= ctx->numplates) { r.push_back(Value()); return; }       /* fisheye.c:1527-1530 */
         float ray[3];
@@ -297,8 +306,8 @@ extern "C" int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char
         else return ctx->fail(BK_E_SCRIPT, "Unsupported map function: %s", fn.c_str());
     }
     auto num_or_zero = [&](const char *g) { Value v = I.get_global(g); return v.t == Value::NUM ? v.n : 0.0; };
-    info.max_fov = (int)num_or_zero("max_fov");                                                               /* :1733-1739 */
-    info.max_vfov = (int)num_or_zero("max_vfov");
+    info.max_fov = h_trunc_to_int(num_or_zero("max_fov"));                                                               /* :1733-1739 */
+    info.max_vfov = h_trunc_to_int(num_or_zero("max_vfov"));
     info.lens_width = num_or_zero("lens_width");                                                              /* :1741-1747 */
     info.lens_height = num_or_zero("lens_height");
     Value onload = I.get_global("onload");                                                                    /* cmd_lens :1087-1095 */
@@ -948,12 +957,6 @@ static const char *err_text(int bits)
 namespace {
 
 float h_dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }     /* mathlib.h:70 */
-int h_trunc_to_int(double v)                                                                          /* cvttsd2si */
-{
-    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
-    return (int)v;
-}
-
 /* who evaluates: the context's interpreter, or a per-thread copy of it (Interp::clone) */
 struct HostEval {
     Interp *I;

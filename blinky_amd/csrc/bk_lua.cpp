@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1518,7 +1519,7 @@ Interp::Interp(const MathLib &m) : math(&m)
     register_builtin("print", [](Interp &I, const Values &a, Values &) {
         std::string line;
         for (size_t i = 0; i < a.size(); ++i) { if (i) line += "\t"; line += I.tostring(a[i]); }
-        if (I.print_sink) I.print_sink(line);
+        if (I.print_sink) I.print_sink(line + "\n");
     });
     register_builtin("tostring", [](Interp &I, const Values &a, Values &r) { r.push_back(Value::string(I.tostring(a.empty() ? Value() : a[0]))); });
     register_builtin("tonumber", [](Interp &, const Values &a, Values &r) {
@@ -1544,6 +1545,100 @@ Interp::Interp(const MathLib &m) : math(&m)
         double n = argnum(a, 0, "select");
         if (n < 1) throw LuaError("bad argument #1 to 'select' (index out of range)");
         for (size_t i = (size_t)n; i < a.size(); ++i) r.push_back(a[i]);
+    });
+    // ---- chunks from strings and files (lbaselib.c load / loadfile / dofile, loadlib.c require): the reference opens the whole
+    // library, so a lens script may keep shared helpers in a file of its own; paths are relative to the working directory, as there
+    auto make_chunk = [](const std::string &src, const std::string &name) {
+        std::shared_ptr<Chunk> ch = parse(src, name);
+        auto cl = std::make_shared<Closure>();
+        cl->proto = ch->main();
+        cl->chunk = ch;
+        return Value::closure(std::move(cl));
+    };
+    auto read_file = [](const std::string &path, std::string *out) {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        char buf[4096];
+        size_t n;
+        out->clear();
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+        fclose(f);
+        if (out->size() >= 1 && (*out)[0] == '#') { const size_t eol = out->find('\n'); out->replace(0, eol == std::string::npos ? out->size() : eol, ""); }   // (a first line starting with # is skipped, lauxlib.c)
+        return true;
+    };
+    auto short_name = [](const std::string &path) { const size_t s = path.find_last_of('/'); return s == std::string::npos ? path : path.substr(s + 1); };
+    register_builtin("load", [make_chunk](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'load' (string expected; reader functions are not supported)");
+        const std::string name = a.size() > 1 && a[1].t == Value::STR ? a[1].str() : "=(load)";
+        try { r.push_back(make_chunk(a[0].str(), name[0] == '=' || name[0] == '@' ? name.substr(1) : name)); }
+        catch (const LuaError &e) { r.clear(); r.push_back(Value()); r.push_back(Value::string(e.what())); }
+    });
+    register_builtin("loadfile", [make_chunk, read_file, short_name](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'loadfile' (string expected)");
+        std::string src;
+        if (!read_file(a[0].str(), &src)) { r.push_back(Value()); r.push_back(Value::string("cannot open " + a[0].str())); return; }
+        try { r.push_back(make_chunk(src, short_name(a[0].str()))); }
+        catch (const LuaError &e) { r.clear(); r.push_back(Value()); r.push_back(Value::string(e.what())); }
+    });
+    register_builtin("dofile", [make_chunk, read_file, short_name](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'dofile' (string expected)");
+        std::string src;
+        if (!read_file(a[0].str(), &src)) throw LuaError("cannot open " + a[0].str());
+        r = I.call(make_chunk(src, short_name(a[0].str())), Values());
+    });
+    {
+        Value pkg = Value::table(std::make_shared<Table>());
+        pkg.tab()->set(Value::string("loaded"), Value::table(std::make_shared<Table>()));
+        const char *env = getenv("LUA_PATH_5_2");
+        if (!env) env = getenv("LUA_PATH");
+        pkg.tab()->set(Value::string("path"), Value::string(env ? env : "./?.lua;./?/init.lua"));
+        globals["package"] = pkg;
+    }
+    register_builtin("require", [make_chunk, read_file, short_name](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'require' (string expected)");
+        const std::string name = a[0].str();
+        Value pkg = I.get_global("package");
+        Value loaded = pkg.t == Value::TABLE ? pkg.tab()->get(Value::string("loaded")) : Value();
+        if (loaded.t != Value::TABLE) throw LuaError("'package.loaded' must be a table");
+        Value have = loaded.tab()->get(Value::string(name));
+        if (have.truthy()) { r.push_back(have); return; }
+        const Value pathv = pkg.tab()->get(Value::string("path"));
+        if (pathv.t != Value::STR) throw LuaError("'package.path' must be a string");
+        std::string file = name, tried;
+        for (char &c : file) if (c == '.') c = '/';
+        const std::string path = pathv.str();
+        for (size_t at = 0; at <= path.size();) {
+            size_t semi = path.find(';', at);
+            if (semi == std::string::npos) semi = path.size();
+            std::string candidate = path.substr(at, semi - at);
+            at = semi + 1;
+            if (candidate.empty()) continue;
+            for (size_t q; (q = candidate.find('?')) != std::string::npos;) candidate.replace(q, 1, file);
+            std::string src;
+            if (!read_file(candidate, &src)) { tried += "\n\tno file '" + candidate + "'"; continue; }
+            Values out = I.call(make_chunk(src, short_name(candidate)), Values{Value::string(name), Value::string(candidate)});
+            Value result = !out.empty() && out[0].t != Value::NIL ? out[0] : Value();
+            Value now = loaded.tab()->get(Value::string(name));                 // (the module may have set package.loaded[name] itself)
+            if (result.t == Value::NIL) result = now.t != Value::NIL ? now : Value::boolean(true);
+            loaded.tab()->set(Value::string(name), result);
+            r.push_back(result);
+            return;
+        }
+        throw LuaError("module '" + name + "' not found:" + tried);
+    });
+    register_builtin("os.time", [](Interp &, const Values &, Values &r) { r.push_back(Value::number((double)time(nullptr))); });
+    register_builtin("os.clock", [](Interp &, const Values &, Values &r) { r.push_back(Value::number((double)clock() / (double)CLOCKS_PER_SEC)); });
+    register_builtin("os.getenv", [](Interp &, const Values &a, Values &r) {
+        const char *v = !a.empty() && a[0].t == Value::STR ? getenv(a[0].str().c_str()) : nullptr;
+        r.push_back(v ? Value::string(v) : Value());
+    });
+    register_builtin("io.write", [](Interp &I, const Values &a, Values &) {       // to where print goes, without its tabs and newline
+        std::string out;
+        for (const Value &v : a) {
+            if (v.t != Value::STR && v.t != Value::NUM) throw LuaError(std::string("bad argument to 'write' (string expected, got ") + v.type_name() + ")");
+            out += I.tostring(v);
+        }
+        if (I.print_sink) I.print_sink(out);
     });
     // pcall(f, ...): true + results, or false + the error message (lua_pcall; messages carry no traceback here either)
     register_builtin("pcall", [](Interp &I, const Values &a, Values &r) {

@@ -238,7 +238,7 @@ struct Interp {
     long steps = 0, max_steps = 200000000;  // runaway-script guard
     std::string call_site;                  // "chunk:line:" of the builtin call being made (error() puts it in front of its message)
     int depth = 0;
-    std::function<void(const std::string &)> print_sink;   // `print` output (Con_Printf)
+    std::function<void(const std::string &)> print_sink;   // `print` / io.write output, newlines included (Con_Printf)
 
     Value get_global(const std::string &name) const;
     void set_global(const std::string &name, const Value &v);

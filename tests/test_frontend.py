@@ -605,3 +605,28 @@ def test_mutated_scripts_are_errors_not_crashes():
     r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_frontend.py"), "0", "150"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     assert "fuzz_frontend seeds 0:150 loaded" in r.stdout
+
+
+def test_scripts_can_keep_helpers_in_files_of_their_own(bk, tmp_path):
+    """require / dofile / loadfile / load (the reference opens the whole Lua library; paths are relative to the working directory or follow
+    package.path); a callback may call into a required module: its functions are known when the kernel is generated"""
+    (tmp_path / "helpers.lua").write_text("local M = {}\nfunction M.double(x) return 2 * x end\nM.name = ...\nreturn M\n")
+    (tmp_path / "sets_global.lua").write_text("shared_value = 41\nreturn 7, 8\n")
+    body = r'''
+package.path = "%s/?.lua;" .. package.path
+local h = require "helpers"
+print(h.double(21), h.name, require("helpers") == h, package.loaded.helpers == h)
+print(dofile("%s/sets_global.lua"), shared_value)
+print(loadfile("%s/nosuch.lua"))
+local g = load("return 1 + 1, ...", "=inline") print(g(5))
+print((load("return +")))
+print((pcall(require, "missing.mod")))
+io.write("a", 1, "b\n")
+print(type(os.time()), type(os.clock()), os.getenv("NO_SUCH_VARIABLE_X"))
+function lens_inverse(x, y) return h.double(x), y, 1 end
+''' % ((str(tmp_path),) * 3)
+    ctx = lens_ctx(bk, body)
+    assert ctx.console() == ("42\thelpers\ttrue\ttrue\n7\t41\nnil\tcannot open %s/nosuch.lua\n2\t5\nnil\nfalse\na1b\nnumber\tnumber\tnil\n" % tmp_path)
+    assert ctx.eval_host(0, 0.25, 0.5) == (0.5, 0.5, 1.0)
+    ctx.resize(64, 48)
+    assert "bk_mul" in ctx.kernel_source(compile=False)
