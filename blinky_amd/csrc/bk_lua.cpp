@@ -899,9 +899,47 @@ struct Exec {
         return false;
     }
 
+    // ---- metatables (lvm.c / ltm.c): only reached where a plain value would have produced nil or an error --------------------
+    static Value metamethod(const Value &v, const char *event)
+    {
+        if (v.t == Value::TABLE && v.tab()->meta) return v.tab()->meta->get(Value::string(event));
+        return Value();
+    }
+    static bool callable(const Value &v) { return v.is_function() || metamethod(v, "__call").is_function(); }
+    // a binary metamethod of the first operand, else of the second; false if neither has one
+    bool binary_meta(const Value &a, const Value &b, const char *event, Value *out)
+    {
+        Value h = metamethod(a, event);
+        if (h.t == Value::NIL) h = metamethod(b, event);
+        if (h.t == Value::NIL) return false;
+        Values r = I.call(h, Values{a, b});
+        *out = r.empty() ? Value() : r[0];
+        return true;
+    }
+    void set_index(Frame &f, const Expr &target, const Value &o, const Value &k, const Value &v, int depth = 0)
+    {
+        if (o.t != Value::TABLE) error(target.line, chunk_of(f), std::string("attempt to index a ") + o.type_name() + " value");
+        Table &t = *o.tab();
+        if (t.meta && t.get(k).t == Value::NIL) {
+            Value h = t.meta->get(Value::string("__newindex"));
+            if (h.is_function()) { I.call(h, Values{o, k, v}); return; }
+            if (h.t != Value::NIL) {
+                if (depth > 100) error(target.line, chunk_of(f), "loop in settable");
+                set_index(f, target, h, k, v, depth + 1);
+                return;
+            }
+        }
+        try { t.set(k, v); } catch (LuaError &err) { error(target.line, chunk_of(f), err.what()); }
+    }
+
     Value arith(Frame &f, const Expr &e, const std::string &op, const Value &a, const Value &b)
     {
         double x, y;
+        if (!tonumber(a, &x) || !tonumber(b, &y)) {
+            const char *event = op[0] == '+' ? "__add" : op[0] == '-' ? "__sub" : op[0] == '*' ? "__mul" : op[0] == '/' ? "__div" : op[0] == '%' ? "__mod" : "__pow";
+            Value out;
+            if (binary_meta(a, b, event, &out)) return out;
+        }
         if (!tonumber(a, &x)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + a.type_name() + " value");
         if (!tonumber(b, &y)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + b.type_name() + " value");
         switch (op[0]) {
@@ -929,12 +967,26 @@ struct Exec {
     {
         if (a.t == Value::NUM && b.t == Value::NUM) return or_equal ? a.n <= b.n : a.n < b.n;
         if (a.t == Value::STR && b.t == Value::STR) return or_equal ? a.str() <= b.str() : a.str() < b.str();
+        Value out;
+        if (binary_meta(a, b, or_equal ? "__le" : "__lt", &out)) return out.truthy();
+        if (or_equal && binary_meta(b, a, "__lt", &out)) return !out.truthy();          // a <= b as not (b < a), lvm.c:luaV_lessequal
         error(e.line, chunk_of(f), std::string("attempt to compare ") + a.type_name() + " with " + b.type_name());
     }
 
     Value index(Frame &f, const Expr &e, const Value &obj, const Value &key)
     {
-        if (obj.t == Value::TABLE) return obj.tab()->get(key);
+        if (obj.t == Value::TABLE) {
+            Value v = obj.tab()->get(key);
+            if (v.t != Value::NIL || !obj.tab()->meta) return v;
+            Value h = obj.tab()->meta->get(Value::string("__index"));
+            if (h.t == Value::NIL) return v;
+            if (h.is_function()) { Values r = I.call(h, Values{obj, key}); return r.empty() ? Value() : r[0]; }
+            if (++I.depth > 180) { --I.depth; error(e.line, chunk_of(f), "loop in gettable"); }
+            Value out;
+            try { out = index(f, e, h, key); } catch (...) { --I.depth; throw; }
+            --I.depth;
+            return out;
+        }
         if (obj.t == Value::STR) {                               // strings index the string library (("x"):len(), s:sub(1, 2))
             Value lib = I.get_global("string");
             if (lib.t == Value::TABLE) return lib.tab()->get(key);
@@ -1016,12 +1068,20 @@ struct Exec {
             if (e.op == Expr::OP_NOT) return Value::boolean(!a.truthy());
             if (e.op == Expr::OP_NEG) {
                 double x;
-                if (!tonumber(a, &x)) error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + a.type_name() + " value");
+                if (!tonumber(a, &x)) {
+                    Value out;
+                    if (binary_meta(a, a, "__unm", &out)) return out;
+                    error(e.line, chunk_of(f), std::string("attempt to perform arithmetic on a ") + a.type_name() + " value");
+                }
                 return Value::number(-x);
             }
             if (e.op == Expr::OP_LEN) {
                 if (a.t == Value::STR) return Value::number((double)a.str().size());
-                if (a.t == Value::TABLE) return Value::number((double)a.tab()->length());
+                if (a.t == Value::TABLE) {
+                    Value h = metamethod(a, "__len");
+                    if (h.t != Value::NIL) { Values r = I.call(h, Values{a}); return r.empty() ? Value() : r[0]; }
+                    return Value::number((double)a.tab()->length());
+                }
                 error(e.line, chunk_of(f), std::string("attempt to get length of a ") + a.type_name() + " value");
             }
             error(e.line, chunk_of(f), "bad unary operator");
@@ -1047,13 +1107,21 @@ struct Exec {
                 default: break;
                 }
             }
-            if (e.op == Expr::OP_EQ) return Value::boolean(raw_equal(a, b));
-            if (e.op == Expr::OP_NE) return Value::boolean(!raw_equal(a, b));
+            if (e.op == Expr::OP_EQ || e.op == Expr::OP_NE) {
+                bool eq = raw_equal(a, b);
+                if (!eq && a.t == Value::TABLE && b.t == Value::TABLE) {            // two different tables with the same __eq handler
+                    Value h = metamethod(a, "__eq");
+                    if (h.t != Value::NIL && raw_equal(h, metamethod(b, "__eq"))) { Values r = I.call(h, Values{a, b}); eq = !r.empty() && r[0].truthy(); }
+                }
+                return Value::boolean(e.op == Expr::OP_EQ ? eq : !eq);
+            }
             if (e.op == Expr::OP_LT) return Value::boolean(less(f, e, a, b, false));
             if (e.op == Expr::OP_LE) return Value::boolean(less(f, e, a, b, true));
             if (e.op == Expr::OP_GT) return Value::boolean(less(f, e, b, a, false));
             if (e.op == Expr::OP_GE) return Value::boolean(less(f, e, b, a, true));
             if (e.op == Expr::OP_CONCAT) {
+                Value out;
+                if (((a.t != Value::STR && a.t != Value::NUM) || (b.t != Value::STR && b.t != Value::NUM)) && binary_meta(a, b, "__concat", &out)) return out;
                 if ((a.t != Value::STR && a.t != Value::NUM) || (b.t != Value::STR && b.t != Value::NUM))
                     error(e.line, chunk_of(f), std::string("attempt to concatenate a ") + (a.t != Value::STR && a.t != Value::NUM ? a : b).type_name() + " value");
                 return Value::string(I.tostring(a) + I.tostring(b));
@@ -1122,7 +1190,7 @@ struct Exec {
     {
         Value obj = eval(f, *e.a);
         Value fn = index(f, e, obj, Value::string(e.str));
-        if (!fn.is_function()) error(e.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value (method '" + e.str + "')");
+        if (!callable(fn)) error(e.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value (method '" + e.str + "')");
         Values args;
         args.push_back(std::move(obj));
         Values rest = eval_list(f, e.args);
@@ -1143,7 +1211,7 @@ struct Exec {
             if (call_direct(f, e, fn, &r)) return r.empty() ? Value() : std::move(r[0]);
         }
         if (args.empty()) args = eval_list(f, e.args);
-        if (!fn.is_function()) not_callable(f, e, fn);
+        if (!callable(fn)) not_callable(f, e, fn);
         if (fn.t == Value::BUILTIN) note_call_site(f, e);
         Values r = I.call(fn, args);
         return r.empty() ? Value() : std::move(r[0]);
@@ -1163,7 +1231,7 @@ struct Exec {
             if (call_direct(f, e, fn, &r)) return r;
         }
         if (args.empty()) args = eval_list(f, e.args);
-        if (!fn.is_function()) not_callable(f, e, fn);
+        if (!callable(fn)) not_callable(f, e, fn);
         if (fn.t == Value::BUILTIN) note_call_site(f, e);
         return I.call(fn, args);
     }
@@ -1178,8 +1246,7 @@ struct Exec {
         }
         Value o = eval(f, *target.a);
         Value k = eval(f, *target.b);
-        if (o.t != Value::TABLE) error(target.line, chunk_of(f), std::string("attempt to index a ") + o.type_name() + " value");
-        try { o.tab()->set(k, v); } catch (LuaError &err) { error(target.line, chunk_of(f), err.what()); }
+        set_index(f, target, o, k, v);
     }
 
     void tick(Frame &f, int line)
@@ -1265,7 +1332,7 @@ struct Exec {
             Value fn = init[0], st = init[1], ctl = init[2];
             for (;;) {
                 tick(f, s.line);
-                if (!fn.is_function()) error(s.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value");
+                if (!callable(fn)) error(s.line, chunk_of(f), std::string("attempt to call a ") + fn.type_name() + " value");
                 Values r = I.call(fn, Values{st, ctl});
                 if (r.empty() || r[0].t == Value::NIL) break;
                 ctl = r[0];
@@ -1351,6 +1418,7 @@ struct Cloner {
         for (const Value &x : t->arr) n->arr.push_back(value(x));
         for (const auto &kv : t->nhash) n->nhash[kv.first] = value(kv.second);
         for (const auto &kv : t->shash) n->shash[kv.first] = value(kv.second);
+        n->meta = table(t->meta);
         return n;
     }
     std::shared_ptr<Closure> closure(const std::shared_ptr<Closure> &c)
@@ -1397,7 +1465,17 @@ std::string Interp::tostring(const Value &v) const
     case Value::BOOL: return v.b ? "true" : "false";
     case Value::NUM: snprintf(buf, sizeof buf, "%.14g", v.n); return buf;     // LUA_NUMBER_FMT
     case Value::STR: return v.str();
-    case Value::TABLE: snprintf(buf, sizeof buf, "table: %p", (void *)v.tab()); return buf;
+    case Value::TABLE:
+        if (v.tab()->meta) {
+            Value h = v.tab()->meta->get(Value::string("__tostring"));
+            if (h.is_function()) {
+                Values r = const_cast<Interp *>(this)->call(h, Values{v});
+                if (r.empty() || r[0].t != Value::STR) throw LuaError("'__tostring' must return a string");
+                return r[0].str();
+            }
+        }
+        snprintf(buf, sizeof buf, "table: %p", (void *)v.tab());
+        return buf;
     case Value::FUNC: snprintf(buf, sizeof buf, "function: %p", (void *)v.fn()); return buf;
     default: return "function: builtin: " + v.bi()->name;
     }
@@ -1409,6 +1487,15 @@ Values Interp::call(const Value &fv, const Values &args)
         Values rets;
         fv.bi()->fn(*this, args, rets);
         return rets;
+    }
+    if (fv.t == Value::TABLE && fv.tab()->meta) {                   // __call: the table itself becomes the first argument
+        Value h = fv.tab()->meta->get(Value::string("__call"));
+        if (h.is_function()) {
+            Values with_self;
+            with_self.push_back(fv);
+            with_self.append(args.begin(), args.end());
+            return call(h, with_self);
+        }
     }
     if (fv.t != Value::FUNC) throw LuaError(std::string("attempt to call a ") + fv.type_name() + " value");
     if (depth > 180) throw LuaError("stack overflow (recursion too deep)");
@@ -1446,6 +1533,204 @@ void Interp::run(const std::string &src, const std::string &chunkname)
     f.p = std::move(cl);
     call(f, Values());
 }
+
+
+// ---- Lua patterns (manual 6.4.1): character classes, sets, the four quantifiers, anchors, captures and position captures,
+// %b, %f and back-references.  A recursive matcher over (subject position, pattern position), written from the manual's rules.
+namespace {
+struct PatternMatch {
+    const std::string &s, &p;
+    struct Cap { size_t start; long len; };          // len -1: still open, -2: position capture
+    std::vector<Cap> caps;
+    int depth = 0;
+    PatternMatch(const std::string &subject, const std::string &pattern) : s(subject), p(pattern) {}
+
+    [[noreturn]] static void bad(const char *what) { throw LuaError(std::string("malformed pattern (") + what + ")"); }
+    static bool class_matches(unsigned char c, unsigned char cl)
+    {
+        bool r;
+        switch (tolower(cl)) {
+        case 'a': r = isalpha(c) != 0; break;
+        case 'c': r = iscntrl(c) != 0; break;
+        case 'd': r = isdigit(c) != 0; break;
+        case 'g': r = isgraph(c) != 0; break;
+        case 'l': r = islower(c) != 0; break;
+        case 'p': r = ispunct(c) != 0; break;
+        case 's': r = isspace(c) != 0; break;
+        case 'u': r = isupper(c) != 0; break;
+        case 'w': r = isalnum(c) != 0; break;
+        case 'x': r = isxdigit(c) != 0; break;
+        default: return cl == c;                     // %<punctuation>: that character itself
+        }
+        return isupper(cl) ? !r : r;
+    }
+    // end of the single-character item that starts at pattern position pi
+    size_t item_end(size_t pi) const
+    {
+        if (pi >= p.size()) bad("ends unexpectedly");
+        const char c = p[pi++];
+        if (c == '%') {
+            if (pi >= p.size()) bad("ends with '%'");
+            return pi + 1;
+        }
+        if (c == '[') {
+            if (pi < p.size() && p[pi] == '^') ++pi;
+            for (bool first = true;; first = false) {      // the first character after [ or [^ belongs to the set, even a ']'
+                if (pi >= p.size()) bad("missing ']'");
+                const char k = p[pi++];
+                if (k == ']' && !first) return pi;
+                if (k == '%') { if (pi >= p.size()) bad("missing ']'"); ++pi; }
+            }
+        }
+        return pi;
+    }
+    bool set_matches(unsigned char c, size_t pi, size_t end) const        // p[pi] == '[', p[end - 1] == ']'
+    {
+        bool negate = false;
+        ++pi;
+        if (p[pi] == '^') { negate = true; ++pi; }
+        const size_t last = end - 1;
+        while (pi < last) {
+            if (p[pi] == '%' && pi + 1 < last) { if (class_matches(c, (unsigned char)p[pi + 1])) return !negate; pi += 2; }
+            else if (pi + 2 < last && p[pi + 1] == '-') { if ((unsigned char)p[pi] <= c && c <= (unsigned char)p[pi + 2]) return !negate; pi += 3; }
+            else { if ((unsigned char)p[pi] == c) return !negate; ++pi; }
+        }
+        return negate;
+    }
+    bool single_matches(size_t si, size_t pi, size_t end) const
+    {
+        if (si >= s.size()) return false;
+        const unsigned char c = (unsigned char)s[si];
+        switch (p[pi]) {
+        case '.': return true;
+        case '%': return class_matches(c, (unsigned char)p[pi + 1]);
+        case '[': return set_matches(c, pi, end);
+        default: return (unsigned char)p[pi] == c;
+        }
+    }
+    static const size_t NO = (size_t)-1;
+    // the subject position after a match of p[pi..] at s[si..], or NO
+    size_t match(size_t si, size_t pi)
+    {
+        if (++depth > 200) { --depth; throw LuaError("pattern too complex"); }
+        struct Leave { int &d; ~Leave() { --d; } } leave{depth};
+        for (;;) {
+            if (pi >= p.size()) return si;
+            switch (p[pi]) {
+            case '(': {
+                const bool position = pi + 1 < p.size() && p[pi + 1] == ')';
+                caps.push_back({si, position ? -2 : -1});
+                const size_t r = match(si, pi + (position ? 2 : 1));
+                if (r == NO) caps.pop_back();
+                return r;
+            }
+            case ')': {
+                int open = -1;
+                for (int i = (int)caps.size() - 1; i >= 0; --i) if (caps[(size_t)i].len == -1) { open = i; break; }
+                if (open < 0) bad("invalid pattern capture");
+                caps[(size_t)open].len = (long)(si - caps[(size_t)open].start);
+                const size_t r = match(si, pi + 1);
+                if (r == NO) caps[(size_t)open].len = -1;
+                return r;
+            }
+            case '$':
+                if (pi + 1 == p.size()) return si == s.size() ? si : NO;
+                break;
+            case '%':
+                if (pi + 1 < p.size() && p[pi + 1] == 'b') {                       // %bxy: balanced
+                    if (pi + 3 >= p.size()) bad("missing arguments to '%b'");
+                    if (si >= s.size() || s[si] != p[pi + 2]) return NO;
+                    const char open = p[pi + 2], close = p[pi + 3];
+                    int level = 1;
+                    size_t k = si + 1;
+                    for (; k < s.size(); ++k) {
+                        if (s[k] == close) { if (--level == 0) break; }
+                        else if (s[k] == open) ++level;
+                    }
+                    if (k >= s.size()) return NO;
+                    si = k + 1;
+                    pi += 4;
+                    continue;
+                }
+                if (pi + 1 < p.size() && p[pi + 1] == 'f') {                       // %f[set]: frontier
+                    pi += 2;
+                    if (pi >= p.size() || p[pi] != '[') bad("missing '[' after '%f' in pattern");
+                    const size_t end = item_end(pi);
+                    const unsigned char before = si == 0 ? 0 : (unsigned char)s[si - 1], here = si < s.size() ? (unsigned char)s[si] : 0;
+                    if (set_matches(before, pi, end) || !set_matches(here, pi, end)) return NO;
+                    pi = end;
+                    continue;
+                }
+                if (pi + 1 < p.size() && isdigit((unsigned char)p[pi + 1])) {      // %1..%9: what that capture matched
+                    const int idx = p[pi + 1] - '1';
+                    if (idx < 0 || idx >= (int)caps.size() || caps[(size_t)idx].len < 0) bad("invalid capture index");
+                    const size_t len = (size_t)caps[(size_t)idx].len;
+                    if (s.size() - si < len || s.compare(si, len, s, caps[(size_t)idx].start, len) != 0) return NO;
+                    si += len;
+                    pi += 2;
+                    continue;
+                }
+                break;
+            default: break;
+            }
+            const size_t end = item_end(pi);
+            const char q = end < p.size() ? p[end] : '\0';
+            if (q == '?') {
+                if (single_matches(si, pi, end)) { const size_t r = match(si + 1, end + 1); if (r != NO) return r; }
+                pi = end + 1;
+                continue;
+            }
+            if (q == '+' || q == '*') {                                            // longest first
+                size_t n = 0;
+                while (single_matches(si + n, pi, end)) ++n;
+                if (q == '+' && n == 0) return NO;
+                for (size_t k = n + 1; k-- > (q == '+' ? 1u : 0u);) { const size_t r = match(si + k, end + 1); if (r != NO) return r; }
+                return NO;
+            }
+            if (q == '-') {                                                        // shortest first
+                for (;;) {
+                    const size_t r = match(si, end + 1);
+                    if (r != NO) return r;
+                    if (!single_matches(si, pi, end)) return NO;
+                    ++si;
+                }
+            }
+            if (!single_matches(si, pi, end)) return NO;
+            ++si;
+            pi = end;
+        }
+    }
+    // capture i of a finished match as a value (the whole match if the pattern has no captures and i == 0)
+    Value capture(size_t i, size_t start, size_t end) const
+    {
+        if (i >= caps.size()) {
+            if (i == 0) return Value::string(s.substr(start, end - start));
+            throw LuaError("invalid capture index");
+        }
+        if (caps[i].len == -2) return Value::number((double)caps[i].start + 1);
+        if (caps[i].len < 0) throw LuaError("unfinished capture");
+        return Value::string(s.substr(caps[i].start, (size_t)caps[i].len));
+    }
+    void push_captures(Values &r, size_t start, size_t end, bool whole_if_none) const
+    {
+        const size_t n = caps.empty() && whole_if_none ? 1 : caps.size();
+        for (size_t i = 0; i < n; ++i) r.push_back(capture(i, start, end));
+    }
+};
+
+// first match of `pat` in `subject` at or after `init` (0-based): (start, end) or false; `m` keeps the captures
+bool pattern_search(PatternMatch &m, size_t init, size_t *start, size_t *end)
+{
+    const bool anchored = !m.p.empty() && m.p[0] == '^';
+    for (size_t si = init; si <= m.s.size(); ++si) {
+        m.caps.clear();
+        const size_t e = m.match(si, anchored ? 1 : 0);
+        if (e != PatternMatch::NO) { *start = si; *end = e; return true; }
+        if (anchored) break;
+    }
+    return false;
+}
+}  // namespace
 
 // ---- standard library subset ----------------------------------------------------------------------------
 static double argnum(const Values &a, size_t i, const char *fn)
@@ -1657,6 +1942,24 @@ Interp::Interp(const MathLib &m) : math(&m)
             r.push_back(Value::string(e.what()));
         }
     });
+    register_builtin("setmetatable", [](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'setmetatable' (table expected)");
+        if (a.size() < 2 || (a[1].t != Value::NIL && a[1].t != Value::TABLE)) throw LuaError("bad argument #2 to 'setmetatable' (nil or table expected)");
+        Table &t = *a[0].tab();
+        if (t.meta && t.meta->get(Value::string("__metatable")).t != Value::NIL) throw LuaError("cannot change a protected metatable");
+        t.meta = a[1].t == Value::TABLE ? a[1].tab_ptr() : nullptr;
+        r.push_back(a[0]);
+    });
+    register_builtin("getmetatable", [](Interp &I, const Values &a, Values &r) {
+        if (!a.empty() && a[0].t == Value::TABLE && a[0].tab()->meta) {
+            Value guard = a[0].tab()->meta->get(Value::string("__metatable"));
+            r.push_back(guard.t != Value::NIL ? guard : Value::table(a[0].tab()->meta));
+        } else if (!a.empty() && a[0].t == Value::STR) {               // every string shares one: { __index = string }
+            Value mt = Value::table(std::make_shared<Table>());
+            mt.tab()->set(Value::string("__index"), I.get_global("string"));
+            r.push_back(mt);
+        } else r.push_back(Value());
+    });
     register_builtin("rawget", [](Interp &, const Values &a, Values &r) {
         if (a.size() < 2 || a[0].t != Value::TABLE) throw LuaError("bad argument #1 to 'rawget' (table expected)");
         r.push_back(a[0].tab()->get(a[1]));
@@ -1736,18 +2039,108 @@ Interp::Interp(const MathLib &m) : math(&m)
         }
         r.push_back(Value::string(out));
     });
-    register_builtin("string.find", [argstr, posrelat](Interp &, const Values &a, Values &r) {
-        const std::string s = argstr(a, 0, "find"), pat = argstr(a, 1, "find");
-        long init = posrelat(a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "find") : 1, s.size());
-        const bool plain = a.size() > 3 && a[3].truthy();
-        if (!plain && pat.find_first_of("^$*+?.([%-") != std::string::npos)
-            throw LuaError("string.find: patterns are not supported by this interpreter (pass plain = true for a substring search)");
+    // string.find / match share str_find_aux: init, plain search when asked for or when the pattern has no magic characters
+    auto find_or_match = [argstr, posrelat](const Values &a, Values &r, bool find) {
+        const char *fn = find ? "find" : "match";
+        const std::string s = argstr(a, 0, fn), pat = argstr(a, 1, fn);
+        long init = posrelat(a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, fn) : 1, s.size());
         if (init < 1) init = 1;
         if ((size_t)init > s.size() + 1) { r.push_back(Value()); return; }
-        const size_t at = s.find(pat, (size_t)init - 1);
-        if (at == std::string::npos) { r.push_back(Value()); return; }
-        r.push_back(Value::number((double)at + 1));
-        r.push_back(Value::number((double)(at + pat.size())));
+        if (find && ((a.size() > 3 && a[3].truthy()) || pat.find_first_of("^$*+?.([%-") == std::string::npos)) {
+            const size_t at = s.find(pat, (size_t)init - 1);
+            if (at == std::string::npos) { r.push_back(Value()); return; }
+            r.push_back(Value::number((double)at + 1));
+            r.push_back(Value::number((double)(at + pat.size())));
+            return;
+        }
+        PatternMatch m(s, pat);
+        size_t b = 0, e = 0;
+        if (!pattern_search(m, (size_t)init - 1, &b, &e)) { r.push_back(Value()); return; }
+        if (find) {
+            r.push_back(Value::number((double)b + 1));
+            r.push_back(Value::number((double)e));
+            m.push_captures(r, b, e, false);
+        } else m.push_captures(r, b, e, true);
+    };
+    register_builtin("string.find", [find_or_match](Interp &, const Values &a, Values &r) { find_or_match(a, r, true); });
+    register_builtin("string.match", [find_or_match](Interp &, const Values &a, Values &r) { find_or_match(a, r, false); });
+    register_builtin("string.gmatch", [argstr](Interp &I, const Values &a, Values &r) {
+        auto subject = std::make_shared<std::string>(argstr(a, 0, "gmatch"));
+        auto pattern = std::make_shared<std::string>(argstr(a, 1, "gmatch"));
+        auto pos = std::make_shared<size_t>(0);
+        Value iter;
+        iter.t = Value::BUILTIN;
+        auto bp = std::make_shared<Builtin>();
+        bp->name = "gmatch iterator";
+        bp->fn = [subject, pattern, pos](Interp &, const Values &, Values &out) {
+            while (*pos <= subject->size()) {
+                PatternMatch m(*subject, *pattern);
+                m.caps.clear();
+                const size_t e = m.match(*pos, 0);                 // (gmatch does not anchor: a '^' is a literal here, lstrlib.c)
+                if (e != PatternMatch::NO) {
+                    const size_t b = *pos;
+                    *pos = e == b ? e + 1 : e;                      // an empty match moves on by one
+                    m.push_captures(out, b, e, true);
+                    return;
+                }
+                ++*pos;
+            }
+            out.push_back(Value());
+        };
+        iter.p = std::move(bp);
+        (void)I;
+        r.push_back(iter);
+    });
+    register_builtin("string.gsub", [argstr](Interp &I, const Values &a, Values &r) {
+        const std::string s = argstr(a, 0, "gsub"), pat = argstr(a, 1, "gsub");
+        if (a.size() < 3 || !(a[2].t == Value::STR || a[2].t == Value::NUM || a[2].t == Value::TABLE || a[2].is_function()))
+            throw LuaError("bad argument #3 to 'gsub' (string/function/table expected)");
+        const Value &repl = a[2];
+        const double max_n = a.size() > 3 && a[3].t != Value::NIL ? argnum(a, 3, "gsub") : (double)s.size() + 1;
+        const bool anchored = !pat.empty() && pat[0] == '^';
+        std::string out;
+        size_t si = 0, n = 0;
+        while ((double)n < max_n) {
+            PatternMatch m(s, pat);
+            const size_t e = m.match(si, anchored ? 1 : 0);
+            if (e != PatternMatch::NO) {
+                ++n;
+                const Value whole = Value::string(s.substr(si, e - si));
+                Value with;
+                if (repl.t == Value::STR || repl.t == Value::NUM) {
+                    const std::string rs = I.tostring(repl);
+                    std::string built;
+                    for (size_t k = 0; k < rs.size(); ++k) {
+                        if (rs[k] != '%') { built += rs[k]; continue; }
+                        if (++k >= rs.size()) throw LuaError("invalid use of '%' in replacement string");
+                        if (rs[k] == '%') built += '%';
+                        else if (rs[k] == '0') built += whole.str();
+                        else if (isdigit((unsigned char)rs[k])) built += I.tostring(m.capture((size_t)(rs[k] - '1'), si, e));
+                        else throw LuaError("invalid use of '%' in replacement string");
+                    }
+                    with = Value::string(built);
+                } else {
+                    const Value key = m.capture(0, si, e);
+                    if (repl.t == Value::TABLE) with = repl.tab()->get(key);
+                    else {
+                        Values args;
+                        m.push_captures(args, si, e, true);
+                        Values res = I.call(repl, args);
+                        with = res.empty() ? Value() : res[0];
+                    }
+                }
+                if (!with.truthy()) out += whole.str();                            // false / nil: keep the match
+                else if (with.t == Value::STR || with.t == Value::NUM) out += I.tostring(with);
+                else throw LuaError(std::string("invalid replacement value (a ") + with.type_name() + ")");
+            }
+            if (e != PatternMatch::NO && e > si) si = e;
+            else if (si < s.size()) out += s[si++];
+            else break;
+            if (anchored) break;
+        }
+        if (si < s.size()) out += s.substr(si);
+        r.push_back(Value::string(out));
+        r.push_back(Value::number((double)n));
     });
     // str_format: one C conversion per directive, flags / width / precision as given (lstrlib.c:scanformat)
     register_builtin("string.format", [argstr](Interp &I, const Values &a, Values &r) {

@@ -210,6 +210,7 @@ struct Table {
     std::vector<Value> arr;                 // t[1..n]
     std::map<double, Value> nhash;          // other numeric keys
     std::map<std::string, Value> shash;
+    std::shared_ptr<Table> meta;            // setmetatable: consulted where a plain table would give nil or an error (host interpreter only)
     Value get(const Value &k) const;
     void set(const Value &k, const Value &v);
     size_t length() const { return arr.size(); }

@@ -630,3 +630,122 @@ function lens_inverse(x, y) return h.double(x), y, 1 end
     assert ctx.eval_host(0, 0.25, 0.5) == (0.5, 0.5, 1.0)
     ctx.resize(64, 48)
     assert "bk_mul" in ctx.kernel_source(compile=False)
+
+
+METATABLES = r'''
+local Vec = {}
+Vec.__index = Vec
+local function vec(x, y) return setmetatable({x = x, y = y}, Vec) end
+function Vec.__add(a, b) return vec(a.x + b.x, a.y + b.y) end
+function Vec.__sub(a, b) return vec(a.x - b.x, a.y - b.y) end
+function Vec.__mul(a, b) if type(a) == "number" then return vec(a * b.x, a * b.y) elseif type(b) == "number" then return vec(a.x * b, a.y * b) end return a.x * b.x + a.y * b.y end
+function Vec.__div(a, k) return vec(a.x / k, a.y / k) end
+function Vec.__unm(a) return vec(-a.x, -a.y) end
+function Vec.__eq(a, b) return a.x == b.x and a.y == b.y end
+function Vec.__lt(a, b) return a:len2() < b:len2() end
+function Vec.__le(a, b) return a:len2() <= b:len2() end
+function Vec.__len(a) return 2 end
+function Vec.__concat(a, b) return tostring(a) .. "&" .. tostring(b) end
+function Vec.__tostring(a) return "(" .. a.x .. "," .. a.y .. ")" end
+function Vec.__call(a, k) return a.x * k + a.y end
+function Vec:len2() return self.x * self.x + self.y * self.y end
+local a, b = vec(1, 2), vec(3, 4)
+print(tostring(a + b), tostring(a - b), a * b, tostring(2 * a), tostring(a * 2), tostring(b / 2), tostring(-a))
+print(a == vec(1, 2), a ~= b, a == b, a < b, a <= b, a > b, a >= b, #a, a .. b, a(10))
+print(getmetatable(a) == Vec, rawequal(a, vec(1, 2)), a:len2(), getmetatable("x").__index == string)
+-- __index / __newindex as functions and tables, inheritance chain
+local Base = {greet = function() return "base" end}
+local Mid = setmetatable({}, {__index = Base})
+local obj = setmetatable({}, {__index = Mid})
+print(obj.greet(), obj.nothing, rawget(obj, "greet"))
+local log = {}
+local proxy = setmetatable({}, {__index = function(t, k) return k .. "!" end, __newindex = function(t, k, v) rawset(log, #log + 1, k .. "=" .. tostring(v)) end})
+proxy.a = 1 proxy.b = 2
+print(proxy.zzz, table.concat(log, ","), rawget(proxy, "a"))
+local store = {}
+local fwd = setmetatable({}, {__newindex = store})
+fwd.k = 5 print(rawget(fwd, "k"), store.k)
+local locked = setmetatable({}, {__metatable = "locked"})
+print(getmetatable(locked), pcall(setmetatable, locked, {}))
+print(pcall(function() return {} + 1 end))
+print(pcall(function() return {} < {} end))
+lens_width = (a + b).x
+function lens_inverse(x, y) return x, y, 1 end
+'''
+METATABLES_OUTPUT = """(4,6)\t(-2,-2)\t11\t(2,4)\t(2,4)\t(1.5,2)\t(-1,-2)
+true\ttrue\tfalse\ttrue\ttrue\tfalse\tfalse\t2\t(1,2)&(3,4)\t12
+true\tfalse\t5\ttrue
+base\tnil\tnil
+zzz!\ta=1,b=2\tnil
+nil\t5
+locked\tfalse\tcannot change a protected metatable
+false\tmeta.lua:36: attempt to perform arithmetic on a table value
+false\tmeta.lua:37: attempt to compare table with table
+"""
+
+
+def test_metatables_on_the_host(bk):
+    """setmetatable / getmetatable with __index / __newindex (functions and tables, chains), __call, the arithmetic, comparison, length,
+    concatenation and __tostring events, __metatable - for the part of a script that runs while it loads (lvm.c / ltm.c semantics)"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(METATABLES, "meta.lua")
+    assert ctx.console() == METATABLES_OUTPUT
+    assert ctx.lens_info().lens_width == 4.0
+
+
+PATTERNS = r'''
+print(string.find("hello world", "o w"), string.find("hello world", "l+"), string.find("hello", "xyz"), string.find("a.b", ".", 1, true))
+print(string.find("key = value", "(%w+)%s*=%s*(%w+)"))
+print(string.match("2026-09-24", "(%d+)-(%d+)-(%d+)"))
+print(string.match("  trim me  ", "^%s*(.-)%s*$") .. "|")
+print(string.match("hello", "()ll()"), string.match("abc", "%a+"), string.match("abc123", "%d+"), string.match("x", "y"))
+print(string.gsub("hello world", "o", "0"), string.gsub("hello", "l", "L", 1), string.gsub("abc", "%w", "%0%0"))
+print(string.gsub("hello world", "(%w+)", "<%1>"), string.gsub("a b c", "%s", ""))
+print(string.gsub("$name is $age", "%$(%w+)", {name = "Bob", age = 42}))
+print(string.gsub("1 2 3", "%d", function(d) return tostring(d * 2) end))
+print(string.gsub("abc", "", "-"))
+local words = {}
+for w in string.gmatch("one two  three", "%a+") do words[#words + 1] = w end
+print(#words, table.concat(words, ","))
+for k, v in string.gmatch("a=1, b=2", "(%w+)=(%w+)") do io.write(k, ":", v, ";") end print()
+print(string.find("f(a(b)c)d", "%b()"), string.match("THE (quick) fox", "%((%a+)%)"))
+print(string.gsub("THE (quick) fox", "%f[%a]%a+", "W"))
+print(string.match("x = 'it''s'", "'(.-)'"), string.match("aXb", "%u"), string.match("[tag]", "%[(.-)%]"), string.match("a-b", "[%w%-]+"))
+print(string.match("hello", "h(.)l"), string.match("hello", "^(h)(e)"), string.find("aaa", "a-", 2), string.match("abcabc", "(abc)%1"))
+print(pcall(string.find, "a", "[a"), pcall(string.match, "a", "%"))
+print(("%5.1f"):format(3.14159), ("x"):rep(3), ("a,b,c"):gsub(",", ";"))
+print(string.match("0x1F", "^0[xX](%x+)$"), string.match("3.5e10", "^[+-]?%d+%.?%d*[eE]?[+-]?%d*$"), string.match(" \t\n", "^%s+$") ~= nil, string.match("abc", "^[^%d]+$"))
+print(string.match("]", "[]]"), string.match("a^b", "[%^]"), string.match("a-z", "[a%-z]+"), string.find("abc", "b", -1), string.find("abc", "", 10))
+function lens_inverse(x, y) return x, y, 1 end
+'''
+PATTERNS_OUTPUT = """5\t3\tnil\t2\t2
+1\t11\tkey\tvalue
+2026\t09\t24
+trim me|
+3\tabc\t123\tnil
+hell0 w0rld\theLlo\taabbcc\t3
+<hello> <world>\tabc\t2
+Bob is 42\t2
+2 4 6\t3
+-a-b-c-\t4
+3\tone,two,three
+a:1;b:2;
+2\tquick
+W (W) W\t3
+it\tX\ttag\ta-b
+e\th\t2\tabc
+false\tfalse\tmalformed pattern (ends with '%')
+  3.1\txxx\ta;b;c\t2
+1F\t3.5e10\ttrue\tabc
+]\t^\ta-z\tnil\tnil
+"""
+
+
+def test_lua_patterns_on_the_host(bk):
+    """string.find / match / gmatch / gsub with Lua's patterns (manual 6.4.1: classes, sets, * + - ?, anchors, captures, position captures,
+    %b, %f, back-references; string / table / function replacements) - expected output as the manual defines it"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(PATTERNS, "pat.lua")
+    assert ctx.console() == PATTERNS_OUTPUT
