@@ -36,7 +36,9 @@ def test_debug_entry_points_live_in_their_own_header():
             if f.endswith((".cpp", ".hip", ".h")) and f != "bk_embed.cpp":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 for env in re.findall(r'getenv\("([A-Z_]+)"\)', txt):
-                    assert env in ("BLINKY_HIP_CACHE", "XDG_CACHE_HOME", "HOME", "BLINKY_HIP_FIXUP_THREADS", "BLINKY_HIP_COMM", "BLINKY_HIP_HOSTCXX", "PATH"), (f, env)
+                    # (LUA_PATH / LUA_PATH_5_2: where Lua's `require` looks, as the reference's VM reads them - loadlib.c)
+                    assert env in ("BLINKY_HIP_CACHE", "XDG_CACHE_HOME", "HOME", "BLINKY_HIP_FIXUP_THREADS", "BLINKY_HIP_COMM", "BLINKY_HIP_HOSTCXX", "PATH",
+                                   "LUA_PATH", "LUA_PATH_5_2"), (f, env)
 
 
 def test_library_exports_every_declared_symbol():
