@@ -775,6 +775,7 @@ struct Emitter {
             return;
         }
         case Stmt::Break: line(f, "break;"); return;
+        case Stmt::Goto: case Stmt::Label: unsupported(f.chunk, s.line, "goto");
         }
     }
 

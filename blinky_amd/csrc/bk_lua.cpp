@@ -752,8 +752,15 @@ struct Parser {
         }
         case T_RETURN: error("'return' must be the last statement of a block");
         case T_BREAK: { StmtP s = mks(Stmt::Break); advance(); return s; }
-        case T_GOTO: error("goto is not supported");
-        case T_DBCOLON: error("labels are not supported");
+        case T_GOTO: { StmtP s = mks(Stmt::Goto); advance(); s->names.push_back(expect_name()); return s; }
+        case T_DBCOLON: {
+            StmtP s = mks(Stmt::Label);
+            advance();
+            s->names.push_back(expect_name());
+            if (tok.t != T_DBCOLON) error("'::' expected");
+            advance();
+            return s;
+        }
         default: break;
         }
         // expression statement: call or assignment
@@ -870,7 +877,7 @@ struct Frame {
     Values varargs;
 };
 
-enum Flow { F_NORMAL, F_BREAK, F_RETURN };
+enum Flow { F_NORMAL, F_BREAK, F_RETURN, F_GOTO };
 
 struct Exec {
     Interp &I;
@@ -1180,7 +1187,7 @@ struct Exec {
             if ((int)i < p->nparams) fr.regs[i] = std::move(v);
         }
         ++I.depth;
-        try { exec_block(fr, p->body, *rets); } catch (...) { --I.depth; throw; }
+        try { if (exec_block(fr, p->body, *rets) == F_GOTO) throw LuaError(chunk_of(fr) + ": no visible label '" + I.goto_label + "' for goto"); } catch (...) { --I.depth; throw; }
         --I.depth;
         return true;
     }
@@ -1256,9 +1263,21 @@ struct Exec {
 
     Flow exec_block(Frame &f, const Block &b, Values &ret)
     {
-        for (const StmtP &sp : b) {
-            Flow fl = exec(f, *sp, ret);
+        for (size_t i = 0; i < b.size();) {
+            Flow fl = exec(f, *b[i], ret);
+            if (fl == F_GOTO) {
+                // a goto continues after its label in the nearest enclosing block that has it (checked as the jump happens, where the
+                // reference's compiler checks while parsing); loops and blocks in between are left
+                size_t at = b.size();
+                for (size_t k = 0; k < b.size(); ++k)
+                    if (b[k]->kind == Stmt::Label && b[k]->names[0] == I.goto_label) { at = k; break; }
+                if (at == b.size()) return F_GOTO;
+                tick(f, b[at]->line);
+                i = at + 1;
+                continue;
+            }
             if (fl != F_NORMAL) return fl;
+            ++i;
         }
         return F_NORMAL;
     }
@@ -1292,7 +1311,7 @@ struct Exec {
                 tick(f, s.line);
                 Flow fl = exec_block(f, s.body, ret);
                 if (fl == F_BREAK) break;
-                if (fl == F_RETURN) return fl;
+                if (fl == F_RETURN || fl == F_GOTO) return fl;
             }
             return F_NORMAL;
         case Stmt::Repeat:
@@ -1300,7 +1319,7 @@ struct Exec {
                 tick(f, s.line);
                 Flow fl = exec_block(f, s.body, ret);
                 if (fl == F_BREAK) break;
-                if (fl == F_RETURN) return fl;
+                if (fl == F_RETURN || fl == F_GOTO) return fl;
                 if (eval(f, *s.cond).truthy()) break;
             }
             return F_NORMAL;
@@ -1322,7 +1341,7 @@ struct Exec {
                 fresh_local(f, s.slots[0], Value::number(idx));
                 Flow fl = exec_block(f, s.body, ret);
                 if (fl == F_BREAK) break;
-                if (fl == F_RETURN) return fl;
+                if (fl == F_RETURN || fl == F_GOTO) return fl;
             }
             return F_NORMAL;
         }
@@ -1340,12 +1359,14 @@ struct Exec {
                     fresh_local(f, s.slots[i], i < r.size() ? r[i] : Value());
                 Flow fl = exec_block(f, s.body, ret);
                 if (fl == F_BREAK) break;
-                if (fl == F_RETURN) return fl;
+                if (fl == F_RETURN || fl == F_GOTO) return fl;
             }
             return F_NORMAL;
         }
         case Stmt::Return: ret = eval_list(f, s.exprs); return F_RETURN;
         case Stmt::Break: return F_BREAK;
+        case Stmt::Goto: I.goto_label = s.names[0]; return F_GOTO;
+        case Stmt::Label: return F_NORMAL;
         }
         return F_NORMAL;
     }
@@ -1516,7 +1537,7 @@ Values Interp::call(const Value &fv, const Values &args)
     Exec ex(*this);
     ++depth;
     try {
-        ex.exec_block(fr, p->body, ret);
+        if (ex.exec_block(fr, p->body, ret) == F_GOTO) throw LuaError(fr.cl->chunk->name + ": no visible label '" + goto_label + "' for goto");
     } catch (...) { --depth; throw; }
     --depth;
     return ret;

@@ -68,7 +68,7 @@ struct Expr {
 };
 
 struct Stmt {
-    enum Kind { Local, Assign, CallStmt, Do, While, Repeat, If, NumFor, GenFor, Return, Break, LocalFunction } kind;
+    enum Kind { Local, Assign, CallStmt, Do, While, Repeat, If, NumFor, GenFor, Return, Break, LocalFunction, Goto, Label } kind;   // (Goto / Label: names[0])
     int line = 0;
     std::vector<int> slots;               // Local / NumFor(var) / GenFor(vars) / LocalFunction
     std::vector<std::string> names;
@@ -237,6 +237,7 @@ struct Interp {
         return *p;
     }
     long steps = 0, max_steps = 200000000;  // runaway-script guard
+    std::string goto_label;                 // the label a `goto` under way is looking for
     std::string call_site;                  // "chunk:line:" of the builtin call being made (error() puts it in front of its message)
     int depth = 0;
     std::function<void(const std::string &)> print_sink;   // `print` / io.write output, newlines included (Con_Printf)

@@ -749,3 +749,50 @@ def test_lua_patterns_on_the_host(bk):
     ctx.load_globe(S.script("globes", "cube"), "cube")
     ctx.load_lens(PATTERNS, "pat.lua")
     assert ctx.console() == PATTERNS_OUTPUT
+
+
+GOTO = r'''
+local out = {}
+for i = 1, 6 do
+   if i % 2 == 0 then goto continue end
+   out[#out + 1] = i
+   ::continue::
+end
+print(table.concat(out, ","))
+local n = 0
+::again::
+n = n + 1
+if n < 5 then goto again end
+print(n)
+for i = 1, 3 do
+   for j = 1, 3 do
+      if i * j == 4 then goto done end
+   end
+end
+::done::
+print("done")
+do
+   local k = 0
+   while true do
+      k = k + 1
+      if k > 3 then goto out end
+   end
+   ::out::
+   print(k)
+end
+print(pcall(function() goto nowhere end))
+function lens_inverse(x, y) return x, y, 1 end
+'''
+
+
+def test_goto_on_the_host(bk):
+    """goto / labels: the continue idiom, backward jumps, leaving nested loops, a label nobody declared; a GPU callback says it cannot"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(GOTO, "goto.lua")
+    assert ctx.console() == "1,3,5\n5\ndone\n4\nfalse\tgoto.lua: no visible label 'nowhere' for goto\n"
+    ctx = lens_ctx(bk, "function lens_inverse(x,y) for i=1,3 do if i==2 then goto cont end x=x+1 ::cont:: end return x,y,1 end")
+    assert ctx.eval_host(0, 0.0, 0.0) == (2.0, 0.0, 1.0)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match="goto"):
+        ctx.kernel_source(compile=False)
