@@ -54,7 +54,7 @@ struct FnInfo {
 
 struct Emitter {
     Interp &I;
-    std::map<const FuncProto *, FnInfo> fns;
+    std::map<std::pair<const FuncProto *, std::string>, FnInfo> fns;   // (a function once per set of function-valued arguments it is called with)
     std::vector<std::string> fn_code;                 // in dependency order
     std::set<std::string> mutable_globals;
     std::map<const Table *, std::pair<std::string, int>> const_tables;   // table -> (array name, n)
@@ -85,6 +85,8 @@ struct Emitter {
         std::map<int, int> array_slots;               // local slot -> capacity (array tables)
         std::map<int, std::string> fn_slots;          // local slot -> the lambda a `local function` / `local f = function` became
         std::set<int> fn_open;                        // ... whose body is being emitted right now (a call from inside is recursion)
+        std::map<int, Value> static_slots;            // local slot -> the script function / builtin it holds for its whole life
+                                                      // (a parameter bound at the call, `local f = math.sin`): calls resolve when the code is generated
         std::string lp = "l", ap = "A";               // names of locals / local arrays (functions defined inside others get their own)
         std::string chunk;
     };
@@ -126,6 +128,13 @@ struct Emitter {
     bool static_value(Fn &f, const Expr &e, Value *v)
     {
         if (e.kind == Expr::Name) {
+            int lslot = 0;
+            if (Fn *o = local_of(f, e, &lslot)) {
+                auto it = o->static_slots.find(lslot);
+                if (it == o->static_slots.end()) return false;
+                *v = it->second;
+                return true;
+            }
             if (e.var == VarKind::Global) {
                 if (mutable_globals.count(e.str)) return false;
                 *v = I.get_global(e.str);
@@ -147,6 +156,19 @@ struct Emitter {
         }
         return false;
     }
+
+    // is local `slot` of `p` ever the target of an assignment (a captured one: taken to be)?
+    static bool assigned_in(const Block &b, int slot)
+    {
+        for (const StmtP &sp : b) {
+            const Stmt &s = *sp;
+            for (auto &t : s.targets) if (t->kind == Expr::Name && t->var == VarKind::Local && t->slot == slot) return true;
+            if (assigned_in(s.body, slot)) return true;
+            for (auto &c : s.clauses) if (assigned_in(c.second, slot)) return true;
+        }
+        return false;
+    }
+    static bool slot_is_constant(const FuncProto *p, int slot) { return !p->is_captured(slot) && !assigned_in(p->body, slot); }
 
     // ---- pre-pass: which globals does device code assign? ------------------------------------
     void scan_closure(const Closure *cl, std::set<const FuncProto *> &seen)
@@ -267,6 +289,7 @@ struct Emitter {
             if (Fn *o = local_of(f, e, &slot)) {
                 if (o->array_slots.count(slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
                 if (o->fn_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (a function defined inside a callback can only be called)");
+                if (o->static_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (it can be called, and passed on to script functions)");
                 return o->lp + std::to_string(slot);
             }
             if (e.var == VarKind::Global && mutable_globals.count(e.str)) return "S.g_" + sanitize(e.str);
@@ -364,6 +387,12 @@ struct Emitter {
     };
     Args emit_args(Fn &f, const std::vector<ExprP> &list)
     {
+        std::vector<const Expr *> ptrs;
+        for (const ExprP &x : list) ptrs.push_back(x.get());
+        return emit_args(f, ptrs);
+    }
+    Args emit_args(Fn &f, const std::vector<const Expr *> &list)
+    {
         Args a;
         for (size_t i = 0; i < list.size(); ++i) {
             const Expr &x = *list[i];
@@ -436,8 +465,21 @@ struct Emitter {
         *arr = tmp("r");
         *cnt = tmp("n");
         if (callee.t == Value::FUNC) {
-            const FnInfo &fi = ensure_function(callee.fn(), e.line, f.chunk);
-            Args a = emit_args(f, e.args);
+            // arguments that are script functions / builtins known now are not values on the device: the callee is generated once
+            // more for this set of them, with the parameter standing for the function (its runtime argument is nil)
+            std::vector<std::pair<int, Value>> bound;
+            std::vector<const Expr *> plain;
+            static const Expr nil_expr = [] { Expr x; x.kind = Expr::Nil; return x; }();
+            for (size_t i = 0; i < e.args.size(); ++i) {
+                Value av;
+                const Expr &x = *e.args[i];
+                if ((int)i < callee.fn()->proto->nparams && (x.kind == Expr::Name || x.kind == Expr::Index) && static_value(f, x, &av) && av.is_function()) {
+                    bound.emplace_back((int)i, av);
+                    plain.push_back(&nil_expr);
+                } else plain.push_back(&x);
+            }
+            const FnInfo &fi = ensure_function(callee.fn(), e.line, f.chunk, bound);
+            Args a = emit_args(f, plain);
             auto packed = pack(f, a, 1);
             line(f, "bkv " + *arr + "[BK_MAXRET];");
             line(f, "const int " + *cnt + " = " + fi.cname + "(S, " + packed.first + ", " + packed.second + ", " + *arr + ");");
@@ -608,6 +650,14 @@ struct Emitter {
         switch (s.kind) {
         case Stmt::Local: {
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Function) { emit_local_function(f, s); return; }
+            if (s.slots.size() == 1 && s.exprs.size() == 1 && (s.exprs[0]->kind == Expr::Name || s.exprs[0]->kind == Expr::Index)) {
+                Value fv;                                              // `local s = math.sin`, `local g = helper`: a name for that function
+                if (static_value(f, *s.exprs[0], &fv) && fv.is_function()) {
+                    if (!slot_is_constant(f.proto, s.slots[0])) unsupported(f.chunk, s.line, "function '" + s.names[0] + "' used as a value (the local is assigned or captured later)");
+                    f.static_slots[s.slots[0]] = fv;
+                    return;
+                }
+            }
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table) {
                 const Expr &t = *s.exprs[0];
                 if (!t.fields.empty()) unsupported(f.chunk, s.line, "table constructors with named fields");
@@ -780,9 +830,15 @@ struct Emitter {
     }
 
     // ---- functions -------------------------------------------------------------------------------------
-    const FnInfo &ensure_function(const Closure *cl, int line_no, const std::string &from_chunk)
+    const FnInfo &ensure_function(const Closure *cl, int line_no, const std::string &from_chunk, const std::vector<std::pair<int, Value>> &bound = {})
     {
-        FnInfo &fi = fns[cl->proto];
+        std::string signature;
+        for (auto &b : bound) {
+            char id[48];
+            snprintf(id, sizeof id, "%d=%p;", b.first, b.second.p.get());
+            signature += id;
+        }
+        FnInfo &fi = fns[{cl->proto, signature}];
         if (fi.done) {
             if (fi.cl != cl) unsupported(from_chunk, line_no, "two closures of the same function body");
             return fi;
@@ -798,6 +854,11 @@ struct Emitter {
         f.proto = cl->proto;
         f.cl = cl;
         f.chunk = cl->chunk->name;
+        for (auto &b : bound) {
+            if (!slot_is_constant(cl->proto, b.first))
+                unsupported(from_chunk, line_no, "a function passed as '" + cl->proto->slot_names[(size_t)b.first] + "' of '" + cl->proto->name + "', which assigns or captures that parameter");
+            f.static_slots[b.first] = b.second;
+        }
         emit_block(f, cl->proto->body);
 
         std::ostringstream o;

@@ -544,9 +544,15 @@ def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monk
 def test_functions_defined_inside_a_callback_build_the_same_table_on_the_gpu(bk):
     """tests/test_frontend.py's pair of scripts - the same arithmetic written plainly and with local functions / closures / chunk
     locals as scratch - through the GPU build, and the second one through the one-scan host build as well"""
-    from test_frontend import NESTED_LENS, PLAIN_LENS
+    from test_frontend import INTEGRALS_HIGHER_ORDER, INTEGRALS_PLAIN, NESTED_LENS, PLAIN_LENS
+    _same_table_on_the_gpu(bk, ((PLAIN_LENS, 0), (NESTED_LENS, 0), (NESTED_LENS, 1)))
+    # ... and functions passed as arguments (the callee generated once per function it is handed)
+    _same_table_on_the_gpu(bk, ((INTEGRALS_PLAIN, 0), (INTEGRALS_HIGHER_ORDER, 0), (INTEGRALS_HIGHER_ORDER, 2)))
+
+
+def _same_table_on_the_gpu(bk, variants):
     tables = []
-    for body, sequential in ((PLAIN_LENS, 0), (NESTED_LENS, 0), (NESTED_LENS, 1)):
+    for body, sequential in variants:
         ctx = bk.Context()
         ctx.load_globe(S.script("globes", "cube"), "cube.lua")
         ctx.load_lens(body, "nested.lua")

@@ -796,3 +796,86 @@ def test_goto_on_the_host(bk):
     ctx.resize(64, 48)
     with pytest.raises(bk.BlinkyError, match="goto"):
         ctx.kernel_source(compile=False)
+
+
+# ---- functions passed to functions ---------------------------------------------------------------------------------------------------
+
+LENS_HEAD = '''
+max_fov = 360
+max_vfov = 180
+onload = "f_contain"
+lens_width = 2*pi
+lens_height = pi
+'''
+INTEGRALS_PLAIN = LENS_HEAD + '''
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   -- midpoint rule, 4 steps, of cos over [0, y] and of a quadratic over [0, x]
+   local h = y / 4
+   local lat = 0
+   for i = 1, 4 do lat = lat + cos((i - 0.5) * h) * h end
+   local g = x / 4
+   local lon = 0
+   for i = 1, 4 do local t = (i - 0.5) * g lon = lon + (1 + 0.01 * t * t) * g end
+   local s = sin(lat)
+   local c = cos(lat)
+   return c * sin(lon), s, c * cos(lon)
+end
+'''
+# the same arithmetic through a higher-order helper: script functions and builtins as arguments (passed on once more), a builtin
+# held in a table field, local names for builtins
+INTEGRALS_HIGHER_ORDER = LENS_HEAD + '''
+local function midpoint(f, a, b, n)
+   local h = (b - a) / n
+   local acc = 0
+   for i = 1, n do acc = acc + f(a + (i - 0.5) * h) * h end
+   return acc
+end
+local function quad(t) return 1 + 0.01 * t * t end
+local function integrate(g, b) return midpoint(g, 0, b, 4) end      -- passes its function parameter on
+local lib = {wave = math.cos}
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local lat = integrate(lib.wave, y)            -- a builtin held in a table field
+   local lon = integrate(quad, x)                -- a script function
+   local s_of = math.sin                         -- a local name for a builtin
+   local c_of = cos
+   local s = s_of(lat)
+   local c = c_of(lat)
+   return c * s_of(lon), s, c * c_of(lon)
+end
+'''
+
+
+def test_functions_passed_as_arguments_translate_to_the_same_table(bk):
+    """a function argument known when the code is generated is not a value on the device: the callee is generated once per set of them
+    (two `midpoint`s, two `integrate`s here); host emulation of both scripts gives the same table, hiprtc takes the code"""
+    from hostemu import emu
+    tables = []
+    for body in (INTEGRALS_PLAIN, INTEGRALS_HIGHER_ORDER):
+        ctx = lens_ctx(bk, body)
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(160, 100)
+        off, tin, flagged, err = emu.build_inverse(ctx)
+        assert err == 0
+        tables.append((off, tin, set(flagged.tolist())))
+        assert ctx.eval_host(0, 0.3, 0.2) == lens_ctx(bk, INTEGRALS_PLAIN).eval_host(0, 0.3, 0.2)
+    assert (tables[0][0] != 0xFFFFFFFF).sum() > 10000
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
+    assert tables[0][2] == tables[1][2]
+    src = ctx.kernel_source(compile=True)
+    assert src.count("_midpoint(BkState") == 2 and src.count("_integrate(BkState") == 2
+
+
+@pytest.mark.parametrize("body,message", [
+    ("local function ap(f, x) f = cos return f(x) end\nfunction lens_inverse(x,y) return ap(sin, x), y, 1 end", "assigns or captures that parameter"),
+    ("local function ap(f, x) return f end\nfunction lens_inverse(x,y) return ap(sin, x), y, 1 end", "used as a value"),
+    ("function lens_inverse(x,y) local f = sin f = cos return f(x), y, 1 end", "assigned or captured later"),
+    ("local ops = {sin, cos}\nfunction lens_inverse(x,y) local i = 1 if x > 0 then i = 2 end return ops[i](x), y, 1 end", "callee must be"),
+])
+def test_function_values_the_device_cannot_resolve_are_named(bk, body, message):
+    ctx = lens_ctx(bk, body)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match=message):
+        ctx.kernel_source(compile=False)
