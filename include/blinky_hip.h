@@ -79,7 +79,13 @@ int         bk_synchronize(bk_ctx *ctx);
  * replaces: LUA_load_globe (fisheye.c:1752-1875) and LUA_load_lens (1659-1750);
  * `src` is the text of <basedir>/lua-scripts/{globes,lenses}/<name>.lua.
  * One interpreter state lives in the context, so script globals leak between
- * loads exactly as in the reference (only the names of fisheye.c:1880-1903 are cleared). */
+ * loads exactly as in the reference (only the names of fisheye.c:1880-1903 are cleared).
+ * The language: what runs while a script LOADS (the chunk, what it calls) is Lua 5.2 without coroutines and without most of
+ * io / os (closures, varargs, metatables, goto, the string library with patterns, table.*, math.*, pcall / error,
+ * load / dofile / require relative to the working directory).  What the per-pixel CALLBACKS (lens_inverse, lens_forward,
+ * globe_plate and everything they call) may use is narrower - they become GPU code at bk_build: numbers, booleans, nil, string
+ * constants, local array tables, constant tables of the chunk, every control structure but goto, the math library, functions
+ * defined inside a callback, functions passed as arguments; bk_build names the construct it cannot take (BK_E_SCRIPT). */
 int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_clear_lens(bk_ctx *ctx);    /* lens.valid = false ("not a valid lens", fisheye.c:1080-1083) */
