@@ -67,6 +67,20 @@ static char *read_script(const char *kind, const char *name, size_t *len)
     return buf;
 }
 
+/* what the scripts print()ed while loading goes where the reference's Lua VM sends it: stdout (lbaselib.c luaB_print) */
+static void flush_script_output(void)
+{
+    static size_t shown;
+    const char *text = bk ? bk_script_console(bk) : "";
+    size_t n = strlen(text);
+    if (n < shown) shown = 0;
+    if (n > shown) {
+        fputs(text + shown, stdout);
+        fflush(stdout);
+        shown = n;
+    }
+}
+
 /* LUA_load_lens (fisheye.c:1659-1750) */
 static qboolean load_lens(void)
 {
@@ -79,6 +93,7 @@ static qboolean load_lens(void)
     snprintf(chunk, sizeof chunk, "%s.lua", lens.name);
     rc = DEV(bk_load_lens(bk, src, len, chunk), bk_multi_load_lens(mg, src, len, chunk));
     free(src);
+    flush_script_output();
     if (rc != BK_OK) { Con_Printf("%s\n", dev_error()); return false; }
     return true;
 }
@@ -96,6 +111,7 @@ static qboolean load_globe(void)
     snprintf(chunk, sizeof chunk, "%s.lua", globe.name);
     rc = DEV(bk_load_globe(bk, src, len, chunk), bk_multi_load_globe(mg, src, len, chunk));
     free(src);
+    flush_script_output();
     if (rc != BK_OK) { Con_Printf("%s\n", dev_error()); return false; }
     bk_get_globe(bk, plates, &numplates);
     return true;

@@ -138,6 +138,10 @@ void ref_script_run(lua_State *L, const char *path)
         ok_globe_def g;
         int i, j;
         if (!ok_find_globe(name, &g)) return;
+        if (!strcmp(name, "tetra")) {                        /* tetra.lua:19 print(fovd): luaB_print -> "%.14g" and a newline on stdout, flushed */
+            printf("%.14g\n", g.fov_deg[0]);
+            fflush(stdout);
+        }
         lua_createtable(L, g.numplates, 0);                  /* plates = { {fwd,up,fov}, ... } */
         for (i = 0; i < g.numplates; ++i) {
             lua_createtable(L, 3, 0);

@@ -30,7 +30,7 @@ CONNECT = ["host_framerate 0.05",      # every frame advances the game by the sa
            "map box"] + ["wait"] * 8
 
 
-def run_engine(binary, script, size=None, env_extra=None, timeout=600):
+def run_engine(binary, script, size=None, env_extra=None, timeout=600, prepare=None):
     """-> (stdout, [frame log lines], {file name: bytes of what the engine wrote into its game directory})"""
     # the reference formats script paths into fixed 100-byte buffers (fisheye.c:1665, 1758): a short game directory
     base = pathlib.Path(tempfile.mkdtemp(prefix="bq", dir="/tmp"))
@@ -38,6 +38,8 @@ def run_engine(binary, script, size=None, env_extra=None, timeout=600):
         shutil.copytree(GAME, base / "g")
         game = base / "g"
         (game / "id1" / "session.cfg").write_text("\n".join(script) + "\n")
+        if prepare:
+            prepare(game)
         # the engine writes (config.cfg, screenshots, plate images) into $HOME/.blinky/<game> (common/common.c:2045)
         env = dict(os.environ, HOME=str(base), BLINKY_HEADLESS_LOG=str(base / "frames.log"), BLINKY_HEADLESS_FRAMES="2000", BLINKY_HIP_SYNC_COMPILE="1")
         env.pop("BLINKY_HIP_DEVICES", None)
@@ -222,3 +224,23 @@ def test_random_sessions_in_the_real_engine_equal_the_reference(seed):
     assert sorted(hip_files) == sorted(ref_files), (seed, size)
     for name in ref_files:
         assert hip_files[name] == ref_files[name], (seed, size, name)
+
+
+@needs_engines
+@pytest.mark.ref
+def test_a_lens_that_requires_a_helper_file_loads_inside_the_engine():
+    """the script library's require / dofile resolve against the engine's working directory, like the reference's Lua (loadlib.c): a lens
+    next to the bundled ones that keeps its arithmetic in lua-scripts/lenses/shared/optics.lua"""
+    helper = "local M = {}\nfunction M.squash(v) return v / (1 + v * v) end\nprint('optics loaded')\nreturn M\n"
+    lens = ("local optics = require 'lua-scripts.lenses.shared.optics'\nmax_fov = 200\nmax_vfov = 200\nonload = 'f_fov 120'\n"
+            "function lens_inverse(x, y) return optics.squash(x), optics.squash(y), 1 end\n")
+
+    def add_files(game):
+        (game / "lua-scripts" / "lenses" / "shared").mkdir()
+        (game / "lua-scripts" / "lenses" / "shared" / "optics.lua").write_text(helper)
+        (game / "lua-scripts" / "lenses" / "with_helper.lua").write_text(lens)
+
+    out, _, _ = run_engine(TQ_HIP, ["f_lens with_helper", "f_lens", "f_fov", "toggleconsole", "quit"], env_extra={"BLINKY_HIP_DEVICE": "none"},
+                           prepare=add_files)
+    text = console_text(out)
+    assert "optics loaded" in text and "f_lens with_helper; f_fov 120" in text and "Currently: with_helper" in text and "Zoom currently: f_fov 120" in text

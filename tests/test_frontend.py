@@ -879,3 +879,16 @@ def test_function_values_the_device_cannot_resolve_are_named(bk, body, message):
     ctx.resize(64, 48)
     with pytest.raises(bk.BlinkyError, match=message):
         ctx.kernel_source(compile=False)
+
+
+def test_check_lens_tool(tmp_path):
+    """tools/check_lens.py: what a script author runs before trying a lens in the engine (no GPU needed)"""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_lens.py")
+    (tmp_path / "eckert4.lua").write_text(S.script("lenses", "eckert4"))
+    (tmp_path / "rec.lua").write_text("function lens_inverse(x,y) local function f(n) if n<1 then return 0 end return f(n-1) end return x,y,f(3) end")
+    ok = subprocess.run([sys.executable, tool, str(tmp_path / "eckert4.lua"), "--no-compile"], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "callbacks translate to GPU code" in ok.stdout and "carry state from pixel to pixel through 'lasty'" in ok.stdout
+    bad = subprocess.run([sys.executable, tool, str(tmp_path / "rec.lua")], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1 and "callbacks do NOT translate" in bad.stdout and "recursion ('f')" in bad.stdout

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Will this lens / globe script run with libblinkyhip?  Loads it on a context without a device (no GPU needed), reports what the
+host layer would see (map type, zoom limits, onload command), whether its per-pixel callbacks translate to GPU code - or which
+construct does not - whether hiprtc compiles the result for gfx950, and whether the callbacks carry state from
+pixel to pixel (bk_lens_carries_state: such a lens needs bk_set_sequential_build to look as it does in the reference).
+
+usage: tools/check_lens.py <lens.lua> [<globe.lua>] [--no-compile]
+"""
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if not args:
+        print(__doc__)
+        return 2
+    import blinky_amd as bk
+    import scripts as S
+    ctx = bk.Context(bk.ffi.DEVICE_NONE)
+    try:
+        if len(args) > 1:
+            ctx.load_globe(open(args[1]).read(), os.path.basename(args[1]))
+        else:
+            ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+        print("globe: %d plates" % len(ctx.globe()))
+        ctx.load_lens(open(args[0]).read(), os.path.basename(args[0]))
+    except bk.BlinkyError as e:
+        print("does not load:", e)
+        return 1
+    if ctx.console():
+        print("script output:\n" + ctx.console().rstrip())
+    info = ctx.lens_info()
+    kind = {bk.ffi.MAP_INVERSE: "inverse (lens_inverse per screen pixel)", bk.ffi.MAP_FORWARD: "forward (lens_forward per globe texel)"}.get(info.map_type, "none")
+    print("map: %s; max_fov %d, max_vfov %d, lens size %g x %g, onload %r" % (kind, info.max_fov, info.max_vfov, info.lens_width, info.lens_height,
+                                                                             info.onload.decode()))
+    if info.map_type not in (bk.ffi.MAP_INVERSE, bk.ffi.MAP_FORWARD):
+        print("no lens_inverse / lens_forward: nothing to build")
+        return 1
+    onload = info.onload.decode().split()
+    if onload and onload[0] in S.ZOOM_CMD:
+        ctx.set_zoom(S.ZOOM_CMD[onload[0]], int(float(onload[1])) if len(onload) > 1 else 0)
+    else:
+        ctx.set_zoom(S.ZOOM_CMD["f_fov"], 90)
+    ctx.resize(640, 480)
+    try:
+        scale = ctx.calc_zoom()
+        print("zoom at 640x480: scale %r" % (scale,))
+    except bk.BlinkyError as e:
+        print("zoom cannot be computed:", e)
+    try:
+        src = ctx.kernel_source(compile="--no-compile" not in sys.argv)
+        print("callbacks translate to GPU code (%d lines)%s" % (src.count("\n"), "" if "--no-compile" in sys.argv else " and compile for gfx950"))
+    except bk.BlinkyError as e:
+        print("callbacks do NOT translate:", e)
+        return 1
+    carries, which = ctx.lens_carries_state()
+    if carries:
+        print("callbacks carry state from pixel to pixel through '%s': on the GPU every pixel starts from the value after load;"
+              " bk_set_sequential_build(ctx, 1) builds such a lens in the reference's scan order on the host" % which)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
