@@ -335,6 +335,11 @@ struct Emitter {
                 int aslot = 0;
                 Fn *ao = local_of(f, *e.a, &aslot);
                 if (ao && ao->array_slots.count(aslot)) return num_literal((double)ao->array_slots[aslot]);
+                Value sv;                                    // a constant table of the chunk (device code cannot store into one), a string constant
+                if (static_value(f, *e.a, &sv) && sv.t == Value::TABLE && sv.tab()->nhash.empty() && sv.tab()->shash.empty() && !sv.tab()->meta)
+                    return num_literal((double)sv.tab()->length());
+                if (static_value(f, *e.a, &sv) && sv.t == Value::STR) return num_literal((double)sv.str().size());
+                if (e.a->kind == Expr::String) return num_literal((double)e.a->str.size());
                 unsupported(f.chunk, e.line, "the length operator on this expression");
             }
             std::string a = emit_expr(f, *e.a), t = tmp();

@@ -3,6 +3,7 @@
 
 #include <mutex>
 
+#include <cerrno>
 #include <cmath>
 #include <ctime>
 #include <cstdio>
@@ -1937,6 +1938,103 @@ Interp::Interp(const MathLib &m) : math(&m)
     register_builtin("os.getenv", [](Interp &, const Values &a, Values &r) {
         const char *v = !a.empty() && a[0].t == Value::STR ? getenv(a[0].str().c_str()) : nullptr;
         r.push_back(v ? Value::string(v) : Value());
+    });
+    // io.open / io.lines and the file methods read / lines / write / close (liolib.c): enough for a script that reads a table of
+    // numbers - a measured lens profile - while it loads.  A file object is a table of its methods over one shared FILE.
+    struct FileBox { FILE *f = nullptr; ~FileBox() { if (f) fclose(f); } };
+    auto read_one = [](FileBox &fb, const Value &fmt, Values &r) -> bool {       // one format of file:read; false at end of file
+        if (!fb.f) throw LuaError("attempt to use a closed file");
+        if (fmt.t == Value::NUM) {
+            std::string out((size_t)fmt.n, '\0');
+            const size_t got = fread(&out[0], 1, out.size(), fb.f);
+            if (got == 0 && out.size() > 0) { r.push_back(Value()); return false; }
+            out.resize(got);
+            r.push_back(Value::string(out));
+            return true;
+        }
+        std::string what = fmt.t == Value::STR ? fmt.str() : "";
+        if (!what.empty() && what[0] == '*') what.erase(0, 1);
+        if (what == "n") {
+            double v;
+            if (fscanf(fb.f, "%lf", &v) != 1) { r.push_back(Value()); return false; }
+            r.push_back(Value::number(v));
+            return true;
+        }
+        if (what == "a") {
+            std::string out;
+            char buf[4096];
+            size_t n;
+            while ((n = fread(buf, 1, sizeof buf, fb.f)) > 0) out.append(buf, n);
+            r.push_back(Value::string(out));
+            return true;
+        }
+        if (what == "l" || what == "L") {
+            std::string out;
+            int c;
+            bool any = false;
+            while ((c = fgetc(fb.f)) != EOF) { any = true; if (c == '\n') { if (what == "L") out += '\n'; break; } out += (char)c; }
+            if (!any) { r.push_back(Value()); return false; }
+            r.push_back(Value::string(out));
+            return true;
+        }
+        throw LuaError("bad argument to 'read' (invalid format)");
+    };
+    auto make_file = [read_one](FILE *fp) {
+        auto fb = std::make_shared<FileBox>();
+        fb->f = fp;
+        Value obj = Value::table(std::make_shared<Table>());
+        auto method = [&obj](const char *name, BuiltinFn fn) {
+            Value v;
+            v.t = Value::BUILTIN;
+            auto bp = std::make_shared<Builtin>();
+            bp->name = std::string("file:") + name;
+            bp->fn = std::move(fn);
+            v.p = std::move(bp);
+            obj.tab()->set(Value::string(name), v);
+        };
+        method("read", [fb, read_one](Interp &, const Values &a, Values &r) {
+            if (a.size() <= 1) { read_one(*fb, Value::string("l"), r); return; }
+            for (size_t i = 1; i < a.size(); ++i) if (!read_one(*fb, a[i], r)) break;
+        });
+        method("lines", [fb, read_one](Interp &, const Values &, Values &r) {
+            Value it;
+            it.t = Value::BUILTIN;
+            auto bp = std::make_shared<Builtin>();
+            bp->name = "file lines iterator";
+            bp->fn = [fb, read_one](Interp &, const Values &, Values &out) { read_one(*fb, Value::string("l"), out); };
+            it.p = std::move(bp);
+            r.push_back(it);
+        });
+        method("write", [fb](Interp &I, const Values &a, Values &r) {
+            if (!fb->f) throw LuaError("attempt to use a closed file");
+            for (size_t i = 1; i < a.size(); ++i) {
+                if (a[i].t != Value::STR && a[i].t != Value::NUM) throw LuaError(std::string("bad argument to 'write' (string expected, got ") + a[i].type_name() + ")");
+                const std::string t = I.tostring(a[i]);
+                fwrite(t.data(), 1, t.size(), fb->f);
+            }
+            r.push_back(a.empty() ? Value() : a[0]);
+        });
+        method("close", [fb](Interp &, const Values &, Values &r) {
+            if (fb->f) { fclose(fb->f); fb->f = nullptr; }
+            r.push_back(Value::boolean(true));
+        });
+        return obj;
+    };
+    register_builtin("io.open", [make_file](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'open' (string expected)");
+        const std::string mode = a.size() > 1 && a[1].t == Value::STR ? a[1].str() : "r";
+        if (mode.empty() || !strchr("rwa", mode[0]) || mode.find_first_not_of("rwa+b") != std::string::npos) throw LuaError("bad argument #2 to 'open' (invalid mode)");
+        FILE *fp = fopen(a[0].str().c_str(), mode.c_str());
+        if (!fp) { r.push_back(Value()); r.push_back(Value::string(a[0].str() + ": " + strerror(errno))); r.push_back(Value::number((double)errno)); return; }
+        r.push_back(make_file(fp));
+    });
+    register_builtin("io.lines", [make_file](Interp &I, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'lines' (file name expected)");
+        FILE *fp = fopen(a[0].str().c_str(), "r");
+        if (!fp) throw LuaError(a[0].str() + ": " + strerror(errno));
+        Value file = make_file(fp);
+        Values it = I.call(file.tab()->get(Value::string("lines")), Values{file});
+        r.push_back(it[0]);                                                      // (the file closes when the iterator is collected)
     });
     register_builtin("io.write", [](Interp &I, const Values &a, Values &) {       // to where print goes, without its tabs and newline
         std::string out;

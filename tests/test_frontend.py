@@ -892,3 +892,57 @@ def test_check_lens_tool(tmp_path):
     assert ok.returncode == 0 and "callbacks translate to GPU code" in ok.stdout and "carry state from pixel to pixel through 'lasty'" in ok.stdout
     bad = subprocess.run([sys.executable, tool, str(tmp_path / "rec.lua")], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "callbacks do NOT translate" in bad.stdout and "recursion ('f')" in bad.stdout
+
+
+PROFILE_LENS_TAIL = '''
+max_fov = 200 max_vfov = 200 lens_width = 2 lens_height = 2
+function lens_inverse(x, y)
+   local r = sqrt(x*x + y*y)
+   local theta = 0
+   for i = 1, #rs - 1 do
+      if r >= rs[i] and r <= rs[i + 1] then theta = as[i] + (as[i + 1] - as[i]) * (r - rs[i]) / (rs[i + 1] - rs[i]) end
+   end
+   if r > rs[#rs] then return nil end
+   if r == 0 then return 0, 0, 1 end
+   local s = sin(theta) / r
+   return x * s, y * s, cos(theta)
+end
+'''
+
+
+def test_a_lens_that_reads_its_profile_from_a_file(bk, tmp_path):
+    """io.open / read('*n', '*l', '*a', n) / lines / write / close, io.lines: a lens that interpolates in a measured radius -> angle table read
+    while it loads builds the table of the same lens with the numbers written into the script (the table is a constant of the chunk for the
+    GPU code, `#rs` included)"""
+    from hostemu import emu
+    data = tmp_path / "profile.txt"
+    data.write_text("# radius  angle\n0.0 0.0\n0.25 0.31\n0.5 0.61\n0.75 0.97\n1.0 1.35\n")
+    reading = r'''
+rs, as = {}, {}
+local f = assert(io.open("%s", "r"))
+print(f:read("*l"))
+while true do
+   local r, a = f:read("*n", "*n")
+   if not r then break end
+   rs[#rs + 1] = r as[#as + 1] = a
+end
+f:close()
+print(#rs, rs[2], as[5], pcall(f.read, f))
+local n = 0 for line in io.lines("%s") do n = n + 1 end print(n)
+print((io.open("%s/nosuch.txt")))
+local w = io.open("%s/out.txt", "w") w:write("a", 1, "\n"):write("b\n") w:close()
+local g = io.open("%s/out.txt") print(g:read("*a")) print(g:read("*a"), g:read("*l"), g:read(1)) g:close()
+''' % (data, data, tmp_path, tmp_path, tmp_path)
+    inline = "rs = {0.0, 0.25, 0.5, 0.75, 1.0}\nas = {0.0, 0.31, 0.61, 0.97, 1.35}\n"
+    tables = []
+    for head in (reading, inline):
+        ctx = lens_ctx(bk, head + PROFILE_LENS_TAIL)
+        if head is reading:
+            assert ctx.console() == "# radius  angle\n5\t0.25\t1.35\tfalse\tattempt to use a closed file\n6\nnil\na1\nb\n\n\tnil\tnil\n"
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(160, 100)
+        off, tin, flagged, err = emu.build_inverse(ctx)
+        assert err == 0 and (off != 0xFFFFFFFF).sum() > 5000
+        tables.append((off, tin))
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
