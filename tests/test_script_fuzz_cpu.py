@@ -1,0 +1,104 @@
+"""The script fuzz of tests/test_script_fuzz_gpu.py on the CPU, with its generator widened by the constructs round 3 added to the code
+generator: functions defined inside the callback (`local function`, `local f = function`, one inside another) that close over its
+parameters, locals and tables; script functions and builtins passed as arguments, passed on, and given local names; locals of the chunk
+that the callback assigns; the length of a constant table of the chunk.  Every random script is run by the host interpreter (portable
+libm) and by the generated code on the host emulation (tests/hostemu: the translation unit hiprtc gets, compiled by g++): every raw
+result of lens_inverse - values bit for bit, NaNs, nil against numbers, the count of results - must agree on every pixel."""
+import os
+
+import numpy as np
+import pytest
+
+import scripts as S
+from test_script_fuzz_gpu import Gen
+
+
+class WideGen(Gen):
+    def block(self, vars_, depth, indent):
+        out, vars_ = super().block(vars_, depth, indent)
+        pad = "  " * indent
+        plain = [v for v in vars_ if "[" not in v]
+        for _ in range(int(self.r.integers(1, 3))):
+            k = int(self.r.integers(0, 6))
+            self.n += 1
+            n = self.n
+            if k == 0:        # a function defined here, closing over everything in sight, called twice
+                out.append(f"{pad}local function f{n}(a, b) local s = a * 0.5 + {self.expr(vars_, 2)} if s > b then return s - b, a end return {self.expr(vars_ + ['a', 'b', 's'], 2)}, b end")
+                out.append(f"{pad}local r{n}, s{n} = f{n}({self.expr(vars_, 2)}, {self.pick(plain)})")
+                out.append(f"{pad}local u{n} = f{n}(r{n}, s{n})")
+                vars_ += [f"r{n}", f"s{n}", f"u{n}"]
+            elif k == 1:      # local f = function, writing an enclosing local and a table of the enclosing function
+                out.append(f"{pad}local m{n} = {{{self.expr(vars_, 1)}, {self.expr(vars_, 1)}, 0}}")
+                out.append(f"{pad}local k{n} = 0")
+                out.append(f"{pad}local g{n} = function(i, v) m{n}[i] = v * 0.5 + m{n}[(i % #m{n}) + 1] k{n} = k{n} + 1 return m{n}[i] end")
+                out.append(f"{pad}local w{n} = g{n}(1, {self.expr(vars_, 2)}) + g{n}(3, {self.pick(plain)}) + k{n}")
+                vars_ += [f"w{n}", f"m{n}[2]", f"k{n}"]
+            elif k == 2:      # a function inside a function inside the callback
+                out.append(f"{pad}local function o{n}(a)")
+                out.append(f"{pad}  local function inner(b) return (a + b) * 0.5 + {self.pick(plain)} end")
+                out.append(f"{pad}  local acc = 0 for i = 1, 3 do acc = acc + inner(i * a) end return acc")
+                out.append(f"{pad}end")
+                out.append(f"{pad}local z{n} = o{n}({self.expr(vars_, 2)})")
+                vars_.append(f"z{n}")
+            elif k == 3:      # functions as arguments: a script function, a builtin, passed on once more
+                fn = self.pick(["helper2", "math.sin", "math.cos", "wave", "math.abs", "lib.tri"])
+                out.append(f"{pad}local h{n} = {self.pick(['apply1', 'twice'])}({fn if fn != 'helper2' else 'wave'}, {self.expr(vars_, 2)})")
+                out.append(f"{pad}local e{n} = fold(helper, {self.expr(vars_, 1)}, {self.pick(plain)})")
+                vars_ += [f"h{n}", f"e{n}"]
+            elif k == 4:      # a local of the chunk as scratch, a local name for a builtin
+                out.append(f"{pad}scratch = {self.expr(vars_, 2)}")
+                out.append(f"{pad}local sn{n} = math.sin")
+                out.append(f"{pad}local c{n} = sn{n}(scratch) + scratch * 0.25")
+                vars_.append(f"c{n}")
+            else:             # a constant table of the chunk: indexed, its length
+                out.append(f"{pad}local q{n} = math.abs({self.pick(plain)}) if not (q{n} < 100) then q{n} = 1 end       -- (a NaN or huge index would be a nil element)")
+                out.append(f"{pad}local d{n} = knots[(math.floor(q{n} * 3) % #knots) + 1] + #knots")
+                vars_.append(f"d{n}")
+        return out, vars_
+
+    def script(self, forward):
+        text = super().script(forward)
+        head = "\n".join([
+            "local scratch = 0.125",
+            "local knots = {0.1, 0.35, 0.7, 1.3}",
+            "local function wave(t) return math.sin(t * 1.5) * 0.5 + t * 0.25 end",
+            "local lib = {tri = function(t) return math.abs(t - math.floor(t + 0.5)) end}",
+            "local function apply1(f, a) return f(a) + 0.5 end",
+            "local function twice(f, a) return apply1(f, apply1(f, a)) end",
+        ])
+        tail = "local function fold(f, a, b) local s = a for i = 1, 3 do s = f(s, b) * 0.5 + s * 0.25 end return s end"
+        # (helper and pair are defined by the base script; fold needs helper, so it goes after them)
+        text = text.replace("local function pair(a, b)", tail + "\nlocal function pair(a, b)", 1)
+        return head + "\n" + text
+
+
+def _seeds():
+    v = os.environ.get("BLINKY_FUZZ_CPU_SEEDS", "0:24")
+    lo, hi = [int(x) for x in v.split(":")]
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_scripts_generated_code_equals_host_interpreter(seed):
+    """BLINKY_FUZZ_CPU_SEEDS=lo:hi runs a longer campaign"""
+    import blinky_amd as bk
+    from hostemu import emu
+    src = WideGen(9000 + seed).script(False).replace('onload = "f_fov 90"', 'lens_width = 5\nlens_height = 3.5\nonload = "f_contain"')
+    ctx = bk.Context(bk.ffi.DEVICE_NONE)
+    ctx.set_host_math(True)
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(src, f"wide{seed}.lua")
+    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+    ctx.resize(48, 32)
+    v = emu.inverse_values(ctx)
+    assert (v["err"] == 0).all(), src
+    xy = np.stack([v["x"], v["y"]], axis=1)
+    h_out, h_n = ctx.eval_host_many(0, xy)
+    np.testing.assert_array_equal(v["nret"], h_n, err_msg=src)
+    d_out = v["val"][:, : h_out.shape[1]]
+    used = np.arange(h_out.shape[1])[None, :] < h_n[:, None]
+    nan_d, nan_h = np.isnan(d_out) & used, np.isnan(h_out) & used
+    np.testing.assert_array_equal(nan_d, nan_h, err_msg=src)
+    same = d_out.view(np.uint64) == h_out.view(np.uint64)
+    assert (same | ~used | nan_h).all(), src
+    assert (h_n > 0).any(), "degenerate script: every pixel returned nil\n" + src
