@@ -87,7 +87,11 @@ struct Emitter {
         std::set<int> fn_open;                        // ... whose body is being emitted right now (a call from inside is recursion)
         std::map<int, Value> static_slots;            // local slot -> the script function / builtin it holds for its whole life
                                                       // (a parameter bound at the call, `local f = math.sin`): calls resolve when the code is generated
-        std::string lp = "l", ap = "A";               // names of locals / local arrays (functions defined inside others get their own)
+        std::map<int, std::vector<std::string>> record_slots;   // local slot -> field names of `local p = {x = .., y = ..}`: one variable per field
+        std::map<int, std::pair<int, int>> matrix_slots;         // local slot -> (rows, columns) of `local m = {{..}, {..}}`: one flat array
+        std::string lp = "l", ap = "A", rp = "R";     // names of locals / local arrays / record fields (functions defined inside others get their own)
+        std::string field_var(int slot, const std::string &name) const { return rp + std::to_string(slot) + "_" + name; }
+        bool is_table(int slot) const { return array_slots.count(slot) || record_slots.count(slot) || matrix_slots.count(slot); }
         std::string chunk;
     };
     // what upvalue `idx` of `s` is: a local of an enclosing function being emitted (*owner, *slot), or (returned) a chunk cell
@@ -287,7 +291,7 @@ struct Emitter {
         case Expr::Name: {
             int slot = 0;
             if (Fn *o = local_of(f, e, &slot)) {
-                if (o->array_slots.count(slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
+                if (o->is_table(slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
                 if (o->fn_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (a function defined inside a callback can only be called)");
                 if (o->static_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (it can be called, and passed on to script functions)");
                 return o->lp + std::to_string(slot);
@@ -306,6 +310,23 @@ struct Emitter {
         case Expr::Index: {
             int aslot = 0;
             Fn *ao = local_of(f, *e.a, &aslot);
+            if (ao && ao->record_slots.count(aslot)) {                         // p.x: the field's variable; a field the constructor did not name is nil
+                if (e.b->kind != Expr::String) unsupported(f.chunk, e.line, "indexing record '" + e.a->str + "' with a computed key");
+                const auto &names = ao->record_slots[aslot];
+                for (const std::string &n : names) if (n == e.b->str) return ao->field_var(aslot, n);
+                return "bk_nil()";
+            }
+            if (ao && ao->matrix_slots.count(aslot)) unsupported(f.chunk, e.line, "a row of table '" + e.a->str + "' used as a value");
+            if (e.a->kind == Expr::Index) {                                    // m[i][j] of a local {{..}, {..}}
+                int mslot = 0;
+                Fn *mo = local_of(f, *e.a->a, &mslot);
+                if (mo && mo->matrix_slots.count(mslot)) {
+                    const std::string row = matrix_row(f, *mo, mslot, *e.a->b);
+                    const std::string k = emit_expr(f, *e.b), t = tmp();
+                    line(f, "bkv " + t + " = bk_aget(S, " + row + ", " + std::to_string(mo->matrix_slots[mslot].second) + ", " + k + ");");
+                    return t;
+                }
+            }
             if (ao && ao->array_slots.count(aslot)) {
                 std::string k = emit_expr(f, *e.b), t = tmp();
                 line(f, "bkv " + t + " = bk_aget(S, " + ao->ap + std::to_string(aslot) + ", " + std::to_string(ao->array_slots[aslot]) + ", " + k + ");");
@@ -335,6 +356,13 @@ struct Emitter {
                 int aslot = 0;
                 Fn *ao = local_of(f, *e.a, &aslot);
                 if (ao && ao->array_slots.count(aslot)) return num_literal((double)ao->array_slots[aslot]);
+                if (ao && ao->matrix_slots.count(aslot)) return num_literal((double)ao->matrix_slots[aslot].first);
+                if (ao && ao->record_slots.count(aslot)) return num_literal(0.0);                      // (no array part)
+                if (e.a->kind == Expr::Index) {                                                         // #m[i]
+                    int mslot = 0;
+                    Fn *mo = local_of(f, *e.a->a, &mslot);
+                    if (mo && mo->matrix_slots.count(mslot)) { (void)matrix_row(f, *mo, mslot, *e.a->b); return num_literal((double)mo->matrix_slots[mslot].second); }
+                }
                 Value sv;                                    // a constant table of the chunk (device code cannot store into one), a string constant
                 if (static_value(f, *e.a, &sv) && sv.t == Value::TABLE && sv.tab()->nhash.empty() && sv.tab()->shash.empty() && !sv.tab()->meta)
                     return num_literal((double)sv.tab()->length());
@@ -573,12 +601,24 @@ struct Emitter {
         return v;
     }
 
+    // m[i] of a local {{..}, {..}}: a pointer expression to the row's array (indexable 1..columns).  A row that does not exist is nil in
+    // Lua, and indexing nil is an error: the script error bit, as for any other one
+    std::string matrix_row(Fn &f, Fn &owner, int slot, const Expr &index)
+    {
+        const int rows = owner.matrix_slots[slot].first, cols = owner.matrix_slots[slot].second;
+        const std::string i = emit_expr(f, index), ti = tmp(), r = tmp("row");
+        line(f, "const bkv " + ti + " = " + i + "; bk_need_exact(S, " + ti + ");");
+        line(f, "const int " + r + " = (" + ti + ".t == BK_TNUM && " + ti + ".n >= 1.0 && " + ti + ".n <= " + std::to_string(rows) + ".0 && " + ti + ".n == bkm_trunc(" + ti + ".n)) ? (int)" + ti + ".n : 0;");
+        line(f, "if (!" + r + ") S.err |= BK_ERR_INDEX;");
+        return "(" + owner.ap + std::to_string(slot) + " + (" + r + " ? " + r + " - 1 : 0) * " + std::to_string(cols) + ")";
+    }
+
     void store(Fn &f, const Expr &target, const std::string &val)
     {
         int slot = 0;
         if (target.kind == Expr::Name) {
             if (Fn *o = local_of(f, target, &slot)) {
-                if (o->array_slots.count(slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
+                if (o->is_table(slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
                 if (o->fn_slots.count(slot)) unsupported(f.chunk, target.line, "re-assigning function '" + target.str + "'");
                 line(f, o->lp + std::to_string(slot) + " = " + val + ";");
             } else if (target.var == VarKind::Global) {
@@ -592,6 +632,21 @@ struct Emitter {
             return;
         }
         Fn *ao = local_of(f, *target.a, &slot);
+        if (ao && ao->record_slots.count(slot)) {
+            if (target.b->kind != Expr::String) unsupported(f.chunk, target.line, "indexing record '" + target.a->str + "' with a computed key");
+            for (const std::string &n : ao->record_slots[slot]) if (n == target.b->str) { line(f, ao->field_var(slot, n) + " = " + val + ";"); return; }
+            unsupported(f.chunk, target.line, "adding field '" + target.b->str + "' to '" + target.a->str + "' (name it in the constructor)");
+        }
+        if (target.a->kind == Expr::Index) {
+            int mslot = 0;
+            Fn *mo = local_of(f, *target.a->a, &mslot);
+            if (mo && mo->matrix_slots.count(mslot)) {
+                const std::string row = matrix_row(f, *mo, mslot, *target.a->b);
+                const std::string k = emit_expr(f, *target.b);
+                line(f, "bk_aset(S, " + row + ", " + std::to_string(mo->matrix_slots[mslot].second) + ", " + k + ", " + val + ");");
+                return;
+            }
+        }
         if (ao && ao->array_slots.count(slot)) {
             std::string k = emit_expr(f, *target.b);
             line(f, "bk_aset(S, " + ao->ap + std::to_string(slot) + ", " + std::to_string(ao->array_slots[slot]) + ", " + k + ", " + val + ");");
@@ -606,7 +661,13 @@ struct Emitter {
         const FuncProto *p = f.proto;
         for (int i = 0; i < p->nslots; ++i) {
             if (f.fn_slots.count(i)) continue;                          // (a function defined inside: declared where it is defined)
-            if (f.array_slots.count(i)) {
+            if (f.record_slots.count(i)) {
+                for (const std::string &name : f.record_slots.at(i)) o << pad << "bkv " << f.field_var(i, name) << " = bk_nil();   /* " << p->slot_names[i] << "." << name << " */\n";
+            } else if (f.matrix_slots.count(i)) {
+                const int cells = f.matrix_slots.at(i).first * f.matrix_slots.at(i).second;
+                o << pad << "bkv " << f.ap << i << "[" << cells + 1 << "];   /* " << p->slot_names[i] << " */\n";
+                o << pad << "for (int q = 0; q <= " << cells << "; ++q) " << f.ap << i << "[q] = bk_nil();\n";
+            } else if (f.array_slots.count(i)) {
                 o << pad << "bkv " << f.ap << i << "[" << f.array_slots.at(i) + 1 << "];   /* " << p->slot_names[i] << " */\n";
                 o << pad << "for (int q = 0; q <= " << f.array_slots.at(i) << "; ++q) " << f.ap << i << "[q] = bk_nil();\n";
             } else if (i < p->nparams) {
@@ -625,7 +686,7 @@ struct Emitter {
         const FuncProto *p = s.exprs[0]->proto;
         const int slot = s.slots[0];
         if (p->is_vararg) unsupported(f.chunk, s.line, "vararg functions");
-        if (f.fn_slots.count(slot) || f.array_slots.count(slot)) unsupported(f.chunk, s.line, "re-declaring '" + s.names[0] + "'");
+        if (f.fn_slots.count(slot) || f.is_table(slot)) unsupported(f.chunk, s.line, "re-declaring '" + s.names[0] + "'");
         const std::string id = std::to_string(++uid);
         Fn g;
         g.proto = p;
@@ -633,6 +694,7 @@ struct Emitter {
         g.chunk = f.chunk;
         g.lp = "n" + id + "_l";
         g.ap = "n" + id + "_A";
+        g.rp = "n" + id + "_R";
         g.indent = f.indent + 1;
         const std::string name = "NF" + id + "_" + sanitize(s.names[0]);
         f.fn_slots[slot] = name;
@@ -663,9 +725,45 @@ struct Emitter {
                     return;
                 }
             }
+            if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table && !s.exprs[0]->fields.empty() && s.exprs[0]->args.empty()) {
+                // local p = {x = .., y = ..}: a record - every field a variable of the C++ function
+                const Expr &t = *s.exprs[0];
+                const int slot = s.slots[0];
+                if (f.fn_slots.count(slot) || f.is_table(slot)) unsupported(f.chunk, s.line, "re-declaring a table");
+                std::vector<std::string> names, vals;
+                for (auto &fld : t.fields) {
+                    if (fld.first->kind != Expr::String || fld.first->str.empty() || !(isalpha((unsigned char)fld.first->str[0]) || fld.first->str[0] == '_'))
+                        unsupported(f.chunk, s.line, "table constructors with computed keys");
+                    for (const std::string &n : names) if (n == fld.first->str) unsupported(f.chunk, s.line, "field '" + n + "' named twice in a table constructor");
+                    names.push_back(fld.first->str);
+                    vals.push_back(emit_expr(f, *fld.second));
+                }
+                f.record_slots[slot] = names;
+                for (size_t i = 0; i < names.size(); ++i) line(f, f.field_var(slot, names[i]) + " = " + vals[i] + ";");
+                return;
+            }
+            if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table && s.exprs[0]->fields.empty() && !s.exprs[0]->args.empty() &&
+                s.exprs[0]->args[0]->kind == Expr::Table) {
+                // local m = {{a, b}, {c, d}}: rows of one length, kept in one flat array
+                const Expr &t = *s.exprs[0];
+                const int slot = s.slots[0];
+                if (f.fn_slots.count(slot) || f.is_table(slot)) unsupported(f.chunk, s.line, "re-declaring a table");
+                const int rows = (int)t.args.size(), cols = (int)t.args[0]->args.size();
+                std::vector<std::string> vals;
+                for (auto &row : t.args) {
+                    if (row->kind != Expr::Table || !row->fields.empty() || (int)row->args.size() != cols || cols == 0)
+                        unsupported(f.chunk, s.line, "nested table constructors other than rows of one length ({{a, b}, {c, d}})");
+                    if (row->args.back()->kind == Expr::Call && !single_valued_call(f, *row->args.back()))
+                        unsupported(f.chunk, s.line, "call expansion inside a table constructor (write '(f(...))' to keep one value)");
+                    for (auto &x : row->args) vals.push_back(emit_expr(f, *x));
+                }
+                f.matrix_slots[slot] = {rows, cols};
+                for (size_t i = 0; i < vals.size(); ++i) line(f, f.ap + std::to_string(slot) + "[" + std::to_string(i + 1) + "] = " + vals[i] + ";");
+                return;
+            }
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table) {
                 const Expr &t = *s.exprs[0];
-                if (!t.fields.empty()) unsupported(f.chunk, s.line, "table constructors with named fields");
+                if (!t.fields.empty()) unsupported(f.chunk, s.line, "table constructors mixing positional and named fields");
                 // a trailing call would expand to all its results; the table's size must be static, so only calls that
                 // always yield exactly one value are taken (the math library; `(f())` truncates any other call)
                 if (!t.args.empty() && t.args.back()->kind == Expr::Call && !single_valued_call(f, *t.args.back()))
@@ -674,6 +772,7 @@ struct Emitter {
                 for (auto &x : t.args) vals.push_back(emit_expr(f, *x));
                 int n = (int)vals.size();
                 if (f.array_slots.count(s.slots[0]) && f.array_slots[s.slots[0]] != n) unsupported(f.chunk, s.line, "re-declaring a table with a different size");
+                if (f.record_slots.count(s.slots[0]) || f.matrix_slots.count(s.slots[0])) unsupported(f.chunk, s.line, "re-declaring a table");
                 f.array_slots[s.slots[0]] = n;
                 for (int i = 0; i < n; ++i) line(f, f.ap + std::to_string(s.slots[0]) + "[" + std::to_string(i + 1) + "] = " + vals[i] + ";");
                 return;

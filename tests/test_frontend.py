@@ -946,3 +946,85 @@ local g = io.open("%s/out.txt") print(g:read("*a")) print(g:read("*a"), g:read("
         tables.append((off, tin))
     np.testing.assert_array_equal(tables[0][0], tables[1][0])
     np.testing.assert_array_equal(tables[0][1], tables[1][1])
+
+
+# ---- records and matrices in callbacks -----------------------------------------------------------------------------------------------
+
+ROTATION_PLAIN = LENS_HEAD + '''
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local c, s = cos(0.3), sin(0.3)
+   local vx, vy, vz = cos(y) * sin(x), sin(y), cos(y) * cos(x)
+   -- rotate about the x axis, then swap two axes with a permutation matrix, scale one component
+   local rx, ry, rz = vx, c * vy - s * vz, s * vy + c * vz
+   local px, py, pz = rz, ry, rx
+   py = py * 1.5
+   local n = sqrt(px * px + py * py + pz * pz)
+   return px / n, py / n, pz / n
+end
+'''
+# the same arithmetic with a record per vector ({x = .., y = .., z = ..}: one variable per field) and matrices as rows of rows
+# ({{..}, {..}, {..}}: one flat array), read and written through a function defined inside the callback, #m and #m[i]
+ROTATION_TABLES = LENS_HEAD + '''
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local c, s = cos(0.3), sin(0.3)
+   local v = {x = cos(y) * sin(x), y = sin(y), z = cos(y) * cos(x)}
+   local rot = {{1, 0, 0}, {0, c, -s}, {0, s, c}}
+   local swap = {{0, 0, 1}, {0, 1, 0}, {1, 0, 0}}
+   local function row_dot(i, ax, ay, az)
+      return rot[i][1] * ax + rot[i][2] * ay + rot[i][3] * az
+   end
+   local r = {x = 0, y = 0, z = 0}
+   r.x = v.x
+   r.y = c * v.y - s * v.z
+   r.z = s * v.y + c * v.z
+   local p = {x = 0, y = 0, z = 0, extra = nil}
+   local comps = {r.x, r.y, r.z}
+   local out = {0, 0, 0}
+   for i = 1, #swap do
+      local acc = 0
+      for j = 1, #swap[i] do if swap[i][j] ~= 0 then acc = comps[j] end end
+      out[i] = acc
+   end
+   p.x, p.y, p.z = out[1], out[2], out[3]
+   swap[2][2] = 1.5
+   p.y = p.y * swap[2][2]
+   local n = sqrt(p.x * p.x + p.y * p.y + p.z * p.z)
+   local one = (#rot - 2) * (#rot[2] - 2) + #p
+   if p.nothing ~= nil then one = 0 end
+   return p.x / n * one, p.y / n, p.z / n
+end
+'''
+
+
+def test_records_and_matrices_translate_to_the_same_table(bk):
+    from hostemu import emu
+    tables = []
+    for body in (ROTATION_PLAIN, ROTATION_TABLES):
+        ctx = lens_ctx(bk, body)
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(160, 100)
+        off, tin, flagged, err = emu.build_inverse(ctx)
+        assert err == 0
+        tables.append((off, tin))
+        assert ctx.eval_host(0, 0.3, 0.2) == lens_ctx(bk, ROTATION_PLAIN).eval_host(0, 0.3, 0.2)
+    assert (tables[0][0] != 0xFFFFFFFF).sum() > 10000
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
+    ctx.kernel_source(compile=True)
+
+
+@pytest.mark.parametrize("body,message", [
+    ("function lens_inverse(x,y) local p = {x = 1} p.y = 2 return x, y, p.x end", "adding field 'y'"),
+    ("function lens_inverse(x,y) local p = {x = 1} local k = 'x' return x, y, p[k] end", "computed key"),
+    ("function lens_inverse(x,y) local p = {x = 1, 2} return x, y, p.x end", "mixing positional and named"),
+    ("function lens_inverse(x,y) local m = {{1, 2}, {3}} return x, y, m[1][1] end", "rows of one length"),
+    ("function lens_inverse(x,y) local m = {{1, 2}, {3, 4}} local r = m[1] return x, y, r[1] end", "a row of table 'm' used as a value"),
+    ("function lens_inverse(x,y) local p = {x = 1} local q = p return x, y, q.x end", "table 'p' used as a value"),
+])
+def test_table_shapes_the_device_cannot_take_are_named(bk, body, message):
+    ctx = lens_ctx(bk, body)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match=message):
+        ctx.kernel_source(compile=False)

@@ -17,9 +17,9 @@ class WideGen(Gen):
     def block(self, vars_, depth, indent):
         out, vars_ = super().block(vars_, depth, indent)
         pad = "  " * indent
-        plain = [v for v in vars_ if "[" not in v]
+        plain = [v for v in vars_ if "[" not in v and "." not in v and "(" not in v]
         for _ in range(int(self.r.integers(1, 3))):
-            k = int(self.r.integers(0, 6))
+            k = int(self.r.integers(0, 8))
             self.n += 1
             n = self.n
             if k == 0:        # a function defined here, closing over everything in sight, called twice
@@ -50,6 +50,17 @@ class WideGen(Gen):
                 out.append(f"{pad}local sn{n} = math.sin")
                 out.append(f"{pad}local c{n} = sn{n}(scratch) + scratch * 0.25")
                 vars_.append(f"c{n}")
+            elif k == 6:      # a record: fields read, written, swapped; an unnamed field is nil
+                out.append(f"{pad}local rec{n} = {{a = {self.expr(vars_, 2)}, b = {self.expr(vars_, 1)}, c = 0}}")
+                out.append(f"{pad}rec{n}.c = rec{n}.a * 0.5 + rec{n}.b")
+                out.append(f"{pad}rec{n}.a, rec{n}.b = rec{n}.b, rec{n}.a")
+                out.append(f"{pad}if rec{n}.missing ~= nil then rec{n}.c = 0 end")
+                vars_ += [f"rec{n}.a", f"rec{n}.b", f"rec{n}.c"]
+            elif k == 7:      # a matrix: constant and computed indices, element stores, both lengths, reached from a function defined here
+                out.append(f"{pad}local mat{n} = {{{{{self.expr(vars_, 1)}, ({self.expr(vars_, 1)})}}, {{{self.expr(vars_, 1)}, 1}}, {{0.5, {self.pick(plain)}}}}}")
+                out.append(f"{pad}local function cell{n}(i, j) return mat{n}[i][j] end")
+                out.append(f"{pad}for i = 1, #mat{n} do for j = 1, #mat{n}[i] do mat{n}[i][j] = mat{n}[i][j] * 0.5 + cell{n}((i % #mat{n}) + 1, j) * 0.25 end end")
+                vars_ += [f"mat{n}[1][2]", f"mat{n}[3][1]", f"cell{n}(2, 2)"]
             else:             # a constant table of the chunk: indexed, its length
                 out.append(f"{pad}local q{n} = math.abs({self.pick(plain)}) if not (q{n} < 100) then q{n} = 1 end       -- (a NaN or huge index would be a nil element)")
                 out.append(f"{pad}local d{n} = knots[(math.floor(q{n} * 3) % #knots) + 1] + #knots")
