@@ -83,6 +83,8 @@ def build_inverse(ctx, defines=()):
     put("flag_count", misc.ctypes.data + 28)
     put("flag_list", flags.ctypes.data)
     C.memmove(C.addressof(bp) + fo["flag_cap"], C.byref(C.c_uint32(cap)), 4)
+    first_bad = np.zeros(2, np.uint32)           # (first_bad is BkBuildParams' last member: a script that returns a malformed result writes here)
+    C.memmove(C.addressof(bp) + fo["size"] - 8, C.byref(C.c_uint64(first_bad.ctypes.data)), 8)
     lib.emu_build_inverse(bp)
     nf = int(misc[7])
     return off, tin, flags[:nf, 0].copy(), int(misc[6])
