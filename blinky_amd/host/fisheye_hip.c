@@ -191,7 +191,7 @@ static void con_rubixgrid(void)                     /* fisheye.c:939-953 */
 static void con_fisheye(void)                       /* fisheye.c:967-977 */
 {
     if (Cmd_Argc() >= 2) {
-        fisheye_enabled = Q_atoi(Cmd_Argv(1)) != 0;
+        fisheye_enabled = Q_atoi(Cmd_Argv(1));       /* (the number as given: "fisheye 2" reads back, and is saved, as 2) */
         vid.recalc_refdef = true;
         return;
     }

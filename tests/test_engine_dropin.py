@@ -245,3 +245,33 @@ def test_a_lens_that_requires_a_helper_file_loads_inside_the_engine():
     text = console_text(out)
     # (the module's print() lands where the reference's Lua would put it: on stdout, in the middle of cmd_lens' "f_lens <name>; <onload>" line)
     assert "f_lens with_helperoptics loaded" in text and "; f_fov 120" in text and "Currently: with_helper" in text and "Zoom currently: f_fov 120" in text
+
+
+def random_console_session(seed):
+    """console commands only (no map: the engine draws its full-screen console and never warps a frame) - every lens and globe by name,
+    the zoom commands with and without arguments, the rubix commands, key bindings, invalid names"""
+    import random
+    names = __import__("scripts")
+    rng = random.Random(seed)
+    script = []
+    for _ in range(rng.randint(15, 40)):
+        script.append(rng.choice([
+            "f_lens " + rng.choice(names.LENSES), "f_globe " + rng.choice(names.GLOBES), "f_lens", "f_globe", "f_fov", "f_vfov",
+            "f_fov %s" % rng.choice(["90", "180.7", "-5", "abc", "1e3", "360"]), "f_vfov %d" % rng.choice([0, 60, 179, 400]), "f_cover", "f_contain",
+            "f_rubix", "f_rubixgrid", "f_rubixgrid %d %s %s" % (rng.randint(0, 20), rng.choice(["4", "2.5", "x"]), rng.choice(["1", "0.25"])),
+            "f_rubixgrid 3", "f_help", "fisheye", "fisheye %d" % rng.randint(0, 2), "f_shortcutkeys", "bind %d" % rng.randint(1, 9), "bind y",
+            "f_saveglobe", "f_lens no_such_lens", "f_globe no_such_globe", "f_lens \"\"", "f_dumppal",
+        ]))
+    return script + ["toggleconsole", "quit"]
+
+
+@needs_engines
+@pytest.mark.ref
+@pytest.mark.parametrize("seed", list(_seeds("0:12")) if "BLINKY_ENGINE_CONSOLE_CAMPAIGN" not in os.environ else
+                         list(range(*[int(v) for v in os.environ["BLINKY_ENGINE_CONSOLE_CAMPAIGN"].split(":")])))
+def test_random_console_sessions_in_the_real_engine_equal_the_reference(seed):
+    script = random_console_session(seed)
+    ref_out, _, ref_files = run_engine(TQ_REF, script)
+    hip_out, _, hip_files = run_engine(TQ_HIP, script, env_extra={"BLINKY_HIP_DEVICE": "none"})
+    assert console_text(hip_out) == console_text(ref_out), seed
+    assert hip_files == ref_files, seed
