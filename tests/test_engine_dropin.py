@@ -261,6 +261,9 @@ def random_console_session(seed):
             "f_rubix", "f_rubixgrid", "f_rubixgrid %d %s %s" % (rng.randint(0, 20), rng.choice(["4", "2.5", "x"]), rng.choice(["1", "0.25"])),
             "f_rubixgrid 3", "f_help", "fisheye", "fisheye %d" % rng.randint(0, 2), "f_shortcutkeys", "bind %d" % rng.randint(1, 9), "bind y",
             "f_saveglobe", "f_lens no_such_lens", "f_globe no_such_globe", "f_lens \"\"", "f_dumppal",
+            "fisheye %s" % rng.choice(["abc", "-1", "7", "0x10", "1.9"]), "f_fov 90 extra words", "f_cover 12", "f_contain now", "f_lens PANINI",
+            "f_lens hammer hammer", "f_globe cube edge", "f_vfov", "f_fov 0", "f_vfov -0.5", "f_rubixgrid -1 -1 -1", "f_rubixgrid 1e9 1e-9 0",
+            "f_help me", "f_shortcutkeys on", "f_dumppal twice", "f_lens %s; f_fov %d" % (rng.choice(names.LENSES), rng.randint(1, 400)),
         ]))
     return script + ["toggleconsole", "quit"]
 
