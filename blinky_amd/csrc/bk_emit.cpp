@@ -285,7 +285,10 @@ struct Emitter {
         case Expr::False: return "bk_bool(false)";
         case Expr::Number: return num_literal(e.num);
         case Expr::String: return str_literal(e.str);       // (compared with == / ~= only; no string operations on the device)
-        case Expr::Vararg: unsupported(f.chunk, e.line, "'...'");
+        case Expr::Vararg: {                           // in a single-value position: the first extra argument, or nil
+            const std::string np = std::to_string(f.proto->nparams);
+            return "(na > " + np + " ? a[" + np + "] : bk_nil())";
+        }
         case Expr::Function: unsupported(f.chunk, e.line, "function values / closures");
         case Expr::Table: unsupported(f.chunk, e.line, "table constructors other than 'local t = {a, b, ...}'");
         case Expr::Name: {
@@ -432,6 +435,14 @@ struct Emitter {
             if (i + 1 == list.size() && x.kind == Expr::Call) {
                 a.multi = true;
                 emit_call(f, x, &a.marr, &a.mcnt);
+            } else if (i + 1 == list.size() && x.kind == Expr::Vararg) {       // the extra arguments of this function, all of them
+                // (value lists hold BK_MAXRET values: more extra arguments than that is this translation's limit - the script error bit)
+                const std::string np = std::to_string(f.proto->nparams), vc = tmp("va");
+                line(f, "int " + vc + " = na > " + np + " ? na - " + np + " : 0;");
+                line(f, "if (" + vc + " > BK_MAXRET) { S.err |= BK_ERR_INDEX; " + vc + " = BK_MAXRET; }");
+                a.multi = true;
+                a.marr = "(a + " + np + ")";
+                a.mcnt = vc;
             } else a.fixed.push_back(emit_expr(f, x));
         }
         return a;
@@ -566,6 +577,27 @@ struct Emitter {
             line(f, "bkv " + *arr + "[2]; bk_f_modf(S, " + A(0) + ", " + *arr + "); const int " + *cnt + " = 2;");
             return;
         }
+        if (bn == "select") {
+            // select('#', ...) counts, select(n, ...) is everything from the n-th on (n from the end when negative); the values are
+            // materialised once, the index is checked as luaB_select checks it
+            if (e.args.empty()) unsupported(f.chunk, e.line, "select without arguments");
+            std::vector<const Expr *> rest;
+            for (size_t i = 1; i < e.args.size(); ++i) rest.push_back(e.args[i].get());
+            Args ra = emit_args(f, rest);
+            auto packed = pack(f, ra, 1);
+            if (e.args[0]->kind == Expr::String && e.args[0]->str == "#") {
+                line(f, "bkv " + *arr + "[1] = {bk_num((double)" + packed.second + ")}; const int " + *cnt + " = 1; (void)" + packed.first + ";");
+                return;
+            }
+            const std::string n = emit_expr(f, *e.args[0]), tn = tmp(), k = tmp("k");
+            line(f, "const bkv " + tn + " = " + n + "; bk_need_exact(S, " + tn + ");");
+            line(f, "int " + k + " = (" + tn + ".t == BK_TNUM && " + tn + ".n > -65.0 && " + tn + ".n < 65.0) ? (int)" + tn + ".n : 0;");   // (luaL_checkint truncates)
+            line(f, "if (" + k + " < 0) " + k + " = " + packed.second + " + " + k + " + 1;");          // from the end
+            line(f, "if (" + k + " < 1) { S.err |= BK_ERR_INDEX; " + k + " = " + packed.second + " + 1; }");     // "index out of range"
+            line(f, "if (" + k + " > " + packed.second + ") " + k + " = " + packed.second + " + 1;");
+            line(f, "bkv *" + *arr + " = " + packed.first + " + (" + k + " - 1); const int " + *cnt + " = " + packed.second + " - (" + k + " - 1);");
+            return;
+        }
         if (bn == "type") { single("bk_typeof(" + A(0) + ")"); return; }
         if (bn == "latlon_to_ray") {
             line(f, "bkv " + *arr + "[3]; const int " + *cnt + " = bk_host_latlon_to_ray(S, " + A(0) + ", " + A(1) + ", " + *arr + ");");
@@ -685,7 +717,6 @@ struct Emitter {
     {
         const FuncProto *p = s.exprs[0]->proto;
         const int slot = s.slots[0];
-        if (p->is_vararg) unsupported(f.chunk, s.line, "vararg functions");
         if (f.fn_slots.count(slot) || f.is_table(slot)) unsupported(f.chunk, s.line, "re-declaring '" + s.names[0] + "'");
         const std::string id = std::to_string(++uid);
         Fn g;
@@ -755,6 +786,8 @@ struct Emitter {
                         unsupported(f.chunk, s.line, "nested table constructors other than rows of one length ({{a, b}, {c, d}})");
                     if (row->args.back()->kind == Expr::Call && !single_valued_call(f, *row->args.back()))
                         unsupported(f.chunk, s.line, "call expansion inside a table constructor (write '(f(...))' to keep one value)");
+                    if (row->args.back()->kind == Expr::Vararg)
+                        unsupported(f.chunk, s.line, "'...' at the end of a table constructor (a table of a size only known at run time)");
                     for (auto &x : row->args) vals.push_back(emit_expr(f, *x));
                 }
                 f.matrix_slots[slot] = {rows, cols};
@@ -768,6 +801,8 @@ struct Emitter {
                 // always yield exactly one value are taken (the math library; `(f())` truncates any other call)
                 if (!t.args.empty() && t.args.back()->kind == Expr::Call && !single_valued_call(f, *t.args.back()))
                     unsupported(f.chunk, s.line, "call expansion inside a table constructor (write '(f(...))' to keep one value)");
+                if (!t.args.empty() && t.args.back()->kind == Expr::Vararg)
+                    unsupported(f.chunk, s.line, "'...' at the end of a table constructor (a table of a size only known at run time)");
                 std::vector<std::string> vals;
                 for (auto &x : t.args) vals.push_back(emit_expr(f, *x));
                 int n = (int)vals.size();
@@ -952,7 +987,6 @@ struct Emitter {
         fi.cl = cl;
         fi.cname = "LF" + std::to_string(++uid) + "_" + sanitize(cl->proto->name);
         fi.emitting = true;
-        if (cl->proto->is_vararg) unsupported(cl->chunk->name, cl->proto->line, "vararg functions");
 
         Fn f;
         f.proto = cl->proto;

@@ -1850,7 +1850,10 @@ Interp::Interp(const MathLib &m) : math(&m)
     register_builtin("select", [](Interp &, const Values &a, Values &r) {
         if (!a.empty() && a[0].t == Value::STR && a[0].str() == "#") { r.push_back(Value::number((double)a.size() - 1)); return; }
         double n = argnum(a, 0, "select");
-        if (n < 1) throw LuaError("bad argument #1 to 'select' (index out of range)");
+        const double count = (double)a.size() - 1;
+        if (n < 0) n = count + n + 1;                       // from the end (luaB_select)
+        else if (n > count) n = count + 1;
+        if (n < 1 || n != n) throw LuaError("bad argument #1 to 'select' (index out of range)");
         for (size_t i = (size_t)n; i < a.size(); ++i) r.push_back(a[i]);
     });
     // ---- chunks from strings and files (lbaselib.c load / loadfile / dofile, loadlib.c require): the reference opens the whole

@@ -486,7 +486,6 @@ def test_functions_defined_inside_a_callback_translate_to_the_same_table(bk):
     ("function lens_inverse(x,y) local function f(n) if n <= 0 then return 0 end return 1 + f(n - 1) end return x, y, f(3) end", "recursion"),
     ("function lens_inverse(x,y) local function f(a) return a end local g = f return x, y, g(1) end", "used as a value"),
     ("function lens_inverse(x,y) local function f(a) return a end f = nil return x, y, 1 end", "re-assigning function"),
-    ("function lens_inverse(x,y) local function f(...) return 1 end return x, y, f(1) end", "vararg"),
     ("local t = {1}\nfunction lens_inverse(x,y) t = {2} return x, y, 1 end", "table constructors"),
 ])
 def test_function_constructs_the_device_cannot_take_are_named(bk, body, message):
@@ -1027,4 +1026,81 @@ def test_table_shapes_the_device_cannot_take_are_named(bk, body, message):
     ctx = lens_ctx(bk, body)
     ctx.resize(64, 48)
     with pytest.raises(bk.BlinkyError, match=message):
+        ctx.kernel_source(compile=False)
+
+
+# ---- varargs in callbacks --------------------------------------------------------------------------------------------------------------
+
+VARARGS_PLAIN = LENS_HEAD + '''
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local lat = (y + y * 0.5 + y * 0.25) / 1.75
+   local lon = x * 0.5 + x * 0.5
+   local c = cos(lat)
+   local m = c * sin(lon)
+   if sin(lat) > m then m = sin(lat) end
+   if c * cos(lon) > m then m = c * cos(lon) end
+   local k = 3 + 2 + m * 0
+   return c * sin(lon) * (k - 4), sin(lat), c * cos(lon)
+end
+'''
+# the same through vararg helpers: select('#', ...), select(i, ...) with a computed and a negative index, `...` passed on, returned and
+# assigned to several locals
+VARARGS_LENS = LENS_HEAD + '''
+local function sum(...)
+   local s = 0
+   for i = 1, select("#", ...) do s = s + (select(i, ...)) end
+   return s
+end
+local function largest(first, ...)
+   local m = first
+   for i = 1, select("#", ...) do
+      local v = select(i, ...)
+      if v > m then m = v end
+   end
+   return m
+end
+local function pass(...) return ... end
+local function count(...) return select("#", ...), select("#", pass(...)) end
+local function tail2(...) return select(-2, ...) end
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local lat = sum(y, y * 0.5, y * 0.25) / 1.75
+   local a, b = pass(x * 0.5, x * 0.5, 99)
+   local lon = a + b
+   local c = cos(lat)
+   local m = largest(c * sin(lon), sin(lat), c * cos(lon))
+   local n1, n2 = count(1, nil, 3)
+   local t1, t2 = tail2(7, 8, n1 - 1)        -- 8, 2
+   local k = n1 + t2 + m * 0 + (n2 - 3) + (t1 - 8)
+   return c * sin(lon) * (k - 4), sin(lat), c * cos(lon)
+end
+'''
+
+
+def test_vararg_functions_translate_to_the_same_table(bk):
+    from hostemu import emu
+    tables = []
+    for body in (VARARGS_PLAIN, VARARGS_LENS):
+        ctx = lens_ctx(bk, body)
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(160, 100)
+        off, tin, flagged, err = emu.build_inverse(ctx)
+        assert err == 0
+        tables.append((off, tin))
+        assert ctx.eval_host(0, 0.3, 0.2) == lens_ctx(bk, VARARGS_PLAIN).eval_host(0, 0.3, 0.2)
+    assert (tables[0][0] != 0xFFFFFFFF).sum() > 10000
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
+    ctx.kernel_source(compile=True)
+    # the interpreter's select: from the end, past the end, not a position
+    ctx = lens_ctx(bk, "print(select(-1, 'a', 'b', 'c'), select(5, 'a'), select('#'), (select(2, 'a', 'b', 'c')), pcall(select, 0, 'a'))\n"
+                       "function lens_inverse(x, y) return x, y, 1 end")
+    assert ctx.console() == "c\tnil\t0\tb\tfalse\tbad argument #1 to 'select' (index out of range)\n"
+
+
+def test_a_table_of_the_extra_arguments_is_refused(bk):
+    ctx = lens_ctx(bk, "local function f(...) local t = {...} return t[1] end\nfunction lens_inverse(x,y) return f(x), y, 1 end")
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match="at the end of a table constructor"):
         ctx.kernel_source(compile=False)

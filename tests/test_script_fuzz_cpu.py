@@ -19,7 +19,7 @@ class WideGen(Gen):
         pad = "  " * indent
         plain = [v for v in vars_ if "[" not in v and "." not in v and "(" not in v]
         for _ in range(int(self.r.integers(1, 3))):
-            k = int(self.r.integers(0, 8))
+            k = int(self.r.integers(0, 9))
             self.n += 1
             n = self.n
             if k == 0:        # a function defined here, closing over everything in sight, called twice
@@ -61,6 +61,10 @@ class WideGen(Gen):
                 out.append(f"{pad}local function cell{n}(i, j) return mat{n}[i][j] end")
                 out.append(f"{pad}for i = 1, #mat{n} do for j = 1, #mat{n}[i] do mat{n}[i][j] = mat{n}[i][j] * 0.5 + cell{n}((i % #mat{n}) + 1, j) * 0.25 end end")
                 vars_ += [f"mat{n}[1][2]", f"mat{n}[3][1]", f"cell{n}(2, 2)"]
+            elif k == 8:      # vararg helpers: counted, indexed from both ends, passed on, spread over locals
+                out.append(f"{pad}local va{n}, vb{n} = spread({self.expr(vars_, 1)}, {self.pick(plain)}, {self.expr(vars_, 1)})")
+                out.append(f"{pad}local vc{n} = total({self.pick(plain)}, va{n}, ({self.expr(vars_, 2)})) + (select(-1, vb{n}, {self.pick(plain)}))")
+                vars_ += [f"va{n}", f"vb{n}", f"vc{n}"]
             else:             # a constant table of the chunk: indexed, its length
                 out.append(f"{pad}local q{n} = math.abs({self.pick(plain)}) if not (q{n} < 100) then q{n} = 1 end       -- (a NaN or huge index would be a nil element)")
                 out.append(f"{pad}local d{n} = knots[(math.floor(q{n} * 3) % #knots) + 1] + #knots")
@@ -76,6 +80,8 @@ class WideGen(Gen):
             "local lib = {tri = function(t) return math.abs(t - math.floor(t + 0.5)) end}",
             "local function apply1(f, a) return f(a) + 0.5 end",
             "local function twice(f, a) return apply1(f, apply1(f, a)) end",
+            "local function total(...) local s = 0 for i = 1, select('#', ...) do s = s * 0.5 + (select(i, ...)) end return s end",
+            "local function spread(first, ...) local n = select('#', ...) return first + n, total(...) end",
         ])
         tail = "local function fold(f, a, b) local s = a for i = 1, 3 do s = f(s, b) * 0.5 + s * 0.25 end return s end"
         # (helper and pair are defined by the base script; fold needs helper, so it goes after them)
