@@ -127,6 +127,18 @@ struct Emitter {
     std::string tmp(const char *p = "t") { return std::string(p) + std::to_string(++uid); }
     static void line(Fn &f, const std::string &s) { f.out << std::string((size_t)f.indent * 4, ' ') << s << "\n"; }
 
+    // t[key] of a table known now, as the interpreter finds it: the table's own field, else along metatables whose __index is a table
+    static Value static_field(const Value &t, const Value &key)
+    {
+        Value cur = t;
+        for (int depth = 0; depth < 32 && cur.t == Value::TABLE; ++depth) {
+            Value v = cur.tab()->get(key);
+            if (v.t != Value::NIL || !cur.tab()->meta) return v;
+            cur = cur.tab()->meta->get(Value::string("__index"));
+        }
+        return Value();
+    }
+
     // ---- static resolution of a callee / constant ------------------------------------------
     // value a Name evaluates to at build time; `known` false for locals
     bool static_value(Fn &f, const Expr &e, Value *v)
@@ -156,7 +168,7 @@ struct Emitter {
         }
         if (e.kind == Expr::Index && e.b->kind == Expr::String) {
             Value o;
-            if (static_value(f, *e.a, &o) && o.t == Value::TABLE) { *v = o.tab()->get(Value::string(e.b->str)); return true; }
+            if (static_value(f, *e.a, &o) && o.t == Value::TABLE) { *v = static_field(o, Value::string(e.b->str)); return true; }
         }
         return false;
     }
@@ -201,6 +213,20 @@ struct Emitter {
             if (known && callee.t == Value::FUNC && !seen.count(callee.fn()->proto)) {
                 seen.insert(callee.fn()->proto);
                 scan_closure(callee.fn(), seen);
+            }
+        }
+        if (e->kind == Expr::Call && !e->str.empty() && e->a->kind == Expr::Name) {          // obj:m(..): the method's body is device code too
+            Value obj;
+            if (e->a->var == VarKind::Global) obj = I.get_global(e->a->str);
+            else if (e->a->var == VarKind::Upvalue) {
+                const Scope *owner = nullptr;
+                int slot = 0;
+                if (const Value *cell = upvalue_of(&sc, e->a->slot, &owner, &slot)) obj = *cell;
+            }
+            const Value m = static_field(obj, Value::string(e->str));
+            if (m.t == Value::FUNC && !seen.count(m.fn()->proto)) {
+                seen.insert(m.fn()->proto);
+                scan_closure(m.fn(), seen);
             }
         }
         if (e->kind == Expr::Function && e->proto) {                  // a function defined inside device code: its body is device code
@@ -296,7 +322,9 @@ struct Emitter {
             if (Fn *o = local_of(f, e, &slot)) {
                 if (o->is_table(slot)) unsupported(f.chunk, e.line, "table '" + e.str + "' used as a value");
                 if (o->fn_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (a function defined inside a callback can only be called)");
-                if (o->static_slots.count(slot)) unsupported(f.chunk, e.line, "function '" + e.str + "' used as a value (it can be called, and passed on to script functions)");
+                if (o->static_slots.count(slot))
+                    unsupported(f.chunk, e.line, std::string(o->static_slots[slot].t == Value::TABLE ? "table" : "function") + " '" + e.str +
+                                                     "' used as a value (it can be " + (o->static_slots[slot].t == Value::TABLE ? "indexed" : "called") + ", and passed on to script functions)");
                 return o->lp + std::to_string(slot);
             }
             if (e.var == VarKind::Global && mutable_globals.count(e.str)) return "S.g_" + sanitize(e.str);
@@ -486,9 +514,16 @@ struct Emitter {
     // a call in multi-value context: results land in *arr (bkv[BK_MAXRET]) with count *cnt
     void emit_call(Fn &f, const Expr &e, std::string *arr, std::string *cnt)
     {
-        if (!e.str.empty()) unsupported(f.chunk, e.line, "method calls (a:" + e.str + "(..))");
-        Value callee;
-        {
+        Value callee, self_obj;
+        const bool method = !e.str.empty();
+        if (method) {
+            // obj:m(..) with obj a table of the chunk known now: m is looked up now, obj is bound to m's first parameter like any
+            // other constant table handed to a function (below)
+            if (!static_value(f, *e.a, &self_obj) || self_obj.t != Value::TABLE)
+                unsupported(f.chunk, e.line, "method calls (a:" + e.str + "(..)) on a value that is not a constant table of the script");
+            callee = static_field(self_obj, Value::string(e.str));
+            if (callee.t != Value::FUNC) unsupported(f.chunk, e.line, "method '" + e.str + "' is not a script function");
+        } else {
             int slot = 0;
             Fn *o = local_of(f, *e.a, &slot);
             if (o && o->fn_slots.count(slot)) {                      // a function defined inside this callback: a lambda of the enclosing C++ function
@@ -502,7 +537,7 @@ struct Emitter {
                 return;
             }
         }
-        if (!static_value(f, *e.a, &callee)) {
+        if (!method && !static_value(f, *e.a, &callee)) {
             std::string n = e.a->kind == Expr::Name ? "'" + e.a->str + "'" : "this expression";
             unsupported(f.chunk, e.line, "calling " + n + " (callee must be a script function or builtin known at build time)");
         }
@@ -514,11 +549,18 @@ struct Emitter {
             std::vector<std::pair<int, Value>> bound;
             std::vector<const Expr *> plain;
             static const Expr nil_expr = [] { Expr x; x.kind = Expr::Nil; return x; }();
+            const int shift = method ? 1 : 0;
+            if (method) {
+                if (callee.fn()->proto->nparams < 1) unsupported(f.chunk, e.line, "method '" + e.str + "' takes no self");
+                bound.emplace_back(0, self_obj);
+                plain.push_back(&nil_expr);
+            }
             for (size_t i = 0; i < e.args.size(); ++i) {
                 Value av;
                 const Expr &x = *e.args[i];
-                if ((int)i < callee.fn()->proto->nparams && (x.kind == Expr::Name || x.kind == Expr::Index) && static_value(f, x, &av) && av.is_function()) {
-                    bound.emplace_back((int)i, av);
+                if ((int)i + shift < callee.fn()->proto->nparams && (x.kind == Expr::Name || x.kind == Expr::Index) && static_value(f, x, &av) &&
+                    (av.is_function() || av.t == Value::TABLE)) {               // (a constant table of the script is bound the same way)
+                    bound.emplace_back((int)i + shift, av);
                     plain.push_back(&nil_expr);
                 } else plain.push_back(&x);
             }
@@ -750,8 +792,8 @@ struct Emitter {
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Function) { emit_local_function(f, s); return; }
             if (s.slots.size() == 1 && s.exprs.size() == 1 && (s.exprs[0]->kind == Expr::Name || s.exprs[0]->kind == Expr::Index)) {
                 Value fv;                                              // `local s = math.sin`, `local g = helper`: a name for that function
-                if (static_value(f, *s.exprs[0], &fv) && fv.is_function()) {
-                    if (!slot_is_constant(f.proto, s.slots[0])) unsupported(f.chunk, s.line, "function '" + s.names[0] + "' used as a value (the local is assigned or captured later)");
+                if (static_value(f, *s.exprs[0], &fv) && (fv.is_function() || fv.t == Value::TABLE)) {
+                    if (!slot_is_constant(f.proto, s.slots[0])) unsupported(f.chunk, s.line, std::string(fv.t == Value::TABLE ? "table" : "function") + " '" + s.names[0] + "' used as a value (the local is assigned or captured later)");
                     f.static_slots[s.slots[0]] = fv;
                     return;
                 }
@@ -994,7 +1036,7 @@ struct Emitter {
         f.chunk = cl->chunk->name;
         for (auto &b : bound) {
             if (!slot_is_constant(cl->proto, b.first))
-                unsupported(from_chunk, line_no, "a function passed as '" + cl->proto->slot_names[(size_t)b.first] + "' of '" + cl->proto->name + "', which assigns or captures that parameter");
+                unsupported(from_chunk, line_no, std::string(b.second.t == Value::TABLE ? "a table" : "a function") + " passed as '" + cl->proto->slot_names[(size_t)b.first] + "' of '" + cl->proto->name + "', which assigns or captures that parameter");
             f.static_slots[b.first] = b.second;
         }
         emit_block(f, cl->proto->body);
@@ -1050,6 +1092,25 @@ struct StateScan {
         expr(e->b.get(), sc, def);
         for (auto &x : e->args) expr(x.get(), sc, def);
         for (auto &x : e->fields) { expr(x.first.get(), sc, def); expr(x.second.get(), sc, def); }
+        if (e->kind == Expr::Call && !e->str.empty() && e->a->kind == Expr::Name) {          // obj:m(..): walk m's body like any callee's
+            Value obj;
+            if (e->a->var == VarKind::Global && !mut.count(e->a->str)) obj = I.get_global(e->a->str);
+            else if (e->a->var == VarKind::Upvalue) {
+                const Emitter::Scope *owner = nullptr;
+                int slot = 0;
+                if (const Value *cell = Emitter::upvalue_of(sc, e->a->slot, &owner, &slot)) obj = *cell;
+            }
+            const Value m = Emitter::static_field(obj, Value::string(e->str));
+            if (m.t == Value::FUNC && !active.count(m.fn()->proto)) {
+                active.insert(m.fn()->proto);
+                Set inner = def;
+                Emitter::Scope callee_scope;
+                callee_scope.proto = m.fn()->proto;
+                callee_scope.cl = m.fn();
+                block(m.fn()->proto->body, &callee_scope, inner);
+                active.erase(m.fn()->proto);
+            }
+        }
         if (e->kind == Expr::Call && e->str.empty()) {
             Value callee;
             bool known = false;

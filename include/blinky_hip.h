@@ -85,7 +85,7 @@ int         bk_synchronize(bk_ctx *ctx);
  * load / dofile / require relative to the working directory).  What the per-pixel CALLBACKS (lens_inverse, lens_forward,
  * globe_plate and everything they call) may use is narrower - they become GPU code at bk_build: numbers, booleans, nil, string
  * constants, local tables (arrays, records {x = ..}, matrices {{..}, {..}}), constant tables of the chunk, every control structure but goto, the math library, functions
- * defined inside a callback, functions passed as arguments, varargs; bk_build names the construct it cannot take (BK_E_SCRIPT). */
+ * defined inside a callback, functions and constant tables passed as arguments, methods of constant objects, varargs; bk_build names the construct it cannot take (BK_E_SCRIPT). */
 int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_clear_lens(bk_ctx *ctx);    /* lens.valid = false ("not a valid lens", fisheye.c:1080-1083) */

@@ -586,7 +586,6 @@ def test_first_math_random_is_the_c_librarys_first_draw(bk):
 
 
 @pytest.mark.parametrize("body,message", [
-    ("local o = {k = 2}\nfunction o:f(x) return x * self.k end\nfunction lens_inverse(x,y) return o:f(x), y, 1 end", "method calls"),
     ("function lens_inverse(x,y) return x, y, math.random() end", "math.random"),
     ("function lens_inverse(x,y) local s = string.format('%d', x) return x, y, 1 end", "string.format"),
 ])
@@ -1103,4 +1102,65 @@ def test_a_table_of_the_extra_arguments_is_refused(bk):
     ctx = lens_ctx(bk, "local function f(...) local t = {...} return t[1] end\nfunction lens_inverse(x,y) return f(x), y, 1 end")
     ctx.resize(64, 48)
     with pytest.raises(bk.BlinkyError, match="at the end of a table constructor"):
+        ctx.kernel_source(compile=False)
+
+
+# ---- constant objects: tables of the script as arguments, method calls on them ---------------------------------------------------------
+
+OBJECT_PLAIN = LENS_HEAD + '''
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local lat = y * 0.9 + 0.05 * sin(3 * y)
+   local lon = (x + 0.1) * 0.95
+   local c = cos(lat)
+   return c * sin(lon), sin(lat), c * cos(lon)
+end
+'''
+# the same with the parameters in an object made while the script loads (setmetatable, methods, a nested array): method calls on it,
+# the object passed to a function and given a local name - a constant table is bound to the parameter like a function is
+OBJECT_LENS = LENS_HEAD + '''
+local Warp = {}
+Warp.__index = Warp
+function Warp.new(gain, ripple, freq) return setmetatable({gain = gain, ripple = ripple, freq = freq, taps = {0.1, 0.95}}, Warp) end
+function Warp:lat(y) return y * self.gain + self.ripple * sin(self.freq * y) end
+function Warp:lon(x) return (x + self.taps[1]) * self.taps[#self.taps] end
+local warp = Warp.new(0.9, 0.05, 3)
+local function through(w, x, y) return w:lat(y), w:lon(x) end       -- an object passed on as an argument
+function lens_inverse(x, y)
+   if abs(x) > pi or abs(y) > pi/2 then return nil end
+   local lat, lon = through(warp, x, y)
+   local w2 = warp                                -- a local name for the object
+   local c = cos(w2:lat(y))
+   return c * sin(lon), sin(lat), c * cos(lon)
+end
+'''
+
+
+def test_method_calls_on_constant_objects_translate_to_the_same_table(bk):
+    from hostemu import emu
+    tables = []
+    for body in (OBJECT_PLAIN, OBJECT_LENS):
+        ctx = lens_ctx(bk, body)
+        ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+        ctx.resize(160, 100)
+        off, tin, flagged, err = emu.build_inverse(ctx)
+        assert err == 0
+        tables.append((off, tin))
+        assert ctx.eval_host(0, 0.3, 0.2) == lens_ctx(bk, OBJECT_PLAIN).eval_host(0, 0.3, 0.2)
+    assert (tables[0][0] != 0xFFFFFFFF).sum() > 10000
+    np.testing.assert_array_equal(tables[0][0], tables[1][0])
+    np.testing.assert_array_equal(tables[0][1], tables[1][1])
+    ctx.kernel_source(compile=True)
+
+
+@pytest.mark.parametrize("body,message", [
+    ("local o = {k = 2}\nfunction o:f(x) self.k = x return x end\nfunction lens_inverse(x,y) return o:f(x), y, 1 end", "storing into this table"),
+    ("local o = {k = 2}\nfunction o:f(x) return self end\nfunction lens_inverse(x,y) return o:f(x), y, 1 end", "table 'self' used as a value"),
+    ("function lens_inverse(x,y) local t = {1, 2} return t:f(x), y, 1 end", "not a constant table of the script"),
+    ("local o = {f = 3}\nfunction lens_inverse(x,y) return o:f(x), y, 1 end", "is not a script function"),
+])
+def test_object_uses_the_device_cannot_take_are_named(bk, body, message):
+    ctx = lens_ctx(bk, body)
+    ctx.resize(64, 48)
+    with pytest.raises(bk.BlinkyError, match=message):
         ctx.kernel_source(compile=False)

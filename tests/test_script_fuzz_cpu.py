@@ -19,7 +19,7 @@ class WideGen(Gen):
         pad = "  " * indent
         plain = [v for v in vars_ if "[" not in v and "." not in v and "(" not in v]
         for _ in range(int(self.r.integers(1, 3))):
-            k = int(self.r.integers(0, 9))
+            k = int(self.r.integers(0, 10))
             self.n += 1
             n = self.n
             if k == 0:        # a function defined here, closing over everything in sight, called twice
@@ -65,6 +65,11 @@ class WideGen(Gen):
                 out.append(f"{pad}local va{n}, vb{n} = spread({self.expr(vars_, 1)}, {self.pick(plain)}, {self.expr(vars_, 1)})")
                 out.append(f"{pad}local vc{n} = total({self.pick(plain)}, va{n}, ({self.expr(vars_, 2)})) + (select(-1, vb{n}, {self.pick(plain)}))")
                 vars_ += [f"va{n}", f"vb{n}", f"vc{n}"]
+            elif k == 9:      # a constant object: methods (one through a metatable), the object and a plain table as arguments
+                out.append(f"{pad}local ob{n} = gadget:bend({self.expr(vars_, 2)}) + gadget:base() + lookup(knots, {self.pick(plain)})")
+                out.append(f"{pad}local kn{n} = knots")
+                out.append(f"{pad}local oc{n} = using(gadget, {self.pick(plain)}) + kn{n}[2]")
+                vars_ += [f"ob{n}", f"oc{n}"]
             else:             # a constant table of the chunk: indexed, its length
                 out.append(f"{pad}local q{n} = math.abs({self.pick(plain)}) if not (q{n} < 100) then q{n} = 1 end       -- (a NaN or huge index would be a nil element)")
                 out.append(f"{pad}local d{n} = knots[(math.floor(q{n} * 3) % #knots) + 1] + #knots")
@@ -80,6 +85,13 @@ class WideGen(Gen):
             "local lib = {tri = function(t) return math.abs(t - math.floor(t + 0.5)) end}",
             "local function apply1(f, a) return f(a) + 0.5 end",
             "local function twice(f, a) return apply1(f, apply1(f, a)) end",
+            "local Gadget = {offset = 0.375}",
+            "Gadget.__index = Gadget",
+            "function Gadget:base() return self.offset + self.gain end",
+            "local gadget = setmetatable({gain = 1.25, taps = {0.5, 0.25}}, Gadget)",
+            "function gadget:bend(v) return v * self.gain + self.taps[2] * math.sin(v) + self:base() end",
+            "local function lookup(t, v) if v > 0 then return t[1] + #t end return t[#t] end",
+            "local function using(g, v) return g:bend(v) * 0.5 + g.taps[1] end",
             "local function total(...) local s = 0 for i = 1, select('#', ...) do s = s * 0.5 + (select(i, ...)) end return s end",
             "local function spread(first, ...) local n = select('#', ...) return first + n, total(...) end",
         ])
