@@ -888,6 +888,11 @@ def test_check_lens_tool(tmp_path):
     (tmp_path / "rec.lua").write_text("function lens_inverse(x,y) local function f(n) if n<1 then return 0 end return f(n-1) end return x,y,f(3) end")
     ok = subprocess.run([sys.executable, tool, str(tmp_path / "eckert4.lua"), "--no-compile"], capture_output=True, text=True, timeout=300)
     assert ok.returncode == 0 and "callbacks translate to GPU code" in ok.stdout and "carry state from pixel to pixel through 'lasty'" in ok.stdout
+    (tmp_path / "hammer.lua").write_text(S.script("lenses", "hammer"))
+    pre = subprocess.run([sys.executable, tool, str(tmp_path / "hammer.lua"), "--no-compile", "--preview", str(tmp_path / "hammer.png")],
+                         capture_output=True, text=True, timeout=300)
+    assert pre.returncode == 0 and "plates used: [0, 1, 2, 3, 4, 5]" in pre.stdout, pre.stdout + pre.stderr
+    assert (tmp_path / "hammer.png").read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
     bad = subprocess.run([sys.executable, tool, str(tmp_path / "rec.lua")], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "callbacks do NOT translate" in bad.stdout and "recursion ('f')" in bad.stdout
 

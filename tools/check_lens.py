@@ -4,7 +4,11 @@ host layer would see (map type, zoom limits, onload command), whether its per-pi
 construct does not - whether hiprtc compiles the result for gfx950, and whether the callbacks carry state from
 pixel to pixel (bk_lens_carries_state: such a lens needs bk_set_sequential_build to look as it does in the reference).
 
-usage: tools/check_lens.py <lens.lua> [<globe.lua>] [--no-compile]
+usage: tools/check_lens.py <lens.lua> [<globe.lua>] [--no-compile] [--preview out.png]
+
+--preview (inverse-map lenses): builds the lensmap at 640x400 by running the generated code on the HOST (tests/hostemu: the very
+translation unit the GPU gets, compiled by g++) and writes a picture of it - one colour per globe plate, shaded by the texel's position
+inside the plate, black where the lens maps nothing - so the shape of a lens can be judged without a GPU.
 """
 import os
 import sys
@@ -14,8 +18,37 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def write_preview(ctx, path):
+    import struct
+    import zlib
+    import numpy as np
+    from hostemu import emu
+    ctx.resize(640, 400)
+    off, tin, flagged, err = emu.build_inverse(ctx)
+    W, H, ps, r0, r1 = ctx.size()
+    ref = emu.device_to_reference_layout(off, ps)                       # plate * ps * ps + py * ps + px, 0xFFFFFFFF = unmapped
+    mapped = ref != 0xFFFFFFFF
+    plate = np.where(mapped, ref // (ps * ps), 0)
+    py = np.where(mapped, (ref % (ps * ps)) // ps, 0).astype(np.float64) / ps
+    px = np.where(mapped, ref % ps, 0).astype(np.float64) / ps
+    base = np.array([[230, 80, 80], [80, 200, 90], [90, 120, 240], [230, 200, 70], [200, 90, 220], [80, 210, 220]], np.float64)
+    shade = 0.45 + 0.55 * (0.5 * px + 0.5 * py) + 0.12 * (((px * 8).astype(int) + (py * 8).astype(int)) & 1)
+    rgb = np.clip(base[plate] * shade[:, None], 0, 255) * mapped[:, None]
+    img = rgb.astype(np.uint8).reshape(r1 - r0, W, 3)
+    raw = b"".join(b"\0" + img[y].tobytes() for y in range(img.shape[0]))
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, img.shape[0], 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) +
+                chunk(b"IEND", b""))
+    print("  %d of %d pixels mapped, %d flagged for the host (libm-dependent), plates used: %s" % (
+        int(mapped.sum()), mapped.size, len(flagged), sorted(set(plate[mapped].tolist()))))
+
+
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--preview"]
     if not args:
         print(__doc__)
         return 2
@@ -58,6 +91,13 @@ def main():
     except bk.BlinkyError as e:
         print("callbacks do NOT translate:", e)
         return 1
+    if "--preview" in sys.argv:
+        out_path = sys.argv[sys.argv.index("--preview") + 1]
+        if info.map_type != bk.ffi.MAP_INVERSE:
+            print("--preview needs an inverse-map lens")
+        else:
+            write_preview(ctx, out_path)
+            print("lensmap preview written to", out_path)
     carries, which = ctx.lens_carries_state()
     if carries:
         print("callbacks carry state from pixel to pixel through '%s': on the GPU every pixel starts from the value after load;"
