@@ -1192,7 +1192,7 @@ struct Exec {
         --I.depth;
         return true;
     }
-    void note_call_site(Frame &f, const Expr &e) { I.call_site = chunk_of(f) + ":" + std::to_string(e.line) + ":"; }
+    void note_call_site(Frame &f, const Expr &e) { I.call_chunk = &chunk_of(f); I.call_line = e.line; }
     // a:b(args): the function is a.b, its first argument a
     Values method_call(Frame &f, const Expr &e)
     {
@@ -1505,6 +1505,7 @@ std::string Interp::tostring(const Value &v) const
 
 Values Interp::call(const Value &fv, const Values &args)
 {
+    if (depth == 0) call_chunk = nullptr;       // (a call from the host: no script call site yet, and the last one's chunk may be gone)
     if (fv.t == Value::BUILTIN) {
         Values rets;
         fv.bi()->fn(*this, args, rets);
@@ -1844,8 +1845,8 @@ Interp::Interp(const MathLib &m) : math(&m)
     // luaB_error: a string message gets the position of the call in front (level 1, the default; level 0 = none)
     register_builtin("error", [](Interp &I, const Values &a, Values &) {
         if (a.empty()) throw LuaError("nil");
-        const bool positioned = a[0].t == Value::STR && !(a.size() > 1 && a[1].t == Value::NUM && a[1].n == 0) && !I.call_site.empty();
-        throw LuaError((positioned ? I.call_site + " " : std::string()) + I.tostring(a[0]));
+        const bool positioned = a[0].t == Value::STR && !(a.size() > 1 && a[1].t == Value::NUM && a[1].n == 0) && I.call_chunk;
+        throw LuaError((positioned ? *I.call_chunk + ":" + std::to_string(I.call_line) + ": " : std::string()) + I.tostring(a[0]));
     });
     register_builtin("select", [](Interp &, const Values &a, Values &r) {
         if (!a.empty() && a[0].t == Value::STR && a[0].str() == "#") { r.push_back(Value::number((double)a.size() - 1)); return; }

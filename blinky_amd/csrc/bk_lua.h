@@ -238,7 +238,8 @@ struct Interp {
     }
     long steps = 0, max_steps = 200000000;  // runaway-script guard
     std::string goto_label;                 // the label a `goto` under way is looking for
-    std::string call_site;                  // "chunk:line:" of the builtin call being made (error() puts it in front of its message)
+    const std::string *call_chunk = nullptr; // where the builtin call being made stands (error() puts "chunk:line:" in front of its message)
+    int call_line = 0;
     int depth = 0;
     std::function<void(const std::string &)> print_sink;   // `print` / io.write output, newlines included (Con_Printf)
 
