@@ -1937,6 +1937,67 @@ Interp::Interp(const MathLib &m) : math(&m)
         }
         throw LuaError("module '" + name + "' not found:" + tried);
     });
+    // ---- bit32 (lbitlib.c): numbers taken modulo 2^32, results in [0, 2^32) -------------------------------------------------------
+    auto bits = [](const Values &a, size_t i, const char *fn) -> uint32_t {
+        const double d = argnum(a, i, fn);
+        const double m = std::fmod(std::floor(d), 4294967296.0);                 // lua_Unsigned conversion: wraps around
+        return (uint32_t)(m < 0 ? m + 4294967296.0 : m);
+    };
+    auto fold = [bits](const char *name, uint32_t start, uint32_t (*op)(uint32_t, uint32_t)) {
+        return [bits, name, start, op](Interp &, const Values &a, Values &r) {
+            uint32_t v = start;
+            for (size_t i = 0; i < a.size(); ++i) v = op(v, bits(a, i, name));
+            r.push_back(Value::number((double)v));
+        };
+    };
+    register_builtin("bit32.band", fold("band", 0xFFFFFFFFu, [](uint32_t x, uint32_t y) { return x & y; }));
+    register_builtin("bit32.bor", fold("bor", 0u, [](uint32_t x, uint32_t y) { return x | y; }));
+    register_builtin("bit32.bxor", fold("bxor", 0u, [](uint32_t x, uint32_t y) { return x ^ y; }));
+    register_builtin("bit32.btest", [bits](Interp &, const Values &a, Values &r) {
+        uint32_t v = 0xFFFFFFFFu;
+        for (size_t i = 0; i < a.size(); ++i) v &= bits(a, i, "btest");
+        r.push_back(Value::boolean(v != 0));
+    });
+    register_builtin("bit32.bnot", [bits](Interp &, const Values &a, Values &r) { r.push_back(Value::number((double)(uint32_t)~bits(a, 0, "bnot"))); });
+    auto shift = [](uint32_t v, long n) -> uint32_t {                             // n > 0: left; |n| >= 32 gives 0
+        if (n <= -32 || n >= 32) return 0;
+        return n >= 0 ? v << n : v >> -n;
+    };
+    register_builtin("bit32.lshift", [bits, shift](Interp &, const Values &a, Values &r) { r.push_back(Value::number((double)shift(bits(a, 0, "lshift"), (long)argnum(a, 1, "lshift")))); });
+    register_builtin("bit32.rshift", [bits, shift](Interp &, const Values &a, Values &r) { r.push_back(Value::number((double)shift(bits(a, 0, "rshift"), -(long)argnum(a, 1, "rshift")))); });
+    register_builtin("bit32.arshift", [bits, shift](Interp &, const Values &a, Values &r) {
+        const uint32_t v = bits(a, 0, "arshift");
+        const long n = (long)argnum(a, 1, "arshift");
+        if (n < 0 || !(v & 0x80000000u)) { r.push_back(Value::number((double)shift(v, -n))); return; }
+        r.push_back(Value::number((double)(n >= 32 ? 0xFFFFFFFFu : ((v >> n) | ~(0xFFFFFFFFu >> n)))));
+    });
+    register_builtin("bit32.lrotate", [bits](Interp &, const Values &a, Values &r) {
+        const uint32_t v = bits(a, 0, "lrotate");
+        const unsigned n = (unsigned)(((long)argnum(a, 1, "lrotate") % 32 + 32) % 32);
+        r.push_back(Value::number((double)(n ? (v << n) | (v >> (32 - n)) : v)));
+    });
+    register_builtin("bit32.rrotate", [bits](Interp &, const Values &a, Values &r) {
+        const uint32_t v = bits(a, 0, "rrotate");
+        const unsigned n = (unsigned)(((-(long)argnum(a, 1, "rrotate")) % 32 + 32) % 32);
+        r.push_back(Value::number((double)(n ? (v << n) | (v >> (32 - n)) : v)));
+    });
+    register_builtin("bit32.extract", [bits](Interp &, const Values &a, Values &r) {
+        const uint32_t v = bits(a, 0, "extract");
+        const long f = (long)argnum(a, 1, "extract"), w = a.size() > 2 && a[2].t != Value::NIL ? (long)argnum(a, 2, "extract") : 1;
+        if (f < 0) throw LuaError("bad argument #2 to 'extract' (field cannot be negative)");
+        if (w <= 0) throw LuaError("bad argument #3 to 'extract' (width must be positive)");
+        if (f + w > 32) throw LuaError("trying to access non-existent bits");
+        r.push_back(Value::number((double)((v >> f) & (w == 32 ? 0xFFFFFFFFu : ((1u << w) - 1)))));
+    });
+    register_builtin("bit32.replace", [bits](Interp &, const Values &a, Values &r) {
+        const uint32_t v = bits(a, 0, "replace"), u = bits(a, 1, "replace");
+        const long f = (long)argnum(a, 2, "replace"), w = a.size() > 3 && a[3].t != Value::NIL ? (long)argnum(a, 3, "replace") : 1;
+        if (f < 0) throw LuaError("bad argument #3 to 'replace' (field cannot be negative)");
+        if (w <= 0) throw LuaError("bad argument #4 to 'replace' (width must be positive)");
+        if (f + w > 32) throw LuaError("trying to access non-existent bits");
+        const uint32_t m = (w == 32 ? 0xFFFFFFFFu : ((1u << w) - 1)) << f;
+        r.push_back(Value::number((double)((v & ~m) | ((u << f) & m))));
+    });
     register_builtin("os.time", [](Interp &, const Values &, Values &r) { r.push_back(Value::number((double)time(nullptr))); });
     register_builtin("os.clock", [](Interp &, const Values &, Values &r) { r.push_back(Value::number((double)clock() / (double)CLOCKS_PER_SEC)); });
     register_builtin("os.getenv", [](Interp &, const Values &a, Values &r) {

@@ -1169,3 +1169,21 @@ def test_object_uses_the_device_cannot_take_are_named(bk, body, message):
     ctx.resize(64, 48)
     with pytest.raises(bk.BlinkyError, match=message):
         ctx.kernel_source(compile=False)
+
+
+BIT32 = r'''
+print(bit32.band(0xFF, 0x0F, 0x3C), bit32.bor(1, 2, 8), bit32.bxor(5, 3), bit32.bnot(0), bit32.bnot(0xFFFFFFFF), bit32.band())
+print(bit32.lshift(1, 31), bit32.lshift(1, 32), bit32.rshift(0x80000000, 31), bit32.lshift(0xFF, -4), bit32.arshift(0x80000000, 4), bit32.arshift(0x70000000, 4))
+print(bit32.lrotate(0x80000001, 1), bit32.rrotate(1, 1), bit32.extract(0xABCD, 4, 8), bit32.replace(0, 0xF, 8, 4), bit32.btest(6, 3), bit32.btest(4, 3))
+print(bit32.band(-1, 0xFF), bit32.bor(2^32 + 5, 0), bit32.arshift(-8, 1), pcall(bit32.extract, 1, 30, 4))
+function lens_inverse(x, y) return x, y, 1 end
+'''
+
+
+def test_bit32_on_the_host(bk):
+    """lbitlib.c: operands modulo 2^32, shifts past the word, arithmetic shift, rotations, fields"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(BIT32, "bit.lua")
+    assert ctx.console() == ("12\t11\t6\t4294967295\t0\t4294967295\n2147483648\t0\t1\t15\t4160749568\t117440512\n"
+                             "3\t2147483648\t188\t3840\ttrue\tfalse\n255\t5\t4294967292\tfalse\ttrying to access non-existent bits\n")
