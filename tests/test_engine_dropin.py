@@ -1,5 +1,5 @@
 """The drop-in inside the engine it is a drop-in for.  oracle/_ref/engine holds the reference's TyrQuake engine (NQ client, software
-renderer) built headless twice from the sources where they lie (oracle/Makefile, target _ref): `tq_ref` with the UNMODIFIED
+renderer) built headless twice from the sources where they lie (oracle/Makefile, target _ref_engine): `tq_ref` with the UNMODIFIED
 engine/NQ/fisheye.c, `tq_hip` with blinky_amd/host/fisheye_hip.c + libblinkyhip.so in its place - every other object file is the same, down
 to the display-less video driver (oracle/ref/engine/headless.c) that logs a hash of every frame the engine presents.  Both run the same
 console script on a generated game directory (oracle/ref/engine/mkgame.py: one textured, lit room; the real id1/pak0.pak is not in the
@@ -22,7 +22,7 @@ TQ_REF = os.path.join(ENGINE, "tq_ref")
 TQ_HIP = os.path.join(ENGINE, "tq_hip")
 GAME = os.path.join(ENGINE, "game")
 needs_engines = pytest.mark.skipif(not (os.path.exists(TQ_REF) and os.path.exists(TQ_HIP) and os.path.isdir(GAME)),
-                                   reason="oracle/_ref/engine not built (needs /root/reference: make -C oracle _ref)")
+                                   reason="oracle/_ref/engine not built (needs /root/reference: make -C oracle _ref _ref_engine)")
 
 CONNECT = ["host_framerate 0.05",      # every frame advances the game by the same 50 ms whatever the wall clock says
            "scr_conspeed 1000000",      # the console leaves the screen at once instead of scrolling out by wall-clock time
