@@ -1187,3 +1187,21 @@ def test_bit32_on_the_host(bk):
     ctx.load_lens(BIT32, "bit.lua")
     assert ctx.console() == ("12\t11\t6\t4294967295\t0\t4294967295\n2147483648\t0\t1\t15\t4160749568\t117440512\n"
                              "3\t2147483648\t188\t3840\ttrue\tfalse\n255\t5\t4294967292\tfalse\ttrying to access non-existent bits\n")
+
+
+@pytest.mark.parametrize("name", ["measured_profile", "thin_lens_object", "integrated_arc", "uses_shared"])
+def test_example_lenses(bk, name, monkeypatch):
+    """examples/lenses: lenses written for this repository to show the script surface beyond the bundled 31 - a profile read from a file,
+    an object with methods, a higher-order integrator with varargs and nested functions, a shared helper module with a matrix: each loads,
+    its generated code builds a sensible map on the host emulation, and hiprtc compiles it for gfx950"""
+    from hostemu import emu
+    root = os.path.dirname(HERE)
+    monkeypatch.chdir(root)                                   # (the examples' io.open / require paths are relative to the repository root)
+    ctx = lens_ctx(bk, open(os.path.join(root, "examples", "lenses", name + ".lua")).read())
+    info = ctx.lens_info()
+    assert info.map_type == bk.ffi.MAP_INVERSE and info.onload.decode() == "f_contain"
+    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+    ctx.resize(160, 100)
+    off, tin, flagged, err = emu.build_inverse(ctx)
+    assert err == 0 and (off != 0xFFFFFFFF).sum() > 6000
+    ctx.kernel_source(compile=True)
