@@ -567,3 +567,46 @@ def _same_table_on_the_gpu(bk, variants):
         np.testing.assert_array_equal(t[0], tables[0][0])
         np.testing.assert_array_equal(t[1], tables[0][1])
         assert t[2:] == tables[0][2:]
+
+
+@pytest.mark.parametrize("pair", ["records_and_matrices", "varargs", "constant_objects"])
+def test_round3_constructs_build_the_same_table_on_the_gpu(bk, pair):
+    """tests/test_frontend.py's remaining differential pairs - records + matrices, vararg helpers / select, method calls on constant
+    objects (one through a metatable) and objects as arguments - through bk_build ON THE DEVICE (round 3 pinned them on the host
+    emulation of the generated code only), the construct version through the one-scan host build as well (fisheye.c:1545-1588)"""
+    import test_frontend as F
+    plain, fancy = {"records_and_matrices": (F.ROTATION_PLAIN, F.ROTATION_TABLES), "varargs": (F.VARARGS_PLAIN, F.VARARGS_LENS),
+                    "constant_objects": (F.OBJECT_PLAIN, F.OBJECT_LENS)}[pair]
+    _same_table_on_the_gpu(bk, ((plain, 0), (fancy, 0), (fancy, 2)))
+
+
+@pytest.mark.parametrize("name", ["measured_profile", "thin_lens_object", "integrated_arc", "uses_shared"])
+def test_example_lenses_build_the_oracle_table_on_the_gpu(bk, name, monkeypatch):
+    """examples/lenses/*.lua (a profile read from a file, an object with methods + a record per pixel, a higher-order integrator with
+    nested functions and varargs, a required helper module with a rotation matrix) through bk_build on the device, against the oracle's
+    fisheye.c restatement whose callbacks the host interpreter evaluates on the platform libm - the way the reference's Lua VM would
+    (fisheye.c:1545-1588, 2084-2124): offsets, tints, display flags and scale identical, on the cube and on the trism globe"""
+    root = os.path.dirname(HERE)
+    monkeypatch.chdir(root)                                   # (the examples' io.open / require paths are relative to the repository root)
+    body = open(os.path.join(root, "examples", "lenses", name + ".lua")).read()
+    for globe, (W, H) in (("cube", (640, 400)), ("trism", (200, 256))):
+        hostctx = bk.Context(bk.ffi.DEVICE_NONE)
+        hostctx.load_globe(S.script("globes", globe), globe + ".lua")
+        hostctx.load_lens(body, name + ".lua")
+        hostctx.resize(W, H)
+        info = hostctx.lens_info()
+        lm = O.lensmap_with_callbacks(globe, info, lambda x, y: hostctx.eval_host(0, x, y), None, info.onload.decode(), W, H)
+        ctx = bk.Context()
+        ctx.load_globe(S.script("globes", globe), globe + ".lua")
+        ctx.load_lens(body, name + ".lua")
+        ctx.set_zoom(*S.zoom_args(info.onload.decode()))
+        ctx.resize(W, H)
+        display, scale = ctx.build()
+        off, tin = ctx.read_lensmap()
+        assert lm.built and scale == lm.scale and display[: lm.numplates] == lm.display, (name, globe)
+        assert (off != O.NULL).sum() > W * H // 4, (name, globe)
+        bad = int((off != lm.offsets).sum())
+        assert bad == 0, f"{name}/{globe}: {bad} of {off.size} lensmap entries differ"
+        np.testing.assert_array_equal(tin, lm.tints)
+        ctx.close()
+        hostctx.close()

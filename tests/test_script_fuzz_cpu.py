@@ -10,95 +10,7 @@ import numpy as np
 import pytest
 
 import scripts as S
-from test_script_fuzz_gpu import Gen
-
-
-class WideGen(Gen):
-    def block(self, vars_, depth, indent):
-        out, vars_ = super().block(vars_, depth, indent)
-        pad = "  " * indent
-        plain = [v for v in vars_ if "[" not in v and "." not in v and "(" not in v]
-        for _ in range(int(self.r.integers(1, 3))):
-            k = int(self.r.integers(0, 10))
-            self.n += 1
-            n = self.n
-            if k == 0:        # a function defined here, closing over everything in sight, called twice
-                out.append(f"{pad}local function f{n}(a, b) local s = a * 0.5 + {self.expr(vars_, 2)} if s > b then return s - b, a end return {self.expr(vars_ + ['a', 'b', 's'], 2)}, b end")
-                out.append(f"{pad}local r{n}, s{n} = f{n}({self.expr(vars_, 2)}, {self.pick(plain)})")
-                out.append(f"{pad}local u{n} = f{n}(r{n}, s{n})")
-                vars_ += [f"r{n}", f"s{n}", f"u{n}"]
-            elif k == 1:      # local f = function, writing an enclosing local and a table of the enclosing function
-                out.append(f"{pad}local m{n} = {{{self.expr(vars_, 1)}, {self.expr(vars_, 1)}, 0}}")
-                out.append(f"{pad}local k{n} = 0")
-                out.append(f"{pad}local g{n} = function(i, v) m{n}[i] = v * 0.5 + m{n}[(i % #m{n}) + 1] k{n} = k{n} + 1 return m{n}[i] end")
-                out.append(f"{pad}local w{n} = g{n}(1, {self.expr(vars_, 2)}) + g{n}(3, {self.pick(plain)}) + k{n}")
-                vars_ += [f"w{n}", f"m{n}[2]", f"k{n}"]
-            elif k == 2:      # a function inside a function inside the callback
-                out.append(f"{pad}local function o{n}(a)")
-                out.append(f"{pad}  local function inner(b) return (a + b) * 0.5 + {self.pick(plain)} end")
-                out.append(f"{pad}  local acc = 0 for i = 1, 3 do acc = acc + inner(i * a) end return acc")
-                out.append(f"{pad}end")
-                out.append(f"{pad}local z{n} = o{n}({self.expr(vars_, 2)})")
-                vars_.append(f"z{n}")
-            elif k == 3:      # functions as arguments: a script function, a builtin, passed on once more
-                fn = self.pick(["helper2", "math.sin", "math.cos", "wave", "math.abs", "lib.tri"])
-                out.append(f"{pad}local h{n} = {self.pick(['apply1', 'twice'])}({fn if fn != 'helper2' else 'wave'}, {self.expr(vars_, 2)})")
-                out.append(f"{pad}local e{n} = fold(helper, {self.expr(vars_, 1)}, {self.pick(plain)})")
-                vars_ += [f"h{n}", f"e{n}"]
-            elif k == 4:      # a local of the chunk as scratch, a local name for a builtin
-                out.append(f"{pad}scratch = {self.expr(vars_, 2)}")
-                out.append(f"{pad}local sn{n} = math.sin")
-                out.append(f"{pad}local c{n} = sn{n}(scratch) + scratch * 0.25")
-                vars_.append(f"c{n}")
-            elif k == 6:      # a record: fields read, written, swapped; an unnamed field is nil
-                out.append(f"{pad}local rec{n} = {{a = {self.expr(vars_, 2)}, b = {self.expr(vars_, 1)}, c = 0}}")
-                out.append(f"{pad}rec{n}.c = rec{n}.a * 0.5 + rec{n}.b")
-                out.append(f"{pad}rec{n}.a, rec{n}.b = rec{n}.b, rec{n}.a")
-                out.append(f"{pad}if rec{n}.missing ~= nil then rec{n}.c = 0 end")
-                vars_ += [f"rec{n}.a", f"rec{n}.b", f"rec{n}.c"]
-            elif k == 7:      # a matrix: constant and computed indices, element stores, both lengths, reached from a function defined here
-                out.append(f"{pad}local mat{n} = {{{{{self.expr(vars_, 1)}, ({self.expr(vars_, 1)})}}, {{{self.expr(vars_, 1)}, 1}}, {{0.5, {self.pick(plain)}}}}}")
-                out.append(f"{pad}local function cell{n}(i, j) return mat{n}[i][j] end")
-                out.append(f"{pad}for i = 1, #mat{n} do for j = 1, #mat{n}[i] do mat{n}[i][j] = mat{n}[i][j] * 0.5 + cell{n}((i % #mat{n}) + 1, j) * 0.25 end end")
-                vars_ += [f"mat{n}[1][2]", f"mat{n}[3][1]", f"cell{n}(2, 2)"]
-            elif k == 8:      # vararg helpers: counted, indexed from both ends, passed on, spread over locals
-                out.append(f"{pad}local va{n}, vb{n} = spread({self.expr(vars_, 1)}, {self.pick(plain)}, {self.expr(vars_, 1)})")
-                out.append(f"{pad}local vc{n} = total({self.pick(plain)}, va{n}, ({self.expr(vars_, 2)})) + (select(-1, vb{n}, {self.pick(plain)}))")
-                vars_ += [f"va{n}", f"vb{n}", f"vc{n}"]
-            elif k == 9:      # a constant object: methods (one through a metatable), the object and a plain table as arguments
-                out.append(f"{pad}local ob{n} = gadget:bend({self.expr(vars_, 2)}) + gadget:base() + lookup(knots, {self.pick(plain)})")
-                out.append(f"{pad}local kn{n} = knots")
-                out.append(f"{pad}local oc{n} = using(gadget, {self.pick(plain)}) + kn{n}[2]")
-                vars_ += [f"ob{n}", f"oc{n}"]
-            else:             # a constant table of the chunk: indexed, its length
-                out.append(f"{pad}local q{n} = math.abs({self.pick(plain)}) if not (q{n} < 100) then q{n} = 1 end       -- (a NaN or huge index would be a nil element)")
-                out.append(f"{pad}local d{n} = knots[(math.floor(q{n} * 3) % #knots) + 1] + #knots")
-                vars_.append(f"d{n}")
-        return out, vars_
-
-    def script(self, forward):
-        text = super().script(forward)
-        head = "\n".join([
-            "local scratch = 0.125",
-            "local knots = {0.1, 0.35, 0.7, 1.3}",
-            "local function wave(t) return math.sin(t * 1.5) * 0.5 + t * 0.25 end",
-            "local lib = {tri = function(t) return math.abs(t - math.floor(t + 0.5)) end}",
-            "local function apply1(f, a) return f(a) + 0.5 end",
-            "local function twice(f, a) return apply1(f, apply1(f, a)) end",
-            "local Gadget = {offset = 0.375}",
-            "Gadget.__index = Gadget",
-            "function Gadget:base() return self.offset + self.gain end",
-            "local gadget = setmetatable({gain = 1.25, taps = {0.5, 0.25}}, Gadget)",
-            "function gadget:bend(v) return v * self.gain + self.taps[2] * math.sin(v) + self:base() end",
-            "local function lookup(t, v) if v > 0 then return t[1] + #t end return t[#t] end",
-            "local function using(g, v) return g:bend(v) * 0.5 + g.taps[1] end",
-            "local function total(...) local s = 0 for i = 1, select('#', ...) do s = s * 0.5 + (select(i, ...)) end return s end",
-            "local function spread(first, ...) local n = select('#', ...) return first + n, total(...) end",
-        ])
-        tail = "local function fold(f, a, b) local s = a for i = 1, 3 do s = f(s, b) * 0.5 + s * 0.25 end return s end"
-        # (helper and pair are defined by the base script; fold needs helper, so it goes after them)
-        text = text.replace("local function pair(a, b)", tail + "\nlocal function pair(a, b)", 1)
-        return head + "\n" + text
+from scriptgen import WideGen
 
 
 def _seeds():
