@@ -6,10 +6,11 @@
 
 static thread_local std::string g_create_error;
 
-static int ensure_device(bk_ctx *ctx)
+static int ensure_device(bk_ctx *ctx, bool keep_resident = false)
 {
     if (ctx->device < 0) return ctx->fail(BK_E_STATE, "this context was created without a device (BK_DEVICE_NONE)");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!keep_resident) bk::resident_quiesce(ctx);       // (a resident apply kernel leaves before anything else is launched)
     return BK_OK;
 }
 
@@ -84,6 +85,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     if (!ctx) return;
     if (ctx->device < 0) { bk::lensprogram_free(ctx->prog); delete ctx; return; }
     hipSetDevice(ctx->device);
+    bk::resident_free(ctx);
     hipStreamSynchronize(ctx->stream);
     free_maps(ctx);
     free_plate_slots(ctx);
@@ -154,7 +156,7 @@ static int alloc_globe(bk_ctx *ctx)
 void bk::empty_context(bk_ctx *ctx)
 {
     const std::string msg = ctx->err;
-    if (ctx->device >= 0) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx->device >= 0) { (void)hipSetDevice(ctx->device); bk::resident_quiesce(ctx); (void)hipStreamSynchronize(ctx->stream); }
     free_maps(ctx);
     (void)hipFree(ctx->d_globe); ctx->d_globe = nullptr; ctx->globe_bytes = 0;
     (void)hipFree(ctx->d_plate_stage); ctx->d_plate_stage = nullptr;
@@ -519,6 +521,64 @@ extern "C" int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_d
     if (int r = upload_pal(ctx, rubix_on, pal)) return r;
     uint8_t *first = (uint8_t *)dst_dev + (size_t)(y0 + ctx->row0) * dst_pitch + x0;
     return bk::launch_apply(ctx, frame0, nframes, first, dst_pitch, frame_stride, rubix_on);
+}
+
+// ---- resident single-frame apply (bk_apply_resident.inc) ------------------------------------------------------------
+extern "C" int bk_apply_resident_begin(bk_ctx *ctx, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256], double idle_ms)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_apply_resident_begin: no lensmap (bk_build / bk_set_lensmap first)");
+    if (ctx->apply_variant == 0) return ctx->fail(BK_E_STATE, "bk_apply_resident_begin: the resident apply is the staged variant (bk_set_apply_variant 2 / -1)");
+    if (ctx->rows() <= 0) return ctx->fail(BK_E_STATE, "bk_apply_resident_begin: this context owns no rows");
+    if (int r = ensure_device(ctx)) return r;
+    if (int r = upload_pal(ctx, rubix_on, pal)) return r;
+    return bk::resident_begin(ctx, rubix_on, idle_ms);
+}
+
+extern "C" int bk_apply_resident_submit(bk_ctx *ctx, int frame, void *dst_dev, int dst_pitch, int x0, int y0, uint64_t *ticket)
+{
+    if (!ctx || !dst_dev) return BK_E_INVALID;
+    if (!ctx->resident) return ctx->fail(BK_E_STATE, "bk_apply_resident_submit without bk_apply_resident_begin");
+    if (dst_pitch < ctx->W + x0 || x0 < 0 || y0 < 0 || frame < 0) return ctx->fail(BK_E_INVALID, "bk_apply_resident_submit: bad pitch/origin/frame");
+    if (int r = ensure_device(ctx, true)) return r;
+    uint8_t *first = (uint8_t *)dst_dev + (size_t)(y0 + ctx->row0) * dst_pitch + x0;
+    return bk::resident_submit(ctx, frame, first, dst_pitch, ticket);
+}
+
+// a batch through the resident kernel: frame f of the batch is globe (frame0 + f) % resident globes -> dst_dev + f * frame_stride
+// (bk_apply_device's addressing); one command per frame, the call blocks only while the command ring is full
+extern "C" int bk_apply_resident_submit_batch(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst_pitch, size_t frame_stride,
+                                              int x0, int y0, uint64_t *last_ticket)
+{
+    if (!ctx || !dst_dev) return BK_E_INVALID;
+    if (!ctx->resident) return ctx->fail(BK_E_STATE, "bk_apply_resident_submit_batch without bk_apply_resident_begin");
+    if (dst_pitch < ctx->W + x0 || x0 < 0 || y0 < 0 || frame0 < 0 || nframes < 1) return ctx->fail(BK_E_INVALID, "bk_apply_resident_submit_batch: bad pitch/origin/frames");
+    if (int r = ensure_device(ctx, true)) return r;
+    uint8_t *first = (uint8_t *)dst_dev + (size_t)(y0 + ctx->row0) * dst_pitch + x0;
+    for (int f = 0; f < nframes; ++f)
+        if (int r = bk::resident_submit(ctx, (frame0 + f) % ctx->nframes, first + (size_t)f * frame_stride, dst_pitch, last_ticket)) return r;
+    return BK_OK;
+}
+
+extern "C" int bk_apply_resident_wait(bk_ctx *ctx, uint64_t ticket, double *gpu_us)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (int r = ensure_device(ctx, true)) return r;
+    return bk::resident_wait(ctx, ticket, gpu_us);
+}
+
+extern "C" int bk_apply_resident_end(bk_ctx *ctx)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (ctx->device < 0) return BK_OK;
+    if (int r = ensure_device(ctx, true)) return r;
+    return bk::resident_stop(ctx);
+}
+
+extern "C" int bk_apply_resident_info(bk_ctx *ctx, int out[12])
+{
+    if (!ctx || !out) return BK_E_INVALID;
+    return bk::resident_info(ctx, out);
 }
 
 // mapped spans of the owned rows from the device bitmap (once per lensmap)

@@ -32,6 +32,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <ctime>
 #include <vector>
 
 #include "bk_internal.h"
@@ -327,8 +329,36 @@ __device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict_
     return ix;
 }
 
+// Stores of the warped frame.  WT = false: non-temporal (the frame is never read back here; a kernel boundary publishes it).
+// WT = true (the resident apply, bk_apply_resident.inc): write-through `sc1` stores - the frame is published by a flag while the
+// kernel goes on running, so its bytes have to be in memory, not in the XCD's L2, when the flag is raised; a 16-byte sc1 store
+// costs what a plain one does and drops the line from L2, which is what a frame nobody reads back wants anyway.  They are inline
+// assembly: the compiler does not count them in vmcnt - the publisher waits with an explicit s_waitcnt vmcnt(0).
+// (WT: the address as a wave-uniform base in SGPRs + a 32-bit byte offset per lane - no 64-bit address arithmetic in VGPRs, which the
+//  resident kernel has none to spare for.  The s_nop: a VALU write of an SGPR (v_readfirstlane) needs five wait states before a vector
+//  memory instruction reads it, and the compiler's hazard recogniser does not look inside inline assembly - without it the store
+//  went out with whatever the SGPR pair held before: found as a memory fault on the first aligned frame.)
+__device__ __forceinline__ uint8_t *bk_uniform_ptr(uint8_t *p)      // a pointer the caller knows to be wave-uniform, as SGPRs
+{
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return reinterpret_cast<uint8_t *>((uintptr_t)lo | ((uintptr_t)hi << 32));
+}
+template <bool WT>
+__device__ __forceinline__ void bk_store_u32(uint8_t *base, uint32_t off, uint32_t v)
+{
+    if (WT) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(base + off));
+}
+template <bool WT>
+__device__ __forceinline__ void bk_store_u8(uint8_t *base, uint32_t off, uint32_t v)
+{
+    if (WT) asm volatile("s_nop 4\n\tglobal_store_byte %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else base[off] = (uint8_t)v;
+}
+
 // one frame of one lane: its 4*RG texels out of the staged chunks, packed and stored
-template <bool RUBIX, int RG>
+template <bool RUBIX, int RG, bool WT = false>
 __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const CoopIdx<RG> &ix, bool fast_store, const uint8_t *pal_s,
                                                   uint8_t *__restrict__ dst, size_t frame_stride, int dst_pitch, int f, int row0, int x, int kflags)
 {
@@ -340,14 +370,27 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
             w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
         }
         if (!(kflags & 4)) {
-            uint8_t *o = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x;
             // non-temporal stores: the frame is never read back here, and keeping it out of L2 leaves the cache to the
             // globe lines neighbouring blocks share (4K panini 3.8 -> 3.3 us/frame)
             typedef uint32_t v2u __attribute__((ext_vector_type(2)));
             typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            if (RG == 1) __builtin_nontemporal_store(w[0], reinterpret_cast<uint32_t *>(o));
-            else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(o)); }
-            else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o)); }
+            if (WT && (kflags & 64)) {             // (developer experiment: the resident kernel with write-BACK non-temporal stores - timing only)
+                uint8_t *o = dst + (size_t)row0 * dst_pitch + x;
+                if (RG == 1) __builtin_nontemporal_store(w[0], reinterpret_cast<uint32_t *>(o));
+                else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(o)); }
+                else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o)); }
+            } else if (WT) {
+                const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)x;       // (f = 0, one frame per command)
+                dst = bk_uniform_ptr(dst);
+                if (RG == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(w[0]), "s"(dst) : "memory");
+                else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
+                else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
+            } else {
+                uint8_t *o = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x;
+                if (RG == 1) __builtin_nontemporal_store(w[0], reinterpret_cast<uint32_t *>(o));
+                else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(o)); }
+                else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o)); }
+            }
         }
     } else {
 #pragma unroll
@@ -362,13 +405,25 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                     if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
                 }
             }
-            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
-            if (fast_store) {
-                __builtin_nontemporal_store(v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), reinterpret_cast<uint32_t *>(out));
-            } else {
+            if (WT) {
+                const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)(x + 4 * r);
+                dst = bk_uniform_ptr(dst);
+                if (fast_store) {
+                    bk_store_u32<true>(dst, off, v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24));
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
+                    for (int k = 0; k < 4; ++k)
+                        if (a[k] != 0xFFFFu) bk_store_u8<true>(dst, off + k, v[k]);
+                }
+            } else {
+                uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
+                if (fast_store) {
+                    __builtin_nontemporal_store(v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), reinterpret_cast<uint32_t *>(out));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
+                }
             }
         }
     }
@@ -810,6 +865,7 @@ void coopmap_free(CoopMap *cm)
 
 void coopmap_invalidate(bk_ctx *ctx)
 {
+    resident_quiesce(ctx);          // (a resident apply kernel holds this block map in its registers)
     if (ctx->coopmap) ctx->coopmap->valid = false;
 }
 
@@ -1357,5 +1413,7 @@ int coopmap_stats(bk_ctx *ctx, int out[6])
     out[4] = 8 * cm->rg + 1000 * 128; out[5] = (int)cm->stats[3];
     return BK_OK;
 }
+
+#include "bk_apply_resident.inc"
 
 }  // namespace bk

@@ -32,6 +32,7 @@ struct Rubix { int numcells = 10; double cell = 4, pad = 1; };   // defaults: fi
 
 struct LensProgram;   // bk_lens.cpp: parsed scripts + hiprtc modules
 struct CoopMap;       // bk_apply_coop.hip: per-block staging plans of the workgroup-cooperative apply kernel
+struct Resident;      // bk_apply_resident.inc: the resident single-frame apply (its kernel, command ring and stream)
 
 }  // namespace bk
 
@@ -101,6 +102,7 @@ struct bk_ctx {
     bool blockmap_tuning = true;     // bk_set_blockmap_tuning: block height of the staged apply chosen by timing the candidates
     int tile_shape = 0;              // coop apply: 0 = block height by cost model, 1/2/4 = force 128x8 / 128x16 / 128x32
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
+    bk::Resident *resident = nullptr;     // owned; freed with bk::resident_free (bk_apply_resident_begin .. _end)
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
     double last_host_eval_ms = 0;    // of that: wall time of the host re-evaluation of the flagged entries
@@ -159,6 +161,16 @@ int coopmap_row_costs(bk_ctx *ctx, uint32_t *rows_out);      // device uint32 [r
 int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev);     // bk_probe.hip: what every owned row costs the apply, into a device uint32 [H]
 namespace bk {
 void coopmap_free(CoopMap *);
+// bk_apply_resident.inc (part of bk_apply_coop.hip): the resident single-frame apply
+int resident_begin(bk_ctx *ctx, int rubix_on, double idle_ms);
+int resident_submit(bk_ctx *ctx, int frame, uint8_t *dst_first_owned_row, int dst_pitch, uint64_t *ticket);
+int resident_wait(bk_ctx *ctx, uint64_t ticket, double *gpu_us);
+int resident_stop(bk_ctx *ctx);          // the kernel leaves (outstanding frames are finished first); begin again to resume
+void resident_free(bk_ctx *ctx);
+int resident_info(bk_ctx *ctx, int out[12]);
+// every other device entry point of a context calls this first: a resident kernel fills the chip, whatever else the context
+// launches would wait for it to leave
+inline void resident_quiesce(bk_ctx *ctx) { if (ctx->resident) (void)resident_stop(ctx); }
 
 // bk_lens.cpp
 void lensprogram_free(LensProgram *);

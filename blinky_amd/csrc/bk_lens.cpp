@@ -1329,6 +1329,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_build: this context has no device");
     if (!ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_build: call bk_resize first");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     LensProgram *P = ctx->prog;
     if (bk::build_module_ready(ctx) == BK_PENDING) return BK_PENDING;
     const size_t px = (size_t)ctx->W * ctx->rows();
@@ -1709,6 +1710,7 @@ extern "C" int bk_truncate_build(bk_ctx *ctx, unsigned int bad_key, int display_
     if (!ctx) return BK_E_INVALID;
     if (!ctx->lensmap_valid || !ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_truncate_build: no lensmap");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     int disp[BK_MAX_PLATES];
     if (bad_key == 0) return BK_OK;
     if (int r = bk::launch_truncate_scan(ctx, bad_key, disp)) return r;
@@ -1739,6 +1741,7 @@ extern "C" int bk_save_plate(bk_ctx *ctx, int frame, int plate, int with_margins
     if (plate < 0 || plate >= ctx->numplates || frame < 0 || frame >= ctx->nframes || dst_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_save_plate: bad frame/plate/pitch");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     LensProgram *P = ctx->prog;
     std::string src;
     if (int r = generate_source(ctx, P, &src)) return r;
@@ -1805,6 +1808,7 @@ extern "C" int bk_debug_eval_device(bk_ctx *ctx, int which, const double *args, 
     LensProgram *P = ctx->prog;
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "no valid lens");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     std::string src;
     if (int r = generate_source(ctx, P, &src)) return r;
     if (int r = compile_module(ctx, P, src)) return r;

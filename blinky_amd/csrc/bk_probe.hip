@@ -44,6 +44,7 @@ int bk_row_costs_device(bk_ctx *ctx, uint32_t *cost_dev)
 {
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "row costs: no lensmap (call bk_build first)");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     BK_HIP(ctx, hipMemsetAsync(cost_dev, 0, (size_t)ctx->H * sizeof(uint32_t), ctx->stream));
     if (ctx->apply_variant != 0) return bk::coopmap_row_costs(ctx, cost_dev + ctx->row0);
     if (ctx->rows() > 0) {
@@ -60,6 +61,7 @@ extern "C" int bk_debug_row_costs(bk_ctx *ctx, uint32_t *host_out)
     if (!ctx || !host_out) return BK_E_INVALID;
     if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_debug_row_costs: this context has no device");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     uint32_t *d = nullptr;
     BK_HIP(ctx, hipMalloc((void **)&d, (size_t)ctx->H * sizeof(uint32_t)));
     const int rc = bk_row_costs_device(ctx, d);
@@ -77,6 +79,7 @@ extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int wr
     if (!ctx || !gbps || bytes < (1u << 20) || period < 1 || writes < 0 || writes > period) return BK_E_INVALID;
     if (ctx->device < 0) return ctx->fail(BK_E_STATE, "bk_debug_stream_mix: this context has no device");
     BK_HIP(ctx, hipSetDevice(ctx->device));
+    bk::resident_quiesce(ctx);
     uint4 *a = nullptr, *b = nullptr;
     uint32_t *sink = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -77,6 +77,12 @@ _SIGS = {
     "bk_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "bk_apply_device": (_i, [_vp, _i, _i, _vp, _i, _sz, _i, _i, _i, _vp]),
     "bk_apply_begin": (_i, [_vp, _i, _i, _vp]),
+    "bk_apply_resident_begin": (_i, [_vp, _i, _vp, _d]),
+    "bk_apply_resident_submit": (_i, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
+    "bk_apply_resident_submit_batch": (_i, [_vp, _i, _i, _vp, _i, _sz, _i, _i, C.POINTER(C.c_uint64)]),
+    "bk_apply_resident_wait": (_i, [_vp, C.c_uint64, C.POINTER(_d)]),
+    "bk_apply_resident_end": (_i, [_vp]),
+    "bk_apply_resident_info": (_i, [_vp, C.POINTER(_i)]),
     "bk_apply_end": (_i, [_vp, _vp, _i, _i, _i]),
     "bk_create_palmap": (None, [_vp, _vp]),
     "bk_get_size": (_i, [_vp] + [C.POINTER(_i)] * 5),
@@ -366,6 +372,37 @@ class Context:
             pal = np.ascontiguousarray(pal, dtype=np.uint8)
         self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
                                       int(rubix_on), _ptr(pal)))
+
+    # ---- the resident single-frame apply (bk_apply_resident_*): one kernel stays on the device, frames are commands
+    def resident_begin(self, rubix_on=False, pal=None, idle_ms=0.0):
+        if pal is not None:
+            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        self._chk(lib.bk_apply_resident_begin(self._h, int(rubix_on), _ptr(pal), float(idle_ms)))
+
+    def resident_submit(self, dst_ptr, pitch, frame=0, x0=0, y0=0):
+        t = C.c_uint64(0)
+        self._chk(lib.bk_apply_resident_submit(self._h, frame, dst_ptr, pitch, x0, y0, C.byref(t)))
+        return t.value
+
+    def resident_submit_batch(self, dst_ptr, pitch, frame_stride, frame0=0, nframes=1, x0=0, y0=0):
+        t = C.c_uint64(0)
+        self._chk(lib.bk_apply_resident_submit_batch(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0, C.byref(t)))
+        return t.value
+
+    def resident_wait(self, ticket):
+        """-> device microseconds from the kernel seeing the command to the frame complete in memory"""
+        us = _d(0)
+        self._chk(lib.bk_apply_resident_wait(self._h, ticket, C.byref(us)))
+        return us.value
+
+    def resident_end(self):
+        self._chk(lib.bk_apply_resident_end(self._h))
+
+    def resident_info(self):
+        out = (_i * 12)()
+        self._chk(lib.bk_apply_resident_info(self._h, out))
+        return dict(running=bool(out[0]), workgroups=out[1], blocks_in_registers=out[2], chunks_per_thread=out[3], block_h=out[4],
+                    per_cu=out[5], launches=out[6], pending=out[7], streamed=(out[8], out[9], out[10]), laggard=out[11] // 10000, laggards=out[11] % 10000)
 
     def host_module_ready(self, wait=False):
         return bool(lib.bk_host_module_ready(self._h, int(wait)))

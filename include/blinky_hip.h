@@ -203,6 +203,35 @@ int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst
                     size_t frame_stride, int x0, int y0, int rubix_on,
                     const uint8_t pal[BK_MAX_PLATES][256]);
 
+/* ---- resident single-frame apply ------------------------------------------------------------------------------------
+ * replaces: the per-frame call of render_lensmap (fisheye.c:803 -> 2406-2424) for hosts whose globes stay in device memory.
+ * One bk_apply_device launch per frame re-reads the whole block map of the staged apply (2 bytes per pixel and more: half of a
+ * 4K frame's traffic) because nothing stays in the caches across a kernel boundary.  bk_apply_resident_begin launches a kernel
+ * that STAYS on the device with the block map in its registers; bk_apply_resident_submit hands it one frame - warp globe `frame`
+ * into dst_dev (same addressing as bk_apply_device: pixel (0,0) of the whole view, only the owned rows are written, unmapped
+ * pixels untouched) - by writing a command into pinned host memory, and returns at once with a ticket; submissions pipeline
+ * (up to 32 in flight).  bk_apply_resident_wait(ticket) returns when that frame - and every earlier one - is complete IN
+ * MEMORY (any stream, DMA or peer may read it); *gpu_us (nullable) = device time from the kernel seeing the command to the
+ * frame's completion.  bk_apply_resident_end makes the kernel leave.
+ * Rules: the globe frame and dst of a submission must not be written by anyone else between submit and wait, and whatever
+ * produced that globe frame must have COMPLETED (host-synchronised) before the submit - the kernel is not ordered with any
+ * stream.  rubix_on / pal are fixed for the session.  The kernel fills the GPU: every other device entry point of this context
+ * ends the session first (the next submit starts it again transparently), kernels of other contexts / libraries queue behind
+ * it, and a device-wide synchronise blocks until it leaves - which it does by itself after idle_ms (<= 0: 200 ms) without a
+ * submission; a later submit relaunches it.  The staged apply variant only. */
+int bk_apply_resident_begin(bk_ctx *ctx, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256], double idle_ms);
+int bk_apply_resident_submit(bk_ctx *ctx, int frame, void *dst_dev, int dst_pitch, int x0, int y0, uint64_t *ticket);
+/* a batch: frame f is warped from globe (frame0 + f) % resident globes into dst_dev + f * frame_stride (bk_apply_device's
+ * addressing), one command per frame; blocks only while the command ring is full; *last_ticket = the last frame's */
+int bk_apply_resident_submit_batch(bk_ctx *ctx, int frame0, int nframes, void *dst_dev, int dst_pitch, size_t frame_stride,
+                                   int x0, int y0, uint64_t *last_ticket);
+int bk_apply_resident_wait(bk_ctx *ctx, uint64_t ticket, double *gpu_us);
+int bk_apply_resident_end(bk_ctx *ctx);
+/* out = {kernel on the device, worker workgroups, blocks per workgroup held in registers, chunk offsets per thread and block,
+ * block height, workgroups per CU, kernel launches so far, submissions not yet known complete; of the last session that was ended:
+ * min / median / max over its workgroups of the frames a workgroup ran on into the next one without draining; 0} */
+int bk_apply_resident_info(bk_ctx *ctx, int out[12]);
+
 /* ---- multi-GPU: row stripes + RCCL over xGMI ---------------------------------------------------------------
  * No counterpart in the reference (fisheye.c is single-threaded CPU code).  Every output pixel is independent, so
  * GPU r of N owns rows [H*r/N, H*(r+1)/N): it builds and keeps only that stripe of the lensmap (no exchange, ever),

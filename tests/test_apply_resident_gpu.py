@@ -1,0 +1,232 @@
+"""Parity of the RESIDENT single-frame apply (bk_apply_resident_begin / submit / wait / end: one kernel stays on the device with the
+block map in its registers, a frame is a command written to pinned host memory) against the CPU oracle's render_lensmap restatement
+(fisheye.c:2406-2424, one frame per F_RenderView call: fisheye.c:803), through the C ABI.  Byte-exact, background untouched."""
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = {(r["globe"], r["lens"], r["zoom"], r["W"], r["H"]): r
+        for r in json.load(open(os.path.join(HERE, "golden", "lensmaps.json")))["lensmaps"]}
+
+
+@pytest.fixture(scope="module")
+def bk():
+    import blinky_amd
+    return blinky_amd
+
+
+@pytest.fixture(scope="module")
+def hip():
+    h = ctypes.CDLL("libamdhip64.so")
+    h.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return h
+
+
+def make_ctx(bk, lm, nframes=1, rows=None):
+    ctx = bk.Context()
+    ctx.set_frames(nframes)
+    ctx.resize(lm.W, lm.H)
+    if rows:
+        ctx.set_rows(*rows)
+    return ctx
+
+
+def background(H, pitch, extra=7):
+    return (np.arange((H + extra) * pitch, dtype=np.uint32) * 7 % 251).astype(np.uint8).reshape(H + extra, pitch)
+
+
+CONFIGS = [
+    ("cube", "panini", None, 640, 480),
+    ("cube", "hammer", None, 960, 540),                 # 30 % unmapped
+    ("cube", "quincuncial", None, 640, 480),
+    ("trism", "panini", None, 960, 540),
+    ("cube", "panini", "f_fov 120", 322, 203),          # W % 4 != 0
+    ("cube", "stereographic", "f_vfov 90", 300, 500),   # portrait, one NULL pixel in the middle
+    ("cube", "eckert5", None, 640, 480),                # forward-built map (ragged mapped region)
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c[0]}-{c[1]}-{c[3]}x{c[4]}")
+@pytest.mark.parametrize("rubix", [False, True])
+def test_resident_frames_match_oracle(bk, hip, cfg, rubix):
+    """three globes, three frames submitted back to back into buffers with pitch > W and an origin; then globe 0 is REWRITTEN behind the
+    running kernel's back (a DMA, no kernel boundary) and warped again: the kernel must not serve stale texels from a cache"""
+    import torch
+    lm = O.lensmap(*cfg)
+    W, H = lm.W, lm.H
+    F = 3
+    globes = [O.lcg_globe(lm.ps, 6, 3 + f) for f in range(F)]
+    pal = O.palmap(O.synthetic_basepal())
+    ctx = make_ctx(bk, lm, nframes=F)
+    for f in range(F):
+        for p in range(6):
+            ctx.upload_plate(f, p, globes[f][p])
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    pitch, x0, y0 = W + 24, 5, 3
+    bg = background(H, pitch)
+    outs = [torch.from_numpy(bg.copy()).cuda() for _ in range(F + 1)]
+    nbytes = 6 * ctx.globe_pitch() * ctx.globe_rows()
+    raw1 = np.empty(nbytes, np.uint8)
+    assert hip.hipMemcpy(raw1.ctypes.data, ctx.globe_device_ptr(1), nbytes, 2) == 0
+    torch.cuda.synchronize()
+    ctx.resident_begin(rubix, pal, idle_ms=2000)
+    info = ctx.resident_info()
+    assert info["running"] and info["workgroups"] > 1 and info["launches"] == 1
+    tickets = [ctx.resident_submit(outs[f].data_ptr(), pitch, frame=f, x0=x0, y0=y0) for f in range(F)]
+    assert tickets == [1, 2, 3]
+    us = [ctx.resident_wait(t) for t in reversed(tickets)]
+    assert all(0 < u < 1e6 for u in us)
+    # globe 0 <- globe 1's bytes by DMA while the kernel stays where it is
+    assert hip.hipMemcpy(ctx.globe_device_ptr(0), raw1.ctypes.data, nbytes, 1) == 0
+    t = ctx.resident_submit(outs[F].data_ptr(), pitch, frame=0, x0=x0, y0=y0)
+    ctx.resident_wait(t)
+    assert ctx.resident_info()["launches"] == 1, "the kernel was meant to stay on the device through all of this"
+    ctx.resident_end()
+    assert not ctx.resident_info()["running"]
+    for f in range(F + 1):
+        want = O.apply(lm.offsets, lm.tints, W, H, globes[f if f < F else 1], bg.copy(), pitch, x0, y0, rubix, pal)
+        np.testing.assert_array_equal(outs[f].cpu().numpy(), want, err_msg=f"frame {f}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["random", "rows", "affine", "sparse"])
+def test_resident_arbitrary_tables(bk, kind):
+    """tables no lens would make - scrambled offsets (blocks without a chunk list: the direct-gather path), runs, 90 % NULL - and a
+    stripe of the rows"""
+    import torch
+    W, H = 517, 260
+    ps = H
+    rng = np.random.default_rng(11)
+    n = 6 * ps * ps
+    if kind == "random":
+        off = rng.integers(0, n, W * H).astype(np.uint32)
+    elif kind == "rows":
+        off = ((np.arange(W * H, dtype=np.int64) * 3 + 1000) % n).astype(np.uint32)
+    elif kind == "affine":
+        yy, xx = np.mgrid[0:H, 0:W]
+        off = (((yy * 7 // 8) % ps) * ps + (xx * 3 // 7) % ps + 2 * ps * ps).astype(np.uint32).ravel()
+    else:
+        off = rng.integers(0, n, W * H).astype(np.uint32)
+        off[rng.random(W * H) < 0.9] = O.NULL
+    tints = rng.integers(0, 6, W * H).astype(np.uint8)
+    tints[rng.random(W * H) < 0.5] = 255
+    globe = O.lcg_globe(ps, 6, 1)
+    pal = O.palmap(O.synthetic_basepal())
+
+    class LM:
+        pass
+    lm = LM()
+    lm.W, lm.H, lm.ps = W, H, ps
+    for rows, rubix in (((0, H), False), ((64, 201), True)):
+        ctx = make_ctx(bk, lm, rows=rows)
+        for p in range(6):
+            ctx.upload_plate(0, p, globe[p])
+        r0, r1 = rows
+        ctx.set_lensmap(off.reshape(H, W)[r0:r1].copy(), tints.reshape(H, W)[r0:r1].copy())
+        bg = background(H, W, 0)
+        out = torch.from_numpy(bg.copy()).cuda()
+        torch.cuda.synchronize()
+        ctx.resident_begin(rubix, pal, idle_ms=2000)
+        ctx.resident_wait(ctx.resident_submit(out.data_ptr(), W))
+        ctx.resident_end()
+        o2, t2 = off.copy().reshape(H, W), tints.copy().reshape(H, W)
+        o2[:r0] = O.NULL
+        o2[r1:] = O.NULL
+        want = O.apply(o2.ravel(), t2.ravel(), W, H, globe, bg.copy(), W, 0, 0, rubix, pal)
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+        ctx.close()
+
+
+def test_resident_kernel_leaves_when_idle_and_comes_back(bk):
+    """nobody can hang the device: without a submission the kernel exits after idle_ms; the next submit starts it again; any
+    other device entry point of the context ends the session first"""
+    import torch
+    lm = O.lensmap("cube", "panini", None, 640, 480)
+    globe = O.lcg_globe(lm.ps, 6, 0)
+    ctx = make_ctx(bk, lm)
+    for p in range(6):
+        ctx.upload_plate(0, p, globe[p])
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    want = O.apply(lm.offsets, lm.tints, lm.W, lm.H, globe, np.zeros((lm.H, lm.W), np.uint8))
+    outs = [torch.zeros((lm.H, lm.W), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    ctx.resident_begin(idle_ms=10)
+    ctx.resident_wait(ctx.resident_submit(outs[0].data_ptr(), lm.W))
+    time.sleep(0.2)
+    assert not ctx.resident_info()["running"]
+    torch.cuda.synchronize()                          # (returns: nothing of ours is on the device any more)
+    ctx.resident_wait(ctx.resident_submit(outs[1].data_ptr(), lm.W))
+    assert ctx.resident_info()["launches"] == 2
+    # another entry point of the context: the session ends by itself, and a submit after it brings the kernel back
+    got = ctx.apply(np.zeros((lm.H, lm.W), np.uint8))
+    np.testing.assert_array_equal(got, want)
+    assert not ctx.resident_info()["running"]
+    ctx.resident_wait(ctx.resident_submit(outs[2].data_ptr(), lm.W))
+    assert ctx.resident_info()["launches"] == 3
+    ctx.resident_end()
+    for o in outs:
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
+    with pytest.raises(bk.BlinkyError):
+        ctx.resident_wait(10 ** 9)
+    ctx.close()
+
+
+def test_resident_pipelined_submissions(bk):
+    """100 frames over a ring of 8 globes into 4 rotating buffers, up to 32 in flight: every frame's bytes, in order"""
+    import torch
+    lm = O.lensmap("cube", "hammer", None, 960, 540)
+    F = 8
+    globes = [O.lcg_globe(lm.ps, 6, f) for f in range(F)]
+    ctx = make_ctx(bk, lm, nframes=F)
+    for f in range(F):
+        for p in range(6):
+            ctx.upload_plate(f, p, globes[f][p])
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    want = [O.apply(lm.offsets, lm.tints, lm.W, lm.H, globes[f], np.zeros((lm.H, lm.W), np.uint8)) for f in range(F)]
+    outs = [torch.zeros((lm.H, lm.W), dtype=torch.uint8, device="cuda") for _ in range(100)]
+    torch.cuda.synchronize()
+    ctx.resident_begin(idle_ms=2000)
+    tickets = [ctx.resident_submit(outs[i].data_ptr(), lm.W, frame=(i * 3) % F) for i in range(100)]
+    assert tickets == list(range(1, 101))
+    ctx.resident_wait(tickets[-1])
+    ctx.resident_end()
+    for i in range(100):
+        np.testing.assert_array_equal(outs[i].cpu().numpy(), want[(i * 3) % F], err_msg=f"submission {i}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("key", [("cube", "panini", None, 3840, 2160), ("cube", "hammer", None, 3840, 2160)], ids=lambda k: k[1])
+def test_resident_4k_frame_hash_equals_reference_golden(bk, key):
+    """BASELINE.json's full size: the frame hash recorded from the unmodified reference, through the resident kernel, on the GPU-built
+    lensmap; prints what the session looked like (workgroups, blocks held in registers) and the device time of a frame"""
+    import torch
+    import scripts as S
+    rec = GOLD[key]
+    globe, lens, zoom, W, H = key
+    ctx = bk.Context()
+    ctx.set_frames(2)
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    ctx.build()
+    for f in range(2):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, seed_frame=0)
+    out = torch.zeros((2, H, W), dtype=torch.uint8, device="cuda")
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    ctx.resident_begin(idle_ms=500)
+    info = ctx.resident_info()
+    us = [ctx.resident_wait(ctx.resident_submit(out[i % 2].data_ptr(), W, frame=i % 2)) for i in range(20)]
+    ctx.resident_end()
+    print(f"\nresident {lens} {W}x{H}: {info}, device us per frame (one at a time): min {min(us):.2f} median {sorted(us)[len(us) // 2]:.2f}")
+    for i in range(2):
+        assert O.fnv(out[i].cpu().numpy()) == rec["fnv_frame"]
+    ctx.close()
