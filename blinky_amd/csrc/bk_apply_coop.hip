@@ -406,9 +406,14 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 }
             }
             if (WT) {
+                // (write-through byte stores are one fabric write each: in a tile that is only PARTLY mapped - the rim of hammer's
+                //  ellipse, the block with stereographic's one NULL pixel - most lanes still have whole words to store, and a word store it
+                //  is whenever its four pixels are mapped and the frame is word-aligned (kflags bit 1024, set per command).  Without
+                //  this the one workgroup with such a tile ran at half the others' pace, and the slowest workgroup sets the frame rate.)
                 const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)(x + 4 * r);
                 dst = bk_uniform_ptr(dst);
-                if (fast_store) {
+                const bool whole = a[0] != 0xFFFFu && a[1] != 0xFFFFu && a[2] != 0xFFFFu && a[3] != 0xFFFFu;
+                if (fast_store || (whole && (kflags & 1024))) {
                     bk_store_u32<true>(dst, off, v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24));
                 } else {
 #pragma unroll

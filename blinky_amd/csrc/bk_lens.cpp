@@ -813,7 +813,15 @@ int bk::build_module_ready(bk_ctx *ctx)
     bk::EmitRequest rq;
     rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
     try { psrc = bk::emit_build_source(rq); } catch (const LuaError &) { return BK_OK; }      // (reported by the normal path)
-    return compile_module_async(ctx, P, psrc) == BK_PENDING ? BK_PENDING : BK_OK;
+    // A module that is ready gets LOADED here (hipModuleLoadData / hipModuleGetFunction): that has to happen on the context's own
+    // device, whatever device the calling thread was left on - bk_multi_build asks on behalf of stripe 0 right after a
+    // bk_multi_apply whose loop ended on the LAST stripe's device, and kernels loaded there would later be launched on stripe 0's
+    // stream (invalid device function on a node with more than one GPU).  The caller's device is put back.
+    int prev = -1;
+    const bool switched = ctx->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != ctx->device && hipSetDevice(ctx->device) == hipSuccess;
+    const int rc = compile_module_async(ctx, P, psrc) == BK_PENDING ? BK_PENDING : BK_OK;
+    if (switched) (void)hipSetDevice(prev);
+    return rc;
 }
 
 extern "C" int bk_set_async_compile(bk_ctx *ctx, int on)

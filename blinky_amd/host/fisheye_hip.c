@@ -506,8 +506,12 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
             /* the reference clears the display flags only once calc_zoom has succeeded (fisheye.c:2376-2385): after a zoom it cannot
              * compute, or with no valid lens / globe, the plates of the previous lensmap go on being rendered (into a lensmap that shows
              * none of them) - kept, so that the engine sees the same R_RenderView calls */
-            if (rc == BK_OK) for (i = 0; i < numplates; ++i) display[i] = newdisplay[i];     /* (only the current globe's plates are reset) */
-            lensmap_ok = rc == BK_OK;
+            /* a lens_inverse that returned a malformed result ends the reference's scan there: what it had set by then stays on screen
+             * and the display flags are those of that partial table (fisheye.c:2113-2115, 1976) - the library reports BK_E_SCRIPT with
+             * exactly that table in place and its flags in newdisplay */
+            const int partial = rc == BK_E_SCRIPT && (mg ? bk_multi_lensmap_valid(mg) : bk_last_build_bad_key(bk) != 0);
+            if (rc == BK_OK || partial) for (i = 0; i < numplates; ++i) display[i] = newdisplay[i];     /* (only the current globe's plates are reset) */
+            lensmap_ok = rc == BK_OK || partial;
             if (rc != BK_OK && lens.valid && globe.valid) Con_Printf("%s\n", dev_error());
         }
     }

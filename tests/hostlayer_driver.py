@@ -4,7 +4,9 @@ frames   - whole F_RenderView frames through libhosttest.so compared byte for by
            several stripe contexts when BLINKY_HIP_DEVICES lists more than one device)
 async    - with asynchronous lens compilation (the default) no frame waits for hiprtc: the previous lensmap keeps being
            drawn until the new module is ready
-complete - tab completion of f_lens / f_globe"""
+complete - tab completion of f_lens / f_globe
+malformed - a lens whose lens_inverse returns a malformed result for part of the screen: the reference's scan stops there and keeps
+           what it had set (fisheye.c:2113-2115); the host layer must draw that partial table and render exactly its plates"""
 import ctypes as C
 import os
 import sys
@@ -125,6 +127,56 @@ def scenario_async(base):
           f"hammer compiled, slowest F_RenderView {worst * 1e3:.1f} ms")
     assert pending_frames >= 1 and shown_old >= 1, "hiprtc was expected to take longer than one frame"
     assert worst < 0.25, f"a frame stalled for {worst * 1e3:.0f} ms"
+
+
+MALFORMED_TAIL = """
+local good = lens_inverse
+function lens_inverse(x, y)
+   if x > 0.3 and y > 0.2 then
+      return x, y            -- two values: LUAtoC_lens_inverse's status -1 (fisheye.c:1579-1584)
+   end
+   return good(x, y)
+end
+"""
+
+
+def scenario_malformed(base):
+    import blinky_amd  # noqa: F401
+    import oracle_ffi as O
+    import scripts as S
+    os.environ["BLINKY_HIP_SYNC_COMPILE"] = "1"
+    with open(os.path.join(base, "lua-scripts", "lenses", "panini_malformed.lua"), "w") as f:
+        f.write(S.script("lenses", "panini") + MALFORMED_TAIL)
+    h = load()
+    assert h.hosttest_init(base.encode()) == 1, h.hosttest_console().decode()
+    W, H, fidx, bg = 320, 200, 2, 7
+    # the previous lens shows every plate of its own; the malformed one must not inherit those flags
+    h.hosttest_cmd(b"f_lens hammer")
+    h.hosttest_resize(W, H, 0, 0, 0)
+    pitch, vh = h.hosttest_rowbytes(), h.hosttest_vidheight()
+    out = np.zeros((vh, pitch), np.uint8)
+    h.hosttest_frame((C.c_int * 6)(0, 1, 2, 3, 4, 5), 6, fidx, bg, out.ctypes.data_as(C.c_void_p))
+    h.hosttest_console_clear()
+    h.hosttest_cmd(b"f_lens panini_malformed")
+    h.hosttest_cmd(b"f_fov 180")
+    lm = O.lensmap("cube", "panini", "f_fov 180", W, H)
+    ly, lx = np.divmod(np.arange(W * H), W)
+    x, y = (lx - W // 2) * lm.scale, -(ly - H // 2) * lm.scale
+    key = ly * W + (W - 1 - lx)                     # larger = earlier in the reference's scan (rows from the bottom up)
+    first = key[(x > 0.3) & (y > 0.2)].max()
+    off = np.where(key > first, lm.offsets, O.NULL).astype(np.uint32)
+    tin = np.where(key > first, lm.tints, 255).astype(np.uint8)
+    plates = sorted(set((off[off != O.NULL] // (lm.ps * lm.ps)).tolist()))
+    assert 0 < len(plates) < sum(lm.display), "the scenario is meant to cut the table before every plate of panini is in use"
+    arr = (C.c_int * len(plates))(*plates)
+    n = h.hosttest_frame(arr, len(plates), fidx, bg, out.ctypes.data_as(C.c_void_p))
+    assert n == len(plates), f"the host rendered {n} plates, the partial table uses {plates}"
+    want = np.full((vh, pitch), bg, np.uint8)
+    O.apply(off, tin, W, H, O.lcg_globe(lm.ps, lm.numplates, fidx), want, pitch, 0, 0, False, None)
+    np.testing.assert_array_equal(out, want)
+    assert "malformed" in h.hosttest_console().decode() or "lens_inverse" in h.hosttest_console().decode()
+    h.hosttest_shutdown()
+    print("malformed ok")
 
 
 def scenario_complete(base):
@@ -263,5 +315,5 @@ def scenario_differential(base, seed_range="0:4", frames="1"):
 
 
 if __name__ == "__main__":
-    {"frames": scenario_frames, "async": scenario_async, "complete": scenario_complete,
+    {"frames": scenario_frames, "async": scenario_async, "complete": scenario_complete, "malformed": scenario_malformed,
      "differential": scenario_differential}[sys.argv[1]](*sys.argv[2:])

@@ -100,6 +100,14 @@ def test_full_frames_with_the_warp_spread_over_three_stripe_contexts(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, "0,0,0"], ids=["one-context", "three-stripes"])
+def test_a_malformed_lens_result_draws_the_partial_table_and_renders_its_plates(tmp_path, devices):
+    """the library's BK_E_SCRIPT-with-the-reference's-truncated-table (fisheye.c:2113-2115) is not discarded by F_RenderView: the
+    display flags become those of the partial table"""
+    assert "malformed ok" in run_scenario("malformed", tmp_path, {"BLINKY_HIP_DEVICES": devices} if devices else None)
+
+
+@pytest.mark.gpu
 def test_no_frame_waits_for_hiprtc(tmp_path):
     """asynchronous lens compilation (default in the host layer): the render loop never stalls on `f_lens`"""
     out = run_scenario("async", tmp_path)
