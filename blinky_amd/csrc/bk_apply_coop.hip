@@ -368,6 +368,10 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
         for (int r = 0; r < RG; ++r) {
             const uint32_t v0 = buf[ix.iw[r].x & 0xFFFFu], v1 = buf[ix.iw[r].x >> 16], v2 = buf[ix.iw[r].y & 0xFFFFu], v3 = buf[ix.iw[r].y >> 16];
             w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+            // (the resident kernel gathers with the next block's chunks in flight in 16-24 registers: four texels at a time, not all
+            //  sixteen byte reads and their addresses in registers at once - the compiler would otherwise spill the block's chunk
+            //  offsets, and a scratch reload in front of every globe load makes the loads wait for one another)
+            if (WT) asm volatile("" ::: "memory");
         }
         if (!(kflags & 4)) {
             // non-temporal stores: the frame is never read back here, and keeping it out of L2 leaves the cache to the
@@ -392,6 +396,65 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o)); }
             }
         }
+    } else if (WT) {
+        // the resident kernel in a tile that is only PARTLY mapped (the rim of hammer's ellipse, the block with stereographic's one NULL
+        // pixel) or with rubix: write-through stores narrower than 16 bytes are a fabric write each (a byte 12x, a word 6x the time
+        // per byte), so a lane stores as wide as its own pixels allow - all of them mapped and the frame aligned: the one wide store
+        // of the fast path; else word by word, and bytes only in the words with a hole.  Without this the ONE workgroup with such a
+        // tile ran at half the others' pace, and the slowest workgroup sets the frame rate.
+        uint32_t w[RG], m = 0;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
+            w[r] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
+                if (RUBIX) {
+                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
+                    if (tt < (uint32_t)BK_MAX_PLATES) v = pal_s[tt * 256 + v];
+                }
+                w[r] |= v << (8 * k);
+                m |= a[k] != 0xFFFFu ? 1u << (4 * r + k) : 0u;
+            }
+        }
+        if (kflags & 4) return;
+        typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)x;
+        dst = bk_uniform_ptr(dst);
+        const bool wide_ok = (kflags & 2048) != 0, word_ok = (kflags & 1024) != 0;      // the frame's alignment (set per command)
+        if (m == (RG == 4 ? 0xFFFFu : RG == 2 ? 0xFFu : 0xFu) && wide_ok) {
+            if (RG == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(w[0]), "s"(dst) : "memory");
+            else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
+            else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
+        } else if (m != 0 && word_ok) {
+            // holes in an aligned frame: read the words with holes, put the mapped bytes in, store whole words - an unmapped pixel
+            // gets back the byte it had (nobody else writes this lane's pixels), and nothing narrower than a word is written through:
+            // the acknowledgement of a byte store takes microseconds (a read-modify-write at the memory side), memory operations
+            // complete in order, and the workgroup's next frame waited for it
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const uint32_t mr = (m >> (4 * r)) & 0xFu;
+                if (mr == 0) continue;
+                uint32_t word = w[r];
+                if (mr != 0xFu) {
+                    uint32_t old;
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(off + 4 * r), "s"(dst) : "memory");
+                    const uint32_t keep = ((mr & 1u) ? 0u : 0xFFu) | ((mr & 2u) ? 0u : 0xFF00u) | ((mr & 4u) ? 0u : 0xFF0000u) | ((mr & 8u) ? 0u : 0xFF000000u);
+                    word = (word & ~keep) | (old & keep);
+                }
+                bk_store_u32<true>(dst, off + 4 * r, word);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const uint32_t mr = (m >> (4 * r)) & 0xFu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((mr >> k) & 1u) bk_store_u8<true>(dst, off + 4 * r + k, (w[r] >> (8 * k)) & 0xFFu);
+            }
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
@@ -405,30 +468,13 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                     if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
                 }
             }
-            if (WT) {
-                // (write-through byte stores are one fabric write each: in a tile that is only PARTLY mapped - the rim of hammer's
-                //  ellipse, the block with stereographic's one NULL pixel - most lanes still have whole words to store, and a word store it
-                //  is whenever its four pixels are mapped and the frame is word-aligned (kflags bit 1024, set per command).  Without
-                //  this the one workgroup with such a tile ran at half the others' pace, and the slowest workgroup sets the frame rate.)
-                const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)(x + 4 * r);
-                dst = bk_uniform_ptr(dst);
-                const bool whole = a[0] != 0xFFFFu && a[1] != 0xFFFFu && a[2] != 0xFFFFu && a[3] != 0xFFFFu;
-                if (fast_store || (whole && (kflags & 1024))) {
-                    bk_store_u32<true>(dst, off, v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (a[k] != 0xFFFFu) bk_store_u8<true>(dst, off + k, v[k]);
-                }
+            uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
+            if (fast_store) {
+                __builtin_nontemporal_store(v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), reinterpret_cast<uint32_t *>(out));
             } else {
-                uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
-                if (fast_store) {
-                    __builtin_nontemporal_store(v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), reinterpret_cast<uint32_t *>(out));
-                } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
             }
         }
     }
