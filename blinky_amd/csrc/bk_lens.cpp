@@ -453,46 +453,172 @@ static std::string cache_dir()
     return std::string();
 }
 
+// ---- what may be loaded from the cache ---------------------------------------------------------------------------------
+// A cached object is CODE - GPU code objects, and since round 3 host shared objects that are dlopen()ed into the engine - so the
+// cache is only ever a directory that belongs to the user and that nobody else can write to, the files in it likewise, opened
+// without following links and checked through the descriptor that is then read / loaded (no check-then-open window).  Names
+// carry 128 bits of a SHA-256 over everything the object was built from (source, embedded headers, target / compiler + its
+// size and modification time, flags, library version): no collisions to speak of, no stale objects after an upgrade.  Every
+// file ends in a trailer - "BKSHA256" + the SHA-256 of what precedes it - that is verified before the object is used: a torn
+// or corrupted file is a cache miss, not wrong lensmap entries.  (The digest is not a signature: against somebody who can
+// write to the directory only the ownership checks help, which is why a directory that fails them is not used at all.)
+namespace {
+struct Sha256 {
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    unsigned char buf[64];
+    uint64_t len = 0;
+    size_t fill = 0;
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const unsigned char *p)
+    {
+        static const uint32_t K[64] = {
+            0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu,
+            0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau,
+            0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u,
+            0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u,
+            0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu,
+            0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const void *data, size_t n)
+    {
+        const unsigned char *p = (const unsigned char *)data;
+        len += n;
+        while (n) {
+            const size_t take = std::min(n, sizeof buf - fill);
+            memcpy(buf + fill, p, take);
+            fill += take; p += take; n -= take;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    void update(const std::string &t) { const uint64_t n = t.size(); update(&n, sizeof n); update(t.data(), t.size()); }      // (length-prefixed: "ab","c" != "a","bc")
+    void finish(unsigned char out[32])
+    {
+        const uint64_t bits = len * 8;
+        const unsigned char one = 0x80, zero = 0;
+        update(&one, 1);
+        while (fill != 56) update(&zero, 1);
+        unsigned char l[8];
+        for (int i = 0; i < 8; ++i) l[i] = (unsigned char)(bits >> (56 - 8 * i));
+        update(l, 8);
+        for (int i = 0; i < 8; ++i) { out[4 * i] = (unsigned char)(h[i] >> 24); out[4 * i + 1] = (unsigned char)(h[i] >> 16); out[4 * i + 2] = (unsigned char)(h[i] >> 8); out[4 * i + 3] = (unsigned char)h[i]; }
+    }
+};
+static std::string hex128(Sha256 &s)
+{
+    unsigned char d[32];
+    s.finish(d);
+    char out[33];
+    for (int i = 0; i < 16; ++i) snprintf(out + 2 * i, 3, "%02x", d[i]);
+    return out;
+}
+static const char kTrailerMagic[8] = {'B', 'K', 'S', 'H', 'A', '2', '5', '6'};
+static void trailer_of(const void *data, size_t n, unsigned char out[40])
+{
+    Sha256 s;
+    s.update(data, n);
+    memcpy(out, kTrailerMagic, 8);
+    s.finish(out + 8);
+}
+}  // namespace
+
+// a directory this user owns, that nobody else can write to and that is no link; made (0700) if it does not exist
+static bool cache_dir_ok(const std::string &dir, bool create)
+{
+    if (dir.empty()) return false;
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) {
+        if (!create) return false;
+        const size_t cut = dir.rfind('/');
+        if (cut != std::string::npos && cut > 0)
+            for (size_t i = 1; i <= cut; ++i)
+                if (i == cut || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);        // (the way there: ordinary directories)
+        if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return false;
+        if (lstat(dir.c_str(), &st) != 0) return false;
+    }
+    return S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// a regular file of this user's that nobody else can write to, opened without following a link; -1 if it is not that
+static int open_checked(const std::string &path)
+{
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) { close(fd); return -1; }
+    return fd;
+}
+// the whole file behind `fd` minus a valid trailer; false if it is short, torn or altered
+static bool read_verified(int fd, std::vector<char> *out)
+{
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 40) return false;
+    out->resize((size_t)st.st_size);
+    size_t got = 0;
+    while (got < out->size()) {
+        const ssize_t n = pread(fd, out->data() + got, out->size() - got, (off_t)got);
+        if (n <= 0) { if (n < 0 && errno == EINTR) continue; return false; }
+        got += (size_t)n;
+    }
+    unsigned char want[40];
+    trailer_of(out->data(), out->size() - 40, want);
+    if (memcmp(want, out->data() + out->size() - 40, 40) != 0) return false;
+    out->resize(out->size() - 40);
+    return true;
+}
+static bool write_all(int fd, const void *data, size_t n)
+{
+    const char *p = (const char *)data;
+    while (n) {
+        const ssize_t w = write(fd, p, n);
+        if (w <= 0) { if (w < 0 && errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
 static std::string cache_path(const std::string &source, const std::string &arch)
 {
     const std::string dir = cache_dir();
     if (dir.empty()) return std::string();
-    uint64_t h = fnv1a64(source.data(), source.size());
-    for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) h = fnv1a64(bk::kEmbeddedHeaders[i].text, strlen(bk::kEmbeddedHeaders[i].text), h);
-    h = fnv1a64(arch.data(), arch.size(), h);
-    const char *ver = bk_version();
-    h = fnv1a64(ver, strlen(ver), h);
-    char name[64];
-    snprintf(name, sizeof name, "/bk_lens_%016llx.hsaco", (unsigned long long)h);
-    return dir + name;
+    Sha256 h;
+    h.update(source);
+    for (int i = 0; i < bk::kNumEmbeddedHeaders; ++i) h.update(std::string(bk::kEmbeddedHeaders[i].text));
+    h.update(arch);
+    h.update(std::string(bk_version()));
+    h.update(std::string("-O3 -std=c++17 -ffp-contract=off"));
+    return dir + "/bk_lens_" + hex128(h) + ".hsaco";
 }
 static bool cache_load(const std::string &path, std::vector<char> *code)
 {
-    if (path.empty()) return false;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    const long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    bool ok = n > 0;
-    if (ok) { code->resize((size_t)n); ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n; }
-    fclose(f);
+    if (path.empty() || !cache_dir_ok(path.substr(0, path.rfind('/')), false)) return false;
+    const int fd = open_checked(path);
+    if (fd < 0) return false;
+    const bool ok = read_verified(fd, code);
+    close(fd);
     return ok;
-}
-static void make_dirs(const std::string &dir)
-{
-    for (size_t i = 1; i <= dir.size(); ++i)
-        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
 }
 static void cache_store(const std::string &path, const std::vector<char> &code)
 {
-    if (path.empty()) return;
-    make_dirs(path.substr(0, path.rfind('/')));
+    if (path.empty() || !cache_dir_ok(path.substr(0, path.rfind('/')), true)) return;       // a cache that cannot be trusted / written is simply not used
     const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return;                                     // a cache that cannot be written is simply not used
-    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-    fclose(f);
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    unsigned char tr[40];
+    trailer_of(code.data(), code.size(), tr);
+    const bool ok = write_all(fd, code.data(), code.size()) && write_all(fd, tr, sizeof tr);
+    close(fd);
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
 }
 
@@ -573,11 +699,12 @@ static CodeResult compile_code(const std::string &source, const std::string &arc
 // results are the same either way (tests/test_hostmod.py holds the two against each other entry for entry).
 struct HostModule {
     void *dl = nullptr;
+    int fd = -1;                       // the descriptor the object was verified and loaded through; kept open: see load_host_module
     void (*inverse)(const BkBuildParams *, const unsigned int *, int, unsigned long, unsigned int *, unsigned char *, int *, int *) = nullptr;
     void (*corners)(const BkBuildParams *, const unsigned int *, int, unsigned long, int *, int *, unsigned char *, int *) = nullptr;
     void (*texel_owns)(const BkBuildParams *, const unsigned int *, int, unsigned long, unsigned char *) = nullptr;
     int (*inverse_scan)(const BkBuildParams *, unsigned int *, unsigned char *, int *) = nullptr;
-    ~HostModule() { if (dl) dlclose(dl); }
+    ~HostModule() { if (dl) dlclose(dl); if (fd >= 0) close(fd); }
 };
 using HostModuleP = std::shared_ptr<HostModule>;
 
@@ -625,12 +752,21 @@ static const char *embedded_text(const char *name)
     return "";
 }
 
+// the shared object is loaded THROUGH the descriptor it was checked and verified on (/proc/self/fd): what is mapped is what was read
 static HostModuleP load_host_module(const std::string &so)
 {
-    void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!dl) return nullptr;
+    const int fd = open_checked(so);
+    if (fd < 0) return nullptr;
+    std::vector<char> content;
+    if (!read_verified(fd, &content)) { close(fd); return nullptr; }
+    // (the descriptor stays open as long as the module lives: the dynamic loader knows an object by the NAME it was opened under, and a
+    //  descriptor number that was closed and handed out again would make "/proc/self/fd/N" answer with the module loaded before)
+    const std::string via = "/proc/self/fd/" + std::to_string(fd);
+    void *dl = dlopen(via.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) { close(fd); return nullptr; }
     HostModuleP m = std::make_shared<HostModule>();
     m->dl = dl;
+    m->fd = fd;
     auto abi = (int (*)(void))dlsym(dl, "bk_hostmod_abi");
     m->inverse = (decltype(m->inverse))dlsym(dl, "bk_hostmod_inverse");
     m->corners = (decltype(m->corners))dlsym(dl, "bk_hostmod_corners");
@@ -652,8 +788,10 @@ static bool write_text(const std::string &path, const std::string &text)
 // compile `source` for the host with `cxx`; the shared object ends up at `so_path` (atomically)
 static HostModuleP compile_host_module(const std::string &source, const std::string &cxx, const std::string &so_path)
 {
-    const std::string dir = so_path + ".build" + std::to_string((long long)getpid());
-    make_dirs(dir);
+    // a scratch directory nobody else can have prepared: mkdtemp (0700, fails if the name exists) inside the checked cache directory
+    std::string tmpl = so_path.substr(0, so_path.rfind('/')) + "/build.XXXXXX";
+    if (!mkdtemp(&tmpl[0])) return nullptr;
+    const std::string dir = tmpl;
     bool ok = write_text(dir + "/bkm.h", embedded_text("bk_hostmod_bkm.h"));
     for (const char *h : {"bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h"}) ok = ok && write_text(dir + "/" + h, embedded_text(h));
     const std::string unit = std::string("#define BK_HOST_MODULE 1\n#define __device__\n#define __forceinline__ inline\n") + source + "\n" +
@@ -674,7 +812,23 @@ static HostModuleP compile_host_module(const std::string &source, const std::str
             while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
         }
         posix_spawn_file_actions_destroy(&fa);
-        if (status == 0 && rename(out.c_str(), so_path.c_str()) == 0) m = load_host_module(so_path);
+        if (status == 0) {
+            // seal it: the trailer goes behind the ELF image (the loader maps by program headers: trailing bytes are not looked at)
+            std::vector<char> img;
+            const int fd = open(out.c_str(), O_RDWR | O_NOFOLLOW | O_CLOEXEC);
+            struct stat st;
+            bool sealed = false;
+            if (fd >= 0 && fstat(fd, &st) == 0 && st.st_size > 0) {
+                img.resize((size_t)st.st_size);
+                if (pread(fd, img.data(), img.size(), 0) == (ssize_t)img.size()) {
+                    unsigned char tr[40];
+                    trailer_of(img.data(), img.size(), tr);
+                    sealed = lseek(fd, 0, SEEK_END) >= 0 && write_all(fd, tr, sizeof tr) && fchmod(fd, 0600) == 0;
+                }
+            }
+            if (fd >= 0) close(fd);
+            if (sealed && rename(out.c_str(), so_path.c_str()) == 0) m = load_host_module(so_path);
+        }
     }
     for (const char *f : {"bkm.h", "bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h", "unit.cpp", "unit.so"}) remove((dir + "/" + f).c_str());
     rmdir(dir.c_str());
@@ -711,14 +865,21 @@ static HostModuleP host_module_for(const std::string &source, bool wait)
                 }
                 dir = private_dir;
             }
-            char name[64];
-            snprintf(name, sizeof name, "/bk_host_%016llx.so", (unsigned long long)fnv1a64(cxx.data(), cxx.size(), key));
-            const std::string so = dir + name;
-            if (access(so.c_str(), R_OK) == 0) {
+            if (!cache_dir_ok(dir, true)) { g_hostmods[key] = nullptr; return nullptr; }       // (not a directory to load code from: the interpreter answers)
+            // the name: 128 bits of a SHA-256 over the source, what it is compiled with (headers, compiler - path, size, modification
+            // time - and flags) and the library version
+            Sha256 h;
+            h.update(source);
+            for (const char *hn : {"bk_hostmod_bkm.h", "bk_hostmod_driver.inc", "bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h"}) h.update(std::string(embedded_text(hn)));
+            h.update(cxx);
+            { struct stat cst; if (stat(cxx.c_str(), &cst) == 0) { const long long id[2] = {(long long)cst.st_size, (long long)cst.st_mtime}; h.update(id, sizeof id); } }
+            h.update(std::string("-O2 -std=c++17 -ffp-contract=off -fno-builtin -fno-fast-math -fPIC -shared"));
+            h.update(std::string(bk_version()));
+            const std::string so = dir + "/bk_host_" + hex128(h) + ".so";
+            {
                 HostModuleP m = load_host_module(so);
                 if (m) { g_hostmods[key] = m; return m; }
             }
-            make_dirs(dir);
             job = std::async(std::launch::async, [source, cxx, so]() { return compile_host_module(source, cxx, so); }).share();
             g_hostmod_jobs[key] = job;
         }

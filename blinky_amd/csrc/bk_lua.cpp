@@ -1508,7 +1508,15 @@ Values Interp::call(const Value &fv, const Values &args)
     if (depth == 0) call_chunk = nullptr;       // (a call from the host: no script call site yet, and the last one's chunk may be gone)
     if (fv.t == Value::BUILTIN) {
         Values rets;
-        fv.bi()->fn(*this, args, rets);
+        // (a builtin that runs into a C++ exception of its own - std::length_error from a string of 1e300 bytes, bad_alloc - is a
+        //  script error like any other: nothing but LuaError may unwind towards the C ABI, where the entry points catch exactly that)
+        try {
+            fv.bi()->fn(*this, args, rets);
+        } catch (const LuaError &) {
+            throw;
+        } catch (const std::exception &e) {
+            throw LuaError(fv.bi()->name + ": " + e.what());
+        }
         return rets;
     }
     if (fv.t == Value::TABLE && fv.tab()->meta) {                   // __call: the table itself becomes the first argument
@@ -2010,6 +2018,8 @@ Interp::Interp(const MathLib &m) : math(&m)
     auto read_one = [](FileBox &fb, const Value &fmt, Values &r) -> bool {       // one format of file:read; false at end of file
         if (!fb.f) throw LuaError("attempt to use a closed file");
         if (fmt.t == Value::NUM) {
+            // (liolib.c reads up to n bytes; n comes from the script: not negative, not NaN, and no more than the file can hold)
+            if (!(fmt.n >= 0) || fmt.n > 1073741824.0) throw LuaError("bad argument #1 to 'read' (invalid count)");
             std::string out((size_t)fmt.n, '\0');
             const size_t got = fread(&out[0], 1, out.size(), fb.f);
             if (got == 0 && out.size() > 0) { r.push_back(Value()); return false; }

@@ -378,10 +378,10 @@ static struct stree_root *cmdarg_globe(const char *arg) { return cmdarg_scripts(
 void F_Init(void)                                   /* fisheye.c:642-676 */
 {
     const char *dev = getenv("BLINKY_HIP_DEVICE"), *devs = getenv("BLINKY_HIP_DEVICES");
-    char cache[1100];
     rubix.enabled = false;
-    /* compiled lens modules are kept next to the game data, so that only the first run of a lens waits for hiprtc */
-    if (!getenv("BLINKY_HIP_CACHE")) { snprintf(cache, sizeof cache, "%s/hipcache", com_basedir); bk_set_cache_dir(cache); }
+    /* compiled lens modules are cached under the USER's cache directory ($BLINKY_HIP_CACHE, else $XDG_CACHE_HOME/blinky_hip, else
+     * ~/.cache/blinky_hip: the library's default) so that only the first run of a lens waits for hiprtc - never next to the game data:
+     * com_basedir is where mods and downloaded content live, and the cache holds code the library loads */
     /* init_lua's counterpart: the script interpreter lives inside the context */
     if (devs && strchr(devs, ',')) {
         int list[16], n = 0;

@@ -261,7 +261,7 @@ def test_compiled_modules_are_cached_on_disk(bk, tmp_path, monkeypatch, request)
     S.configure(ctx3, "cube", "panini", None, (320, 240))
     ctx3.kernel_source(compile=True)
     assert not ctx3.module_from_cache() and len(list(cache.iterdir())) == 2
-    # the host's own choice (fisheye_hip.c: <basedir>/hipcache) beats the environment; NULL hands it back
+    # a host's own choice (bk_set_cache_dir) beats the environment; NULL hands it back
     other = tmp_path / "other"
     bk.lib.bk_set_cache_dir(str(other).encode())
     try:
@@ -278,6 +278,58 @@ def test_compiled_modules_are_cached_on_disk(bk, tmp_path, monkeypatch, request)
     S.configure(ctx5, "cube", "stereographic", None, (320, 240))
     ctx5.kernel_source(compile=True)
     assert len(list((tmp_path / "home" / ".cache" / "blinky_hip").iterdir())) == 1
+
+
+def test_the_module_cache_only_trusts_what_belongs_to_the_user(bk, tmp_path, monkeypatch, request):
+    """Cached objects are code (GPU code objects; host shared objects that get dlopen()ed): a directory somebody else could write to
+    is not used at all, a file that is a link, or group / world writable, or whose SHA-256 trailer does not match its content is a
+    miss - and is replaced by a fresh compile - and names carry a 128-bit digest of everything the object was built from"""
+    import stat
+    bk.debug_set_option("no_memcache", 1)
+    request.addfinalizer(lambda: bk.debug_set_option("no_memcache", 0))
+
+    def compile_once(lens="hammer"):
+        ctx = host_ctx(bk)
+        S.configure(ctx, "cube", lens, None, (320, 240))
+        ctx.kernel_source(compile=True)
+        return ctx.module_from_cache()
+
+    # (1) a world-writable directory: nothing is stored there, nothing is loaded from there
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    shared.chmod(0o777)
+    monkeypatch.setenv("BLINKY_HIP_CACHE", str(shared))
+    assert not compile_once() and not compile_once()
+    assert list(shared.iterdir()) == []
+    # (2) a directory of the user's own: made 0700, one sealed file with a 128-bit name
+    own = tmp_path / "own" / "cache"
+    monkeypatch.setenv("BLINKY_HIP_CACHE", str(own))
+    assert not compile_once() and compile_once()
+    assert stat.S_IMODE(own.stat().st_mode) == 0o700
+    (f,) = list(own.iterdir())
+    assert f.name.startswith("bk_lens_") and len(f.stem) == len("bk_lens_") + 32 and stat.S_IMODE(f.stat().st_mode) == 0o600
+    blob = f.read_bytes()
+    assert blob[-40:-32] == b"BKSHA256"
+    import hashlib
+    assert blob[-32:] == hashlib.sha256(blob[:-40]).digest()
+    # (3) one flipped byte: a miss, and the file is written again whole
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x40
+    f.write_bytes(bytes(bad))
+    assert not compile_once() and f.read_bytes() == blob and compile_once()
+    # (4) a truncated file, a group-writable file, a link to a good file elsewhere: all misses
+    f.write_bytes(blob[: len(blob) // 2])
+    assert not compile_once() and compile_once()
+    f.chmod(0o660)
+    assert not compile_once()
+    f.chmod(0o600)
+    assert compile_once()
+    elsewhere = tmp_path / "elsewhere.hsaco"
+    elsewhere.write_bytes(blob)
+    f.unlink()
+    f.symlink_to(elsewhere)
+    assert not compile_once()
+    assert not f.is_symlink() and compile_once()                 # (the fresh object replaced the link)
 
 
 def test_min_max_over_an_expanded_call_translate(bk):
@@ -911,6 +963,19 @@ function lens_inverse(x, y)
    return x * s, y * s, cos(theta)
 end
 '''
+
+
+def test_hostile_counts_in_file_reads_are_script_errors_not_aborts(bk, tmp_path):
+    """file:read(n) with a negative, NaN or absurd n, string.rep of 1e18 bytes: C++ exceptions of the library's own builtins must not
+    unwind through the C ABI into the engine (std::terminate) - they are script errors, as in the reference's Lua (ADVICE r3)"""
+    f = tmp_path / "data.txt"
+    f.write_text("abc")
+    for expr in (f'io.open("{f}"):read(-1)', f'io.open("{f}"):read(0/0)', f'io.open("{f}"):read(1e300)', 'string.rep("x", 1e18)'):
+        ctx = host_ctx(bk)
+        ctx.load_globe(S.script("globes", "cube"), "cube")
+        with pytest.raises(bk.BlinkyError):
+            ctx.load_lens(f"local v = {expr}\nfunction lens_inverse(x, y) return x, y, 1 end", "hostile.lua")
+        ctx.close()
 
 
 def test_a_lens_that_reads_its_profile_from_a_file(bk, tmp_path):

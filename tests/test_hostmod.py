@@ -96,6 +96,13 @@ def test_module_is_cached_on_disk_and_optional(bk, tmp_path, monkeypatch):
     files = [f.name for f in tmp_path.iterdir()]
     assert any(f.startswith("bk_host_") and f.endswith(".so") for f in files), files
     assert not any("build" in f for f in files), files            # the scratch directory is gone
+    # the shared object is sealed (SHA-256 trailer) and private; a tampered one is not loaded: the next process compiles again
+    import hashlib
+    import stat
+    (so,) = [f for f in tmp_path.iterdir() if f.name.startswith("bk_host_")]
+    blob = so.read_bytes()
+    assert stat.S_IMODE(so.stat().st_mode) == 0o600 and blob[-40:-32] == b"BKSHA256" and blob[-32:] == hashlib.sha256(blob[:-40]).digest()
+    assert len(so.stem) == len("bk_host_") + 32
     # host math switched to the portable libm: the module (platform libm only) must not answer
     ctx.set_host_math(True)
     assert not ctx.host_module_ready(wait=True)
