@@ -334,28 +334,18 @@ __device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict_
 // kernel goes on running, so its bytes have to be in memory, not in the XCD's L2, when the flag is raised; a 16-byte sc1 store
 // costs what a plain one does and drops the line from L2, which is what a frame nobody reads back wants anyway.  They are inline
 // assembly: the compiler does not count them in vmcnt - the publisher waits with an explicit s_waitcnt vmcnt(0).
-// (WT: the address as a wave-uniform base in SGPRs + a 32-bit byte offset per lane - no 64-bit address arithmetic in VGPRs, which the
-//  resident kernel has none to spare for.  The s_nop: a VALU write of an SGPR (v_readfirstlane) needs five wait states before a vector
-//  memory instruction reads it, and the compiler's hazard recogniser does not look inside inline assembly - without it the store
-//  went out with whatever the SGPR pair held before: found as a memory fault on the first aligned frame.)
+// (WT: write-through BUFFER stores - the frame's base in a resource descriptor (SGPRs), a 32-bit byte offset per lane, aux 16 = sc1.
+//  They are builtins, not inline assembly, on purpose: the compiler counts them in vmcnt.  Memory operations complete in order, and
+//  a wait for the next block's chunk loads is "until at most N younger operations are outstanding" - with stores it cannot see, N
+//  comes out too small and every such wait also sat out the acknowledgement of the previous block's write-through stores: a trip
+//  to memory per block that nothing was waiting for.)
 __device__ __forceinline__ uint8_t *bk_uniform_ptr(uint8_t *p)      // a pointer the caller knows to be wave-uniform, as SGPRs
 {
     const uintptr_t u = reinterpret_cast<uintptr_t>(p);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
     return reinterpret_cast<uint8_t *>((uintptr_t)lo | ((uintptr_t)hi << 32));
 }
-template <bool WT>
-__device__ __forceinline__ void bk_store_u32(uint8_t *base, uint32_t off, uint32_t v)
-{
-    if (WT) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
-    else __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(base + off));
-}
-template <bool WT>
-__device__ __forceinline__ void bk_store_u8(uint8_t *base, uint32_t off, uint32_t v)
-{
-    if (WT) asm volatile("s_nop 4\n\tglobal_store_byte %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
-    else base[off] = (uint8_t)v;
-}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bk_frame_rsrc(uint8_t *dst) { return __builtin_amdgcn_make_buffer_rsrc(bk_uniform_ptr(dst), 0, 0x7FFFFFFF, 0x00020000); }
 
 // one frame of one lane: its 4*RG texels out of the staged chunks, packed and stored
 template <bool RUBIX, int RG, bool WT = false>
@@ -366,7 +356,9 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
         uint32_t w[RG];
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const uint32_t v0 = buf[ix.iw[r].x & 0xFFFFu], v1 = buf[ix.iw[r].x >> 16], v2 = buf[ix.iw[r].y & 0xFFFFu], v3 = buf[ix.iw[r].y >> 16];
+            uint32_t i0 = ix.iw[r].x, i1 = ix.iw[r].y;
+            if (WT) asm volatile("" : "+v"(i0), "+v"(i1));    // (the resident kernel: the unpacked addresses are not to be kept from frame to frame)
+            const uint32_t v0 = buf[i0 & 0xFFFFu], v1 = buf[i0 >> 16], v2 = buf[i1 & 0xFFFFu], v3 = buf[i1 >> 16];
             w[r] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
             // (the resident kernel gathers with the next block's chunks in flight in 16-24 registers: four texels at a time, not all
             //  sixteen byte reads and their addresses in registers at once - the compiler would otherwise spill the block's chunk
@@ -378,17 +370,12 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
             // globe lines neighbouring blocks share (4K panini 3.8 -> 3.3 us/frame)
             typedef uint32_t v2u __attribute__((ext_vector_type(2)));
             typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            if (WT && (kflags & 64)) {             // (developer experiment: the resident kernel with write-BACK non-temporal stores - timing only)
-                uint8_t *o = dst + (size_t)row0 * dst_pitch + x;
-                if (RG == 1) __builtin_nontemporal_store(w[0], reinterpret_cast<uint32_t *>(o));
-                else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(o)); }
-                else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o)); }
-            } else if (WT) {
+            if (WT) {
                 const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)x;       // (f = 0, one frame per command)
-                dst = bk_uniform_ptr(dst);
-                if (RG == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(w[0]), "s"(dst) : "memory");
-                else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
-                else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
+                const __amdgpu_buffer_rsrc_t rd = bk_frame_rsrc(dst);
+                if (RG == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rd, (int)off, 0, 16);
+                else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rd, (int)off, 0, 16); }
+                else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 16); }
             } else {
                 uint8_t *o = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x;
                 if (RG == 1) __builtin_nontemporal_store(w[0], reinterpret_cast<uint32_t *>(o));
@@ -405,7 +392,9 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
         uint32_t w[RG], m = 0;
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const uint32_t a[4] = {ix.iw[r].x & 0xFFFFu, ix.iw[r].x >> 16, ix.iw[r].y & 0xFFFFu, ix.iw[r].y >> 16};
+            uint32_t i0 = ix.iw[r].x, i1 = ix.iw[r].y;
+            asm volatile("" : "+v"(i0), "+v"(i1));            // (likewise: no unpacked copies of the addresses kept from frame to frame)
+            const uint32_t a[4] = {i0 & 0xFFFFu, i0 >> 16, i1 & 0xFFFFu, i1 >> 16};
             w[r] = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -416,43 +405,33 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 }
                 w[r] |= v << (8 * k);
                 m |= a[k] != 0xFFFFu ? 1u << (4 * r + k) : 0u;
+                asm volatile("" : "+v"(w[r]));               // (one texel at a time: sixteen conditional byte reads are not to be in flight - in registers - at once)
             }
         }
         if (kflags & 4) return;
         typedef uint32_t v2u __attribute__((ext_vector_type(2)));
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-        const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)x;
-        dst = bk_uniform_ptr(dst);
+        uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)x;
+        // (this path is rare; the compiler must not keep its sixteen per-pixel offsets in registers across the frame loop for it - it did,
+        //  and paid with spills of the chunk offsets on the path that matters: the value is opaque from here on)
+        asm volatile("" : "+v"(off));
+        const __amdgpu_buffer_rsrc_t rd = bk_frame_rsrc(dst);
         const bool wide_ok = (kflags & 2048) != 0, word_ok = (kflags & 1024) != 0;      // the frame's alignment (set per command)
         if (m == (RG == 4 ? 0xFFFFu : RG == 2 ? 0xFFu : 0xFu) && wide_ok) {
-            if (RG == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(w[0]), "s"(dst) : "memory");
-            else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
-            else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(dst) : "memory"); }
-        } else if (m != 0 && word_ok) {
-            // holes in an aligned frame: read the words with holes, put the mapped bytes in, store whole words - an unmapped pixel
-            // gets back the byte it had (nobody else writes this lane's pixels), and nothing narrower than a word is written through:
-            // the acknowledgement of a byte store takes microseconds (a read-modify-write at the memory side), memory operations
-            // complete in order, and the workgroup's next frame waited for it
-#pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                const uint32_t mr = (m >> (4 * r)) & 0xFu;
-                if (mr == 0) continue;
-                uint32_t word = w[r];
-                if (mr != 0xFu) {
-                    uint32_t old;
-                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(off + 4 * r), "s"(dst) : "memory");
-                    const uint32_t keep = ((mr & 1u) ? 0u : 0xFFu) | ((mr & 2u) ? 0u : 0xFF00u) | ((mr & 4u) ? 0u : 0xFF0000u) | ((mr & 8u) ? 0u : 0xFF000000u);
-                    word = (word & ~keep) | (old & keep);
-                }
-                bk_store_u32<true>(dst, off + 4 * r, word);
-            }
+            if (RG == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rd, (int)off, 0, 16);
+            else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rd, (int)off, 0, 16); }
+            else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 16); }
         } else {
 #pragma unroll
             for (int r = 0; r < RG; ++r) {
                 const uint32_t mr = (m >> (4 * r)) & 0xFu;
+                if (mr == 0xFu && word_ok) {
+                    __builtin_amdgcn_raw_buffer_store_b32(w[r], rd, (int)(off + 4 * r), 0, 16);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if ((mr >> k) & 1u) bk_store_u8<true>(dst, off + 4 * r + k, (w[r] >> (8 * k)) & 0xFFu);
+                    for (int k = 0; k < 4; ++k)
+                        if ((mr >> k) & 1u) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w[r] >> (8 * k)), rd, (int)(off + 4 * r + k), 0, 16);
+                }
             }
         }
     } else {

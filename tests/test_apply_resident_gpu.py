@@ -204,8 +204,9 @@ def test_resident_pipelined_submissions(bk):
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", [0, 1], ids=["shape-chosen", "128x8-blocks"])
 @pytest.mark.parametrize("key", [("cube", "panini", None, 3840, 2160), ("cube", "hammer", None, 3840, 2160)], ids=lambda k: k[1])
-def test_resident_4k_frame_hash_equals_reference_golden(bk, key):
+def test_resident_4k_frame_hash_equals_reference_golden(bk, key, shape):
     """BASELINE.json's full size: the frame hash recorded from the unmodified reference, through the resident kernel, on the GPU-built
     lensmap; prints what the session looked like (workgroups, blocks held in registers) and the device time of a frame"""
     import torch
@@ -220,10 +221,13 @@ def test_resident_4k_frame_hash_equals_reference_golden(bk, key):
         for p in range(6):
             ctx.fill_plate_lcg(f, p, seed_frame=0)
     out = torch.zeros((2, H, W), dtype=torch.uint8, device="cuda")
+    if shape:
+        ctx.set_tile_shape(shape)             # 128x8 blocks: 8160 of them - more than three per workgroup, the rest is fetched per frame
     ctx.synchronize()
     torch.cuda.synchronize()
     ctx.resident_begin(idle_ms=500)
     info = ctx.resident_info()
+    assert info["block_h"] == (8 if shape else info["block_h"])
     us = [ctx.resident_wait(ctx.resident_submit(out[i % 2].data_ptr(), W, frame=i % 2)) for i in range(20)]
     ctx.resident_end()
     print(f"\nresident {lens} {W}x{H}: {info}, device us per frame (one at a time): min {min(us):.2f} median {sorted(us)[len(us) // 2]:.2f}")

@@ -41,6 +41,12 @@ def main():
                 wl.launch(i, 1)
             med, lo, hi = wl.kernel_ms(nframes=1, launches=100, repeats=7)
             stats = ctx.tile_stats()
+            one = []
+            for i in range(200):                      # one launch, then wait for it: what a caller that needs every frame before the next pays
+                t0 = time.perf_counter()
+                wl.launch(i, 1)
+                torch.cuda.synchronize()
+                one.append((time.perf_counter() - t0) * 1e6)
             outs = [wl.origin(o) for o in wl.out]
             torch.cuda.synchronize()
             ctx.resident_begin(idle_ms=200)
@@ -60,7 +66,7 @@ def main():
                 dev.append(ctx.resident_wait(t))
                 wall.append((time.perf_counter() - t0) * 1e6)
             ctx.resident_end()
-            print(f"{lens:14s} {W}x{H} 128x{stats['tile_h'] % 1000}: launches {med * 1e3:6.2f} us/frame (min {lo * 1e3:.2f}) | resident [{info['workgroups']} wgs, "
+            print(f"{lens:14s} {W}x{H} 128x{stats['tile_h'] % 1000}: launches {med * 1e3:6.2f} us/frame back to back (min {lo * 1e3:.2f}), {statistics.median(one):6.2f} us launch + synchronize | resident [{info['workgroups']} wgs, "
                   f"{info['blocks_in_registers']} blocks x {info['chunks_per_thread']} chunks in registers, {info['per_cu']}/CU]: pipelined {statistics.median(pipe):6.2f} us/frame "
                   f"(min {min(pipe):.2f}) | one at a time: host {statistics.median(wall):6.2f} us, device {statistics.median(dev):6.2f} us (min {min(dev):.2f})", flush=True)
         wl.close()
