@@ -98,6 +98,12 @@ def cpu_baseline(frames_budget_s=6.0):
             "build_ms": round(build_s * 1e3, 1)}
 
 
+def synthetic_basepal():
+    """pal[i] = (i * 37) mod 256, i < 768 (the real gfx/palette.lmp is not in the tree)"""
+    import numpy as np
+    return ((np.arange(768) * 37) % 256).astype(np.uint8)
+
+
 def compulsory_bytes(model, F):
     """what the staged apply has to move per F-frame launch: every mapped pixel stored once, every distinct globe line the
     lensmap touches read once per frame, the block map (headers + chunk lists + 16-bit pixel addresses) once per block visit"""
@@ -107,12 +113,48 @@ def compulsory_bytes(model, F):
     return F * (model["mapped_pixels"] + 128 * model["unique_globe_lines"]) + visits * model["blockmap_bytes_per_visit"]
 
 
+def resident_measure(torch, ctx, dst, W, rows, R, rubix=False, pal=None, frames=600, repeats=5, singles=100):
+    """The engine's real call is ONE frame per F_RenderView (fisheye.c:803): the resident apply (bk_apply_resident_*) - one kernel
+    that stays on the device with the block map in registers, a frame is a command - over the same cold ring.  -> dict:
+    pipelined = `frames` submissions back to back (bk_apply_resident_submit_batch), host wall clock / frames, median of
+    `repeats`; one_at_a_time = submit, wait, submit ...: host wall clock and the device's own figure per frame."""
+    torch.cuda.synchronize()
+    ctx.resident_begin(rubix, pal, idle_ms=200)
+    info = ctx.resident_info()
+    ctx.resident_wait(ctx.resident_submit(dst, W, frame=0))
+    pipe = []
+    for rep in range(repeats):
+        t0 = time.perf_counter()
+        last = ctx.resident_submit_batch(dst, W, 0, frame0=(rep * frames) % R, nframes=frames)
+        ctx.resident_wait(last)
+        pipe.append((time.perf_counter() - t0) / frames * 1e6)
+    wall, dev = [], []
+    for i in range(singles):
+        t0 = time.perf_counter()
+        t = ctx.resident_submit(dst, W, frame=(7 * i) % R)
+        dev.append(ctx.resident_wait(t))
+        wall.append((time.perf_counter() - t0) * 1e6)
+    ctx.resident_end()
+    px = W * rows
+    med = statistics.median(pipe)
+    bpp = ALGO_BYTES_PER_PX + (1 if rubix else 0)
+    return {"us": round(med, 3), "us_min": round(min(pipe), 3),
+            "algorithmic_frac": round(bpp * px / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "mpx_s": round(px / med, 1), "frames_per_measurement": frames,
+            "one_at_a_time_host_us": round(statistics.median(wall), 2), "one_at_a_time_device_us": round(statistics.median(dev), 2),
+            "workgroups": info["workgroups"], "blocks_in_registers": info["blocks_in_registers"], "block_h": info["block_h"],
+            "what": "bk_apply_resident_*: one frame per command to a kernel that stays on the device (block map in registers); "
+                    "pipelined submissions, host wall clock per frame, cold ring"}
+
+
 class OneGpuWorkload:
     """One lensmap + a resident ring of LCG globes on one GPU, timed the way the headline is: K-step regions between
     synchronizes (wall clock, steps alternating between two streams) and the kernel alone under HIP events."""
 
-    def __init__(self, torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=None, ring_bytes=1.8e9, ring_max=64):
+    def __init__(self, torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=None, ring_bytes=1.8e9, ring_max=64, rubix=False):
         self.torch, self.W, self.H, self.F = torch, W, H, F
+        self.rubix = rubix
+        self.pal = blinky_amd.ffi.create_palmap(synthetic_basepal()) if rubix else None
         self.ctx = ctx = blinky_amd.Context(device_index)
         self.stream = torch.cuda.current_stream()
         ctx.set_stream(self.stream.cuda_stream)
@@ -141,7 +183,8 @@ class OneGpuWorkload:
 
     def launch(self, i, nframes=None, ring=None):
         nf = nframes or self.F
-        self.ctx.apply_device(self.origin(self.out[i % 4]), self.W, self.rows * self.W, frame0=(i * nf) % (ring or self.R), nframes=nf)
+        self.ctx.apply_device(self.origin(self.out[i % 4]), self.W, self.rows * self.W, frame0=(i * nf) % (ring or self.R), nframes=nf,
+                              rubix_on=self.rubix, pal=self.pal)
 
     def kernel_ms(self, nframes=None, launches=50, repeats=9, ring=None):
         """median / min / max over `repeats` of HIP events around `launches` back-to-back launches on one stream"""
@@ -174,59 +217,85 @@ class OneGpuWorkload:
         self.ctx.set_stream(self.stream.cuda_stream)
         return statistics.median(out)
 
+    def resident_us(self, frames=600):
+        return resident_measure(self.torch, self.ctx, self.origin(self.out[0]), self.W, self.rows, self.R, self.rubix, self.pal, frames=frames)
+
     def close(self):
         self.torch.cuda.synchronize()
         self.ctx.close()
         self.out = None
 
 
-def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W, H, F, steps, args=None):
+def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W, H, F, steps, args=None, rubix=False, ring_max=64):
     """one more BASELINE.json configuration, driver-timed beside the headline (N = 1 only); with `args`, its HBM traffic is measured
-    the way the headline's is (measure_traffic: two rocprofv3 --pmc child runs of the same launch)"""
-    wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F)
+    the way the headline's is (measure_traffic: two rocprofv3 --pmc child runs of the same launch).  rubix: the tint LUT path
+    (fisheye.c:2416-2419), 7 algorithmic bytes per pixel."""
+    wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, ring_max=ring_max, rubix=rubix)
     for i in range(5):
         wl.launch(i)
     k_med, k_min, k_max = wl.kernel_ms(launches=steps)
-    s_med, _, _ = wl.kernel_ms(nframes=1, launches=steps)
+    s_med, _, _ = wl.kernel_ms(nframes=1, launches=max(steps, 30))
     job2 = wl.job_seconds_per_step(steps=steps, nstreams=2)
     job1 = wl.job_seconds_per_step(steps=steps, repeats=11, nstreams=1)
     model = wl.ctx.traffic_model()
-    comp = compulsory_bytes(model, F)
-    algo = ALGO_BYTES_PER_PX * W * H * F
-    rec = {"name": name, "workload": f"{W}x{H} {globe}/{lens} {zoom or 'onload zoom'}, {F} frames/step from a ring of {wl.R} distinct globes",
+    comp = compulsory_bytes(model, F) + (F * model["mapped_pixels"] if rubix else 0)          # (rubix: + one tint byte per mapped pixel and frame ... per visit, counted per frame as the contract does)
+    bpp = ALGO_BYTES_PER_PX + (1 if rubix else 0)
+    algo = bpp * W * H * F
+    rec = {"name": name, "workload": f"{W}x{H} {globe}/{lens} {zoom or 'onload zoom'}{' rubix on' if rubix else ''}, {F} frames/step from a ring of {wl.R} distinct globes",
            "value": round(W * H * F / job2 / 1e6, 1), "value_one_stream": round(W * H * F / job1 / 1e6, 1), "unit": "Mpixels/s",
            "ms_per_step": round(job2 * 1e3, 5), "kernel_us_per_launch": round(k_med * 1e3, 3), "kernel_us_min": round(k_min * 1e3, 3),
            "kernel_us_max": round(k_max * 1e3, 3), "us_per_frame": round(k_med * 1e3 / F, 4),
+           "algorithmic_bytes_per_px": bpp,
            "algorithmic_frac": round(algo / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "frac_compulsory": round(comp / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "compulsory_bytes_per_launch": int(comp),
            "single_frame": {"us": round(s_med * 1e3, 3),
-                            "algorithmic_frac": round(ALGO_BYTES_PER_PX * W * H / (s_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                            "algorithmic_frac": round(bpp * W * H / (s_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "what": "one bk_apply_device launch per frame, HIP events around a train of them, cold ring"},
            "lensmap_build_ms": round(wl.build_ms, 3), "tile_stats": wl.tile_stats, "lens_scale": wl.scale}
+    try:
+        rec["single_frame"]["resident"] = wl.resident_us(frames=max(100, min(600, int(3000 / max(1.0, s_med * 1e3)))))
+    except Exception as e:      # noqa: BLE001
+        rec["single_frame"]["resident"] = {"error": f"{type(e).__name__}: {e}"}
     ring, block_h = wl.R, int(wl.tile_stats["tile_h"]) % 1000
     wl.close()
     if args is not None and not args.no_live_traffic:
-        traffic, src = measure_traffic(args, F, ring, block_h, config=f"{W}x{H}:{globe}:{lens}:{zoom or ''}")
+        traffic, src = measure_traffic(args, F, ring, block_h, config=f"{W}x{H}:{globe}:{lens}:{zoom or ''}:{1 if rubix else 0}")
         rec["traffic"] = traffic
         rec["traffic_source"] = src
         rec["frac_traffic"] = round(traffic / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
     return rec
 
 
-def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, steps, t1_ms):
-    """What row-striping would give on N GPUs, measured on ONE: for N = 2 / 4 / 8 every rank's stripe [H*r/N, H*(r+1)/N) is
-    built and its F-frame launch timed here; a step of the N-GPU job lasts as long as its slowest rank's launch
-    (stripe-complete throughput: nothing is exchanged)."""
-    out = {}
+def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, steps, t1_ms=None):
+    """What row-striping would give on N GPUs, measured on ONE: for N = 2 / 4 / 8 every rank's stripe is built and its F-frame launch
+    timed here; a step of the N-GPU job lasts as long as its slowest rank's launch (stripe-complete throughput: nothing is exchanged).
+    The stripes are the ones `bench.py --gpus N` uses: cut by the block map's row costs (bk_comm_rebalance), multiples of 8 rows.
+    t1_ms None: the one-GPU launch of the same F frames is timed here too."""
+    from blinky_amd import ffi
+    if t1_ms is None:
+        wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, ring_max=32)
+        for i in range(3):
+            wl.launch(i)
+        t1_ms = wl.kernel_ms(launches=max(10, steps // 2), repeats=5)[0]
+        wl.close()
+    full = blinky_amd.Context(device_index)
+    S.configure(full, globe, lens, zoom, (W, H))
+    full.build()
+    cost = full.row_costs()
+    full.close()
+    out = {"frames_per_launch": F, "one_gpu_us_per_launch": round(t1_ms * 1e3, 2)}
     for n in (2, 4, 8):
+        bounds = ffi.stripe_bounds_from_costs(cost, 0, n)
         per_rank = []
         for r in range(n):
-            wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=(H * r // n, H * (r + 1) // n), ring_max=32)
+            wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=(bounds[r], bounds[r + 1]), ring_max=32)
             for i in range(3):
                 wl.launch(i)
             per_rank.append(wl.kernel_ms(launches=max(10, steps // 2), repeats=5)[0])
             wl.close()
         worst = max(per_rank)
         out[str(n)] = {"slowest_rank_us_per_launch": round(worst * 1e3, 2), "fastest_rank_us_per_launch": round(min(per_rank) * 1e3, 2),
+                       "stripe_rows": [bounds[r + 1] - bounds[r] for r in range(n)],
                        "stripe_complete_mpx_s": round(W * H * F / (worst * 1e-3) / 1e6, 1), "speedup_vs_1": round(t1_ms / worst, 3)}
     return out
 
@@ -240,10 +309,14 @@ def traffic_child(args):
     import scripts as S
     F, R = args.frames, max(args.ring, args.frames)
     W, H, globe, lens, zoom = globals()["W"], globals()["H"], GLOBE, LENS, ZOOM
-    if args.child_config:                                   # "WxH:globe:lens:zoom" - configs_extra
-        size, globe, lens, zoom = args.child_config.split(":")
+    rubix, pal = False, None
+    if args.child_config:                                   # "WxH:globe:lens:zoom[:rubix]" - configs_extra
+        parts = args.child_config.split(":")
+        size, globe, lens, zoom = parts[:4]
         W, H = [int(v) for v in size.split("x")]
         zoom = zoom or None
+        rubix = len(parts) > 4 and parts[4] == "1"
+        pal = blinky_amd.ffi.create_palmap(synthetic_basepal()) if rubix else None
     ctx = blinky_amd.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_frames(R)
@@ -258,8 +331,8 @@ def traffic_child(args):
             ctx.fill_plate_lcg(f, p, f)
     out = [torch.zeros((F, H, W), dtype=torch.uint8, device="cuda") for _ in range(4)]
     torch.cuda.synchronize()
-    for i in range(23):
-        ctx.apply_device(out[i % 4].data_ptr(), W, H * W, frame0=(i * F) % R, nframes=F)
+    for i in range(23 if W * H * F < 5e8 else 8):
+        ctx.apply_device(out[i % 4].data_ptr(), W, H * W, frame0=(i * F) % R, nframes=F, rubix_on=rubix, pal=pal)
     torch.cuda.synchronize()
 
 
@@ -283,7 +356,7 @@ def measure_traffic(args, F, R, block_h, config=None):
         if config:
             cmd += ["--child-config", config]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, {"error": f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})", "stderr_tail": r.stderr[-300:]}
@@ -323,7 +396,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=16, help="frames per step (batch warped by one launch)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per step (batch warped by one launch); default 16 on one GPU, 64 on several: a 270-row stripe of 16 "
+                         "frames is a ~10 us launch against a ~5.5 us back-to-back launch floor (launch-bound, not bandwidth-bound)")
+    ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep stripes of equal height instead of stripes of equal block-map cost")
     ap.add_argument("--ring", type=int, default=64, help="distinct resident globes the steps cycle through")
     ap.add_argument("--repeats", type=int, default=0,
                     help="how many times the K-step timed region is measured (median reported); 0 = as many as keep the GPU busy "
@@ -343,8 +419,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region, compare every reassembled frame this rank owns with a full-frame warp")
+    ap.add_argument("--no-first-step-check", action="store_true",
+                    help="N > 1: skip the check of the first step's reassembled frames against a full-frame warp (on by default: the first "
+                         "time the exchange runs on a node is the time to find out)")
     args = ap.parse_args()
     if args.traffic_child:
+        if args.frames <= 0:
+            args.frames = 16
         return traffic_child(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -379,6 +460,8 @@ def main():
     import scripts as S
     from blinky_amd import multigpu
 
+    if args.frames <= 0:
+        args.frames = 16 if world == 1 else 64
     F, R = args.frames, max(args.ring, args.frames)
     ctx = blinky_amd.Context(local_rank)
     stream = torch.cuda.current_stream()
@@ -394,14 +477,26 @@ def main():
     if world > 1 and not host_exchange:
         # (should libblinkyhip's own communicator not come up on this node, say so and exchange through the process
         # group's RCCL instead of losing the measurement; every rank takes the same decision)
-        try:
-            comm = multigpu.rccl_comm(ctx, world, rank, dev)
-            assert comm.stripe(rank) == (r0, r1)
-            ok = 1
-        except Exception as e:      # noqa: BLE001
-            print(f"[bench] rank {rank}: bk_comm could not be created ({type(e).__name__}: {e}); using torch.distributed for the exchange",
-                  file=sys.stderr, flush=True)
+        # (ncclCommInitRank blocks until every rank has joined: should one of them never arrive, a minute is enough to know)
+        import threading
+        box = {}
+
+        def create():
+            try:
+                torch.cuda.set_device(local_rank)
+                box["comm"] = multigpu.rccl_comm(ctx, world, rank, dev)
+            except Exception as e:      # noqa: BLE001
+                box["error"] = e
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("BLINKY_BENCH_COMM_TIMEOUT", "60")))
+        if th.is_alive() or "error" in box or "comm" not in box:
+            why = "timed out after 60 s" if th.is_alive() else f"{type(box.get('error')).__name__}: {box.get('error')}"
+            print(f"[bench] rank {rank}: bk_comm could not be created ({why}); using torch.distributed for the exchange", file=sys.stderr, flush=True)
             comm, ok = None, 0
+        else:
+            comm = box["comm"]
+            ok = 1 if comm.stripe(rank) == (r0, r1) else 0
         t = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) == 0 and comm is not None:
@@ -414,6 +509,25 @@ def main():
     t0 = time.time()
     ctx.build()                                   # includes hiprtc compilation of the lens (or the module cache)
     build_first_wall_ms = (time.time() - t0) * 1e3
+    # stripes of equal WORK instead of equal height (bk_comm_rebalance: the block map's costs row by row, summed over the ranks by one
+    # all-reduce; multiples of 8 rows): a lens that leaves part of the screen unmapped or samples the globe unevenly would otherwise
+    # give the ranks that own the top and the bottom of the screen a fraction of the middle ranks' work
+    rebalanced = False
+    if world > 1 and not args.no_rebalance:
+        try:
+            if comm:
+                comm.rebalance()
+                bounds = [comm.stripe(r)[0] for r in range(world)] + [H]
+            else:
+                cost = torch.from_numpy(ctx.row_costs().astype("int64")).to(dev if not host_exchange else "cpu")
+                dist.all_reduce(cost)
+                bounds = blinky_amd.ffi.stripe_bounds_from_costs(cost.cpu().numpy().astype("uint32"), 0, world)
+                ctx.set_rows(bounds[rank], bounds[rank + 1])
+            r0, r1 = bounds[rank], bounds[rank + 1]
+            ctx.build()
+            rebalanced = True
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] rank {rank}: stripes not rebalanced ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
     t0 = time.time()
     display, scale = ctx.build()                  # module cached: emit + launch (+ host fix-up of flagged pixels) only
     display = comm.or_display(display) if comm else multigpu.or_display(display, world, dev)   # which plates the whole frame reads
@@ -562,6 +676,46 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
+    first_step_check = None
+    if world > 1 and not args.no_first_step_check and exchange_mode == "rotating":
+        # step 0 for real, then every frame this rank ends up holding against the same frame warped whole here; every rank's
+        # verdict (and its error text) travels to rank 0 and into the JSON line
+        msg = "ok"
+        try:
+            run_step(0)
+            drain()
+            torch.cuda.synchronize()
+            chk = blinky_amd.Context(local_rank)
+            chk.set_stream(stream.cuda_stream)
+            chk.set_frames(F)
+            S.configure(chk, GLOBE, LENS, ZOOM, (W, H))
+            chk.build()
+            g0 = first_globe(0)
+            mine = multigpu.owned_frames(F, rank, world)
+            for f in mine:
+                for p in range(6):
+                    chk.fill_plate_lcg(f, p, (g0 + f) % R)
+            whole = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+            bad = []
+            for f in mine:
+                chk.apply_device(whole.data_ptr(), W, H * W, frame0=f, nframes=1)
+                torch.cuda.synchronize()
+                if not torch.equal(frames_out[0][f // world].to(dev), whole):
+                    bad.append(f)
+            chk.close()
+            if bad:
+                msg = f"MISMATCH in frames {bad}"
+        except Exception as e:      # noqa: BLE001
+            msg = f"{type(e).__name__}: {e}"
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, msg)
+        first_step_check = {"ranks": verdicts, "ok": all(v == "ok" for v in verdicts)}
+        if not first_step_check["ok"]:
+            if rank == 0:
+                print(f"[bench] first-step check FAILED: {verdicts}", file=sys.stderr, flush=True)
+                print(json.dumps({"metric": "warped Mpixels/s (lensmap apply)", "value": None, "n_gpus": world, "error": "first-step check failed",
+                                  "first_step_check": first_step_check}))
+            sys.exit(3)
     for i in range(args.warmup):
         run_step(i)
     drain()
@@ -623,6 +777,12 @@ def main():
     else:
         stripe_complete_mpx = stripe_mpx
     single_ms, _, _ = kernel_ms(R, nframes=1)            # single-frame launches (what the engine drop-in issues), cold ring
+    single_resident = None
+    if world == 1:
+        try:
+            single_resident = resident_measure(torch, ctx, origin(stripes[0]), W, rows, R)
+        except Exception as e:      # noqa: BLE001
+            single_resident = {"error": f"{type(e).__name__}: {e}"}
 
     if args.check:
         # every frame this rank ends up holding == the same frame warped whole by a full-height context
@@ -723,7 +883,10 @@ def main():
                          # the engine's real call: ONE frame per launch, nothing amortised - the one contract-formula figure <= 1
                          "single_frame": {"us": round(single_ms * 1e3, 3),
                                           "algorithmic_frac": round(ALGO_BYTES_PER_PX * W * rows / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                          "target_us_at_0.70": round(ALGO_BYTES_PER_PX * W * rows / (0.70 * HBM_PEAK_GBS * 1e9) * 1e6, 3)},
+                                          "target_us_at_0.70": round(ALGO_BYTES_PER_PX * W * rows / (0.70 * HBM_PEAK_GBS * 1e9) * 1e6, 3),
+                                          "what": "one bk_apply_device launch per frame (HIP events around a train of them, cold ring); `resident`: "
+                                                  "the same frames as commands to the resident kernel",
+                                          "resident": single_resident},
                          "frac_is": "ALGORITHMIC bytes (6 B/px, SURVEY.md 8(d)) / kernel time / peak, as the bench contract defines it; the "
                                     "kernel moves fewer bytes than that (2-byte LDS addresses read once per 8 frames instead of a 4-byte "
                                     "index per pixel and frame), so this ratio can exceed 1 and is NOT a bandwidth utilisation - "
@@ -759,21 +922,35 @@ def main():
                 "bytes_received_per_rank_per_step": int(len(multigpu.owned_frames(F, 0, world)) * (H - (bounds[1] - bounds[0])) * W),
                 "xgmi_link_GBps_assumed": 64, "bound_mpx_s": round(world * world * 64e9 / 1e6, 1),
                 "bound_all_on_rank0_mpx_s": round(64e9 * world / 1e6, 1)},
+            "stripes": {"rows_per_rank": [bounds[r + 1] - bounds[r] for r in range(world)], "rebalanced": rebalanced},
+            "first_step_check": first_step_check,
             "single_frame_launch_us": round(single_ms * 1e3, 2),
             "single_frame_mpx_s": round(W * rows / (single_ms * 1e-3) / 1e6, 1),
             "lens_scale": scale,
         }
         if world == 1 and not args.no_extra:
+            # the other configurations BASELINE.json names that fit one GPU, timed by this same run: C2 (1080p stereographic), C3 (4K
+            # quincuncial, the inverse-only full-sphere lens), C5 (8K hammer, 64 frames in ONE launch over a ring of 64 distinct 8K
+            # globes = 7.2 GB), the headline with the rubix tint LUTs on (7 B/px), and 4K hammer as the whole-globe single-frame case
+            extras = [("C2 (BASELINE.json configs[1])", "cube", "stereographic", None, 1920, 1080, F, args.steps, False, 64),
+                      ("C3 (BASELINE.json configs[2])", "cube", "quincuncial", None, 3840, 2160, F, args.steps, False, 64),
+                      ("C5 (BASELINE.json configs[4], on one GPU)", "cube", "hammer", None, 7680, 4320, 64, max(6, args.steps // 5), False, 64),
+                      ("headline, rubix on (fisheye.c:2416-2419)", GLOBE, LENS, ZOOM, W, H, F, args.steps, True, 64),
+                      ("4K cube/hammer (whole-globe lens)", "cube", "hammer", None, 3840, 2160, F, args.steps, False, 64)]
+            out["configs_extra"] = []
+            for (nm, g, l, z, w_, h_, f_, st_, rb_, rm_) in extras:
+                try:
+                    out["configs_extra"].append(extra_config(torch, blinky_amd, S, local_rank, nm, g, l, z, w_, h_, f_, st_, args, rubix=rb_, ring_max=rm_))
+                except Exception as e:      # noqa: BLE001
+                    out["configs_extra"].append({"name": nm, "error": f"{type(e).__name__}: {e}"})
             try:
-                out["configs_extra"] = [extra_config(torch, blinky_amd, S, local_rank, "C2 (BASELINE.json configs[1])", "cube", "stereographic",
-                                                     None, 1920, 1080, F, args.steps, args)]
-            except Exception as e:      # noqa: BLE001
-                out["configs_extra"] = [{"error": f"{type(e).__name__}: {e}"}]
-            try:
+                # with the launch `bench.py --gpus N` issues: 64 frames per step, stripes of equal block-map cost
                 out["predicted_stripe_complete"] = dict(
-                    what="rank r's stripe for N = 2 / 4 / 8 built and timed on this one GPU (same launch as roofline.kernel_ms_per_launch); "
-                         "a step lasts as long as the slowest rank; no exchange", one_gpu_us_per_launch=round(k_med * 1e3, 2),
-                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, F, args.steps, k_med))
+                    what="rank r's stripe for N = 2 / 4 / 8 built and timed on this one GPU with the launch `bench.py --gpus N` issues (64 frames "
+                         "per step, stripes cut by the block map's row costs); a step lasts as long as the slowest rank; no exchange",
+                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, 64, args.steps),
+                    frames16=predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, F, args.steps, k_med),
+                    C4_trism_panini=predicted_stripes(torch, blinky_amd, S, local_rank, "trism", "panini", "f_fov 180", W, H, 64, args.steps))
             except Exception as e:      # noqa: BLE001
                 out["predicted_stripe_complete"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:

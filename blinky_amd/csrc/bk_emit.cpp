@@ -1060,132 +1060,262 @@ struct Emitter {
 
 namespace {
 
-// definite-assignment walk for callbacks_carry_state
+// Does a callback read a script global that callbacks assign before assigning it itself - state carried from pixel to pixel in the
+// reference's one sequential scan (fisheye.c:2084-2124), fresh per pixel on the GPU?  A definite-assignment walk over the callbacks
+// and what they call, with ONE carried read recognised as harmless: the KEYED CACHE (eckert4.lua:14-21)
+//     if P ~= K then  G1 = ..; G2 = ..;  K = P  end          -- then G1, G2 are read
+// where P is one of the callback's own parameters handed down unchanged, everything stored in the branch is computed from that
+// parameter alone (no other parameter, no carried state), K and the G's are stored nowhere else, and K does not start out as a
+// number.  Then whatever the G's hold after the `if` is what the branch would compute for this pixel: taken or not, carried over or
+// fresh, the pixel's result is the same - not state.  Every value therefore carries which callback parameters it depends on
+// (bits 0..2; IMPURE = carried state or something the walk cannot see through) and whether it IS such a parameter, unchanged.
 struct StateScan {
     Interp &I;
     const std::set<std::string> &mut;
     std::string culprit;
     std::set<const FuncProto *> active;
-    using Set = std::set<std::string>;
+    static constexpr uint8_t IMPURE = 0x80;
+    struct Val { uint8_t dep = 0; int copy_of = -1; };
+    using State = std::map<std::string, Val>;            // the mutable globals definitely assigned on this path, and what they hold
+    struct Frame { std::vector<Val> loc; uint8_t ret = 0; };
+    std::map<std::string, std::string> cache_key;        // a cache global (the key global included) -> its key global
+    std::string refresh_key;                             // walking the branch of `if P ~= <refresh_key> then`
+    std::vector<std::pair<std::string, std::string>> stores;      // every store to a mutable global: (name, refresh_key it was made under)
 
-    void read_global(const std::string &name, const Set &def)
+    static Val join(Val a, Val b) { Val o; o.dep = (uint8_t)(a.dep | b.dep); o.copy_of = a.copy_of == b.copy_of ? a.copy_of : -1; return o; }
+    static State meet(const State &a, const State &b)
     {
-        if (culprit.empty() && mut.count(name) && !def.count(name)) culprit = name;
+        State o;
+        for (auto &kv : a) { auto it = b.find(kv.first); if (it != b.end()) o[kv.first] = join(kv.second, it->second); }
+        return o;
     }
-    void expr(const Expr *e, const Emitter::Scope *sc, Set &def)
+    Val local_of(Frame &fr, int slot) { if (slot < 0) return Val{IMPURE, -1}; if ((size_t)slot >= fr.loc.size()) fr.loc.resize((size_t)slot + 1); return fr.loc[(size_t)slot]; }
+    void set_local(Frame &fr, int slot, Val v, bool fresh)
     {
-        if (!e) return;
-        if (e->kind == Expr::Name && e->var == VarKind::Global) { read_global(e->str, def); return; }
-        if (e->kind == Expr::Function) {
+        if (slot < 0) return;
+        if ((size_t)slot >= fr.loc.size()) fr.loc.resize((size_t)slot + 1);
+        fr.loc[(size_t)slot] = fresh ? v : join(fr.loc[(size_t)slot], v);       // (a re-assignment may sit in a branch or a loop: never less than it was)
+    }
+    Val read_global(const std::string &name, const State &st)
+    {
+        if (!mut.count(name)) return Val{};                                    // nobody assigns it: a constant of the script
+        auto it = st.find(name);
+        if (it != st.end()) return it->second;
+        if (culprit.empty()) culprit = name;
+        return Val{IMPURE, -1};
+    }
+    Val call_script(const Closure *cl, const std::vector<Val> &args, const State &st)
+    {
+        if (active.count(cl->proto)) return Val{IMPURE, -1};                    // (recursion is refused by the code generator anyway)
+        active.insert(cl->proto);
+        Frame fr;
+        fr.loc.resize((size_t)std::max(cl->proto->nslots, cl->proto->nparams));
+        for (int i = 0; i < cl->proto->nparams; ++i) fr.loc[(size_t)i] = (size_t)i < args.size() ? args[(size_t)i] : Val{};
+        if (cl->proto->is_vararg) for (size_t i = (size_t)cl->proto->nparams; i < args.size(); ++i) fr.ret |= args[i].dep;      // (`...` may come back out)
+        Emitter::Scope callee_scope;
+        callee_scope.proto = cl->proto;
+        callee_scope.cl = cl;
+        State inner = st;                                    // the callee sees what is assigned so far; its own stores stay its own
+        block(cl->proto->body, &callee_scope, inner, fr);
+        active.erase(cl->proto);
+        Val out;
+        out.dep = fr.ret;
+        return out;
+    }
+    Val expr(const Expr *e, const Emitter::Scope *sc, State &st, Frame &fr)
+    {
+        if (!e) return Val{};
+        switch (e->kind) {
+        case Expr::Nil: case Expr::True: case Expr::False: case Expr::Number: case Expr::String: return Val{};
+        case Expr::Vararg: return Val{fr.ret, -1};           // (what came in through `...` was folded into ret by call_script)
+        case Expr::Name:
+            if (e->var == VarKind::Global) return read_global(e->str, st);
+            if (e->var == VarKind::Local) return local_of(fr, e->slot);
+            return Val{};                                    // an upvalue: callbacks that assign one count as carrying state before this walk starts
+        case Expr::Function:
             // a function defined inside device code can only be called after this point, where at least as much is assigned as here:
-            // its body is walked once, now, as if it were called here (its own assignments stay its own)
+            // its body is walked once, now, as if it were called here (its own stores stay its own)
             if (e->proto) {
                 Emitter::Scope inner_scope;
                 inner_scope.proto = e->proto;
                 inner_scope.parent = sc;
-                Set inner = def;
-                block(e->proto->body, &inner_scope, inner);
+                State inner = st;
+                Frame ifr;
+                ifr.loc.assign((size_t)e->proto->nslots, Val{IMPURE, -1});      // (its parameters: whatever it will be called with)
+                block(e->proto->body, &inner_scope, inner, ifr);
             }
-            return;
+            return Val{IMPURE, -1};
+        default: break;
         }
-        expr(e->a.get(), sc, def);
-        expr(e->b.get(), sc, def);
-        for (auto &x : e->args) expr(x.get(), sc, def);
-        for (auto &x : e->fields) { expr(x.first.get(), sc, def); expr(x.second.get(), sc, def); }
-        if (e->kind == Expr::Call && !e->str.empty() && e->a->kind == Expr::Name) {          // obj:m(..): walk m's body like any callee's
-            Value obj;
-            if (e->a->var == VarKind::Global && !mut.count(e->a->str)) obj = I.get_global(e->a->str);
-            else if (e->a->var == VarKind::Upvalue) {
-                const Emitter::Scope *owner = nullptr;
-                int slot = 0;
-                if (const Value *cell = Emitter::upvalue_of(sc, e->a->slot, &owner, &slot)) obj = *cell;
-            }
-            const Value m = Emitter::static_field(obj, Value::string(e->str));
-            if (m.t == Value::FUNC && !active.count(m.fn()->proto)) {
-                active.insert(m.fn()->proto);
-                Set inner = def;
-                Emitter::Scope callee_scope;
-                callee_scope.proto = m.fn()->proto;
-                callee_scope.cl = m.fn();
-                block(m.fn()->proto->body, &callee_scope, inner);
-                active.erase(m.fn()->proto);
-            }
-        }
-        if (e->kind == Expr::Call && e->str.empty()) {
+        if (e->kind == Expr::Call) {
+            std::vector<Val> args;
+            Val all;
+            for (auto &x : e->args) { args.push_back(expr(x.get(), sc, st, fr)); all.dep |= args.back().dep; }
             Value callee;
             bool known = false;
-            if (e->a->kind == Expr::Name && e->a->var == VarKind::Global && !mut.count(e->a->str)) { callee = I.get_global(e->a->str); known = true; }
+            if (!e->str.empty()) {                                               // obj:m(..): m's body is walked like any callee's
+                expr(e->a.get(), sc, st, fr);
+                Value obj;
+                if (e->a->kind == Expr::Name && e->a->var == VarKind::Global && !mut.count(e->a->str)) obj = I.get_global(e->a->str);
+                else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) {
+                    const Emitter::Scope *owner = nullptr;
+                    int slot = 0;
+                    if (const Value *cell = Emitter::upvalue_of(sc, e->a->slot, &owner, &slot)) obj = *cell;
+                }
+                callee = Emitter::static_field(obj, Value::string(e->str));
+                known = callee.t == Value::FUNC;
+                if (known) args.insert(args.begin(), Val{});                     // self: a constant table
+            } else if (e->a->kind == Expr::Name && e->a->var == VarKind::Global && !mut.count(e->a->str)) { callee = I.get_global(e->a->str); known = true; }
             else if (e->a->kind == Expr::Name && e->a->var == VarKind::Upvalue) {
                 const Emitter::Scope *owner = nullptr;
                 int slot = 0;
                 if (const Value *cell = Emitter::upvalue_of(sc, e->a->slot, &owner, &slot)) { callee = *cell; known = true; }
+            } else {
+                const Val f = expr(e->a.get(), sc, st, fr);                      // math.sin, lib.f, a function held in a local ...
+                if (e->a->kind == Expr::Index) { all.dep |= f.dep; return Val{all.dep, -1}; }      // a field of a table: builtins and constant tables' functions are pure in their arguments
+                return Val{IMPURE, -1};                                          // a function VALUE (parameter, local): not followed
             }
-            if (known && callee.t == Value::FUNC && !active.count(callee.fn()->proto)) {
-                active.insert(callee.fn()->proto);
-                Set inner = def;                                     // the callee sees what is assigned so far; its own assignments stay its own
-                Emitter::Scope callee_scope;
-                callee_scope.proto = callee.fn()->proto;
-                callee_scope.cl = callee.fn();
-                block(callee.fn()->proto->body, &callee_scope, inner);
-                active.erase(callee.fn()->proto);
-            }
+            if (known && callee.t == Value::FUNC) return call_script(callee.fn(), args, st);
+            return Val{all.dep, -1};                                             // a builtin: a pure function of its arguments
         }
+        Val out;
+        out = join(out, expr(e->a.get(), sc, st, fr));
+        if (e->kind == Expr::Unop && e->op == Expr::OP_PAREN) return out;        // (x) is still x
+        out.copy_of = -1;
+        if (e->b) out.dep |= expr(e->b.get(), sc, st, fr).dep;
+        for (auto &x : e->args) out.dep |= expr(x.get(), sc, st, fr).dep;
+        for (auto &x : e->fields) { out.dep |= expr(x.first.get(), sc, st, fr).dep; out.dep |= expr(x.second.get(), sc, st, fr).dep; }
+        return out;
+    }
+    // `if P ~= K then .. end` as the refresh of a keyed cache (see above); true = handled, st updated
+    bool keyed_refresh(const Stmt &s, const Emitter::Scope *sc, State &st, Frame &fr)
+    {
+        if (s.clauses.size() != 1 || !s.clauses[0].first || !refresh_key.empty()) return false;
+        const Expr *c = s.clauses[0].first.get();
+        if (c->kind != Expr::Binop || c->op != Expr::OP_NE) return false;
+        const Expr *k = c->b.get(), *p = c->a.get();
+        auto is_key = [&](const Expr *x) { return x && x->kind == Expr::Name && x->var == VarKind::Global && mut.count(x->str) && !st.count(x->str); };
+        if (!is_key(k)) std::swap(k, p);
+        if (!is_key(k) || !p || p->kind != Expr::Name || p->var != VarKind::Local) return false;
+        const Val pv = local_of(fr, p->slot);
+        if (pv.copy_of < 0 || pv.dep != (uint8_t)(1u << pv.copy_of)) return false;             // the key must BE a callback parameter
+        if (I.get_global(k->str).t == Value::NUM) return false;                                  // (a key that starts out as a number could match the first pixel)
+        const std::string saved_culprit = culprit;
+        State body = st;
+        Frame bfr = fr;
+        refresh_key = k->str;
+        const size_t stores_before = stores.size();
+        const bool falls = block(s.clauses[0].second, sc, body, bfr);
+        refresh_key.clear();
+        bool ok = falls && culprit == saved_culprit;
+        auto kv = body.find(k->str);
+        ok = ok && kv != body.end() && kv->second.copy_of == pv.copy_of;                        // K = P on every way through the branch
+        std::vector<std::string> fresh;
+        for (auto &g : body) if (!st.count(g.first)) { fresh.push_back(g.first); ok = ok && (g.second.dep & ~(uint8_t)(1u << pv.copy_of)) == 0; }
+        for (size_t i = stores_before; ok && i < stores.size(); ++i) ok = body.count(stores[i].first) != 0;      // every store of the branch is a definite one
+        if (!ok) {                                           // not that pattern: undo, let the ordinary rules speak
+            culprit = saved_culprit;
+            stores.resize(stores_before);
+            return false;
+        }
+        for (const std::string &g : fresh) {
+            auto had = cache_key.find(g);
+            if (had != cache_key.end() && had->second != k->str && culprit.empty()) culprit = g;      // two keys for one cache
+            cache_key[g] = k->str;
+            st[g] = body[g];
+        }
+        fr.loc = bfr.loc;                                    // (locals the branch re-assigned: joined, never less than they were)
+        return true;
     }
     // returns whether control can fall out of the end of the block
-    bool block(const Block &b, const Emitter::Scope *sc, Set &def)
+    bool block(const Block &b, const Emitter::Scope *sc, State &st, Frame &fr)
     {
         for (const StmtP &sp : b) {
             const Stmt &s = *sp;
             switch (s.kind) {
             case Stmt::Return:
-                for (auto &x : s.exprs) expr(x.get(), sc, def);
+                for (auto &x : s.exprs) fr.ret |= expr(x.get(), sc, st, fr).dep;
                 return false;
             case Stmt::Break: return false;
+            case Stmt::Goto: case Stmt::Label: break;        // (refused by the code generator)
             case Stmt::If: {
-                Set meet;
+                if (keyed_refresh(s, sc, st, fr)) break;
+                State met;
                 bool any = false, has_else = false;
                 for (auto &c : s.clauses) {
-                    if (c.first) expr(c.first.get(), sc, def); else has_else = true;
-                    Set d = def;
-                    if (block(c.second, sc, d)) { meet = any ? intersect(meet, d) : d; any = true; }
+                    if (c.first) expr(c.first.get(), sc, st, fr); else has_else = true;
+                    State d = st;
+                    if (block(c.second, sc, d, fr)) { met = any ? meet(met, d) : d; any = true; }
                 }
-                if (!has_else) { meet = any ? intersect(meet, def) : def; any = true; }
+                if (!has_else) { met = any ? meet(met, st) : st; any = true; }
                 if (!any) return false;                               // every branch returned
-                def = meet;
+                st = met;
                 break;
             }
             case Stmt::While: case Stmt::NumFor: case Stmt::GenFor: {
-                expr(s.cond.get(), sc, def);
-                for (auto &x : s.exprs) expr(x.get(), sc, def);
-                Set d = def;
-                block(s.body, sc, d);                                 // may run zero times: nothing it assigns is definite afterwards
+                Val ctl;
+                if (s.cond) ctl.dep |= expr(s.cond.get(), sc, st, fr).dep;
+                for (auto &x : s.exprs) ctl.dep |= expr(x.get(), sc, st, fr).dep;
+                for (int slot : s.slots) set_local(fr, slot, Val{ctl.dep, -1}, true);
+                for (int pass = 0; pass < 3; ++pass) {                // (what a local depends on can grow from one trip to the next)
+                    State d = st;
+                    block(s.body, sc, d, fr);                         // may run zero times: nothing it stores is definite afterwards
+                    if (s.cond) expr(s.cond.get(), sc, d, fr);
+                }
                 break;
             }
             case Stmt::Repeat: {
-                Set d = def;
-                const bool falls = block(s.body, sc, d);
-                expr(s.cond.get(), sc, d);
-                if (falls) def = d;                                   // the body runs at least once
+                State d = st;
+                bool falls = true;
+                for (int pass = 0; pass < 3; ++pass) { d = st; falls = block(s.body, sc, d, fr); expr(s.cond.get(), sc, d, fr); }
+                if (falls) st = d;                                    // the body runs at least once
                 break;
             }
-            case Stmt::Do: if (!block(s.body, sc, def)) return false; break;
-            default:
-                for (auto &x : s.exprs) expr(x.get(), sc, def);       // right-hand sides first ...
-                expr(s.call.get(), sc, def);
-                for (auto &t : s.targets) {
-                    if (t->kind == Expr::Name && t->var == VarKind::Global) def.insert(t->str);      // ... then the assignment
-                    else if (t->kind == Expr::Index) { expr(t->a.get(), sc, def); expr(t->b.get(), sc, def); }
+            case Stmt::Do: if (!block(s.body, sc, st, fr)) return false; break;
+            case Stmt::LocalFunction:
+                for (int slot : s.slots) set_local(fr, slot, Val{}, true);
+                for (auto &x : s.exprs) expr(x.get(), sc, st, fr);
+                break;
+            case Stmt::Local: {
+                std::vector<Val> vals;
+                for (auto &x : s.exprs) vals.push_back(expr(x.get(), sc, st, fr));
+                for (size_t i = 0; i < s.slots.size(); ++i) {
+                    Val v;                                            // (no initialiser: nil)
+                    if (i < vals.size()) v = vals[i];
+                    else if (!vals.empty() && s.exprs.back()->kind == Expr::Call) v = Val{vals.back().dep, -1};     // a call's further results
+                    if (i + 1 >= vals.size() && !vals.empty() && s.exprs.back()->kind == Expr::Call) v.copy_of = -1;
+                    set_local(fr, s.slots[i], v, true);
                 }
                 break;
+            }
+            default: {
+                std::vector<Val> vals;
+                for (auto &x : s.exprs) vals.push_back(expr(x.get(), sc, st, fr));       // right-hand sides first ...
+                expr(s.call.get(), sc, st, fr);
+                for (size_t i = 0; i < s.targets.size(); ++i) {
+                    const Expr *t = s.targets[i].get();
+                    Val v;
+                    if (i < vals.size()) v = vals[i];
+                    else if (!vals.empty() && s.exprs.back()->kind == Expr::Call) v = Val{vals.back().dep, -1};
+                    if (i + 1 >= vals.size() && !vals.empty() && s.exprs.back()->kind == Expr::Call) v.copy_of = -1;
+                    if (t->kind == Expr::Name && t->var == VarKind::Global) {           // ... then the store
+                        if (mut.count(t->str)) { st[t->str] = v; stores.emplace_back(t->str, refresh_key); }
+                    } else if (t->kind == Expr::Name && t->var == VarKind::Local) set_local(fr, t->slot, v, false);
+                    else if (t->kind == Expr::Index) { expr(t->a.get(), sc, st, fr); expr(t->b.get(), sc, st, fr); }
+                }
+                break;
+            }
             }
         }
         return true;
     }
-    static Set intersect(const Set &a, const Set &b)
+    // after every callback has been walked: a cache global stored anywhere but in its own refresh branch is state after all
+    void check_caches()
     {
-        Set o;
-        for (const std::string &x : a) if (b.count(x)) o.insert(x);
-        return o;
+        for (auto &sv : stores) {
+            auto c = cache_key.find(sv.first);
+            if (c != cache_key.end() && sv.second != c->second && culprit.empty()) culprit = sv.first;
+        }
     }
 };
 
@@ -1207,17 +1337,23 @@ bool callbacks_carry_state(const EmitRequest &req, std::string *which)
         return true;
     }
     if (em.mutable_globals.empty()) return false;
-    StateScan sc{*req.interp, em.mutable_globals, std::string(), {}};
+    StateScan sc{*req.interp, em.mutable_globals, std::string(), {}, {}, std::string(), {}};
     for (const Value *v : roots)
         if (v->t == Value::FUNC) {
-            StateScan::Set def;
+            StateScan::State st;
+            StateScan::Frame fr;
+            const FuncProto *pr = v->fn()->proto;
+            fr.loc.resize((size_t)std::max(pr->nslots, pr->nparams));
+            for (int i = 0; i < pr->nparams && i < 3; ++i) fr.loc[(size_t)i] = StateScan::Val{(uint8_t)(1u << i), i};       // the callback's own parameters
+            for (int i = 3; i < pr->nparams; ++i) fr.loc[(size_t)i] = StateScan::Val{};
             Emitter::Scope root;
-            root.proto = v->fn()->proto;
+            root.proto = pr;
             root.cl = v->fn();
-            sc.active.insert(v->fn()->proto);
-            sc.block(v->fn()->proto->body, &root, def);
-            sc.active.erase(v->fn()->proto);
+            sc.active.insert(pr);
+            sc.block(pr->body, &root, st, fr);
+            sc.active.erase(pr);
         }
+    sc.check_caches();
     if (which) *which = sc.culprit;
     return !sc.culprit.empty();
 }

@@ -120,12 +120,14 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * on nil, a runaway loop - Lua errors the reference's unprotected lua_call does not survive; a malformed lens_forward result)
  * returns BK_E_SCRIPT and leaves an EMPTY lensmap.
  * Script globals (and locals of the script's chunk) that lens_inverse / lens_forward / globe_plate ASSIGN are per-pixel state
- * on the GPU, initialised from their value after the chunk ran: fine for scratch variables and pure caches (all bundled scripts), but a
- * script that accumulates state from one pixel to the next does not behave as in the reference's sequential scan -
- * unless bk_set_sequential_build asks for that scan: mode 1 = an inverse-map lens whose callbacks read a script global before
- * assigning it, or assign a chunk local at all (bk_lens_carries_state: eckert4's per-row cache counts, a pixel counter certainly does) is built as ONE sequential
- * scan on the host, in the reference's order, by the compiled host module (else the script interpreter) - seconds instead of
- * milliseconds at 4K, the reference's result for any script; mode 2 = every inverse-map lens; 0 (default) = never. */
+ * on the GPU, initialised from their value after the chunk ran: the reference's result for scratch variables and for caches
+ * keyed by one of the callback's parameters (`if y ~= lasty then maxx = ..; lasty = y end`: eckert4.lua) - every bundled script.
+ * A script that really carries state from one pixel to the next (a counter, a running sum) would not behave as in the reference's
+ * sequential scan (fisheye.c:2084-2124), so by DEFAULT (bk_set_sequential_build mode 1) an inverse-map lens whose callbacks read
+ * a script global before assigning it outside such a keyed cache, or assign a chunk local at all (bk_lens_carries_state), is built
+ * as ONE sequential scan on the host, in the reference's order, by the compiled host module (else the script interpreter):
+ * seconds instead of milliseconds at 4K, the reference's result for any script.  mode 2 = every inverse-map lens; 0 = never
+ * (the GPU build whatever the script does). */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
 int bk_set_sequential_build(bk_ctx *ctx, int mode);
 int bk_lens_carries_state(bk_ctx *ctx, char *global_name /* nullable */, size_t cap);

@@ -51,19 +51,33 @@ def test_bench_line_and_check_single_gpu():
     # the engine's real call inside `roofline`: one frame per launch, the contract's algorithmic formula, <= 1
     sf = rf["single_frame"]
     assert sf["us"] > 0 and 0 < sf["algorithmic_frac"] <= 1.0, sf
-    # BASELINE.json configs[1] (1920x1080 cube/stereographic) timed in the same run
-    (c2,) = out["configs_extra"]
-    assert "error" not in c2, c2
-    assert c2["workload"].startswith("1920x1080 cube/stereographic") and c2["value"] > 0 and c2["kernel_us_per_launch"] > 0
-    assert 0 < c2["frac_compulsory"] <= 1.0 and 0 < c2["single_frame"]["algorithmic_frac"] <= 1.0
-    # ... and its HBM bytes counted the way the headline's are (FETCH_SIZE / WRITE_SIZE under rocprofv3): at least what 16 frames
-    # of output weigh, and no more than 1.5x the compulsory model
+    # ... and the same frames as commands to the resident kernel (bk_apply_resident_*): pipelined submissions, host wall clock per frame
+    rs = sf["resident"]
+    assert "error" not in rs, rs
+    assert 0 < rs["us"] < 1.5 * sf["us"] and rs["blocks_in_registers"] >= 1 and 0 < rs["algorithmic_frac"], (rs, sf)
+    # the other BASELINE.json configurations that fit one GPU, timed in the same run: C2 (1080p stereographic), C3 (4K quincuncial),
+    # C5 (8K hammer x 64 in one launch), the headline with rubix on (7 B/px), 4K hammer
+    extras = {c["name"].split(" ")[0]: c for c in out["configs_extra"]}
+    assert set(extras) == {"C2", "C3", "C5", "headline,", "4K"}, list(extras)
+    for c in out["configs_extra"]:
+        assert "error" not in c, c
+        assert c["value"] > 0 and c["kernel_us_per_launch"] > 0 and 0 < c["frac_compulsory"] <= 1.0 and 0 < c["single_frame"]["algorithmic_frac"] <= 1.0, c
+        assert "error" not in c["single_frame"]["resident"], c["single_frame"]
+    c2, c3, c5, rbx = extras["C2"], extras["C3"], extras["C5"], extras["headline,"]
+    assert c2["workload"].startswith("1920x1080 cube/stereographic") and c3["workload"].startswith("3840x2160 cube/quincuncial")
+    assert c5["workload"].startswith("7680x4320 cube/hammer") and ", 64 frames/step from a ring of 64" in c5["workload"]
+    assert rbx["algorithmic_bytes_per_px"] == 7 and "rubix on" in rbx["workload"]
+    # ... and their HBM bytes counted the way the headline's are (FETCH_SIZE / WRITE_SIZE under rocprofv3): at least what the frames
+    # of output weigh (mapped pixels), and no more than 1.5x the compulsory model
     assert "traffic" in c2 and (c2["traffic"] is None or 1920 * 1080 * 16 < c2["traffic"] < 1.5 * c2["compulsory_bytes_per_launch"]), c2
-    assert c2["traffic"] is None or 0 < c2["frac_traffic"] <= 1.0
+    for c in out["configs_extra"]:
+        assert c["traffic"] is None or (0 < c["frac_traffic"] <= 1.0 and c["traffic"] < 1.6 * c["compulsory_bytes_per_launch"]), c
     # the scaling curve predicted on one GPU: rank r's stripe for N = 2 / 4 / 8, slowest rank
     ps = out["predicted_stripe_complete"]
     assert "error" not in ps, ps
     assert all(ps[n]["speedup_vs_1"] > 0.5 for n in ("2", "4", "8")), ps
+    assert ps["frames_per_launch"] == 64 and all(sum(ps[n]["stripe_rows"]) == 2160 for n in ("2", "4", "8")), ps
+    assert all(ps["C4_trism_panini"][n]["speedup_vs_1"] > 0.5 and ps["frames16"][n]["speedup_vs_1"] > 0.5 for n in ("2", "4", "8")), ps
 
 
 def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():
@@ -76,6 +90,13 @@ def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():
     assert "[check] rank 0: OK" in r.stderr and "[check] rank 1: OK" in r.stderr
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 5
+    # the same JSON keys the RCCL path prints (the driver's SCALE run parses this line at N = 2 / 4 / 8), stripes cut by work, and the
+    # first step checked on every rank before anything was timed
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "stripe_complete_mpx_s", "assembled_on_rank0_mpx_s", "exchange", "stripes", "first_step_check"):
+        assert k in out, k
+    assert out["first_step_check"] == {"ranks": ["ok", "ok"], "ok": True}
+    assert out["stripes"]["rebalanced"] and sum(out["stripes"]["rows_per_rank"]) == 2160 and all(r % 8 == 0 for r in out["stripes"]["rows_per_rank"][:-1])
 
 
 def test_bench_gpus_flag_launches_its_own_ranks():

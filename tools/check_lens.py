@@ -2,7 +2,7 @@
 """Will this lens / globe script run with libblinkyhip?  Loads it on a context without a device (no GPU needed), reports what the
 host layer would see (map type, zoom limits, onload command), whether its per-pixel callbacks translate to GPU code - or which
 construct does not - whether hiprtc compiles the result for gfx950, and whether the callbacks carry state from
-pixel to pixel (bk_lens_carries_state: such a lens needs bk_set_sequential_build to look as it does in the reference).
+pixel to pixel (bk_lens_carries_state: such a lens is built by one sequential scan on the host, as the reference builds every lens).
 
 usage: tools/check_lens.py <lens.lua> [<globe.lua>] [--no-compile] [--preview out.png]
 
@@ -100,8 +100,11 @@ def main():
             print("lensmap preview written to", out_path)
     carries, which = ctx.lens_carries_state()
     if carries:
-        print("callbacks carry state from pixel to pixel through '%s': on the GPU every pixel starts from the value after load;"
-              " bk_set_sequential_build(ctx, 1) builds such a lens in the reference's scan order on the host" % which)
+        print("callbacks carry state from pixel to pixel through '%s': such a lens is built as ONE scan on the host, in the reference's"
+              " order (bk_set_sequential_build mode 1, the default) - seconds instead of milliseconds at 4K; mode 0 builds it on the GPU,"
+              " where every pixel starts from the value after load" % which)
+    else:
+        print("callbacks carry no state from pixel to pixel (scratch globals and keyed caches do not count): built on the GPU")
     return 0
 
 
