@@ -78,6 +78,7 @@ struct CoopMap {
     int lds_bytes = 0;              // bytes of the staging buffer of the apply launch
     int tuned_frames = 0;           // frames per launch the block height was measured with (0 = cost model alone)
     int single_form = 0;            // single-frame launches: 0 = the launcher's rule, 1 = one block per workgroup, 2 = strided walk (measured)
+    int fchunk = 0;                 // batch launches: frames a workgroup keeps a block for, 0 = the launcher's 8 (measured: 4 where the grid is small)
     bool lds_fixed = false;         // the staging buffer size was measured: the exact statistics do not re-choose it
     uint32_t stats[BK_COOP_STATS] = {0};
     uint32_t *h_stats = nullptr;    // pinned [64][BK_COOP_STATS]: the full compile's statistics land here asynchronously ...
@@ -1005,6 +1006,14 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
 {
     if (!ctx->coopmap) ctx->coopmap = new CoopMap();
     CoopMap *cm = ctx->coopmap;
+    // The measured choice (below) holds for the KIND of launch it was measured with: single frames, batches of up to 16, long batches
+    // (a 270-row stripe x 64 frames ran 40.8 us on the 128x8 blocks a 16-frame measurement had picked, 32.5 us on 128x16).  A caller
+    // that changes kind gets a fresh measurement - ~1.5 ms once, against every launch after it (tuned_frames was written
+    // and never read, throughput depended on which launch happened to come first after a build).
+    auto kind_of = [](int frames) { return frames <= 1 ? 0 : frames <= 16 ? 1 : 2; };
+    if (cm->valid && ctx->blockmap_tuning && launch_frames > 0 && cm->tuned_frames > 0 && kind_of(launch_frames) != kind_of(cm->tuned_frames) &&
+        !(ctx->tile_shape == 1 || ctx->tile_shape == 2 || ctx->tile_shape == 4))
+        cm->valid = false;
     if (cm->valid) return BK_OK;
     const int rows = ctx->rows();
     const int forced = ctx->tile_shape == 1 || ctx->tile_shape == 2 || ctx->tile_shape == 4 ? ctx->tile_shape : 0;   // developer knob
@@ -1102,28 +1111,44 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     // A lensmap is built once per lens / zoom change and applied every frame: ~0.7 ms more here for up to 17 % per frame.
     int measured = 0;
     cm->single_form = 0;
+    cm->fchunk = 0;
     cm->lds_fixed = false;
+    cm->tuned_frames = 0;
     if (ctx->blockmap_tuning && !forced && nc > 0 && ctx->d_globe && !(ctx->apply_flags & (2 | 4 | 32))) {
         int keep = 1;
         while (keep < nc && c_cost[keep] <= 1.2 * c_cost[0]) ++keep;
-        const int nf = launch_frames > 0 ? (launch_frames < 16 ? launch_frames : 16) : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
+        // (timed with the caller's own frame count, as far as a scratch frame buffer of 256 MB goes - in whole groups of 8 frames)
+        int nf = launch_frames > 0 ? launch_frames : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
+        {
+            const size_t frame_bytes = (size_t)rows * ctx->W;
+            const int fit = (int)std::max<size_t>(16, ((size_t)256 << 20) / std::max<size_t>(1, frame_bytes) / 8 * 8);
+            if (nf > 16 && nf > fit) nf = fit;
+            if (nf > 64) nf = 64;
+        }
         // Single-frame launches have two more things worth measuring per height.  (a) The form: one block per workgroup (dealt out by
         // the hardware as places free up) or the strided walk (prefetch, but a static split) - the launcher's rule of thumb is right
         // for most maps and 10-20 % off for some.  (b) The staging buffer: a launch is a whole number of ROUNDS of blocks - 4050 live
         // blocks on 7 x 256 places are 2.26 rounds and take 3 (4K mercator: 16.5 us where its bytes cost 12.8) - and a buffer of 20 KiB
         // instead of the 21-26 KiB that hold every block lets 8 workgroups share a CU: 1.98 rounds, with the few larger blocks going
         // through the buffer in two passes.  The buffer is a launch parameter, so (b) costs no compile.
-        struct Variant { int form, kb; };
+        // Batch launches have one: the frames a workgroup keeps a block for.  Eight amortise the block's plan best, but a SMALL map -
+        // 1080p: 1020 blocks x 2 frame groups on ~1800 places - then does not fill the chip for the 20 us the launch lasts
+        // (C2 x16 moved 0.545 of the peak); four frames per visit double the workgroups.
+        struct Variant { int form, kb, fchunk; };
         auto variants_of = [&](int kb, Variant *v) {
             int n = 0;
-            v[n++] = {0, kb};
+            v[n++] = {0, kb, 0};
             if (nf == 1 && ctx->apply_wgs_per_cu == 16) {
-                v[n++] = {1, kb};
-                if (ctx->apply_lds_kb <= 0 && kb > 20 && kb <= 28) v[n++] = {1, 20};
+                v[n++] = {1, kb, 0};
+                if (ctx->apply_lds_kb <= 0 && kb > 20 && kb <= 28) v[n++] = {1, 20, 0};
+            }
+            if (nf >= 8 && ctx->apply_fchunk <= 0) {
+                const long long live = (long long)cm->blocks_x * cm->blocks_y - (cm->stats_pending ? 0 : (long long)cm->stats[2]);
+                if (live * ((nf + 7) / 8) < 2ll * ctx->num_cus * 7) v[n++] = {0, kb, 4};
             }
             return n;
         };
-        Variant vtmp[3];
+        Variant vtmp[4];
         if (keep > 1 || variants_of(c_kb[0], vtmp) > 1) {
             uint8_t *scratch = nullptr;
             hipEvent_t t0, t1;
@@ -1136,7 +1161,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             BK_HIP(ctx, hipEventCreate(&t0));
             BK_HIP(ctx, hipEventCreate(&t1));
             int rc = BK_OK, win = 0;
-            Variant win_v = {0, c_kb[0]};
+            Variant win_v = {0, c_kb[0], 0};
             float best_ms = -1;
             // every candidate: one warm-up launch, then a train of launches between two events - back to back, as a caller's
             // steady state issues them; the globe frames advance through the context's ring from launch to launch, candidate
@@ -1152,10 +1177,11 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                 // (timed in the configuration the caller's steady state runs in: with the block map's statistics there - live
                 //  blocks, uneven bands - the launch may take another form than in the first microseconds after a compile)
                 if (rc == BK_OK) rc = coop_stats_wait(ctx, cm);
-                Variant vs[3];
+                Variant vs[4];
                 const int nv = variants_of(cm->lds_bytes / 1024, vs);
                 for (int k = 0; k < nv && rc == BK_OK; ++k) {
                     cm->single_form = vs[k].form;
+                    cm->fchunk = vs[k].fchunk;
                     cm->lds_bytes = clamp_kb(vs[k].kb) * 1024;
                     rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
                     if (rc == BK_OK && hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
@@ -1166,7 +1192,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                                         hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
                         rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
                     if (g_debug.print_model)
-                        fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d form %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], vs[k].kb, vs[k].form, ms * 1e3 / train);
+                        fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d form %d frames per visit %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], vs[k].kb, vs[k].form, vs[k].fchunk ? vs[k].fchunk : 8, ms * 1e3 / train);
                     // the first variant of candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
                     if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = i; win_v = vs[k]; }
                 }
@@ -1185,6 +1211,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                 if (int r = compile_full(best_rg, best_kb)) return r;
             measured = -1;
             cm->single_form = win_v.form;
+            cm->fchunk = win_v.fchunk;
             cm->lds_bytes = clamp_kb(win_v.kb) * 1024;
             cm->lds_fixed = true;
         }
@@ -1212,8 +1239,8 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     const int blocks_x = cm->blocks_x, nblocks = blocks_x * cm->blocks_y;
     // frames per block visit: 8, but a batch of 8..15 frames is split in two groups so that the grid has more
     // workgroups than one scheduling round holds (8 frames: 3.86 -> 3.70 us/frame)
-    int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : 8;
-    if (ctx->apply_fchunk <= 0 && nframes >= 8 && nframes < 16) fmax = (nframes + 1) / 2;
+    int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : cm->fchunk > 0 ? cm->fchunk : 8;
+    if (ctx->apply_fchunk <= 0 && cm->fchunk <= 0 && nframes >= 8 && nframes < 16) fmax = (nframes + 1) / 2;
     const int fchunk = nframes < fmax ? nframes : fmax;
     const int fblocks = (nframes + fchunk - 1) / fchunk;
     const int per = (nblocks + 7) / 8;

@@ -30,6 +30,7 @@ from blinky_amd import ffi  # noqa: E402
 
 CONFIGS = {
     "panini4k": ("cube", "panini", "f_fov 180", 3840, 2160, 16, False),
+    "panini4k64": ("cube", "panini", "f_fov 180", 3840, 2160, 64, False),     # what bench.py --gpus N issues: 64 frames per step
     "trism4k": ("trism", "panini", "f_fov 180", 3840, 2160, 16, False),      # C4
     "hammer4k": ("cube", "hammer", None, 3840, 2160, 16, True),
     "quincuncial4k": ("cube", "quincuncial", None, 3840, 2160, 16, True),    # C3
