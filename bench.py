@@ -98,6 +98,12 @@ def cpu_baseline(frames_budget_s=6.0):
             "build_ms": round(build_s * 1e3, 1)}
 
 
+def trace(msg):
+    """progress notes on stderr (BENCH_TRACE=1): which phase a crash or a hang belongs to"""
+    if os.environ.get("BENCH_TRACE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def synthetic_basepal():
     """pal[i] = (i * 37) mod 256, i < 768 (the real gfx/palette.lmp is not in the tree)"""
     import numpy as np
@@ -230,13 +236,19 @@ def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W,
     """one more BASELINE.json configuration, driver-timed beside the headline (N = 1 only); with `args`, its HBM traffic is measured
     the way the headline's is (measure_traffic: two rocprofv3 --pmc child runs of the same launch).  rubix: the tint LUT path
     (fisheye.c:2416-2419), 7 algorithmic bytes per pixel."""
+    trace(f"extra {name}: workload")
     wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, ring_max=ring_max, rubix=rubix)
     for i in range(5):
         wl.launch(i)
+    trace("  kernel")
     k_med, k_min, k_max = wl.kernel_ms(launches=steps)
+    trace("  single frames")
     s_med, _, _ = wl.kernel_ms(nframes=1, launches=max(steps, 30))
+    trace("  job, two streams")
     job2 = wl.job_seconds_per_step(steps=steps, nstreams=2)
+    trace("  job, one stream")
     job1 = wl.job_seconds_per_step(steps=steps, repeats=11, nstreams=1)
+    trace("  resident")
     model = wl.ctx.traffic_model()
     comp = compulsory_bytes(model, F) + (F * model["mapped_pixels"] if rubix else 0)          # (rubix: + one tint byte per mapped pixel and frame ... per visit, counted per frame as the contract does)
     bpp = ALGO_BYTES_PER_PX + (1 if rubix else 0)
@@ -258,6 +270,7 @@ def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W,
         rec["single_frame"]["resident"] = {"error": f"{type(e).__name__}: {e}"}
     ring, block_h = wl.R, int(wl.tile_stats["tile_h"]) % 1000
     wl.close()
+    trace("  traffic")
     if args is not None and not args.no_live_traffic:
         traffic, src = measure_traffic(args, F, ring, block_h, config=f"{W}x{H}:{globe}:{lens}:{zoom or ''}:{1 if rubix else 0}")
         rec["traffic"] = traffic
@@ -272,6 +285,7 @@ def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, 
     The stripes are the ones `bench.py --gpus N` uses: cut by the block map's row costs (bk_comm_rebalance), multiples of 8 rows.
     t1_ms None: the one-GPU launch of the same F frames is timed here too."""
     from blinky_amd import ffi
+    trace(f"predicted stripes {globe}/{lens} x{F}")
     if t1_ms is None:
         wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, ring_max=32)
         for i in range(3):
@@ -824,6 +838,7 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "apply_traffic.json")
         if world == 1 and not args.no_live_traffic:
+            trace("traffic children")
             traffic, traffic_src = measure_traffic(args, F, R, int(model["block_height"]))
         if traffic is None and os.path.exists(tpath) and world == 1:
             live_error = traffic_src
@@ -850,6 +865,7 @@ def main():
             rd = max(1, compulsory - wr)
             period = 64
             writes = max(0, min(period, int(round(period * wr / rd))))
+            trace("stream mix")
             gbps = ctx.stream_mix(1 << 30, period, writes)
             used = traffic if traffic else compulsory
             stream_mix = {"GB/s": round(gbps, 1), "read_KiB_per_written_KiB": round(period / max(1, writes), 3),

@@ -40,6 +40,7 @@
 
 namespace bk {
 
+constexpr int BK_COOP_MAX_FLIPS = 4;                   // recompiles per lensmap for a caller that alternates kinds of launch wanting different block heights
 constexpr int BK_COOP_LDS_CAP = 65536;                 // max bytes of the staging buffer (a block has <= 4095 chunks)
 constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
 constexpr uint32_t CF_ALL = 0x1, CF_NONE = 0x10;       // << wave: that wave's rows of the block fully mapped / empty
@@ -80,6 +81,11 @@ struct CoopMap {
     int single_form = 0;            // single-frame launches: 0 = the launcher's rule, 1 = one block per workgroup, 2 = strided walk (measured)
     int fchunk = 0;                 // batch launches: frames a workgroup keeps a block for, 0 = the launcher's 8 (measured: 4 where the grid is small)
     bool lds_fixed = false;         // the staging buffer size was measured: the exact statistics do not re-choose it
+    // what was measured, per KIND of launch (single frame / up to 16 / more): a caller that goes back and forth between kinds
+    // measures each once; going back costs a recompile only where the kinds want different block heights, and that at most
+    // BK_COOP_MAX_FLIPS times per lensmap (after that the map stays as it is)
+    struct Tuned { int rg = 0, kb = 0, form = 0, fchunk = 0, frames = 0; } tuned[3];
+    int flips = 0;
     uint32_t stats[BK_COOP_STATS] = {0};
     uint32_t *h_stats = nullptr;    // pinned [64][BK_COOP_STATS]: the full compile's statistics land here asynchronously ...
     hipEvent_t stats_ready = nullptr;   // ... and are folded into `stats` when somebody asks (coopmap_stats / traffic model)
@@ -897,7 +903,11 @@ void coopmap_free(CoopMap *cm)
 void coopmap_invalidate(bk_ctx *ctx)
 {
     resident_quiesce(ctx);          // (a resident apply kernel holds this block map in its registers)
-    if (ctx->coopmap) ctx->coopmap->valid = false;
+    if (ctx->coopmap) {
+        ctx->coopmap->valid = false;
+        for (auto &t : ctx->coopmap->tuned) t = CoopMap::Tuned();
+        ctx->coopmap->flips = 0;
+    }
 }
 
 static void fold_stats(const uint32_t *rep, uint32_t *out, uint32_t scale)
@@ -1011,9 +1021,34 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     // that changes kind gets a fresh measurement - ~1.5 ms once, against every launch after it (tuned_frames was written
     // and never read, throughput depended on which launch happened to come first after a build).
     auto kind_of = [](int frames) { return frames <= 1 ? 0 : frames <= 16 ? 1 : 2; };
+    int recompile_rg = 0, recompile_kb = 0;               // != 0: this kind was measured before, on blocks of another height
+    bool retune = false;
     if (cm->valid && ctx->blockmap_tuning && launch_frames > 0 && cm->tuned_frames > 0 && kind_of(launch_frames) != kind_of(cm->tuned_frames) &&
-        !(ctx->tile_shape == 1 || ctx->tile_shape == 2 || ctx->tile_shape == 4))
+        !(ctx->tile_shape == 1 || ctx->tile_shape == 2 || ctx->tile_shape == 4)) {
+        const CoopMap::Tuned &t = cm->tuned[kind_of(launch_frames)];
+        if (t.rg == cm->rg) {                            // same blocks: only launch parameters differ
+            cm->single_form = t.form; cm->fchunk = t.fchunk; cm->lds_bytes = t.kb * 1024; cm->lds_fixed = true; cm->tuned_frames = t.frames;
+            return BK_OK;
+        }
+        if (t.rg != 0) {
+            if (cm->flips >= BK_COOP_MAX_FLIPS) return BK_OK;
+            ++cm->flips;
+            recompile_rg = t.rg; recompile_kb = t.kb;
+        }
+        retune = true;
         cm->valid = false;
+    }
+    if (cm->valid) return BK_OK;
+    // The block map is rewritten IN PLACE.  On the way here from a build nothing can be reading it (bk_build orders itself after the
+    // context's stream, and a caller with two streams synchronizes after a build: INTEGRATION.md); a change of kind in the middle of
+    // a caller's steady state can find launches of the old map in flight on another stream - found as a memory fault in bench.py's
+    // two-stream job - so that case drains the device first, and every compile is complete before this function returns: the launch
+    // that follows may be on one stream and the one after it on another.
+    if (retune) BK_HIP(ctx, hipDeviceSynchronize());
+    struct Settle {                                       // (every way out of this function below)
+        bk_ctx *c;
+        ~Settle() { (void)hipStreamSynchronize(c->stream); }
+    } settle{ctx};
     if (cm->valid) return BK_OK;
     const int rows = ctx->rows();
     const int forced = ctx->tile_shape == 1 || ctx->tile_shape == 2 || ctx->tile_shape == 4 ? ctx->tile_shape : 0;   // developer knob
@@ -1114,11 +1149,19 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     cm->fchunk = 0;
     cm->lds_fixed = false;
     cm->tuned_frames = 0;
+    if (recompile_rg) {                                   // measured before: compile what won then
+        const CoopMap::Tuned &t = cm->tuned[kind_of(launch_frames)];
+        if (int r = compile_full(recompile_rg, recompile_kb)) return r;
+        cm->single_form = t.form; cm->fchunk = t.fchunk; cm->lds_bytes = t.kb * 1024; cm->lds_fixed = true; cm->tuned_frames = t.frames;
+        cm->valid = true;
+        return BK_OK;
+    }
     if (ctx->blockmap_tuning && !forced && nc > 0 && ctx->d_globe && !(ctx->apply_flags & (2 | 4 | 32))) {
         int keep = 1;
         while (keep < nc && c_cost[keep] <= 1.2 * c_cost[0]) ++keep;
         // (timed with the caller's own frame count, as far as a scratch frame buffer of 256 MB goes - in whole groups of 8 frames)
         int nf = launch_frames > 0 ? launch_frames : (ctx->nframes >= 16 ? 16 : ctx->nframes >= 8 ? 8 : 1);
+        const int for_frames = nf;
         {
             const size_t frame_bytes = (size_t)rows * ctx->W;
             const int fit = (int)std::max<size_t>(16, ((size_t)256 << 20) / std::max<size_t>(1, frame_bytes) / 8 * 8);
@@ -1204,7 +1247,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             else { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(scratch); }
             if (rc != BK_OK) return rc;
             best_rg = c_rg[win]; best_kb = win_v.kb;
-            cm->tuned_frames = nf;
+            cm->tuned_frames = for_frames;
             if (win == measured) measured = -1;           // the winner is what is compiled right now
             else measured = 0;
             if (measured != -1)
@@ -1214,6 +1257,14 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             cm->fchunk = win_v.fchunk;
             cm->lds_bytes = clamp_kb(win_v.kb) * 1024;
             cm->lds_fixed = true;
+            // (filed under the CALLER's kind of launch: an 8K x 64 launch is measured with the 16 frames a scratch buffer holds, and
+            //  filed under 16 it would be measured again on every launch)
+            CoopMap::Tuned &t = cm->tuned[kind_of(for_frames)];
+            t.rg = best_rg; t.kb = cm->lds_bytes / 1024; t.form = win_v.form; t.fchunk = win_v.fchunk; t.frames = for_frames;
+        } else {                                          // nothing to choose between for this kind: the model's pick, remembered like a measured one
+            CoopMap::Tuned &t = cm->tuned[kind_of(for_frames)];
+            t.rg = best_rg; t.kb = clamp_kb(best_kb); t.form = 0; t.fchunk = 0; t.frames = for_frames;
+            cm->tuned_frames = for_frames;
         }
     }
     if (measured != -1)

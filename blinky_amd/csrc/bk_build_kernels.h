@@ -42,6 +42,8 @@ BK_DEV int bk_ray_to_plate_index(BkState &S, const float *ray)
 /* set_lensmap_grid, fisheye.c:1922-1960: true when the texel is NOT on a grid line */
 BK_DEV bool bk_offgrid(const BkBuildParams &P, int px, int py)
 {
+    if (P.grid_n)                                     /* (0 <= px, py < ps <= grid_n: the callers' range checks) */
+        return !(((P.grid_bits[px >> 5] >> (px & 31)) | (P.grid_bits[py >> 5] >> (py & 31))) & 1u);
     double ux = (double)px / P.rubix_unit_px;
     double uy = (double)py / P.rubix_unit_px;
     bool ongrid = bkm_fmod(ux, P.rubix_block) < P.rubix_pad || bkm_fmod(uy, P.rubix_block) < P.rubix_pad;

@@ -17,6 +17,12 @@ typedef struct {
     int numplates, has_globe_plate;
     double scale;            /* lens.scale */
     double rubix_block, rubix_pad, rubix_unit_px;   /* set_lensmap_grid constants (fisheye.c:1938-1948) */
+    /* ... and what they say about every texel column / row p of a plate: bit p = "p lies on a grid line", i.e.
+     * fmod((double)p / rubix_unit_px, rubix_block) < rubix_pad (fisheye.c:1950-1957), evaluated once per build on the host - exact
+     * operations, the same on any machine - instead of two divisions and two fmods per pixel in the kernel.  grid_n = ps when the
+     * table is filled (ps <= 8192), 0 = evaluate the formula. */
+    unsigned int grid_bits[256];
+    int grid_n;
     BkPlateDev plates[6];
     unsigned int *offsets;   /* [rows][W] device-layout offsets (bk_texel_offset), 0xFFFFFFFF = NULL */
     unsigned char *tints;    /* [rows][W] */

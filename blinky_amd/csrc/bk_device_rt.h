@@ -312,10 +312,10 @@ BK_DEV void bk_vector_normalize(float *v)                                       
 /* latlon_to_ray, fisheye.c:1184: double products narrowed into a vec3_t; `elat`/`elon` bound the arguments */
 BK_DEV void bk_latlon_to_ray(BkState &S, double lat, double elat, double lon, double elon, float *ray)
 {
-    const double clat = bkm_cos(lat), ec = bk_elibm(S, clat, elat);
-    const double slon = bkm_sin(lon), es = bk_elibm(S, slon, elon);
-    const double clon = bkm_cos(lon), ek = bk_elibm(S, clon, elon);
-    const double slat = bkm_sin(lat);
+    double slat, clat, slon, clon;                     /* (one argument reduction per angle: bkm_sincos == bkm_sin, bkm_cos bit for bit) */
+    bkm_sincos(lat, &slat, &clat);
+    bkm_sincos(lon, &slon, &clon);
+    const double ec = bk_elibm(S, clat, elat), es = bk_elibm(S, slon, elon), ek = bk_elibm(S, clon, elon);
     const double p0 = slon * clat, p2 = clon * clat;
     ray[0] = bk_narrow(S, p0, bk_eop(S, p0, bk_abs(slon) * ec + bk_abs(clat) * es + ec * es));
     ray[1] = bk_narrow(S, slat, bk_elibm(S, slat, elat));

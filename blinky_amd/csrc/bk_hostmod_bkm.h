@@ -20,6 +20,7 @@ static inline double bkm_sqrt(double x) { return sqrt(x); }
 static inline double bkm_fmod(double x, double y) { return fmod(x, y); }
 static inline double bkm_sin(double x) { return sin(x); }
 static inline double bkm_cos(double x) { return cos(x); }
+static inline void bkm_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }   /* two calls, as the reference makes them */
 static inline double bkm_tan(double x) { return tan(x); }
 static inline double bkm_asin(double x) { return asin(x); }
 static inline double bkm_acos(double x) { return acos(x); }

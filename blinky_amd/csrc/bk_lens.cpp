@@ -1090,6 +1090,11 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
     bp->rubix_block = block_size;
     bp->rubix_pad = ctx->rubix.pad;
     bp->rubix_unit_px = (double)ctx->ps / num_units;
+    if (ctx->ps <= 32 * (int)(sizeof bp->grid_bits / sizeof bp->grid_bits[0])) {
+        for (int p = 0; p < ctx->ps; ++p)                /* fisheye.c:1950-1957; division and fmod are exact operations */
+            if (__builtin_fmod((double)p / bp->rubix_unit_px, bp->rubix_block) < bp->rubix_pad) bp->grid_bits[p >> 5] |= 1u << (p & 31);
+        bp->grid_n = ctx->ps;
+    }
     for (int i = 0; i < ctx->numplates; ++i) {
         const bk_plate &p = ctx->plates[i];
         BkPlateDev &d = bp->plates[i];

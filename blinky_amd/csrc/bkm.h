@@ -107,14 +107,15 @@ BKM_FN bkm_dd bkm_two_prod(double a, double b)
     r.lo = __builtin_fma(a, b, -r.hi);
     return r;
 }
-/* (ah+al) / (bh+bl) as a double-double, |al|<<|ah|, |bl|<<|bh| */
+/* (ah+al) / (bh+bl) as a double-double, |al|<<|ah|, |bl|<<|bh|: ONE division (a reciprocal); the quotient's head need not be
+ * correctly rounded, its tail makes up for it */
 BKM_FN bkm_dd bkm_dd_div(double ah, double al, double bh, double bl)
 {
     bkm_dd q;
-    double rem;
-    q.hi = ah / bh;
+    double rem, r = 1.0 / bh;
+    q.hi = ah * r;
     rem = __builtin_fma(-q.hi, bh, ah);
-    q.lo = ((rem + al) - q.hi * bl) / bh;
+    q.lo = ((rem + al) - q.hi * bl) * r;
     return bkm_fast_two_sum(q.hi, q.lo);
 }
 
@@ -213,16 +214,31 @@ BKM_FN int bkm_rem_pio2(double x, double *rh, double *rl)
     return n;
 }
 
-/* Second-stage reduction and evaluation.  With x = n*(pi/2) + r (bkm_rem_pio2) write
- * r = j*(pi/32) + t, |t| <= pi/64, so that x = m*(pi/32) + t with m = 16 n + j (mod 64) and
+/* Reduction and evaluation.  Write x = m*(pi/32) + t, |t| <= pi/64, m mod 64; then
  *   sin(x) = S + C*t + [ S*(cos t - 1) + C*(sin t - t) ],   S = sin(m pi/32), C = cos(m pi/32)
  * where S, C come from a table as hi+lo pairs and the bracket is <= 1.3e-3 |result|: its
- * rounding errors are invisible, the dominant C*t is formed exactly (two_prod). */
+ * rounding errors are invisible, the dominant C*t is formed exactly (two_prod).
+ *
+ * |x| < 2^16 - every argument a lens script produces - takes ONE Cody-Waite step with pi/32 = P1 + P2 + P2T (33 + 53 + 53
+ * bits): fn = rint(x * 32/pi) has at most 20 bits, so fn*P1 is exact; x - fn*P1 is exact as well (for fn != 0 both lie on a
+ * grid no finer than 2^-57 and the difference is below 2^-4); what is left of pi/32 after 139 bits is below 2^-143, i.e. the
+ * reduced argument is off by < 2^-123 where no double in range comes closer than 2^-70 to a multiple of pi/32.  Larger
+ * arguments go through pi/2 first (Cody-Waite to 2^20.6, Payne-Hanek beyond), then pi/32. */
 BKM_FN int bkm_rem_pio32(double x, double *th, double *tl)
 {
     double rh, rl, fj, a;
-    int n = bkm_rem_pio2(x, &rh, &rl), j;
+    int n, j;
     bkm_dd s, p, h, r;
+    if (bkm_fabs(x) < 0x1p16) {
+        fj = bkm_rint(x * BKM_32OPI);
+        a = __builtin_fma(-fj, BKM_PIO32_1, x);     /* exact */
+        p = bkm_two_prod(fj, BKM_PIO32_2);
+        s = bkm_two_sum(a, -p.hi);
+        r = bkm_fast_two_sum(s.hi, (s.lo - p.lo) - fj * BKM_PIO32_2T);
+        *th = r.hi; *tl = r.lo;
+        return (int)fj & 63;
+    }
+    n = bkm_rem_pio2(x, &rh, &rl);
     fj = bkm_rint(rh * BKM_32OPI);                  /* |fj| <= 8 */
     j = (int)fj;
     a = __builtin_fma(-fj, BKM_PIO32_1, rh);        /* exact */
@@ -234,30 +250,34 @@ BKM_FN int bkm_rem_pio32(double x, double *th, double *tl)
     return (16 * n + j) & 63;
 }
 
+/* sin t - t and cos t - 1 for |t| <= pi/64 (+ an ulp): Taylor through t^9 / t^10; what is dropped is below 2^-68 of t and
+ * 2^-80 of 1.  One pair serves sin AND cos of the same argument. */
+typedef struct { double sp, cp; } bkm_scp;
+BKM_FN bkm_scp bkm_sincos_poly(double th)
+{
+    bkm_scp q;
+    double z = th * th, sp, cp;
+    sp = bkm_sin_c[3];
+    sp = __builtin_fma(sp, z, bkm_sin_c[2]);
+    sp = __builtin_fma(sp, z, bkm_sin_c[1]);
+    sp = __builtin_fma(sp, z, bkm_sin_c[0]);
+    q.sp = (th * z) * sp;
+    cp = bkm_cos_c[3];
+    cp = __builtin_fma(cp, z, bkm_cos_c[2]);
+    cp = __builtin_fma(cp, z, bkm_cos_c[1]);
+    cp = __builtin_fma(cp, z, bkm_cos_c[0]);
+    q.cp = __builtin_fma(z * z, cp, -0.5 * z);
+    return q;
+}
+
 /* sin(m*pi/32 + t) as a double-double */
-BKM_FN bkm_dd bkm_sin_mt(int m, double th, double tl)
+BKM_FN bkm_dd bkm_sin_mt(int m, double th, double tl, bkm_scp q)
 {
     double Sh = bkm_sin_tab[m][0], Sl = bkm_sin_tab[m][1];
     double Ch = bkm_sin_tab[(m + 16) & 63][0], Cl = bkm_sin_tab[(m + 16) & 63][1];
-    double z = th * th, sp, cp, rest;
-    bkm_dd p, s;
-    sp = bkm_sin_c[5];
-    sp = sp * z + bkm_sin_c[4];
-    sp = sp * z + bkm_sin_c[3];
-    sp = sp * z + bkm_sin_c[2];
-    sp = sp * z + bkm_sin_c[1];
-    sp = sp * z + bkm_sin_c[0];
-    sp = (th * z) * sp;                              /* sin t - t */
-    cp = bkm_cos_c[5];
-    cp = cp * z + bkm_cos_c[4];
-    cp = cp * z + bkm_cos_c[3];
-    cp = cp * z + bkm_cos_c[2];
-    cp = cp * z + bkm_cos_c[1];
-    cp = cp * z + bkm_cos_c[0];
-    cp = (z * z) * cp - 0.5 * z;                     /* cos t - 1 */
-    rest = ((Sh * cp + Ch * sp) + (Ch * tl + Cl * th)) + Sl;
-    p = bkm_two_prod(Ch, th);
-    s = bkm_two_sum(Sh, p.hi);
+    double rest = (__builtin_fma(Sh, q.cp, Ch * q.sp) + __builtin_fma(Ch, tl, Cl * th)) + Sl;
+    bkm_dd p = bkm_two_prod(Ch, th);
+    bkm_dd s = bkm_fast_two_sum(Sh, p.hi);           /* S = 0 exactly (m = 0, 32) or |S| >= sin(pi/32) > |C t| */
     return bkm_fast_two_sum(s.hi, s.lo + (p.lo + rest));
 }
 
@@ -268,7 +288,7 @@ BKM_FN double bkm_sin(double x)
     if (bkm_isnan(x) || bkm_isinf(x)) return BKM_NAN;
     if (bkm_fabs(x) < 0x1p-26) return x;
     m = bkm_rem_pio32(x, &th, &tl);
-    return bkm_sin_mt(m, th, tl).hi;
+    return bkm_sin_mt(m, th, tl, bkm_sincos_poly(th)).hi;
 }
 BKM_FN double bkm_cos(double x)
 {
@@ -277,82 +297,101 @@ BKM_FN double bkm_cos(double x)
     if (bkm_isnan(x) || bkm_isinf(x)) return BKM_NAN;
     if (bkm_fabs(x) < 0x1p-27) return 1.0;
     m = bkm_rem_pio32(x, &th, &tl);
-    return bkm_sin_mt((m + 16) & 63, th, tl).hi;
+    return bkm_sin_mt((m + 16) & 63, th, tl, bkm_sincos_poly(th)).hi;
+}
+/* both at once: one reduction, one pair of polynomials; *s == bkm_sin(x) and *c == bkm_cos(x) bit for bit */
+BKM_FN void bkm_sincos(double x, double *s, double *c)
+{
+    double th, tl, ax = bkm_fabs(x);
+    bkm_scp q;
+    int m;
+    if (bkm_isnan(x) || bkm_isinf(x)) { *s = BKM_NAN; *c = BKM_NAN; return; }
+    m = bkm_rem_pio32(x, &th, &tl);
+    q = bkm_sincos_poly(th);
+    *s = ax < 0x1p-26 ? x : bkm_sin_mt(m, th, tl, q).hi;
+    *c = ax < 0x1p-27 ? 1.0 : bkm_sin_mt((m + 16) & 63, th, tl, q).hi;
 }
 BKM_FN double bkm_tan(double x)
 {
     double th, tl;
     bkm_dd s, c, q;
+    bkm_scp pq;
     int m;
     if (bkm_isnan(x) || bkm_isinf(x)) return BKM_NAN;
     if (bkm_fabs(x) < 0x1p-27) return x;
     m = bkm_rem_pio32(x, &th, &tl);
-    s = bkm_sin_mt(m, th, tl);
-    c = bkm_sin_mt((m + 16) & 63, th, tl);
+    pq = bkm_sincos_poly(th);
+    s = bkm_sin_mt(m, th, tl, pq);
+    c = bkm_sin_mt((m + 16) & 63, th, tl, pq);
     q = bkm_dd_div(s.hi, s.lo, c.hi, c.lo);
     return q.hi;
 }
 
 /* ---- atan family -------------------------------------------------------------------------- */
-/* atan(qh+ql) for qh >= 0 (may be +inf), as a double-double */
-BKM_FN bkm_dd bkm_atan_dd(double qh, double ql)
+/* atan(N/D) for 0 <= N <= D given as double-doubles (nh <= dh, dh finite and normal), as an UNNORMALISED hi + lo.
+ * u = N/D is never formed: with c = i/8 the table entry nearest to u,
+ *   atan(N/D) = atan(c) + atan(t),   t = (N - c D) / (D + c N),   |t| <= 1/16 (+ 2^-12)
+ * costs ONE division, the reciprocal of D + c N.  i only has to be near 8u, so it comes from a rough 1/dh (exponent trick +
+ * two Newton steps: 7e-6) - biased down by 2^-10 so that i >= 1 implies nh >= dh/16, which makes nh - c dh exact.
+ * atan t - t: Taylor through t^15; what is dropped is below 2^-68 of t. */
+BKM_FN bkm_dd bkm_atan_frac(double nh, double nl, double dh, double dl)
 {
-    double uh = qh, ul = ql, th, tl, z, a, pl;
-    bkm_dd r, s;
-    int inv = 0, i;
-    if (qh == BKM_INF) { r.hi = BKM_PIO2_HI; r.lo = BKM_PIO2_LO; return r; }
-    if (qh > 1.0) {
-        double e;
-        inv = 1;
-        uh = 1.0 / qh;
-        e = __builtin_fma(-uh, qh, 1.0);
-        ul = (e - uh * ql) / qh;
-    }
-    i = (int)bkm_rint(uh * 8.0);
-    if (i == 0) {
-        th = uh; tl = ul;
-    } else {
-        double c = (double)i * 0.125;
-        double nh = uh - c;                         /* exact (Sterbenz) */
-        bkm_dd d = bkm_two_sum(1.0, uh * c);        /* uh*c exact: c has <= 4 bits */
-        bkm_dd t;
-        d.lo += ul * c;
-        t = bkm_dd_div(nh, ul, d.hi, d.lo);
-        th = t.hi; tl = t.lo;
-    }
+    double r, e, c, Nh, Nl, rD, th, tl, rem, z, a, pl;
+    bkm_dd cn, D, s, o;
+    int i;
+    r = bkm_from_bits(0x7FDE623822FC16E6ull - bkm_bits(dh));
+    e = __builtin_fma(-dh, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-dh, r, 1.0); r = __builtin_fma(r, e, r);
+    i = (int)bkm_rint(__builtin_fma(nh * r, 8.0, -0x1p-10));    /* 0 .. 8 */
+    c = (double)i * 0.125;
+    Nh = __builtin_fma(-c, dh, nh);                            /* exact */
+    Nl = __builtin_fma(-c, dl, nl);
+    cn = bkm_two_prod(c, nh);
+    D = bkm_fast_two_sum(dh, cn.hi);                           /* dh >= c nh */
+    D.lo += cn.lo + __builtin_fma(c, nl, dl);
+    rD = 1.0 / D.hi;
+    th = Nh * rD;
+    rem = __builtin_fma(-th, D.hi, Nh);
+    tl = ((rem + Nl) - th * D.lo) * rD;
     z = th * th;
-    a = bkm_atan_c[8];
-    a = a * z + bkm_atan_c[7];
-    a = a * z + bkm_atan_c[6];
-    a = a * z + bkm_atan_c[5];
-    a = a * z + bkm_atan_c[4];
-    a = a * z + bkm_atan_c[3];
-    a = a * z + bkm_atan_c[2];
-    a = a * z + bkm_atan_c[1];
-    a = a * z + bkm_atan_c[0];
+    a = bkm_atan_c[6];
+    a = __builtin_fma(a, z, bkm_atan_c[5]);
+    a = __builtin_fma(a, z, bkm_atan_c[4]);
+    a = __builtin_fma(a, z, bkm_atan_c[3]);
+    a = __builtin_fma(a, z, bkm_atan_c[2]);
+    a = __builtin_fma(a, z, bkm_atan_c[1]);
+    a = __builtin_fma(a, z, bkm_atan_c[0]);
     pl = (th * z) * a;
-    s = bkm_two_sum(bkm_atan_tab[i][0], th);
-    r = bkm_fast_two_sum(s.hi, s.lo + ((bkm_atan_tab[i][1] + tl) + pl));
-    if (inv) {
-        s = bkm_two_sum(BKM_PIO2_HI, -r.hi);
-        r = bkm_fast_two_sum(s.hi, s.lo + (BKM_PIO2_LO - r.lo));
-    }
-    return r;
+    s = bkm_fast_two_sum(bkm_atan_tab[i][0], th);              /* entry 0 is 0; the others are >= 0.124 > |t| */
+    o.hi = s.hi;
+    o.lo = s.lo + ((bkm_atan_tab[i][1] + tl) + pl);
+    return o;
 }
 
+/* the angle of the point (+-X, Y), X, Y >= 0, from r = atan(min/max) (bkm_atan_frac): swapped = Y was the larger one */
+BKM_FN double bkm_atan_place(bkm_dd r, int swapped, int xneg)
+{
+    double kh = 0.0, kl = 0.0, sg = 1.0;
+    bkm_dd f;
+    if (swapped) { kh = BKM_PIO2_HI; kl = BKM_PIO2_LO; sg = xneg ? 1.0 : -1.0; }      /* pi/2 -+ r */
+    else if (xneg) { kh = BKM_PI_HI; kl = BKM_PI_LO; sg = -1.0; }                     /* pi - r */
+    f = bkm_fast_two_sum(kh, sg * r.hi);                       /* k = 0 or k >= pi/2 > r */
+    return f.hi + (f.lo + (kl + sg * r.lo));
+}
+
+BKM_FN double bkm_atan2(double y, double x);
 BKM_FN double bkm_atan(double x)
 {
-    bkm_dd r;
     if (bkm_isnan(x)) return x;
     if (bkm_fabs(x) < 0x1p-27) return x;
-    r = bkm_atan_dd(bkm_fabs(x), 0.0);
-    return bkm_copysign(r.hi, x);
+    return bkm_atan2(x, 1.0);
 }
 
 BKM_FN double bkm_atan2(double y, double x)
 {
-    double ax, ay;
-    bkm_dd q, a;
+    double ax, ay, num, den;
+    bkm_dd r;
+    int swapped, en, ed;
     if (bkm_isnan(x) || bkm_isnan(y)) return BKM_NAN;
     ax = bkm_fabs(x); ay = bkm_fabs(y);
     if (ay == 0.0) {                                            /* y = +-0 */
@@ -365,38 +404,18 @@ BKM_FN double bkm_atan2(double y, double x)
         return (bkm_bits(x) >> 63) ? bkm_copysign(BKM_PI_HI, y) : bkm_copysign(0.0, y);
     }
     if (ay == BKM_INF) return bkm_copysign(BKM_PIO2_HI, y);
-    /* q = ay/ax as a double-double (scaled away from overflow/underflow of the remainder) */
-    {
-        int ex = (int)((bkm_bits(ax) >> 52) & 0x7FF), ey = (int)((bkm_bits(ay) >> 52) & 0x7FF);
-        if (ey - ex > 60) {                                     /* |y/x| > 2^59: pi/2 to full precision */
-            a.hi = BKM_PIO2_HI; a.lo = BKM_PIO2_LO;
-            if (ey - ex < 200) {                                /* first-order correction -x/y */
-                double c = ax / ay;
-                a = bkm_fast_two_sum(a.hi, a.lo - c);
-            }
-        } else if (ex - ey > 1000 || ex == 0 || ey == 0 || ex > 2000 || ey > 2000) {
-            /* tiny quotient or subnormal/huge operands: rescale both into the normal range */
-            double sx = ax, sy = ay;
-            if (ex > 1500 || ey > 1500) { sx *= 0x1p-600; sy *= 0x1p-600; }
-            else if (ex < 500 && ey < 500) { sx *= 0x1p600; sy *= 0x1p600; }
-            q.hi = sy / sx;
-            if (q.hi < 0x1p-900) {                              /* atan(q) = q to full precision */
-                if (bkm_bits(x) >> 63) return bkm_copysign(BKM_PI_HI, y);
-                return bkm_copysign(ay / ax, y);
-            }
-            q.lo = __builtin_fma(-q.hi, sx, sy) / sx;
-            a = bkm_atan_dd(q.hi, q.lo);
-        } else {
-            q.hi = ay / ax;
-            q.lo = __builtin_fma(-q.hi, ax, ay) / ax;
-            a = bkm_atan_dd(q.hi, q.lo);
-        }
+    swapped = ay > ax;
+    num = swapped ? ax : ay; den = swapped ? ay : ax;
+    en = (int)(bkm_bits(num) >> 52); ed = (int)(bkm_bits(den) >> 52);
+    if (ed - en > 60) {
+        /* the smaller one is below 2^-59 of the larger: atan q = q to full precision (q may be subnormal or 0: so is the result) */
+        r.hi = num / den; r.lo = 0.0;
+    } else {
+        if (ed > 1900) { num *= 0x1p-600; den *= 0x1p-600; }    /* exact: num >= 2^-61 den */
+        else if (ed < 200) { num *= 0x1p600; den *= 0x1p600; }  /* exact, and both normal afterwards */
+        r = bkm_atan_frac(num, 0.0, den, 0.0);
     }
-    if (bkm_bits(x) >> 63) {                                    /* x < 0: pi - a */
-        bkm_dd s = bkm_two_sum(BKM_PI_HI, -a.hi);
-        a = bkm_fast_two_sum(s.hi, s.lo + (BKM_PI_LO - a.lo));
-    }
-    return bkm_copysign(a.hi, y);
+    return bkm_copysign(bkm_atan_place(r, swapped, (int)(bkm_bits(x) >> 63)), y);
 }
 
 /* sqrt((1-ax)(1+ax)) as a double-double, 0 <= ax <= 1 */
@@ -411,36 +430,30 @@ BKM_FN bkm_dd bkm_sqrt1mx2(double ax)
     return s;
 }
 
-BKM_FN double bkm_asin(double x)
+BKM_FN double bkm_asin(double x)                   /* atan2(|x|, sqrt(1 - x^2)) */
 {
     double ax = bkm_fabs(x);
-    bkm_dd s, q, a;
+    bkm_dd s, r;
     if (bkm_isnan(x)) return x;
     if (ax > 1.0) return BKM_NAN;
     if (ax < 0x1p-27) return x;
     s = bkm_sqrt1mx2(ax);
     if (s.hi == 0.0) return bkm_copysign(BKM_PIO2_HI, x);
-    q = bkm_dd_div(ax, 0.0, s.hi, s.lo);
-    a = bkm_atan_dd(q.hi, q.lo);
-    return bkm_copysign(a.hi, x);
+    r = ax > s.hi ? bkm_atan_frac(s.hi, s.lo, ax, 0.0) : bkm_atan_frac(ax, 0.0, s.hi, s.lo);
+    return bkm_copysign(bkm_atan_place(r, ax > s.hi, 0), x);
 }
 
-BKM_FN double bkm_acos(double x)
+BKM_FN double bkm_acos(double x)                   /* atan2(sqrt(1 - x^2), x) */
 {
     double ax = bkm_fabs(x);
-    bkm_dd s, q, a;
+    bkm_dd s, r;
     if (bkm_isnan(x)) return x;
     if (ax > 1.0) return BKM_NAN;
     if (x == 1.0) return 0.0;
     if (ax < 0x1p-60) return BKM_PIO2_HI;
     s = bkm_sqrt1mx2(ax);
-    q = bkm_dd_div(s.hi, s.lo, ax, 0.0);          /* s/|x|, may be large; s = 0 -> 0 */
-    a = bkm_atan_dd(q.hi, q.lo);
-    if (x < 0) {
-        bkm_dd t = bkm_two_sum(BKM_PI_HI, -a.hi);
-        a = bkm_fast_two_sum(t.hi, t.lo + (BKM_PI_LO - a.lo));
-    }
-    return a.hi;
+    r = s.hi > ax ? bkm_atan_frac(ax, 0.0, s.hi, s.lo) : bkm_atan_frac(s.hi, s.lo, ax, 0.0);
+    return bkm_atan_place(r, s.hi > ax, x < 0);
 }
 
 /* ---- exp family ----------------------------------------------------------------------------- */
@@ -688,26 +701,38 @@ BKM_FN double bkm_pow(double x, double y)
     return sign * bkm_scale_dd(m, k);
 }
 
-/* ---- fmod: exact, by shift-and-subtract on the integer significands ------------------------------ */
+/* ---- fmod: exact ------------------------------------------------------------------------------------
+ * Quotients below 2^52 (every call a lens script or the rubix grid makes): q = trunc(|x| / |y|) is the true integer quotient or,
+ * when the division rounded up across an integer, one more; x - q y is exactly representable either way (a multiple of ulp(y) of
+ * magnitude <= |y|), so ONE fma gives it exactly and a negative result is put right by adding |y|, exactly again.  Anything else:
+ * shift-and-subtract on the integer significands. */
 BKM_FN double bkm_fmod(double x, double y)
 {
     bkm_u64 ux = bkm_bits(x), uy = bkm_bits(y), sx = ux & 0x8000000000000000ull, mx, my;
-    int ex, ey;
+    int ex, ey, sh;
     ux &= 0x7FFFFFFFFFFFFFFFull; uy &= 0x7FFFFFFFFFFFFFFFull;
     if (uy == 0 || ux >= 0x7FF0000000000000ull || uy > 0x7FF0000000000000ull) return BKM_NAN;
     if (ux < uy) return x;
     if (ux == uy) return bkm_from_bits(sx);              /* +-0 */
+    {
+        const double ax = bkm_from_bits(ux), ay = bkm_from_bits(uy), q = ax / ay;
+        if (q < 0x1p52) {
+            double r = __builtin_fma(-bkm_trunc(q), ay, ax);
+            if (r < 0.0) r += ay;
+            return bkm_from_bits(bkm_bits(r) | sx);
+        }
+    }
     ex = (int)(ux >> 52); ey = (int)(uy >> 52);
     mx = ux & 0x000FFFFFFFFFFFFFull; my = uy & 0x000FFFFFFFFFFFFFull;
-    if (ex == 0) { ex = 1; while (!(mx >> 52)) { mx <<= 1; --ex; } } else mx |= 1ull << 52;
-    if (ey == 0) { ey = 1; while (!(my >> 52)) { my <<= 1; --ey; } } else my |= 1ull << 52;
+    if (ex == 0) { sh = __builtin_clzll(mx) - 11; mx <<= sh; ex = 1 - sh; } else mx |= 1ull << 52;
+    if (ey == 0) { sh = __builtin_clzll(my) - 11; my <<= sh; ey = 1 - sh; } else my |= 1ull << 52;
     for (; ex > ey; --ex) {
         if (mx >= my) mx -= my;
         mx <<= 1;
     }
     if (mx >= my) mx -= my;
     if (mx == 0) return bkm_from_bits(sx);
-    while (!(mx >> 52)) { mx <<= 1; --ex; }
+    sh = __builtin_clzll(mx) - 11; mx <<= sh; ex -= sh;
     if (ex > 0) ux = (mx & 0x000FFFFFFFFFFFFFull) | ((bkm_u64)ex << 52);
     else ux = mx >> (1 - ex);
     return bkm_from_bits(ux | sx);

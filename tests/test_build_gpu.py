@@ -235,10 +235,10 @@ end
 @pytest.mark.parametrize("host_module", [0, 2], ids=["compiled", "interpreter"])
 @pytest.mark.parametrize("counter", ["global", "local"])
 def test_sequential_build_reproduces_a_script_that_counts_pixels(bk, host_module, counter, request):
-    """bk_set_sequential_build(1): a lens whose callback carries state from pixel to pixel - here a counter that drops every 7th
+    """bk_set_sequential_build(1), the default: a lens whose callback carries state from pixel to pixel - here a counter that drops every 7th
     pixel it is asked for - is built as ONE scan in the reference's order (rows from the bottom up, pixels left to right,
     fisheye.c:2093-2103) on the host.  Expected: the oracle's panini table with the entry of the k-th scanned pixel gone where
-    k % 7 == 0.  The parallel GPU build (the default) gives every pixel count = 1 instead: documented, and shown here."""
+    k % 7 == 0.  The parallel GPU build (mode 0) gives every pixel count = 1 instead: documented, and shown here."""
     W, H = 200, 120
     lm = O.lensmap("cube", "panini", "f_fov 180", W, H)
     ly, lx = np.divmod(np.arange(W * H), W)
@@ -252,10 +252,11 @@ def test_sequential_build_reproduces_a_script_that_counts_pixels(bk, host_module
     ctx.set_zoom(bk.ffi.ZOOM_FOV, 180)
     ctx.resize(W, H)
     assert ctx.lens_carries_state() == (True, "count")
-    ctx.build()                                         # default: parallel, per-pixel state -> every pixel sees count == 1
+    ctx.set_sequential_build(0)
+    ctx.build()                                         # mode 0: parallel, per-pixel state -> every pixel sees count == 1
     off, _ = ctx.read_lensmap()
     np.testing.assert_array_equal(off, lm.offsets)
-    ctx.set_sequential_build(1)
+    ctx.set_sequential_build(1)                         # (the default since round 4)
     display, scale = ctx.build()
     off, tin = ctx.read_lensmap()
     np.testing.assert_array_equal(off, want)
