@@ -54,18 +54,21 @@ BK_DEV double bk_abs(double x) { return __builtin_fabs(x); }
 /* A NaN or infinity that arises from exact arguments arises on every libm alike (domain errors, overflow, x/0) and then
  * propagates by IEEE rules: it carries no bound.  One that arises from INEXACT arguments cannot be bounded: flagged. */
 BK_DEV bool bk_finite(double z) { return bk_abs(z) < BKM_INF; }
-/* bound after an IEEE operation whose inputs are inexact: propagated part + the two roundings */
+/* bound after an IEEE operation whose inputs are inexact: propagated part + the two roundings (one fma; its result is finite
+ * exactly when z and the propagated part are - overflow aside, which is flagged like them) */
 BK_DEV double bk_eop(BkState &S, double z, double eprop)
 {
     if (eprop == 0.0) return 0.0;
-    if (!bk_finite(z) || !bk_finite(eprop)) { S.flag = 1; return 0.0; }
-    return eprop + bk_abs(z) * BK_ROUND_REL;
+    const double r = __builtin_fma(bk_abs(z), BK_ROUND_REL, eprop);
+    if (!(r < BKM_INF)) { S.flag = 1; return 0.0; }
+    return r;
 }
 /* bound after a libm call: propagated part + the libm discrepancy itself (also for exact inputs) */
 BK_DEV double bk_elibm(BkState &S, double z, double eprop)
 {
-    if (!bk_finite(z) || !bk_finite(eprop)) { if (eprop != 0.0) S.flag = 1; return 0.0; }
-    return eprop + bk_abs(z) * BK_LIBM_REL;
+    const double r = __builtin_fma(bk_abs(z), BK_LIBM_REL, eprop);
+    if (!(r < BKM_INF)) { if (eprop != 0.0) S.flag = 1; return 0.0; }
+    return r;
 }
 /* the decision "which integer is floor/trunc/rint of x" is stable over [x-e, x+e] */
 BK_DEV void bk_need_same_floor(BkState &S, double x, double e)
@@ -185,6 +188,14 @@ BK_DEV void bk_aset(BkState &S, bkv *arr, int n, bkv idx, bkv v)
 /* ---- the math library (lmathlib.c on the reference side), value + bound --------------------------- */
 BK_DEV bkv bk_f_sin(BkState &S, bkv a) { const double z = bkm_sin(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
 BK_DEV bkv bk_f_cos(BkState &S, bkv a) { const double z = bkm_cos(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
+/* math.sin(a) and math.cos(a) of one operand in one statement (bk_emit.cpp): one argument reduction for the two */
+BK_DEV void bk_f_sincos(BkState &S, bkv a, bkv *s, bkv *c)
+{
+    double zs, zc;
+    bkm_sincos(bk_tonum(S, a), &zs, &zc);
+    *s = bk_nume(zs, bk_elibm(S, zs, a.e));
+    *c = bk_nume(zc, bk_elibm(S, zc, a.e));
+}
 BK_DEV bkv bk_f_atan(BkState &S, bkv a) { const double z = bkm_atan(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
 BK_DEV bkv bk_f_tanh(BkState &S, bkv a) { const double z = bkm_tanh(bk_tonum(S, a)); return bk_nume(z, bk_elibm(S, z, a.e)); }
 BK_DEV bkv bk_f_tan(BkState &S, bkv a)

@@ -60,6 +60,12 @@ struct Emitter {
     std::map<const Table *, std::pair<std::string, int>> const_tables;   // table -> (array name, n)
     std::ostringstream table_code;
     int uid = 0;
+    // sin(v) and cos(v) of the same operand inside ONE statement share an argument reduction (bk_f_sincos: the values are the two
+    // single calls' bit for bit).  An entry holds for the C++ scope and the stretch of straight-line code it was made in: `epoch`
+    // moves on at every statement, block, short-circuit branch and call of a script function (which may assign the operand).
+    struct SinCos { std::string s, c; long epoch; };
+    std::map<std::string, SinCos> sincos;
+    long epoch = 0;
     // string constants: device code only ever compares them, so a string is its number in this table
     std::map<std::string, int> strings{{"nil", 1}, {"boolean", 2}, {"number", 3}, {"string", 4}};   // (type() results first)
     std::string str_literal(const std::string &v)
@@ -413,10 +419,12 @@ struct Emitter {
                 line(f, "bkv " + t + " = " + a + ";");
                 line(f, std::string("if (") + (op == "and" ? "" : "!") + "bk_truthy(" + t + ")) {");
                 f.indent++;
+                ++epoch;
                 std::string b = emit_expr(f, *e.b);
                 line(f, t + " = " + b + ";");
                 f.indent--;
                 line(f, "}");
+                ++epoch;
                 return t;
             }
             if (op == "..") unsupported(f.chunk, e.line, "string concatenation");
@@ -534,6 +542,7 @@ struct Emitter {
                 auto packed = pack(f, a, 1);
                 line(f, "bkv " + *arr + "[BK_MAXRET];");
                 line(f, "const int " + *cnt + " = " + o->fn_slots[slot] + "(" + packed.first + ", " + packed.second + ", " + *arr + ");");
+                ++epoch;
                 return;
             }
         }
@@ -569,6 +578,7 @@ struct Emitter {
             auto packed = pack(f, a, 1);
             line(f, "bkv " + *arr + "[BK_MAXRET];");
             line(f, "const int " + *cnt + " = " + fi.cname + "(S, " + packed.first + ", " + packed.second + ", " + *arr + ");");
+            ++epoch;
             return;
         }
         if (callee.t != Value::BUILTIN) {
@@ -591,6 +601,17 @@ struct Emitter {
             {"math.acos", "bk_f_acos"}, {"math.atan", "bk_f_atan"}, {"math.sinh", "bk_f_sinh"}, {"math.cosh", "bk_f_cosh"},
             {"math.tanh", "bk_f_tanh"}, {"math.exp", "bk_f_exp"}, {"math.log10", "bk_f_log10"}, {"math.sqrt", "bk_f_sqrt"},
             {"math.abs", "bk_f_abs"}, {"math.floor", "bk_f_floor"}, {"math.ceil", "bk_f_ceil"}};
+        if (bn == "math.sin" || bn == "math.cos") {
+            const std::string operand = A(0);
+            auto hit = sincos.find(operand);
+            if (hit == sincos.end() || hit->second.epoch != epoch) {
+                SinCos sc{tmp("sn"), tmp("cs"), epoch};
+                line(f, "bkv " + sc.s + ", " + sc.c + "; bk_f_sincos(S, " + operand + ", &" + sc.s + ", &" + sc.c + ");");
+                hit = sincos.insert_or_assign(operand, sc).first;
+            }
+            single(bn == "math.sin" ? hit->second.s : hit->second.c);
+            return;
+        }
         auto u = unary.find(bn);
         if (u != unary.end()) { single(u->second + "(S, " + A(0) + ")"); return; }
         if (bn == "math.atan2") { single("bk_f_atan2(S, " + A(0) + ", " + A(1) + ")"); return; }
@@ -659,7 +680,9 @@ struct Emitter {
     // ---- statements ---------------------------------------------------------------------------------
     void emit_block(Fn &f, const Block &b)
     {
+        ++epoch;
         for (const StmtP &s : b) emit_stmt(f, *s);
+        ++epoch;
     }
 
     // evaluate an expression list adjusted to exactly `want` values (temps)
@@ -787,6 +810,7 @@ struct Emitter {
 
     void emit_stmt(Fn &f, const Stmt &s)
     {
+        ++epoch;
         switch (s.kind) {
         case Stmt::Local: {
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Function) { emit_local_function(f, s); return; }
