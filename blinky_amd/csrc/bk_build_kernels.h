@@ -176,12 +176,8 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
 #ifdef BK_HAS_FORWARD
 /* uv_to_screen (fisheye.c:2227-2243) for every texel-corner of every plate:
  * corner (i,j), i,j in 0..ps, is (u,v) = ((i-0.5)/ps, (j-0.5)/ps) */
-BK_DEV void bk_corner_entry(const BkBuildParams &P, BkState &S, long long id, int *sx_out, int *sy_out, unsigned char *ok_out)
+BK_DEV void bk_corner_at(const BkBuildParams &P, BkState &S, int plate, int j, int i, int *sx_out, int *sy_out, unsigned char *ok_out)
 {
-    const int n1 = P.ps + 1;
-    const int plate = (int)(id / ((long long)n1 * n1));
-    const int rem = (int)(id - (long long)plate * n1 * n1);
-    const int j = rem / n1, i = rem - j * n1;
     const double u = ((double)i - 0.5) / P.ps;
     const double v = ((double)j - 0.5) / P.ps;
     float ray[3];
@@ -205,16 +201,29 @@ BK_DEV void bk_corner_entry(const BkBuildParams &P, BkState &S, long long id, in
     *sy_out = sy;
     *ok_out = ok;
 }
+/* the same by corner number id = (plate * (ps+1) + j) * (ps+1) + i (the flagged list's and the host module's way to name one) */
+BK_DEV void bk_corner_entry(const BkBuildParams &P, BkState &S, long long id, int *sx_out, int *sy_out, unsigned char *ok_out)
+{
+    const int n1 = P.ps + 1;
+    const int plate = (int)(id / ((long long)n1 * n1));
+    const int rem = (int)(id - (long long)plate * n1 * n1);
+    const int j = rem / n1, i = rem - j * n1;
+    bk_corner_at(P, S, plate, j, i, sx_out, sy_out, ok_out);
+}
 
 /* forward build: does the ray through texel `id` select its own plate (fisheye.c:2193-2196) */
-BK_DEV bool bk_texel_owns(const BkBuildParams &P, BkState &S, long long id)
+BK_DEV bool bk_texel_owns_at(const BkBuildParams &P, BkState &S, int plate, int py, int px)
+{
+    float ray[3];
+    bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
+    return plate == bk_ray_to_plate_index(S, ray);                              /* :2196 */
+}
+BK_DEV bool bk_texel_owns(const BkBuildParams &P, BkState &S, long long id)     /* id = (plate * ps + py) * ps + px */
 {
     const int plate = (int)(id / ((long long)P.ps * P.ps));
     const int rem = (int)(id - (long long)plate * P.ps * P.ps);
     const int py = rem / P.ps, px = rem - py * P.ps;
-    float ray[3];
-    bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
-    return plate == bk_ray_to_plate_index(S, ray);                              /* :2196 */
+    return bk_texel_owns_at(P, S, plate, py, px);
 }
 
 #endif
@@ -222,35 +231,53 @@ BK_DEV bool bk_texel_owns(const BkBuildParams &P, BkState &S, long long id)
 /* ---- everything below is device-only (the host module of the flagged-entry re-derivation stops here) ---- */
 #ifndef BK_HOST_MODULE
 #ifdef BK_HAS_FORWARD
+/* grid (ceil((ps+1)/256), ps+1, plates): a corner's plate and row come from the block, nothing is divided */
 extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildParams P)
 {
     const int n1 = P.ps + 1;
-    const long long total = (long long)P.numplates * n1 * n1;
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), j = (int)blockIdx.y, plate = (int)blockIdx.z;
+    const bool live = i < n1;
+    const unsigned int id = ((unsigned int)plate * (unsigned int)n1 + (unsigned int)j) * (unsigned int)n1 + (unsigned int)i;
     BkState S;
     bk_state_init(S, &P);
-    unsigned char ok;
-    int sx, sy;
-    bk_corner_entry(P, S, id, &sx, &sy, &ok);
-    P.corner_xy[2 * id] = sx;
-    P.corner_xy[2 * id + 1] = sy;
-    P.corner_ok[id] = ok;
-    bk_push_flagged_wave(P, S.flag != 0, (unsigned int)id, (unsigned int)sx, (unsigned int)sy, ok);
-    if (S.err) atomicOr(P.err, S.err);
+    unsigned char ok = 0;
+    int sx = 0, sy = 0;
+    if (live) {
+        bk_corner_at(P, S, plate, j, i, &sx, &sy, &ok);
+        P.corner_xy[2 * (size_t)id] = sx;
+        P.corner_xy[2 * (size_t)id + 1] = sy;
+        P.corner_ok[id] = ok;
+    }
+    bk_push_flagged_wave(P, live && S.flag != 0, id, (unsigned int)sx, (unsigned int)sy, ok);
+    if (live && S.err) atomicOr(P.err, S.err);
 }
 
 /* set_lensmap_from_plate (fisheye.c:1963-1982) as an ordered-overwrite commit */
-BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key, bool offgrid, int *wrote)
+/* A workgroup's window on the screen, in LDS: a tile of neighbouring texels lands on a small patch of pixels, several texels per
+ * pixel under a minifying lens (28 M texels on 8 M pixels at 4K, most of them straddling two to four) - 64 M atomicMax to memory,
+ * which is what the quad pass cost (2.7 ms of the 3.4 ms of a 4K forward build; profiles/r04_build_counters.txt).  The patch is
+ * reduced in LDS first and written out once; what falls outside the window goes to memory directly, as before. */
+#define BK_FWD_TILE 16
+#define BK_FWD_WIN 48
+struct BkFwdWin {
+    int x0, y0;                       /* window origin on the screen (INT_MAX: no window) */
+    unsigned int *px, *tint;          /* [BK_FWD_WIN * BK_FWD_WIN] keys, 0 = none */
+};
+BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
 {
     if (lx < 0 || lx >= P.W || ly < 0 || ly >= P.H) return;                  /* :1966 */
     *wrote = 1;                                                               /* display (:1976) is global, not per stripe */
     if (ly < P.row0 || ly >= P.row0 + P.rows) return;                        /* stripe-filtered commit */
+    if (win.px && lx >= win.x0 && ly >= win.y0 && lx - win.x0 < BK_FWD_WIN && ly - win.y0 < BK_FWD_WIN) {   /* (0 <= lx, ly here; x0, y0 > -2^24) */
+        const int k = (ly - win.y0) * BK_FWD_WIN + (lx - win.x0);
+        atomicMax(&win.px[k], key);
+        if (offgrid) atomicMax(&win.tint[k], key);
+        return;
+    }
     const size_t o = (size_t)(ly - P.row0) * P.W + lx;
     atomicMax(&P.fwd_key_px[o], key);
     if (offgrid) atomicMax(&P.fwd_key_tint[o], key);
 }
-
 /* draw_quad (fisheye.c:2246-2338); int overflow on INT_MIN coordinates wraps as on x86-64.
  * A NaN projection becomes INT_MIN in uv_to_screen (cvttsd2si), and abs(INT_MIN - 0) is INT_MIN again: a quad with one bound at
  * INT_MIN and the other at exactly 0 PASSES the reference's 20-pixel size check and its loops then run over 2^31 rows or columns,
@@ -260,7 +287,7 @@ BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key,
  * not seen; the top-left pixel's neighbourhood under a lens that returns NaN for both coordinates). */
 BK_DEV int bk_wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, const int *bl, const int *br,
-                         unsigned int key, bool offgrid, int *wrote)
+                         unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
 {
     const int *p[4] = {tl, tr, br, bl};
     int x = tl[0], y = tl[1];
@@ -279,9 +306,9 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, c
     /* the part of [min, max] that is on the screen (all of a normal, <= 21-long range that matters; one end of a 2^31-long one) */
     const int vx0 = minx < 0 ? 0 : minx, vx1 = maxx >= P.W ? P.W - 1 : maxx;
     const int vy0 = miny < 0 ? 0 : miny, vy1 = maxy >= P.H ? P.H - 1 : maxy;
-    if (miny == maxy && minx == maxx) { bk_fwd_set(P, x, y, key, offgrid, wrote); return; }
-    if (miny == maxy) { for (int tx = vx0; tx <= vx1; ++tx) bk_fwd_set(P, tx, miny, key, offgrid, wrote); return; }
-    if (minx == maxx) { for (int ty = vy0; ty <= vy1; ++ty) bk_fwd_set(P, x, ty, key, offgrid, wrote); return; }
+    if (miny == maxy && minx == maxx) { bk_fwd_set(P, x, y, key, offgrid, wrote, win); return; }
+    if (miny == maxy) { for (int tx = vx0; tx <= vx1; ++tx) bk_fwd_set(P, tx, miny, key, offgrid, wrote, win); return; }
+    if (minx == maxx) { for (int ty = vy0; ty <= vy1; ++ty) bk_fwd_set(P, x, ty, key, offgrid, wrote, win); return; }
     const bool tall = bk_wrap_sub(maxy, miny) < 0;                            /* 2^31 rows: visible ones only (see above) */
     const int y_first = tall ? vy0 : miny, nrows = bk_wrap_sub(tall ? vy1 : maxy, y_first);      /* <= 20, or <= H - 1; < 0: none */
     for (int ky = 0; ky <= nrows; ++ky) {
@@ -302,53 +329,80 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, c
         if (tx[0] > tx[1]) { int t = tx[0]; tx[0] = tx[1]; tx[1] = t; }
         if (bk_wrap_sub(tx[1], tx[0]) > maxdiff) return;                     /* :2327 aborts the quad */
         const int x_first = tx[0] < 0 ? 0 : tx[0], x_last = tx[1] >= P.W ? P.W - 1 : tx[1];
-        for (x = x_first; x <= x_last; ++x) bk_fwd_set(P, x, y, key, offgrid, wrote);
+        for (x = x_first; x <= x_last; ++x) bk_fwd_set(P, x, y, key, offgrid, wrote, win);
     }
 }
 
 /* the quad loop of resume_lensmap_forward (fisheye.c:2189-2202): one thread per plate texel.
  * The reference writes plate-major, py descending, px ascending, later writers overwriting;
  * key = 1 + that sequence number, committed with atomicMax, reproduces the final state. */
-extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams P)
+extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams P)      /* grid (ceil(ps/16), ceil(ps/16), plates): a tile of 16 x 16 texels */
 {
     __shared__ int s_disp[6];
-    if (threadIdx.x < 6) s_disp[threadIdx.x] = 0;
+    __shared__ int s_org[2];
+    __shared__ unsigned int s_px[BK_FWD_WIN * BK_FWD_WIN], s_tint[BK_FWD_WIN * BK_FWD_WIN];
+    const int tid = (int)threadIdx.x;
+    if (tid < 6) s_disp[tid] = 0;
+    if (tid < 2) s_org[tid] = 0x7FFFFFFF;
+    for (int k = tid; k < BK_FWD_WIN * BK_FWD_WIN; k += (int)blockDim.x) { s_px[k] = 0u; s_tint[k] = 0u; }
     __syncthreads();
-    const long long total = (long long)P.numplates * P.ps * P.ps;
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int px = (int)blockIdx.x * BK_FWD_TILE + (tid & (BK_FWD_TILE - 1)), py = (int)blockIdx.y * BK_FWD_TILE + tid / BK_FWD_TILE, plate = (int)blockIdx.z;
     int err = 0;
-    if (id < total) {
-        const int plate = (int)(id / ((long long)P.ps * P.ps));
-        const int rem = (int)(id - (long long)plate * P.ps * P.ps);
-        const int py = rem / P.ps, px = rem - py * P.ps;
+    bool have = false;                               /* this texel owns its ray and all four of its corners project */
+    const int *tl = nullptr, *bl = nullptr;
+    if (px < P.ps && py < P.ps) {
+        const unsigned int id = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)py) * (unsigned int)P.ps + (unsigned int)px;
         BkState S;
         bk_state_init(S, &P);
-        bool own = bk_texel_owns(P, S, id);
+        bool own = bk_texel_owns_at(P, S, plate, py, px);
 #ifdef BK_HAS_GLOBE_PLATE
         if (P.ovr_count) {                          /* second pass: the host's answers for the texels the first pass flagged */
             unsigned int lo = 0, hi = P.ovr_count;
             while (lo < hi) {
                 const unsigned int mid = (lo + hi) >> 1;
-                if ((P.ovr_list[mid] >> 1) < (unsigned int)id) lo = mid + 1; else hi = mid;
+                if ((P.ovr_list[mid] >> 1) < id) lo = mid + 1; else hi = mid;
             }
-            if (lo < P.ovr_count && (P.ovr_list[lo] >> 1) == (unsigned int)id) own = P.ovr_list[lo] & 1u;
-        } else if (S.flag) bk_push_flagged(P, (unsigned int)id, own ? 1u : 0u, 0u, 0u);
+            if (lo < P.ovr_count && (P.ovr_list[lo] >> 1) == id) own = P.ovr_list[lo] & 1u;
+        } else if (S.flag) bk_push_flagged(P, id, own ? 1u : 0u, 0u, 0u);
 #endif
         if (own) {
             const int n1 = P.ps + 1;
-            const long long base = (long long)plate * n1 * n1;
-            const long long c_tl = base + (long long)py * n1 + px, c_bl = c_tl + n1;
+            const size_t c_tl = ((size_t)plate * n1 + py) * n1 + px, c_bl = c_tl + n1;
             if (P.corner_ok[c_tl] && P.corner_ok[c_tl + 1] && P.corner_ok[c_bl] && P.corner_ok[c_bl + 1]) {
-                const unsigned int order = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)(P.ps - 1 - py)) * (unsigned int)P.ps + (unsigned int)px;
-                int wrote = 0;
-                bk_draw_quad(P, &P.corner_xy[2 * c_tl], &P.corner_xy[2 * (c_tl + 1)], &P.corner_xy[2 * c_bl],
-                             &P.corner_xy[2 * (c_bl + 1)], order + 1u, bk_offgrid(P, px, py), &wrote);
-                if (wrote) s_disp[plate] = 1;
+                have = true;
+                tl = &P.corner_xy[2 * c_tl];
+                bl = &P.corner_xy[2 * c_bl];
+                /* the window starts at the tile's top-left-most pixel (corners that are nowhere near a screen - a NaN projection is
+                 * INT_MIN - do not vote) */
+                int mx = tl[0], my = tl[1];
+                if (tl[2] < mx) mx = tl[2]; if (bl[0] < mx) mx = bl[0]; if (bl[2] < mx) mx = bl[2];
+                if (tl[3] < my) my = tl[3]; if (bl[1] < my) my = bl[1]; if (bl[3] < my) my = bl[3];
+                if (mx > -(1 << 24) && my > -(1 << 24)) { atomicMin(&s_org[0], mx < 0 ? 0 : mx); atomicMin(&s_org[1], my < 0 ? 0 : my); }
             }
         }
         err = S.err;
     }
     __syncthreads();
+    BkFwdWin win;
+    win.x0 = s_org[0]; win.y0 = s_org[1];
+    win.px = win.x0 != 0x7FFFFFFF ? s_px : nullptr;
+    win.tint = s_tint;
+    if (have) {
+        const unsigned int key = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)(P.ps - 1 - py)) * (unsigned int)P.ps + (unsigned int)px + 1u;
+        int wrote = 0;
+        bk_draw_quad(P, tl, tl + 2, bl, bl + 2, key, bk_offgrid(P, px, py), &wrote, win);
+        if (wrote) s_disp[plate] = 1;
+    }
+    __syncthreads();
+    if (win.px)                                      /* the window's pixels, once each (they passed bk_fwd_set's tests when they went in) */
+        for (int k = tid; k < BK_FWD_WIN * BK_FWD_WIN; k += (int)blockDim.x) {
+            const unsigned int key = s_px[k];
+            if (!key) continue;
+            const int wy = k / BK_FWD_WIN, wx = k - wy * BK_FWD_WIN;
+            const size_t o = (size_t)(win.y0 + wy - P.row0) * P.W + (size_t)(win.x0 + wx);
+            atomicMax(&P.fwd_key_px[o], key);
+            if (s_tint[k]) atomicMax(&P.fwd_key_tint[o], s_tint[k]);
+        }
     bk_publish_flags(s_disp, P.display, err, P.err);
 }
 

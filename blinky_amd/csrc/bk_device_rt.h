@@ -70,6 +70,21 @@ BK_DEV double bk_elibm(BkState &S, double z, double eprop)
     if (!(r < BKM_INF)) { if (eprop != 0.0) S.flag = 1; return 0.0; }
     return r;
 }
+/* A step of a self-correcting iteration (bk_emit.cpp, contraction_pattern): the variable carried from step to step entered this
+ * step with bound e0 and was taken as exact inside it; `d` is the derivative of the value this bound belongs to with respect to
+ * the carried variable, `el` its bound within the step.  First order in e0 with a factor of two of slack, plus e0 * 2^20 * (the
+ * libm bound) for what first order leaves out where d vanishes: the step's own libm errors are priced at THIS side's value of the
+ * carried variable, the other side's is e0 away (a Newton step that lands on a root at 0 exactly computes 0 with el = 0, where
+ * a libm one ulp off leaves 4 ulp * e0), and d itself moves by (second derivative) * e0.  Both are e0 times a condition number
+ * times something small; 2^20 covers condition numbers of a million.  Refused (flagged) where the incoming bound is too wide for
+ * any of this to mean anything. */
+BK_DEV double bk_contract(BkState &S, double d, double e0, double el)
+{
+    if (e0 == 0.0) return el;
+    const double r = __builtin_fma(__builtin_fma(2.0, bk_abs(d), 0x1p20 * BK_LIBM_REL), e0, el);
+    if (!(e0 < 0x1p20 * BK_LIBM_REL) || !(r < BKM_INF)) { S.flag = 1; return el; }     /* (2^-30 with the libm bound of 2^-50) */
+    return r;
+}
 /* the decision "which integer is floor/trunc/rint of x" is stable over [x-e, x+e] */
 BK_DEV void bk_need_same_floor(BkState &S, double x, double e)
 {

@@ -113,6 +113,25 @@ struct Emitter {
         return s->cl->upvals[(size_t)idx].get();
     }
     // is `e` the name of a local variable of f or of a function around it?  -> that function, the slot
+    // Self-correcting iterations (`for i = 1, 20 do dt = -f(t) / f'(t); t = t + dt end`).  The bound of bk_device_rt.h treats t and
+    // dt as independent and grows by |d dt / d t| per step - thousands where f' is small (eckert4's rows near the poles: 640 000
+    // flagged pixels at 4K) - while a Newton step FORGETS most of the error it starts with.  For a loop whose body is straight-line
+    // arithmetic with ONE variable carried from step to step, the body is differentiated along with being evaluated (plain doubles,
+    // forward mode): the carried variable enters a step as exact, every variable the step assigns then gets
+    //   bound = 2 |d variable / d carried| * (the carried variable's bound at the start of the step) + (its bound within the step)
+    // (bk_contract).  First order, like every other bound here; the test is tests/test_exactness_cpu.py's adversarial libm.
+    bool ad_active = false;
+    Fn *ad_fn = nullptr;
+    std::map<int, std::string> ad_slot;           // local slot -> its derivative variable
+    std::map<std::string, std::string> ad_d;      // value expression (a temp, a local) -> derivative expression
+    std::string ad_call;                          // derivative of the builtin call emit_call has just emitted ("" = none)
+    std::string d_of(const std::string &v) const { auto it = ad_d.find(v); return it == ad_d.end() ? std::string("0.0") : it->second; }
+    void ad_note(Fn &f, const std::string &value, const std::string &dexpr)
+    {
+        const std::string dn = tmp("dd");
+        line(f, "const double " + dn + " = " + dexpr + ";");
+        ad_d[value] = dn;
+    }
     static Fn *local_of(Fn &f, const Expr &e, int *slot)
     {
         if (e.kind != Expr::Name) return nullptr;
@@ -385,6 +404,8 @@ struct Emitter {
             emit_call(f, e, &arr, &cnt);
             std::string t = tmp();
             line(f, "bkv " + t + " = " + cnt + " > 0 ? " + arr + "[0] : bk_nil();");
+            if (ad_active && !ad_call.empty()) ad_note(f, t, ad_call);
+            ad_call.clear();
             return t;
         }
         case Expr::Unop: {
@@ -409,7 +430,10 @@ struct Emitter {
             }
             std::string a = emit_expr(f, *e.a), t = tmp();
             if (e.str == "not") line(f, "bkv " + t + " = bk_not(" + a + ");");
-            else line(f, "bkv " + t + " = bk_unm(S, " + a + ");");
+            else {
+                line(f, "bkv " + t + " = bk_unm(S, " + a + ");");
+                if (ad_active && d_of(a) != "0.0") ad_note(f, t, "-" + d_of(a));
+            }
             return t;
         }
         case Expr::Binop: {
@@ -445,6 +469,14 @@ struct Emitter {
             else if (op == ">=") call = "bk_le(S, " + b + ", " + a + ")";
             else unsupported(f.chunk, e.line, "operator '" + op + "'");
             line(f, "bkv " + t + " = " + call + ";");
+            if (ad_active && (d_of(a) != "0.0" || d_of(b) != "0.0")) {
+                const std::string da = d_of(a), db = d_of(b);
+                const bool za = da == "0.0", zb = db == "0.0";
+                if (op == "+") ad_note(f, t, za ? db : zb ? da : da + " + " + db);
+                else if (op == "-") ad_note(f, t, za ? "-" + db : zb ? da : da + " - " + db);
+                else if (op == "*") ad_note(f, t, za ? a + ".n * " + db : zb ? b + ".n * " + da : a + ".n * " + db + " + " + b + ".n * " + da);
+                else if (op == "/") ad_note(f, t, zb ? da + " / " + b + ".n" : za ? "-" + t + ".n * " + db + " / " + b + ".n" : "(" + da + " - " + t + ".n * " + db + ") / " + b + ".n");
+            }
             return t;
         }
         }
@@ -468,9 +500,9 @@ struct Emitter {
         Args a;
         for (size_t i = 0; i < list.size(); ++i) {
             const Expr &x = *list[i];
-            if (i + 1 == list.size() && x.kind == Expr::Call) {
-                a.multi = true;
-                emit_call(f, x, &a.marr, &a.mcnt);
+            if (i + 1 == list.size() && x.kind == Expr::Call && !(ad_active && single_valued_call(f, x))) {
+                a.multi = true;               // (inside a contracted loop a math call in the last place is taken as the ONE value it is:
+                emit_call(f, x, &a.marr, &a.mcnt);   //  its derivative hangs on the temp emit_expr gives it)
             } else if (i + 1 == list.size() && x.kind == Expr::Vararg) {       // the extra arguments of this function, all of them
                 // (value lists hold BK_MAXRET values: more extra arguments than that is this translation's limit - the script error bit)
                 const std::string np = std::to_string(f.proto->nparams), vc = tmp("va");
@@ -522,6 +554,7 @@ struct Emitter {
     // a call in multi-value context: results land in *arr (bkv[BK_MAXRET]) with count *cnt
     void emit_call(Fn &f, const Expr &e, std::string *arr, std::string *cnt)
     {
+        ad_call.clear();
         Value callee, self_obj;
         const bool method = !e.str.empty();
         if (method) {
@@ -610,11 +643,35 @@ struct Emitter {
                 hit = sincos.insert_or_assign(operand, sc).first;
             }
             single(bn == "math.sin" ? hit->second.s : hit->second.c);
+            if (ad_active && d_of(operand) != "0.0")
+                ad_call = bn == "math.sin" ? hit->second.c + ".n * " + d_of(operand) : "-" + hit->second.s + ".n * " + d_of(operand);
             return;
         }
         auto u = unary.find(bn);
-        if (u != unary.end()) { single(u->second + "(S, " + A(0) + ")"); return; }
-        if (bn == "math.atan2") { single("bk_f_atan2(S, " + A(0) + ", " + A(1) + ")"); return; }
+        if (u != unary.end()) {
+            single(u->second + "(S, " + A(0) + ")");
+            if (ad_active && d_of(A(0)) != "0.0") {              // (contraction_pattern admits exactly these)
+                const std::string x = A(0) + ".n", r = *arr + "[0].n", d = d_of(A(0));
+                if (bn == "math.tan") ad_call = "(1.0 + " + r + " * " + r + ") * " + d;
+                else if (bn == "math.asin") ad_call = d + " / bkm_sqrt((1.0 - " + x + ") * (1.0 + " + x + "))";
+                else if (bn == "math.acos") ad_call = "-" + d + " / bkm_sqrt((1.0 - " + x + ") * (1.0 + " + x + "))";
+                else if (bn == "math.atan") ad_call = d + " / (1.0 + " + x + " * " + x + ")";
+                else if (bn == "math.sqrt") ad_call = d + " / (2.0 * " + r + ")";
+                else if (bn == "math.exp") ad_call = r + " * " + d;
+                else if (bn == "math.tanh") ad_call = "(1.0 - " + r + " * " + r + ") * " + d;
+                else if (bn == "math.sinh") ad_call = "bkm_cosh(" + x + ") * " + d;
+                else if (bn == "math.cosh") ad_call = "bkm_sinh(" + x + ") * " + d;
+            }
+            return;
+        }
+        if (bn == "math.atan2") {
+            single("bk_f_atan2(S, " + A(0) + ", " + A(1) + ")");
+            if (ad_active && (d_of(A(0)) != "0.0" || d_of(A(1)) != "0.0")) {
+                const std::string y = A(0) + ".n", x = A(1) + ".n";
+                ad_call = "(" + x + " * " + d_of(A(0)) + " - " + y + " * " + d_of(A(1)) + ") / (" + x + " * " + x + " + " + y + " * " + y + ")";
+            }
+            return;
+        }
         if (bn == "math.pow") { single("bk_powv(S, " + A(0) + ", " + A(1) + ")"); return; }
         if (bn == "math.fmod") { single("bk_f_fmod(S, " + A(0) + ", " + A(1) + ")"); return; }
         if (bn == "math.deg") { single("bk_f_scale(S, " + A(0) + ", 0x1.921fb54442d18p+1 / 180.0, true)"); return; }
@@ -677,6 +734,83 @@ struct Emitter {
         unsupported(f.chunk, e.line, "builtin '" + bn + "'");
     }
 
+    // ---- the loops bk_contract applies to -----------------------------------------------------------------
+    // an expression the forward-mode rules of emit_expr / emit_call cover: numbers, plain locals of this function, constants of the
+    // script, + - * /, unary minus, and the smooth one- and two-argument math functions (arguments not calls themselves)
+    bool ad_expr_ok(Fn &f, const Expr &e, std::vector<int> *reads)
+    {
+        switch (e.kind) {
+        case Expr::Number: return true;
+        case Expr::Name: {
+            int slot = 0;
+            if (Fn *o = local_of(f, e, &slot)) {
+                if (o != &f || o->is_table(slot) || o->fn_slots.count(slot) || o->static_slots.count(slot) || f.proto->is_captured(slot)) return false;
+                reads->push_back(slot);
+                return true;
+            }
+            if (e.var == VarKind::Global && mutable_globals.count(e.str)) return false;
+            if (e.var == VarKind::Upvalue) {
+                const Scope *owner = nullptr;
+                if (cell_field(upvalue_of(&f, e.slot, &owner, &slot))) return false;
+            }
+            Value v;
+            return static_value(f, e, &v) && v.t == Value::NUM;
+        }
+        case Expr::Unop: return (e.str == "-" || e.str == "()") && ad_expr_ok(f, *e.a, reads);
+        case Expr::Binop: return (e.str == "+" || e.str == "-" || e.str == "*" || e.str == "/") && ad_expr_ok(f, *e.a, reads) && ad_expr_ok(f, *e.b, reads);
+        case Expr::Call: {
+            Value callee;
+            if (!e.str.empty() || !static_value(f, *e.a, &callee) || callee.t != Value::BUILTIN) return false;
+            static const std::set<std::string> one = {"math.sin", "math.cos", "math.tan", "math.asin", "math.acos", "math.atan", "math.sqrt",
+                                                      "math.exp", "math.sinh", "math.cosh", "math.tanh"};
+            const std::string &bn = callee.bi()->name;
+            const size_t want = one.count(bn) ? 1 : bn == "math.atan2" ? 2 : 0;
+            if (!want || e.args.size() != want) return false;
+            for (const ExprP &x : e.args)
+                if (x->kind == Expr::Vararg || !ad_expr_ok(f, *x, reads)) return false;      // (a call among them is one of these: single-valued)
+            return true;
+        }
+        default: return false;
+        }
+    }
+    // `for i = a, b do <assignments> end`: every statement assigns plain locals of this function from ad_expr_ok expressions, and exactly
+    // ONE of the assigned locals is read in a step before that step assigns it (it is carried from step to step; the others start
+    // every step dead)
+    bool contraction_pattern(Fn &f, const Stmt &loop, int *carried, std::vector<int> *assigned)
+    {
+        std::set<int> all;
+        for (const StmtP &sp : loop.body) {
+            const Stmt &s = *sp;
+            if (s.kind == Stmt::Local) {
+                if (s.exprs.size() != s.slots.size()) return false;
+                for (int slot : s.slots) all.insert(slot);
+            } else if (s.kind == Stmt::Assign) {
+                if (s.exprs.size() != s.targets.size()) return false;
+                for (const ExprP &t : s.targets) {
+                    int slot = 0;
+                    if (t->kind != Expr::Name || local_of(f, *t, &slot) != &f || f.is_table(slot) || f.fn_slots.count(slot) || f.static_slots.count(slot) ||
+                        f.proto->is_captured(slot)) return false;
+                    all.insert(slot);
+                }
+            } else return false;
+        }
+        if (all.count(loop.slots[0])) return false;                     // (the loop variable itself)
+        std::set<int> done, live;
+        for (const StmtP &sp : loop.body) {
+            const Stmt &s = *sp;
+            std::vector<int> reads;
+            for (const ExprP &x : s.exprs)
+                if (!ad_expr_ok(f, *x, &reads)) return false;
+            for (int r : reads) if (all.count(r) && !done.count(r)) live.insert(r);
+            if (s.kind == Stmt::Local) for (int slot : s.slots) done.insert(slot);
+            else for (const ExprP &t : s.targets) { int slot = 0; (void)local_of(f, *t, &slot); done.insert(slot); }
+        }
+        if (live.size() != 1) return false;
+        *carried = *live.begin();
+        assigned->assign(all.begin(), all.end());
+        return true;
+    }
+
     // ---- statements ---------------------------------------------------------------------------------
     void emit_block(Fn &f, const Block &b)
     {
@@ -693,6 +827,7 @@ struct Emitter {
         for (size_t i = 0; i < want; ++i) {
             std::string t = tmp();
             line(f, "const bkv " + t + " = " + arg_at(a, i) + ";");
+            if (ad_active && d_of(arg_at(a, i)) != "0.0") ad_note(f, t, d_of(arg_at(a, i)));       // (a snapshot, like the value: a, b = b, a)
             v.push_back(t);
         }
         return v;
@@ -718,6 +853,7 @@ struct Emitter {
                 if (o->is_table(slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
                 if (o->fn_slots.count(slot)) unsupported(f.chunk, target.line, "re-assigning function '" + target.str + "'");
                 line(f, o->lp + std::to_string(slot) + " = " + val + ";");
+                if (ad_active && o == ad_fn && ad_slot.count(slot)) line(f, ad_slot[slot] + " = " + d_of(val) + ";");
             } else if (target.var == VarKind::Global) {
                 line(f, "S.g_" + sanitize(target.str) + " = " + val + ";");
             } else {
@@ -879,7 +1015,10 @@ struct Emitter {
                 return;
             }
             auto v = emit_values(f, s.exprs, s.slots.size());
-            for (size_t i = 0; i < s.slots.size(); ++i) line(f, f.lp + std::to_string(s.slots[i]) + " = " + v[i] + ";");
+            for (size_t i = 0; i < s.slots.size(); ++i) {
+                line(f, f.lp + std::to_string(s.slots[i]) + " = " + v[i] + ";");
+                if (ad_active && &f == ad_fn && ad_slot.count(s.slots[i])) line(f, ad_slot[s.slots[i]] + " = " + d_of(v[i]) + ";");
+            }
             return;
         }
         case Stmt::LocalFunction: emit_local_function(f, s); return;
@@ -962,7 +1101,32 @@ struct Emitter {
             line(f, "if (!(0 < " + st + " ? " + idx + " <= " + lim + " : " + lim + " <= " + idx + ")) break;");
             line(f, "if (!bk_tick(S)) break;");
             line(f, f.lp + std::to_string(s.slots[0]) + " = bk_num(" + idx + ");");
+            int carried = -1;
+            std::vector<int> assigned;
+            const bool contract = !ad_active && contraction_pattern(f, s, &carried, &assigned);
+            std::string e0;
+            if (contract) {
+                const std::string k = std::to_string(++uid), cv = f.lp + std::to_string(carried);
+                e0 = "ce" + k;
+                line(f, "const double " + e0 + " = " + cv + ".e; " + cv + ".e = 0.0;     /* " + f.proto->slot_names[(size_t)carried] + " enters the step as exact (bk_contract below) */");
+                for (int slot : assigned) {
+                    const std::string dn = "cd" + k + "_" + std::to_string(slot);
+                    line(f, "double " + dn + " = " + (slot == carried ? "1.0" : "0.0") + ";");
+                    ad_slot[slot] = dn;
+                    ad_d[f.lp + std::to_string(slot)] = dn;
+                }
+                ad_active = true;
+                ad_fn = &f;
+            }
             emit_block(f, s.body);
+            if (contract) {
+                ad_active = false;
+                for (int slot : assigned)
+                    line(f, f.lp + std::to_string(slot) + ".e = bk_contract(S, " + ad_slot[slot] + ", " + e0 + ", " + f.lp + std::to_string(slot) + ".e);");
+                ad_slot.clear();
+                ad_d.clear();
+                ad_fn = nullptr;
+            }
             f.indent--;
             line(f, "}");
             return;

@@ -80,6 +80,10 @@ struct bk_ctx {
     unsigned int last_bad_key = 0;   // of the last bk_build: 1 + scan key of the first pixel whose callback returned a malformed result (0 = none)
     uint32_t *d_flag_list = nullptr; // entries a build flagged for re-evaluation on the platform libm (bk_device_rt.h)
     size_t flag_cap = 0;
+    // scratch of the forward build, kept from one build to the next (four hipMalloc / hipFree of 320 MB at 4K cost more wall time than
+    // its kernels): texel-corner screen coordinates, corner flags, the two key planes; released when an inverse map is built
+    void *fwd_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t fwd_scratch_bytes[4] = {0, 0, 0, 0};
     int last_flagged = 0, last_changed = 0;   // of the last bk_build: entries re-evaluated on the host / entries that changed
     uint8_t *h_frame = nullptr;      // pinned, [row1-row0][W]
     uint64_t *h_mask = nullptr;      // pinned

@@ -1573,6 +1573,10 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     try {
         if (P->info.map_type == BK_MAP_INVERSE) {
             if (!P->k_inverse) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_inverse (map = \"lens_inverse\" without the function)"); }
+            for (int k = 0; k < 4; ++k) {                     // (a forward build's scratch is not kept under an inverse lens)
+                (void)hipFree(ctx->fwd_scratch[k]);
+                ctx->fwd_scratch[k] = nullptr; ctx->fwd_scratch_bytes[k] = 0;
+            }
             BK_HIP_C(hipEventRecord(e0, ctx->stream));
             const auto tk0 = std::chrono::steady_clock::now();
             for (;;) {
@@ -1625,19 +1629,22 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             if (!P->k_corners || !P->k_quads || !P->k_resolve) { cleanup(); return ctx->fail(BK_E_STATE, "lens has no lens_forward"); }
             const size_t n1 = (size_t)ctx->ps + 1;
             const size_t ncorner = (size_t)ctx->numplates * n1 * n1;
-            BK_HIP_C(hipMalloc(&scratch[0], ncorner * 2 * sizeof(int)));
-            BK_HIP_C(hipMalloc(&scratch[1], ncorner));
-            BK_HIP_C(hipMalloc(&scratch[2], px * 4));
-            BK_HIP_C(hipMalloc(&scratch[3], px * 4));
-            bp.corner_xy = (int *)scratch[0];
-            bp.corner_ok = (unsigned char *)scratch[1];
-            bp.fwd_key_px = (unsigned int *)scratch[2];
-            bp.fwd_key_tint = (unsigned int *)scratch[3];
-            const size_t ntexel = (size_t)ctx->numplates * ctx->ps * ctx->ps;
+            const size_t want[4] = {ncorner * 2 * sizeof(int), ncorner, px * 4, px * 4};
+            for (int k = 0; k < 4; ++k)
+                if (ctx->fwd_scratch_bytes[k] < want[k]) {
+                    (void)hipFree(ctx->fwd_scratch[k]);
+                    ctx->fwd_scratch[k] = nullptr; ctx->fwd_scratch_bytes[k] = 0;
+                    BK_HIP_C(hipMalloc(&ctx->fwd_scratch[k], want[k]));
+                    ctx->fwd_scratch_bytes[k] = want[k];
+                }
+            bp.corner_xy = (int *)ctx->fwd_scratch[0];
+            bp.corner_ok = (unsigned char *)ctx->fwd_scratch[1];
+            bp.fwd_key_px = (unsigned int *)ctx->fwd_scratch[2];
+            bp.fwd_key_tint = (unsigned int *)ctx->fwd_scratch[3];
             BK_HIP_C(hipEventRecord(e0, ctx->stream));
             // texel corners -> screen; the flagged ones re-derived on the host
             for (;;) {
-                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((ncorner + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
                 BK_HIP_C(read_counters());
                 bool retry = false;
                 BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
@@ -1685,9 +1692,10 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 bool again = false;
                 for (;;) {
                     BK_HIP_C(reset_counters());
-                    BK_HIP_C(hipMemsetAsync(scratch[2], 0, px * 4, ctx->stream));
-                    BK_HIP_C(hipMemsetAsync(scratch[3], 0, px * 4, ctx->stream));
-                    BK_HIP_C(hipModuleLaunchKernel(P->k_quads, (unsigned)((ntexel + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                    BK_HIP_C(hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, ctx->stream));
+                    BK_HIP_C(hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, ctx->stream));
+                    BK_HIP_C(hipModuleLaunchKernel(P->k_quads, (unsigned)((ctx->ps + 15) / 16), (unsigned)((ctx->ps + 15) / 16), (unsigned)ctx->numplates, 256, 1, 1, 0,
+                                                   ctx->stream, args, nullptr));       // (BK_FWD_TILE = 16: bk_build_kernels.h)
                     BK_HIP_C(read_counters());
                     if (pass == 1) break;
                     bool retry = false;
