@@ -949,6 +949,8 @@ def main():
             # quincuncial, the inverse-only full-sphere lens), C5 (8K hammer, 64 frames in ONE launch over a ring of 64 distinct 8K
             # globes = 7.2 GB), the headline with the rubix tint LUTs on (7 B/px), and 4K hammer as the whole-globe single-frame case
             extras = [("C2 (BASELINE.json configs[1])", "cube", "stereographic", None, 1920, 1080, F, args.steps, False, 64),
+                      ("C2x64 (the same map, 64 frames per launch: as many bytes per launch as the headline's)", "cube", "stereographic", None, 1920, 1080, 64,
+                       max(6, args.steps // 3), False, 64),
                       ("C3 (BASELINE.json configs[2])", "cube", "quincuncial", None, 3840, 2160, F, args.steps, False, 64),
                       ("C5 (BASELINE.json configs[4], on one GPU)", "cube", "hammer", None, 7680, 4320, 64, max(6, args.steps // 5), False, 64),
                       ("headline, rubix on (fisheye.c:2416-2419)", GLOBE, LENS, ZOOM, W, H, F, args.steps, True, 64),

@@ -58,7 +58,7 @@ def test_bench_line_and_check_single_gpu():
     # the other BASELINE.json configurations that fit one GPU, timed in the same run: C2 (1080p stereographic), C3 (4K quincuncial),
     # C5 (8K hammer x 64 in one launch), the headline with rubix on (7 B/px), 4K hammer
     extras = {c["name"].split(" ")[0]: c for c in out["configs_extra"]}
-    assert set(extras) == {"C2", "C3", "C5", "headline,", "4K"}, list(extras)
+    assert set(extras) == {"C2", "C2x64", "C3", "C5", "headline,", "4K"}, list(extras)
     for c in out["configs_extra"]:
         assert "error" not in c, c
         assert c["value"] > 0 and c["kernel_us_per_launch"] > 0 and 0 < c["frac_compulsory"] <= 1.0 and 0 < c["single_frame"]["algorithmic_frac"] <= 1.0, c
