@@ -40,6 +40,7 @@
 
 namespace bk {
 
+constexpr int BK_PAL_BYTES = (BK_MAX_PLATES + 1) * 256;   // the tint LUTs in LDS + an identity row (tint 255: the texel as it is)
 constexpr int BK_COOP_MAX_FLIPS = 4;                   // recompiles per lensmap for a caller that alternates kinds of launch wanting different block heights
 constexpr int BK_COOP_LDS_CAP = 65536;                 // max bytes of the staging buffer (a block has <= 4095 chunks)
 constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
@@ -408,7 +409,7 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 uint32_t v = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt < (uint32_t)BK_MAX_PLATES) v = pal_s[tt * 256 + v];
+                    v = pal_s[min(tt, (uint32_t)BK_MAX_PLATES) * 256 + v];          // (row BK_MAX_PLATES is the identity: tint 255 = no LUT)
                 }
                 w[r] |= v << (8 * k);
                 m |= a[k] != 0xFFFFu ? 1u << (4 * r + k) : 0u;
@@ -452,7 +453,7 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 v[k] = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
+                    v[k] = pal_s[min(tt, (uint32_t)BK_MAX_PLATES) * 256 + v[k]];    // (row BK_MAX_PLATES is the identity: tint 255 = no LUT, no branch)
                 }
             }
             w[r] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
@@ -630,7 +631,7 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                 v[k] = (w[r] >> (8 * k)) & 0xFFu;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
+                    v[k] = pal_s[min(tt, (uint32_t)BK_MAX_PLATES) * 256 + v[k]];    // (row BK_MAX_PLATES is the identity: tint 255 = no LUT, no branch)
                 }
             }
             w[r] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
@@ -752,7 +753,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                                                   \
     uint8_t *pal_s = smem + lds_buf;                                                                                               \
     if (RUBIX) {                                                                                                                   \
-        for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += 256) pal_s[i] = pal[i];                                           \
+        for (int i = threadIdx.x; i < BK_PAL_BYTES; i += 256) pal_s[i] = i < BK_MAX_PLATES * 256 ? pal[i] : (uint8_t)i;         \
         __syncthreads();                                                                                                           \
     }                                                                                                                              \
     const int per = (nblocks + 7) / 8;                                                                                             \
@@ -1009,7 +1010,7 @@ static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num
             blocks_fit += passes * cm->stats[8 + b];
             chunks_fit += (b <= bin ? 1.0 : 1.5) * cm->stats[8 + 2 * BK_COOP_BINS + b];
         }
-        int wgs = (160 * 1024) / (bin * 1024 + BK_MAX_PLATES * 256);
+        int wgs = (160 * 1024) / (bin * 1024 + BK_PAL_BYTES);
         if (wgs > vg) wgs = vg;
         if (wgs < 1) wgs = 1;
         const double t_thr = 0.013 * lines_fit + 0.08 * blocks_fit + 0.00048 * npixels;
@@ -1320,7 +1321,7 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     // size the kernel is told and the palette's place behind it must all come from the same value.
     if (cm->stats_pending && hipEventQuery(cm->stats_ready) == hipSuccess) (void)coop_stats_wait(ctx, cm);
     const int lds_buf = cm->lds_bytes;
-    const size_t shmem = (size_t)lds_buf + (rubix_on ? BK_MAX_PLATES * 256 : 0);
+    const size_t shmem = (size_t)lds_buf + (rubix_on ? BK_PAL_BYTES : 0);
     // Grid.  One block per workgroup (the finest split, dealt to the CUs by the hardware as they free up) when that many
     // workgroups are about what the chip holds - `apply_wgs_per_cu` = 16 per CU, deliberately generous: 4K panini x16 runs
     // 3.93 us/frame that way against 4.08 for a strided walk by the 7 per CU that are truly resident - and otherwise a strided
