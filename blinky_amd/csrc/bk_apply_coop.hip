@@ -40,7 +40,7 @@
 
 namespace bk {
 
-constexpr int BK_PAL_BYTES = (BK_MAX_PLATES + 1) * 256;   // the tint LUTs in LDS + an identity row (tint 255: the texel as it is)
+constexpr int BK_PAL_BYTES = BK_MAX_PLATES * 256;         // the tint LUTs in LDS
 constexpr int BK_COOP_MAX_FLIPS = 4;                   // recompiles per lensmap for a caller that alternates kinds of launch wanting different block heights
 constexpr int BK_COOP_LDS_CAP = 65536;                 // max bytes of the staging buffer (a block has <= 4095 chunks)
 constexpr uint32_t BK_COOP_MAX_CHUNKS = 4095;          // 16-bit LDS addresses: slot*16 + byte, 0xFFFF = unmapped
@@ -409,7 +409,7 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 uint32_t v = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    v = pal_s[min(tt, (uint32_t)BK_MAX_PLATES) * 256 + v];          // (row BK_MAX_PLATES is the identity: tint 255 = no LUT)
+                    if (tt < (uint32_t)BK_MAX_PLATES) v = pal_s[tt * 256 + v];
                 }
                 w[r] |= v << (8 * k);
                 m |= a[k] != 0xFFFFu ? 1u << (4 * r + k) : 0u;
@@ -453,7 +453,7 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                 v[k] = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    v[k] = pal_s[min(tt, (uint32_t)BK_MAX_PLATES) * 256 + v[k]];    // (row BK_MAX_PLATES is the identity: tint 255 = no LUT, no branch)
+                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
                 }
             }
             w[r] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
@@ -631,7 +631,7 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                 v[k] = (w[r] >> (8 * k)) & 0xFFu;
                 if (RUBIX) {
                     const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    v[k] = pal_s[min(tt, (uint32_t)BK_MAX_PLATES) * 256 + v[k]];    // (row BK_MAX_PLATES is the identity: tint 255 = no LUT, no branch)
+                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
                 }
             }
             w[r] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
@@ -753,7 +753,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                                                   \
     uint8_t *pal_s = smem + lds_buf;                                                                                               \
     if (RUBIX) {                                                                                                                   \
-        for (int i = threadIdx.x; i < BK_PAL_BYTES; i += 256) pal_s[i] = i < BK_MAX_PLATES * 256 ? pal[i] : (uint8_t)i;         \
+        for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += 256) pal_s[i] = pal[i];                                           \
         __syncthreads();                                                                                                           \
     }                                                                                                                              \
     const int per = (nblocks + 7) / 8;                                                                                             \
