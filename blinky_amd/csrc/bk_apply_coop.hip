@@ -770,7 +770,9 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
 // XCD's band of the LIVE blocks in walk order, the bands cut at equal cost (CoopMap::d_order / d_bands; ablation bit 64:
 // bands of equal block count over all blocks, empty ones included, as in rounds 1 and 2a).
 template <bool RUBIX, int RG, int MAXQ = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
+// (the tinted forms carry a word of tints per pixel row as well: at the plain forms' register budgets they spilled 124-220 bytes per lane
+//  into scratch - in the frame loop; one workgroup per CU fewer costs less than that)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX && RG == 4 ? 4 : 5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
     (void)wgmap;
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // (8 waves per SIMD = 8 workgroups per CU: the 128x32 form would take 67 VGPRs and 7; at 4K that is 1792 places for 2040
 // blocks, and the 248 left over wait a whole block's latency for theirs - single frame 9.4 -> 8.4 us at <= 64 VGPRs)
 template <bool RUBIX, int RG, bool DMA = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX ? (RG == 4 ? 5 : 7) : 8, 8))) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
     (void)wgs_per_band; (void)order; (void)bands;
