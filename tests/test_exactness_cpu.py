@@ -406,3 +406,51 @@ def test_contracted_iterations_hold_against_an_adversarial_libm(name, mode):
         # step, twenty times over; contracted, it stays a few hundred libm errors at most
         assert np.nanmax(dev["bound"][unflagged, 0]) < 1e4 * 2.0 ** -30, np.nanmax(dev["bound"][unflagged, 0])
     ctx.close()
+
+
+def _random_iteration(rng):
+    """a random loop of the contracted kind: Newton or a damped fixed point on a random smooth f, one carried variable, sometimes a second local"""
+    c = [float(np.round(rng.uniform(0.2, 1.5), 3)) for _ in range(4)]
+    fs = [  # (f(t), f'(t)) with parameters from x, y
+        (f"(t + {c[0]} * sin(t) - x * {c[1]} - y)", f"(1 + {c[0]} * cos(t))"),
+        (f"(t * {c[0]} + tanh(t) - x)", f"({c[0]} + 1 - tanh(t) * tanh(t))"),
+        (f"(exp(t * {c[0] * 0.3}) + t - 2 - x * {c[1]})", f"({c[0] * 0.3} * exp(t * {c[0] * 0.3}) + 1)"),
+        (f"(atan(t) * {c[0]} + t * {c[1]} - y * 2 - x)", f"({c[0]} / (1 + t * t) + {c[1]})"),
+        (f"(t + sin(t) * cos(t) * {min(c[0], 0.9)} - x)", f"(1 + {min(c[0], 0.9)} * (cos(t) * cos(t) - sin(t) * sin(t)))"),
+    ]
+    f, df = fs[int(rng.integers(len(fs)))]
+    steps = int(rng.integers(3, 25))
+    kind = int(rng.integers(3))
+    if kind == 0:       # Newton
+        body = f"local t = x * {c[2]}\n   local d = 0\n   for i = 1, {steps} do\n      d = {f} / {df}\n      t = t - d\n   end\n"
+        return body, "t * 0.2", "d + y"
+    if kind == 1:       # damped fixed point (linear convergence, or slow divergence)
+        lam = float(np.round(rng.uniform(0.1, 0.9), 3))
+        body = f"local t = y\n   for i = 1, {steps} do\n      t = t - {lam} * {f}\n   end\n"
+        return body, "t * 0.1", "x"
+    body = (f"local t = x\n   local u = 0\n   for i = 1, {steps} do\n      local g = {f}\n      t = t - g / {df}\n      u = sqrt(1 + t * t) * {c[3]} + g\n   end\n")
+    return body, "u * 0.1", "t * 0.2"
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_contracted_iterations_hold_against_an_adversarial_libm(seed):
+    """The contraction-aware bound on random iterations (Newton / damped fixed point on five families of smooth functions, 3-24 steps, random
+    coefficients, with and without a second assigned local), libm stand-in chosen by the seed: every unflagged value within its bound."""
+    import blinky_amd
+    rng = np.random.default_rng(9100 + seed)
+    body, lat, lon = _random_iteration(rng)
+    src = (RAW_LATLON + "max_fov = 360\nmax_vfov = 180\nlens_width = 2.6\nlens_height = 2\nonload = \"f_contain\"\n"
+           "function lens_inverse(x, y)\n   " + body + "   return latlon_to_ray(" + lat + ", " + lon + ")\nend\n")
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    ctx.set_host_math(30 + 64 * (seed % 3))
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(src, f"iter{seed}.lua")
+    ctx.set_zoom(blinky_amd.ffi.ZOOM_CONTAIN)
+    W, H = 64, 48
+    ctx.resize(W, H)
+    ctx.calc_zoom()
+    assert "bk_contract(" in ctx.kernel_source(compile=False), src
+    dev = emu.inverse_values(ctx, defines=("BK_LIBM_REL=0x1p-30",))
+    args = np.stack([dev["x"], dev["y"]], axis=1)
+    check_bounds(ctx, 0, dev, args, range(W * H), f"iter{seed}")
+    ctx.close()
