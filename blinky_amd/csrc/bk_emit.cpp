@@ -60,12 +60,14 @@ struct Emitter {
     std::map<const Table *, std::pair<std::string, int>> const_tables;   // table -> (array name, n)
     std::ostringstream table_code;
     int uid = 0;
-    // sin(v) and cos(v) of the same operand inside ONE statement share an argument reduction (bk_f_sincos: the values are the two
-    // single calls' bit for bit).  An entry holds for the C++ scope and the stretch of straight-line code it was made in: `epoch`
-    // moves on at every statement, block, short-circuit branch and call of a script function (which may assign the operand).
+    // sin(v) and cos(v) of the same operand share an argument reduction (bk_f_sincos: the values are the two single calls' bit for
+    // bit) - inside a statement and from one plain assignment to the next (`local c = cos(phi)  local s = sin(phi)`).  An entry holds
+    // for the C++ scope and the stretch of straight-line code it was made in: `epoch` moves on at every block, compound statement,
+    // short-circuit branch and call of a script function (which may assign the operand), and an assignment to the operand forgets it.
     struct SinCos { std::string s, c; long epoch; };
     std::map<std::string, SinCos> sincos;
     long epoch = 0;
+    void forget(const std::string &var) { sincos.erase(var); }
     // string constants: device code only ever compares them, so a string is its number in this table
     std::map<std::string, int> strings{{"nil", 1}, {"boolean", 2}, {"number", 3}, {"string", 4}};   // (type() results first)
     std::string str_literal(const std::string &v)
@@ -853,21 +855,24 @@ struct Emitter {
                 if (o->is_table(slot)) unsupported(f.chunk, target.line, "re-assigning table '" + target.str + "'");
                 if (o->fn_slots.count(slot)) unsupported(f.chunk, target.line, "re-assigning function '" + target.str + "'");
                 line(f, o->lp + std::to_string(slot) + " = " + val + ";");
+                forget(o->lp + std::to_string(slot));
                 if (ad_active && o == ad_fn && ad_slot.count(slot)) line(f, ad_slot[slot] + " = " + d_of(val) + ";");
             } else if (target.var == VarKind::Global) {
                 line(f, "S.g_" + sanitize(target.str) + " = " + val + ";");
+                forget("S.g_" + sanitize(target.str));
             } else {
                 const Scope *owner = nullptr;
                 const std::string *field = cell_field(upvalue_of(&f, target.slot, &owner, &slot));
                 if (!field) unsupported(f.chunk, target.line, "assigning to the enclosing function's local '" + target.str + "'");
                 line(f, "S." + *field + " = " + val + ";");
+                forget("S." + *field);
             }
             return;
         }
         Fn *ao = local_of(f, *target.a, &slot);
         if (ao && ao->record_slots.count(slot)) {
             if (target.b->kind != Expr::String) unsupported(f.chunk, target.line, "indexing record '" + target.a->str + "' with a computed key");
-            for (const std::string &n : ao->record_slots[slot]) if (n == target.b->str) { line(f, ao->field_var(slot, n) + " = " + val + ";"); return; }
+            for (const std::string &n : ao->record_slots[slot]) if (n == target.b->str) { line(f, ao->field_var(slot, n) + " = " + val + ";"); forget(ao->field_var(slot, n)); return; }
             unsupported(f.chunk, target.line, "adding field '" + target.b->str + "' to '" + target.a->str + "' (name it in the constructor)");
         }
         if (target.a->kind == Expr::Index) {
@@ -946,7 +951,14 @@ struct Emitter {
 
     void emit_stmt(Fn &f, const Stmt &s)
     {
-        ++epoch;
+        // (plain assignments leave the sin / cos memory alone - store() forgets what they assign; everything else opens scopes or repeats)
+        const bool plain = s.kind == Stmt::Local || s.kind == Stmt::Assign;
+        if (!plain) ++epoch;
+        emit_stmt_body(f, s);
+        if (!plain) ++epoch;
+    }
+    void emit_stmt_body(Fn &f, const Stmt &s)
+    {
         switch (s.kind) {
         case Stmt::Local: {
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Function) { emit_local_function(f, s); return; }
@@ -972,7 +984,7 @@ struct Emitter {
                     vals.push_back(emit_expr(f, *fld.second));
                 }
                 f.record_slots[slot] = names;
-                for (size_t i = 0; i < names.size(); ++i) line(f, f.field_var(slot, names[i]) + " = " + vals[i] + ";");
+                for (size_t i = 0; i < names.size(); ++i) { line(f, f.field_var(slot, names[i]) + " = " + vals[i] + ";"); forget(f.field_var(slot, names[i])); }
                 return;
             }
             if (s.slots.size() == 1 && s.exprs.size() == 1 && s.exprs[0]->kind == Expr::Table && s.exprs[0]->fields.empty() && !s.exprs[0]->args.empty() &&
@@ -1017,6 +1029,7 @@ struct Emitter {
             auto v = emit_values(f, s.exprs, s.slots.size());
             for (size_t i = 0; i < s.slots.size(); ++i) {
                 line(f, f.lp + std::to_string(s.slots[i]) + " = " + v[i] + ";");
+                forget(f.lp + std::to_string(s.slots[i]));
                 if (ad_active && &f == ad_fn && ad_slot.count(s.slots[i])) line(f, ad_slot[s.slots[i]] + " = " + d_of(v[i]) + ";");
             }
             return;
