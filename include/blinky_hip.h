@@ -127,7 +127,10 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * a script global before assigning it outside such a keyed cache, or assign a chunk local at all (bk_lens_carries_state), is built
  * as ONE sequential scan on the host, in the reference's order, by the compiled host module (else the script interpreter):
  * seconds instead of milliseconds at 4K, the reference's result for any script.  mode 2 = every inverse-map lens; 0 = never
- * (the GPU build whatever the script does). */
+ * (the GPU build whatever the script does).
+ * Memory: a FORWARD-map build (lenses with lens_forward only) keeps its scratch - screen coordinates of every texel corner and two
+ * key planes, about 10 bytes per plate texel + 8 per pixel: 320 MB at 3840x2160 on a cube globe - in the context from one build to
+ * the next (allocating it cost more than the build's kernels); it is released when the context builds an inverse map or is destroyed. */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
 int bk_set_sequential_build(bk_ctx *ctx, int mode);
 int bk_lens_carries_state(bk_ctx *ctx, char *global_name /* nullable */, size_t cap);
