@@ -454,3 +454,47 @@ def test_random_contracted_iterations_hold_against_an_adversarial_libm(seed):
     args = np.stack([dev["x"], dev["y"]], axis=1)
     check_bounds(ctx, 0, dev, args, range(W * H), f"iter{seed}")
     ctx.close()
+
+
+NOT_CONTRACTED = {
+    # two variables carried from step to step: a Jacobian, not a derivative - left to the classic rule
+    "two-carried": "local a, b = x, y\n   for i = 1, 5 do\n      a = a + 0.1 * sin(b)\n      b = b - 0.1 * sin(a)\n   end\n   return a, b, 0",
+    # a comparison inside the step: a discrete decision on a value whose bound was set to 0 for the step would go unnoticed
+    "comparison": "local t = x\n   for i = 1, 8 do\n      local d = (t - cos(t)) / (1 + sin(t))\n      if d < 0.001 then break end\n      t = t - d\n   end\n   return t, y, 0",
+    # a script function in the step (it may do anything)
+    "call": "local function f(v) return v - cos(v) end\n   local t = x\n   for i = 1, 8 do\n      t = t - f(t) / (1 + sin(t))\n   end\n   return t, y, 0",
+    # a global as the carried variable: another callback could read it
+    "global": "g = x\n   for i = 1, 8 do\n      g = g - (g - cos(g)) / (1 + sin(g))\n   end\n   return g, y, 0",
+    # operations without a derivative rule here
+    "floor": "local t = x\n   for i = 1, 4 do\n      t = t + math.floor(t) * 0.1 + sin(t)\n   end\n   return t, y, 0",
+    "power": "local t = x\n   for i = 1, 4 do\n      t = t - (t ^ 3 - y) * 0.1\n   end\n   return t, y, 0",
+    # nothing carried at all: every step starts from the arguments
+    "nothing-carried": "local t = 0\n   for i = 1, 4 do\n      t = sin(x * i) + cos(y)\n   end\n   return t, y, 0",
+    # a while loop (its condition is a comparison)
+    "while": "local t = x\n   local n = 0\n   while n < 5 do\n      t = t - (t - cos(t)) / (1 + sin(t))\n      n = n + 1\n   end\n   return t, y, 0",
+}
+
+
+@pytest.mark.parametrize("name", sorted(NOT_CONTRACTED))
+def test_loops_outside_the_pattern_keep_the_classic_bound(name):
+    """contraction_pattern is deliberately narrow: one carried local, straight-line smooth arithmetic.  Everything else is generated as
+    before (no bk_contract in the source) - and still correct against the interpreter."""
+    import blinky_amd
+    src = ("g = 0\nmax_fov = 360\nmax_vfov = 180\nlens_width = 2.6\nlens_height = 2\nonload = \"f_contain\"\n"
+           "function lens_inverse(x, y)\n   " + NOT_CONTRACTED[name] + "\nend\n")
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    ctx.set_host_math(True)
+    ctx.load_globe(S.script("globes", "cube"), "cube.lua")
+    ctx.load_lens(src, name + ".lua")
+    ctx.set_zoom(blinky_amd.ffi.ZOOM_CONTAIN)
+    ctx.resize(32, 24)
+    ctx.calc_zoom()
+    assert "bk_contract(" not in ctx.kernel_source(compile=False), name
+    v = emu.inverse_values(ctx)
+    xy = np.stack([v["x"], v["y"]], axis=1)
+    h_out, h_n = ctx.eval_host_many(0, xy)
+    np.testing.assert_array_equal(v["nret"], h_n)
+    d_out = v["val"][:, : h_out.shape[1]]
+    used = np.arange(h_out.shape[1])[None, :] < h_n[:, None]
+    assert (((d_out.view(np.uint64) == h_out.view(np.uint64)) | (np.isnan(d_out) & np.isnan(h_out))) | ~used).all()
+    ctx.close()
