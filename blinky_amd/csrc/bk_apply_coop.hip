@@ -1238,7 +1238,11 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
             const int train = work < 20e6 ? 12 : work < 40e6 ? 6 : 2;
             const int span = ctx->nframes > nf ? ctx->nframes - nf + 1 : 1;
             int seq = 0;
-            for (int i = 0; i < keep && rc == BK_OK; ++i) {
+            // (the cost model's pick is measured LAST: when it wins - the usual case - it is what is compiled at the end, and the map is not
+            //  compiled a third time)
+            float ms_pick = -1;
+            Variant pick_v = {0, c_kb[0], 0};
+            for (int i = keep - 1; i >= 0 && rc == BK_OK; --i) {
                 rc = compile_full(c_rg[i], c_kb[i]);
                 // (timed in the configuration the caller's steady state runs in: with the block map's statistics there - live
                 //  blocks, uneven bands - the launch may take another form than in the first microseconds after a compile)
@@ -1259,11 +1263,13 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                         rc = ctx->fail(BK_E_HIP, "block map tuning: timing failed");
                     if (g_debug.print_model)
                         fprintf(stderr, "TUNE %dx%d x%d rg %d kb %d form %d frames per visit %d: %.2f us per launch\n", ctx->W, rows, nf, c_rg[i], vs[k].kb, vs[k].form, vs[k].fchunk ? vs[k].fchunk : 8, ms * 1e3 / train);
-                    // the first variant of candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
-                    if (rc == BK_OK && (best_ms < 0 || ms < 0.97f * best_ms)) { best_ms = ms; win = i; win_v = vs[k]; }
+                    if (rc == BK_OK && (best_ms < 0 || ms < best_ms)) { best_ms = ms; win = i; win_v = vs[k]; }
+                    if (rc == BK_OK && i == 0 && k == 0) { ms_pick = ms; pick_v = vs[k]; }
                 }
                 measured = i;
             }
+            // the first variant of candidate 0 is the cost model's pick: another one replaces it only when it is measurably (3 %) faster
+            if (rc == BK_OK && ms_pick >= 0 && !(best_ms < 0.97f * ms_pick)) { win = 0; win_v = pick_v; }
             (void)hipEventDestroy(t0);
             (void)hipEventDestroy(t1);
             if (pooled) (void)hipFreeAsync(scratch, ctx->stream);
