@@ -137,3 +137,35 @@ def test_agreement_with_platform_libm_is_high():
         got = f1(name, xs)
         same = sum(1 for x, g in zip(xs, got) if fn(float(x)) == g)
         assert same >= 0.995 * len(xs), (name, same)
+
+
+def test_round4_rewrites_at_their_seams():
+    """The round-4 forms have seams of their own: sin / cos switch reductions at 2^16, the one-division atan family picks a table entry from a rough
+    reciprocal (biased so that its subtraction is exact), atan2 scales operands at the ends of the exponent range, fmod takes one fma below a quotient
+    of 2^52.  Accuracy right there, and fmod against C's on a hundred thousand pairs."""
+    def worst1(name, xs, exact):
+        return max(err_ulps(float(g), exact(mp.mpf(float(x)))) for x, g in zip(xs, f1(name, xs)))
+    # multiples of pi/32 and their neighbours, both sides of 2^16
+    k = np.arange(-3000, 3000)
+    near = np.concatenate([k * math.pi / 32 + d for d in (0.0, 1e-9, -1e-13, 3e-16)])
+    edge = np.concatenate([65536.0 + rng.uniform(-40, 40, 400), -65536.0 + rng.uniform(-40, 40, 400), [65535.99999999999, 65536.0, 65536.00000000001]])
+    for nm, ex in (("sin", mp.sin), ("cos", mp.cos), ("tan", mp.tan)):
+        assert worst1(nm, np.concatenate([near, edge]), ex) < 0.52, nm
+    # atan: the table's decision points i/8 - 1/16 (+ the 2^-13 bias), both sides, and their reciprocals
+    pts = (np.arange(1, 17) - 0.5) / 8.0
+    at = np.concatenate([pts + d for d in (0.0, 2.0 ** -13, -2.0 ** -13, 1e-15, -1e-15)])
+    at = np.concatenate([at, 1.0 / at[at > 0], [1.0, 1.0 - 2.0 ** -53, 1.0 + 2.0 ** -52]])
+    assert worst1("atan", at, mp.atan) < 0.52
+    assert worst1("asin", np.concatenate([at[at <= 1], [math.sqrt(0.5), 0.7071067811865475, 0.7071067811865477]]), mp.asin) < 0.52
+    assert worst1("acos", np.concatenate([at[at <= 1], -at[at <= 1], [math.sqrt(0.5), -math.sqrt(0.5)]]), mp.acos) < 0.52
+    # atan2 at the ends of the exponent range and across the "quotient below 2^-59" switch
+    ys = np.array([5e-324, 1e-310, 1e-300, 1e300, 1.7e308, 1e-320, 3.0, 1e-17, 1e-18, 2.0 ** -60, 2.0 ** -61, 1e308, 1e-308, 1e-308, 4e-324])
+    xs = np.array([5e-324, 3e-310, 1e300, 1e-300, 1.7e308, 1e-322, -1e-320, 1.0, 1.0, 1.0, 1.0, -1e308, 1e308, -1e-308, 1e-323])
+    for sy in (1.0, -1.0):
+        got = f2("atan2", sy * ys, xs)
+        assert max(err_ulps(float(g), mp.atan2(mp.mpf(float(sy * y)), mp.mpf(float(x)))) for x, y, g in zip(xs, ys, got)) < 0.52
+    # fmod: the fma path, its fallback above 2^52, subnormals
+    n = 100000
+    fx = np.concatenate([rng.uniform(-1e4, 1e4, n), logu(1e-300, 1e300, n // 2), rng.integers(0, 2 ** 53, n // 2).astype(float), logu(1e-320, 1e-305, 2000), [2.0 ** 60, 2.0 ** 53 + 2, 7.0]])
+    fy = np.concatenate([rng.uniform(-9, 9, n), logu(1e-300, 1e300, n // 2), rng.integers(1, 2 ** 20, n // 2).astype(float), logu(1e-320, 1e-305, 2000), [3.0, 3.0, 2.0 ** -1074]])
+    assert (f2("fmod", fx, fy).view(np.uint64) == np.fmod(fx, fy).view(np.uint64)).all()
