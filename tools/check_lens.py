@@ -88,6 +88,11 @@ def main():
     try:
         src = ctx.kernel_source(compile="--no-compile" not in sys.argv)
         print("callbacks translate to GPU code (%d lines)%s" % (src.count("\n"), "" if "--no-compile" in sys.argv else " and compile for gfx950"))
+        loops = src.count("= bk_contract(")
+        if loops:
+            print("  %d assignment(s) inside self-correcting loops (one carried variable, smooth arithmetic) get the contraction-aware error bound" % loops)
+        if src.count("bk_f_sincos("):
+            print("  sin / cos pairs of one operand share an argument reduction in %d place(s)" % src.count("bk_f_sincos("))
     except bk.BlinkyError as e:
         print("callbacks do NOT translate:", e)
         return 1
