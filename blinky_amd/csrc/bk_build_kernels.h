@@ -260,15 +260,15 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
 #define BK_FWD_TILE 16
 #define BK_FWD_WIN 48
 struct BkFwdWin {
-    int x0, y0;                       /* window origin on the screen (INT_MAX: no window) */
-    unsigned int *px, *tint;          /* [BK_FWD_WIN * BK_FWD_WIN] keys, 0 = none */
+    int x0, y0, w, h;                 /* window on the screen: origin, extent (<= BK_FWD_WIN each; rows are BK_FWD_WIN apart in LDS) */
+    unsigned int *px, *tint;          /* [BK_FWD_WIN * BK_FWD_WIN] keys, 0 = none; px == nullptr: no window */
 };
 BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
 {
     if (lx < 0 || lx >= P.W || ly < 0 || ly >= P.H) return;                  /* :1966 */
     *wrote = 1;                                                               /* display (:1976) is global, not per stripe */
     if (ly < P.row0 || ly >= P.row0 + P.rows) return;                        /* stripe-filtered commit */
-    if (win.px && lx >= win.x0 && ly >= win.y0 && lx - win.x0 < BK_FWD_WIN && ly - win.y0 < BK_FWD_WIN) {   /* (0 <= lx, ly here; x0, y0 > -2^24) */
+    if (win.px && lx >= win.x0 && ly >= win.y0 && lx - win.x0 < win.w && ly - win.y0 < win.h) {   /* (0 <= lx, ly here; 0 <= x0, y0) */
         const int k = (ly - win.y0) * BK_FWD_WIN + (lx - win.x0);
         atomicMax(&win.px[k], key);
         if (offgrid) atomicMax(&win.tint[k], key);
@@ -339,17 +339,18 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, c
 extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams P)      /* grid (ceil(ps/16), ceil(ps/16), plates): a tile of 16 x 16 texels */
 {
     __shared__ int s_disp[6];
-    __shared__ int s_org[2];
+    __shared__ int s_box[4];                         /* the tile's bounding box on the screen: min x, min y, max x, max y */
     __shared__ unsigned int s_px[BK_FWD_WIN * BK_FWD_WIN], s_tint[BK_FWD_WIN * BK_FWD_WIN];
     const int tid = (int)threadIdx.x;
     if (tid < 6) s_disp[tid] = 0;
-    if (tid < 2) s_org[tid] = 0x7FFFFFFF;
-    for (int k = tid; k < BK_FWD_WIN * BK_FWD_WIN; k += (int)blockDim.x) { s_px[k] = 0u; s_tint[k] = 0u; }
+    if (tid < 2) s_box[tid] = 0x7FFFFFFF;
+    else if (tid < 4) s_box[tid] = -1;
     __syncthreads();
     const int px = (int)blockIdx.x * BK_FWD_TILE + (tid & (BK_FWD_TILE - 1)), py = (int)blockIdx.y * BK_FWD_TILE + tid / BK_FWD_TILE, plate = (int)blockIdx.z;
     int err = 0;
     bool have = false;                               /* this texel owns its ray and all four of its corners project */
     const int *tl = nullptr, *bl = nullptr;
+    int mx = 0x7FFFFFFF, my = 0x7FFFFFFF, Mx = -1, My = -1;       /* this lane's vote for the box (none: the neutral elements) */
     if (px < P.ps && py < P.ps) {
         const unsigned int id = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)py) * (unsigned int)P.ps + (unsigned int)px;
         BkState S;
@@ -372,21 +373,41 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
                 have = true;
                 tl = &P.corner_xy[2 * c_tl];
                 bl = &P.corner_xy[2 * c_bl];
-                /* the window starts at the tile's top-left-most pixel (corners that are nowhere near a screen - a NaN projection is
-                 * INT_MIN - do not vote) */
-                int mx = tl[0], my = tl[1];
-                if (tl[2] < mx) mx = tl[2]; if (bl[0] < mx) mx = bl[0]; if (bl[2] < mx) mx = bl[2];
-                if (tl[3] < my) my = tl[3]; if (bl[1] < my) my = bl[1]; if (bl[3] < my) my = bl[3];
-                if (mx > -(1 << 24) && my > -(1 << 24)) { atomicMin(&s_org[0], mx < 0 ? 0 : mx); atomicMin(&s_org[1], my < 0 ? 0 : my); }
+                /* the window covers the tile's quads from its top-left-most pixel on (corners that are nowhere near a screen - a NaN
+                 * projection is INT_MIN - do not vote) */
+                int a0 = tl[0], a1 = tl[1], b0 = tl[0], b1 = tl[1];
+                const int cx[3] = {tl[2], bl[0], bl[2]}, cy[3] = {tl[3], bl[1], bl[3]};
+                for (int c = 0; c < 3; ++c) {
+                    a0 = cx[c] < a0 ? cx[c] : a0; b0 = cx[c] > b0 ? cx[c] : b0;
+                    a1 = cy[c] < a1 ? cy[c] : a1; b1 = cy[c] > b1 ? cy[c] : b1;
+                }
+                if (a0 > -(1 << 24) && a1 > -(1 << 24) && b0 < (1 << 24) && b1 < (1 << 24)) { mx = a0 < 0 ? 0 : a0; my = a1 < 0 ? 0 : a1; Mx = b0; My = b1; }
             }
         }
         err = S.err;
     }
+    /* the votes are settled inside the wave first: 256 lanes of a tile on four LDS words cost more than everything they decide saves
+     * (measured: four contended LDS atomics per thread made the pass 0.4 ms longer); eight waves' worth do not */
+    for (int o = 32; o > 0; o >>= 1) {
+        const int q0 = __shfl_xor(mx, o), q1 = __shfl_xor(my, o), q2 = __shfl_xor(Mx, o), q3 = __shfl_xor(My, o);
+        mx = q0 < mx ? q0 : mx; my = q1 < my ? q1 : my; Mx = q2 > Mx ? q2 : Mx; My = q3 > My ? q3 : My;
+    }
+    if ((tid & 63) == 0 && mx != 0x7FFFFFFF) { atomicMin(&s_box[0], mx); atomicMin(&s_box[1], my); atomicMax(&s_box[2], Mx); atomicMax(&s_box[3], My); }
     __syncthreads();
     BkFwdWin win;
-    win.x0 = s_org[0]; win.y0 = s_org[1];
+    win.x0 = s_box[0]; win.y0 = s_box[1];
     win.px = win.x0 != 0x7FFFFFFF ? s_px : nullptr;
     win.tint = s_tint;
+    win.w = win.px ? s_box[2] - win.x0 + 1 : 0;
+    win.h = win.px ? s_box[3] - win.y0 + 1 : 0;
+    win.w = win.w < 0 ? 0 : win.w > BK_FWD_WIN ? BK_FWD_WIN : win.w;
+    win.h = win.h < 0 ? 0 : win.h > BK_FWD_WIN ? BK_FWD_WIN : win.h;
+    /* only the part of the window the tile can touch is cleared and written out: a tile of 16 x 16 texels under a minifying lens
+     * covers a dozen pixels each way, not 48 */
+    const int col = tid & 63, row0w = tid >> 6;
+    if (col < win.w)
+        for (int wy = row0w; wy < win.h; wy += 4) { s_px[wy * BK_FWD_WIN + col] = 0u; s_tint[wy * BK_FWD_WIN + col] = 0u; }
+    __syncthreads();
     if (have) {
         const unsigned int key = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)(P.ps - 1 - py)) * (unsigned int)P.ps + (unsigned int)px + 1u;
         int wrote = 0;
@@ -394,14 +415,14 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
         if (wrote) s_disp[plate] = 1;
     }
     __syncthreads();
-    if (win.px)                                      /* the window's pixels, once each (they passed bk_fwd_set's tests when they went in) */
-        for (int k = tid; k < BK_FWD_WIN * BK_FWD_WIN; k += (int)blockDim.x) {
-            const unsigned int key = s_px[k];
+    if (col < win.w)                                 /* the window's pixels, once each (they passed bk_fwd_set's tests when they went in) */
+        for (int wy = row0w; wy < win.h; wy += 4) {
+            const unsigned int key = s_px[wy * BK_FWD_WIN + col];
             if (!key) continue;
-            const int wy = k / BK_FWD_WIN, wx = k - wy * BK_FWD_WIN;
-            const size_t o = (size_t)(win.y0 + wy - P.row0) * P.W + (size_t)(win.x0 + wx);
+            const size_t o = (size_t)(win.y0 + wy - P.row0) * P.W + (size_t)(win.x0 + col);
             atomicMax(&P.fwd_key_px[o], key);
-            if (s_tint[k]) atomicMax(&P.fwd_key_tint[o], s_tint[k]);
+            const unsigned int kt = s_tint[wy * BK_FWD_WIN + col];
+            if (kt) atomicMax(&P.fwd_key_tint[o], kt);
         }
     bk_publish_flags(s_disp, P.display, err, P.err);
 }

@@ -23,5 +23,6 @@ static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m
 static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
 static inline int __shfl(int v, int) { return v; }
 static inline int __shfl_down(int v, unsigned int) { return v; }   /* (a wave of one lane: no neighbour) */
+static inline int __shfl_xor(int v, int) { return v; }
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
