@@ -43,6 +43,8 @@ W, H = 3840, 2160
 GLOBE, LENS, ZOOM = "cube", "panini", "f_fov 180"
 ALGO_BYTES_PER_PX = 6          # 4 B lensmap index + 1 B texel + 1 B store
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+DEFAULT_FRAMES = 64            # frames per step at every --gpus N (one workload for the whole scaling curve)
+EXTRA_FRAMES = 16              # configs_extra / value_at_16_frames: the 16-frame launches rounds 1-4 reported
 KERNEL_SOURCES = ("blinky_amd/csrc/bk_apply_coop.hip", "blinky_amd/csrc/bk_apply.hip", "blinky_amd/csrc/bk_build_params.h")
 
 
@@ -411,8 +413,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=0,
-                    help="frames per step (batch warped by one launch); default 16 on one GPU, 64 on several: a 270-row stripe of 16 "
-                         "frames is a ~10 us launch against a ~5.5 us back-to-back launch floor (launch-bound, not bandwidth-bound)")
+                    help="frames per step (batch warped by one launch); default 64 for EVERY --gpus N, so that the driver's 1/2/4/8 curve divides "
+                         "like by like (rounds 1-4 ran 16 at N = 1: `value_at_16_frames` keeps that figure); a 270-row stripe of 16 frames is a "
+                         "~10 us launch against a ~5.5 us back-to-back launch floor (launch-bound, not bandwidth-bound)")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep stripes of equal height instead of stripes of equal block-map cost")
     ap.add_argument("--ring", type=int, default=64, help="distinct resident globes the steps cycle through")
     ap.add_argument("--repeats", type=int, default=0,
@@ -439,7 +442,7 @@ def main():
     args = ap.parse_args()
     if args.traffic_child:
         if args.frames <= 0:
-            args.frames = 16
+            args.frames = DEFAULT_FRAMES
         return traffic_child(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -475,7 +478,7 @@ def main():
     from blinky_amd import multigpu
 
     if args.frames <= 0:
-        args.frames = 16 if world == 1 else 64
+        args.frames = DEFAULT_FRAMES                # the same workload at every N
     F, R = args.frames, max(args.ring, args.frames)
     ctx = blinky_amd.Context(local_rank)
     stream = torch.cuda.current_stream()
@@ -750,6 +753,37 @@ def main():
         drain()
         one_stream_elapsed = statistics.median([timed_region(args.warmup + k * args.steps) for k in range(max(1, nrep // 4))])
         nstreams = nstreams_saved
+    # N = 1: the same job in 16-frame steps (the headline of rounds 1-4), for continuity - not `value`
+    elapsed16 = None
+    if world == 1 and F != EXTRA_FRAMES and F > EXTRA_FRAMES:
+        def region16(first):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(first, first + args.steps):
+                ctx.set_stream(stream_handles[i % nstreams])
+                ctx.apply_device(origin(stripes[i % NB]), W, rows * W, frame0=(i * EXTRA_FRAMES) % R, nframes=EXTRA_FRAMES)
+            barrier()
+            return time.perf_counter() - t0
+        region16(0)
+        elapsed16 = statistics.median([region16(k * args.steps) for k in range(max(5, min(61, nrep // 8)))])
+        ctx.set_stream(stream.cuda_stream)
+    # N > 1: rank 0 alone also runs the ONE-GPU job on the same workload (whole frames, same F, same streams) while the others wait:
+    # the denominator of the scaling curve measured in the same run, on the same box (`scaling_reference_mpx_s`)
+    scaling_reference = None
+    if world > 1 and not os.environ.get("BLINKY_BENCH_NO_REFERENCE"):
+        ref_elapsed = 0.0
+        if rank == 0:
+            try:
+                ref = OneGpuWorkload(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, F, ring_max=R, ring_bytes=0)
+                for i in range(3):
+                    ref.launch(i)
+                ref_elapsed = ref.job_seconds_per_step(steps=args.steps, repeats=max(5, min(31, nrep // 8)), nstreams=nstreams)
+                ref.close()
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] rank 0: one-GPU scaling reference failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        barrier()
+        if ref_elapsed > 0:
+            scaling_reference = W * H * F / ref_elapsed / 1e6
     root_elapsed = None
     if world > 1:
         # extra (not `value`): all frames assembled on rank 0 - bounded by one GPU's xGMI ingest
@@ -881,6 +915,11 @@ def main():
             "ms_per_step_one_stream": round(one_stream_elapsed / args.steps * 1e3, 4) if one_stream_elapsed else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            # (rounds 1-4 reported the N = 1 job in 16-frame steps; the same job, same run)
+            "value_at_16_frames": round(W * H * EXTRA_FRAMES * args.steps / elapsed16 / 1e6, 1) if elapsed16 else None,
+            # N > 1: the one-GPU job on the same workload (whole frames, same frames per step), timed by rank 0 in this run
+            "scaling_reference_mpx_s": round(scaling_reference, 1) if scaling_reference else None,
+            "speedup_vs_scaling_reference": round(value / scaling_reference, 3) if scaling_reference else None,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step from a resident ring of {R} distinct globes "
                                    f"({R * 6 * 2160 * 2176 / 1e9:.2f} GB, advanced every step), one lensmap",
@@ -948,13 +987,14 @@ def main():
             # the other configurations BASELINE.json names that fit one GPU, timed by this same run: C2 (1080p stereographic), C3 (4K
             # quincuncial, the inverse-only full-sphere lens), C5 (8K hammer, 64 frames in ONE launch over a ring of 64 distinct 8K
             # globes = 7.2 GB), the headline with the rubix tint LUTs on (7 B/px), and 4K hammer as the whole-globe single-frame case
-            extras = [("C2 (BASELINE.json configs[1])", "cube", "stereographic", None, 1920, 1080, F, args.steps, False, 64),
+            FX = EXTRA_FRAMES
+            extras = [("C2 (BASELINE.json configs[1])", "cube", "stereographic", None, 1920, 1080, FX, args.steps, False, 64),
                       ("C2x64 (the same map, 64 frames per launch: as many bytes per launch as the headline's)", "cube", "stereographic", None, 1920, 1080, 64,
                        max(6, args.steps // 3), False, 64),
-                      ("C3 (BASELINE.json configs[2])", "cube", "quincuncial", None, 3840, 2160, F, args.steps, False, 64),
+                      ("C3 (BASELINE.json configs[2])", "cube", "quincuncial", None, 3840, 2160, FX, args.steps, False, 64),
                       ("C5 (BASELINE.json configs[4], on one GPU)", "cube", "hammer", None, 7680, 4320, 64, max(6, args.steps // 5), False, 64),
-                      ("headline, rubix on (fisheye.c:2416-2419)", GLOBE, LENS, ZOOM, W, H, F, args.steps, True, 64),
-                      ("4K cube/hammer (whole-globe lens)", "cube", "hammer", None, 3840, 2160, F, args.steps, False, 64)]
+                      ("headline, rubix on (fisheye.c:2416-2419)", GLOBE, LENS, ZOOM, W, H, FX, args.steps, True, 64),
+                      ("4K cube/hammer (whole-globe lens)", "cube", "hammer", None, 3840, 2160, FX, args.steps, False, 64)]
             out["configs_extra"] = []
             for (nm, g, l, z, w_, h_, f_, st_, rb_, rm_) in extras:
                 try:
@@ -966,8 +1006,9 @@ def main():
                 out["predicted_stripe_complete"] = dict(
                     what="rank r's stripe for N = 2 / 4 / 8 built and timed on this one GPU with the launch `bench.py --gpus N` issues (64 frames "
                          "per step, stripes cut by the block map's row costs); a step lasts as long as the slowest rank; no exchange",
-                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, 64, args.steps),
-                    frames16=predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, F, args.steps, k_med),
+                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, 64, args.steps, k_med if F == 64 else None),
+                    frames16=predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, EXTRA_FRAMES, args.steps,
+                                               k_med if F == EXTRA_FRAMES else None),
                     C4_trism_panini=predicted_stripes(torch, blinky_amd, S, local_rank, "trism", "panini", "f_fov 180", W, H, 64, args.steps))
             except Exception as e:      # noqa: BLE001
                 out["predicted_stripe_complete"] = {"error": f"{type(e).__name__}: {e}"}

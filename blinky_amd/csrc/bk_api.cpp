@@ -4,7 +4,31 @@
 #include <algorithm>
 #include <cstring>
 
+#include <dlfcn.h>
+
 static thread_local std::string g_create_error;
+
+// ---- roctx ranges (bk::Range) --------------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        for (const char *name : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }
+}  // namespace
+bk::Range::Range(const char *name) { if (roctx().push) (void)roctx().push(name); }
+bk::Range::~Range() { if (roctx().pop) (void)roctx().pop(); }
 
 static int ensure_device(bk_ctx *ctx, bool keep_resident = false)
 {
@@ -407,6 +431,7 @@ extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t 
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_upload_plate: bad frame/plate/pitch");
     if (int r = ensure_device(ctx)) return r;
+    bk::Range range("bk_upload_plate");
     const size_t ps = ctx->ps;
     uint8_t *dst = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
     // the row memcpy loop of render_plate, fisheye.c:2441-2449: rows land in the staging buffer (gp bytes
@@ -519,6 +544,7 @@ extern "C" int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_d
     if (dst_pitch < ctx->W + x0 || x0 < 0 || y0 < 0 || frame0 < 0 || nframes < 1)
         return ctx->fail(BK_E_INVALID, "bk_apply_device: bad pitch/origin/frames");
     if (int r = ensure_device(ctx)) return r;
+    bk::Range range("bk_apply_device");
     if (int r = upload_pal(ctx, rubix_on, pal)) return r;
     uint8_t *first = (uint8_t *)dst_dev + (size_t)(y0 + ctx->row0) * dst_pitch + x0;
     return bk::launch_apply(ctx, frame0, nframes, first, dst_pitch, frame_stride, rubix_on);
@@ -532,6 +558,7 @@ extern "C" int bk_apply_resident_begin(bk_ctx *ctx, int rubix_on, const uint8_t 
     if (ctx->apply_variant == 0) return ctx->fail(BK_E_STATE, "bk_apply_resident_begin: the resident apply is the staged variant (bk_set_apply_variant 2 / -1)");
     if (ctx->rows() <= 0) return ctx->fail(BK_E_STATE, "bk_apply_resident_begin: this context owns no rows");
     if (int r = ensure_device(ctx)) return r;
+    bk::Range range("bk_apply_resident_begin");
     if (int r = upload_pal(ctx, rubix_on, pal)) return r;
     return bk::resident_begin(ctx, rubix_on, idle_ms);
 }
@@ -620,6 +647,7 @@ extern "C" int bk_apply_begin(bk_ctx *ctx, int frame, int rubix_on, const uint8_
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_apply: no lensmap (bk_build / bk_set_lensmap first)");
     if (frame < 0 || frame >= ctx->nframes) return ctx->fail(BK_E_INVALID, "bk_apply: bad frame %d", frame);
     if (int r = ensure_device(ctx)) return r;
+    bk::Range range("bk_apply_begin");
     if (int r = ensure_spans(ctx)) return r;
     if (int r = upload_pal(ctx, rubix_on, pal)) return r;
     // warp the owned rows into a tight staging frame

@@ -1064,6 +1064,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     // a caller's steady state can find launches of the old map in flight on another stream - found as a memory fault in bench.py's
     // two-stream job - so that case drains the device first, and every compile is complete before this function returns: the launch
     // that follows may be on one stream and the one after it on another.
+    bk::Range range("blockmap compile + tuning");
     if (retune) BK_HIP(ctx, hipDeviceSynchronize());
     struct Settle {                                       // (every way out of this function below)
         bk_ctx *c;

@@ -24,6 +24,16 @@ namespace bk {
 struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0, host_module = 0; };
 extern DebugOptions g_debug;
 
+// roctx ranges around the library's phases (bk_build, block-map compile, apply launches, plate uploads, the resident session):
+// `rocprofv3 --marker-trace --kernel-trace` then groups the kernels by phase instead of by name.
+// libroctx64 is resolved with dlopen on first use; without it (or without a profiler attached) a range costs two indirect calls.
+struct Range {
+    explicit Range(const char *name);
+    ~Range();
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
+
 // A run of mapped pixels in one output row (host-side, for merging a warped
 // frame into the caller's vid.buffer without touching unmapped pixels).
 struct Span { int row, x0, x1; };

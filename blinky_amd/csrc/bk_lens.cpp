@@ -1504,6 +1504,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     if (!ctx->d_offsets) return ctx->fail(BK_E_STATE, "bk_build: call bk_resize first");
     BK_HIP(ctx, hipSetDevice(ctx->device));
     bk::resident_quiesce(ctx);
+    bk::Range range("bk_build");
     LensProgram *P = ctx->prog;
     if (bk::build_module_ready(ctx) == BK_PENDING) return BK_PENDING;
     const size_t px = (size_t)ctx->W * ctx->rows();

@@ -180,6 +180,78 @@ def test_resident_kernel_leaves_when_idle_and_comes_back(bk):
     ctx.close()
 
 
+def test_resident_submit_without_a_lensmap_is_an_error_not_a_launch(bk):
+    """a session outlives the calls that end the kernel: after bk_set_rows / bk_resize (the tables are freed, nothing is built) a submit
+    must answer BK_E_STATE like bk_apply_device does - not compile a block map from freed tables; once there is a lensmap again the
+    same session resumes transparently (bk_api.cpp:539)"""
+    import torch
+    lm = O.lensmap("cube", "panini", None, 640, 480)
+    W, H = lm.W, lm.H
+    globe = O.lcg_globe(lm.ps, 6, 0)
+    ctx = make_ctx(bk, lm)
+    for p in range(6):
+        ctx.upload_plate(0, p, globe[p])
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.resident_begin(idle_ms=500)
+    ctx.resident_wait(ctx.resident_submit(out.data_ptr(), W))
+    ctx.set_rows(120, 360)                            # ends the kernel, frees the tables: no lensmap for these rows yet
+    with pytest.raises(bk.BlinkyError):
+        ctx.resident_submit(out.data_ptr(), W)
+    with pytest.raises(bk.BlinkyError):
+        ctx.resident_submit_batch(out.data_ptr(), W, H * W, frame0=0, nframes=2)
+    assert not ctx.resident_info()["running"]
+    ctx.set_lensmap(lm.offsets.reshape(H, W)[120:360].copy(), lm.tints.reshape(H, W)[120:360].copy())
+    out.zero_()
+    torch.cuda.synchronize()
+    ctx.resident_wait(ctx.resident_submit(out.data_ptr(), W))      # the session comes back by itself
+    ctx.resident_end()
+    want = np.zeros((H, W), np.uint8)
+    want[120:360] = O.apply(lm.offsets, lm.tints, W, H, globe, np.zeros((H, W), np.uint8))[120:360]
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    ctx.resize(W + 64, H)                             # a new size: nothing built for it
+    with pytest.raises(bk.BlinkyError):
+        ctx.resident_submit(out.data_ptr(), W + 64)
+    ctx.close()
+
+
+def test_resident_frame_is_in_memory_when_wait_returns_while_later_frames_stream(bk, hip):
+    """bk_apply_resident_wait(n) promises frame n COMPLETE IN MEMORY while frames n+1.. are still being warped (the flag is raised two
+    staging barriers after the frame's last write-through store, without a drain): a DMA reads every frame back the moment its wait
+    returns, 48 frames streaming behind one another (bk_apply_resident.inc:407)"""
+    import torch
+    lm = O.lensmap("cube", "hammer", None, 960, 540)
+    W, H = lm.W, lm.H
+    F = 4
+    globes = [O.lcg_globe(lm.ps, 6, 10 + f) for f in range(F)]
+    ctx = make_ctx(bk, lm, nframes=F)
+    for f in range(F):
+        for p in range(6):
+            ctx.upload_plate(f, p, globes[f][p])
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    want = [O.apply(lm.offsets, lm.tints, W, H, globes[f], np.full((H, W), 9, np.uint8)) for f in range(F)]
+    N = 48
+    outs = [torch.full((H, W), 9, dtype=torch.uint8, device="cuda") for _ in range(N)]
+    torch.cuda.synchronize()
+    host = np.empty((H, W), np.uint8)
+    ctx.resident_begin(idle_ms=2000)
+    for rnd in range(3):
+        tickets = []
+        for i in range(24):                          # 24 in flight, then top up as the reads go on
+            tickets.append(ctx.resident_submit(outs[i].data_ptr(), W, frame=(i + rnd) % F))
+        for i in range(N):
+            ctx.resident_wait(tickets[i])
+            assert hip.hipMemcpy(host.ctypes.data, outs[i].data_ptr(), W * H, 2) == 0      # a DMA, not a kernel: it does not wait for the resident kernel
+            np.testing.assert_array_equal(host, want[(i + rnd) % F], err_msg=f"round {rnd} frame {i} read right after its wait")
+            if i + 24 < N:
+                tickets.append(ctx.resident_submit(outs[i + 24].data_ptr(), W, frame=(i + 24 + rnd) % F))
+        # (the buffers are overwritten by the next round's frames: every mapped pixel changes with the globe, the background stays 9)
+    assert ctx.resident_info()["launches"] == 1
+    ctx.resident_end()
+    ctx.close()
+
+
 def test_resident_pipelined_submissions(bk):
     """100 frames over a ring of 8 globes into 4 rotating buffers, up to 32 in flight: every frame's bytes, in order"""
     import torch
@@ -204,8 +276,13 @@ def test_resident_pipelined_submissions(bk):
     ctx.close()
 
 
+RES_4K = [("cube", "panini", None, 3840, 2160), ("cube", "hammer", None, 3840, 2160),
+          ("cube", "quincuncial", None, 3840, 2160),       # C3 (BASELINE.json configs[2])
+          ("trism", "panini", None, 3840, 2160)]           # C4's map (configs[3]) on one GPU
+
+
 @pytest.mark.parametrize("shape", [0, 1], ids=["shape-chosen", "128x8-blocks"])
-@pytest.mark.parametrize("key", [("cube", "panini", None, 3840, 2160), ("cube", "hammer", None, 3840, 2160)], ids=lambda k: k[1])
+@pytest.mark.parametrize("key", RES_4K, ids=lambda k: f"{k[0]}-{k[1]}")
 def test_resident_4k_frame_hash_equals_reference_golden(bk, key, shape):
     """BASELINE.json's full size: the frame hash recorded from the unmodified reference, through the resident kernel, on the GPU-built
     lensmap; prints what the session looked like (workgroups, blocks held in registers) and the device time of a frame"""
@@ -218,11 +295,11 @@ def test_resident_4k_frame_hash_equals_reference_golden(bk, key, shape):
     S.configure(ctx, globe, lens, zoom, (W, H))
     ctx.build()
     for f in range(2):
-        for p in range(6):
+        for p in range(len(rec["display"])):
             ctx.fill_plate_lcg(f, p, seed_frame=0)
     out = torch.zeros((2, H, W), dtype=torch.uint8, device="cuda")
     if shape:
-        ctx.set_tile_shape(shape)             # 128x8 blocks: 8160 of them - more than three per workgroup, the rest is fetched per frame
+        ctx.set_tile_shape(shape)             # 128x8 blocks: 8160 of them - far more than a workgroup's share in registers
     ctx.synchronize()
     torch.cuda.synchronize()
     ctx.resident_begin(idle_ms=500)
@@ -234,3 +311,72 @@ def test_resident_4k_frame_hash_equals_reference_golden(bk, key, shape):
     for i in range(2):
         assert O.fnv(out[i].cpu().numpy()) == rec["fnv_frame"]
     ctx.close()
+
+
+def test_resident_c5_8k_frames_equal_reference_golden(bk):
+    """BASELINE.json configs[4] (7680x4320 cube/hammer) through the resident kernel: frames 0, 1, 5 and 63 of the 64-frame golden
+    batch (frame 0 recorded from the unmodified reference, the others from the oracle's gather over the reference's lensmap), submitted
+    back to back - the deep form: more blocks per workgroup than any 4K map"""
+    import torch
+    import scripts as S
+    key = ("cube", "hammer", None, 7680, 4320)
+    rec = GOLD[key]
+    globe, lens, zoom, W, H = key
+    picks = [0, 1, 5, 63]
+    ctx = bk.Context()
+    ctx.set_frames(len(picks))
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    ctx.build()
+    for i, f in enumerate(picks):
+        for p in range(6):
+            ctx.fill_plate_lcg(i, p, seed_frame=f)
+    out = torch.zeros((len(picks), H, W), dtype=torch.uint8, device="cuda")
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    ctx.resident_begin(idle_ms=1000)
+    info = ctx.resident_info()
+    last = ctx.resident_submit_batch(out.data_ptr(), W, H * W, frame0=0, nframes=len(picks))
+    ctx.resident_wait(last)
+    # ... and once more one at a time into the same buffers (a drained pipeline starts differently from a streaming one)
+    out2 = torch.zeros_like(out)
+    for i in range(len(picks)):
+        ctx.resident_wait(ctx.resident_submit(out2[i].data_ptr(), W, frame=i))
+    ctx.resident_end()
+    print(f"\nresident C5 {W}x{H}: {info}")
+    for i, f in enumerate(picks):
+        assert O.fnv(out[i].cpu().numpy()) == rec["fnv_frames"][f], f"frame {f} (pipelined)"
+        assert O.fnv(out2[i].cpu().numpy()) == rec["fnv_frames"][f], f"frame {f} (one at a time)"
+    ctx.close()
+
+
+def test_resident_4k_rubix_and_stripe_equal_oracle(bk):
+    """the headline map (3840x2160 cube/panini) with the rubix tints on (fisheye.c:2416-2419), whole and as the 270-row stripe rank 3 of 8
+    owns (bk_set_rows): frames byte-equal to the oracle's render_lensmap over the oracle's own 4K lensmap"""
+    import torch
+    import scripts as S
+    key = ("cube", "panini", None, 3840, 2160)
+    lm = O.lensmap(*key)
+    W, H = lm.W, lm.H
+    globe = O.lcg_globe(lm.ps, 6, 2)
+    pal = O.palmap(O.synthetic_basepal())
+    want_rubix = O.apply(lm.offsets, lm.tints, W, H, globe, np.zeros((H, W), np.uint8), W, 0, 0, True, pal)
+    want_plain = O.apply(lm.offsets, lm.tints, W, H, globe, np.zeros((H, W), np.uint8))
+    assert O.fnv(lm.offsets) == GOLD[key]["fnv_offsets"]
+    for rows, rubix in (((0, H), True), ((810, 1080), False), ((810, 1080), True)):
+        ctx = bk.Context()
+        S.configure(ctx, *key[:3], (W, H))
+        ctx.set_rows(*rows)
+        ctx.build()
+        for p in range(6):
+            ctx.upload_plate(0, p, globe[p])
+        out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.resident_begin(rubix, pal, idle_ms=500)
+        info = ctx.resident_info()
+        for _ in range(3):
+            ctx.resident_wait(ctx.resident_submit(out.data_ptr(), W))
+        ctx.resident_end()
+        want = np.zeros((H, W), np.uint8)
+        want[rows[0]:rows[1]] = (want_rubix if rubix else want_plain)[rows[0]:rows[1]]
+        np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"rows {rows} rubix {rubix} {info}")
+        ctx.close()

@@ -33,6 +33,9 @@ def test_bench_line_and_check_single_gpu():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["dtype"] == "u8" and out["value"] > 0
+    # one workload for the whole 1/2/4/8 curve: 64 frames per step at N = 1 too (the 16-frame job of rounds 1-4 rides along)
+    assert out["config"]["frames_per_step"] == 64 and ", 64 frames/step" in out["config"]["workload"]
+    assert out["value_at_16_frames"] > 0 and out["scaling_reference_mpx_s"] is None
     rf = out["roofline"]
     assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "compulsory_bytes_per_launch",
                        "frac_compulsory", "ring_globes", "warm_ring"}
@@ -104,11 +107,15 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     measured one GPU); here both ranks share the one GPU over gloo."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(BLINKY_BENCH_BACKEND="gloo", BLINKY_BENCH_ONE_GPU="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4",
-                        "--ring", "8", "--repeats", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--repeats", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 2
+    # the N > 1 line runs the SAME frames per step as the N = 1 line (no --frames given: the default), names the transport that was
+    # timed, and carries the one-GPU job of that very workload, timed by rank 0 in the same run, as the curve's denominator
+    assert out["config"]["frames_per_step"] == 64 and "gloo host exchange" in out["config"]["parallelism"]
+    assert out["scaling_reference_mpx_s"] > 0 and out["speedup_vs_scaling_reference"] > 0
 
 
 def test_stream_mix_calibration_entry():
