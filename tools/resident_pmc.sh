@@ -7,7 +7,9 @@ mkdir -p "$(dirname "$OUT")"
 cd /tmp && export TMPDIR=/tmp
 : > "$OUT"
 for LENS in "$@"; do
-  for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_READ_sum TCC_WRITE_sum"; do
+  # (PASSES="FETCH_SIZE|WRITE_SIZE" restricts the counter groups, '|' separated)
+  IFS='|' read -r -a GROUPS_ <<< "${PASSES:-FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum|TCC_HIT_sum TCC_MISS_sum TCC_READ_sum TCC_WRITE_sum}"
+  for C in "${GROUPS_[@]}"; do
     rm -rf /tmp/rpmc
     timeout 120 rocprofv3 --pmc $C --kernel-trace -d /tmp/rpmc -o pmc -- python $R/tools/resident_traffic.py $LENS $N ${RES_ARGS} > /tmp/rpmc.log 2>&1
     grep RESIDENT /tmp/rpmc.log >> "$OUT"

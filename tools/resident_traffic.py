@@ -2,7 +2,7 @@
 """Developer probe for counter passes: ONE resident-apply session of N pipelined frames over the cold ring, then exit - the
 session's kernel is one dispatch, so `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/resident_traffic.py hammer 2000`
 gives bytes per N frames (tools/resident_pmc.sh runs the passes and divides).
-usage: python tools/resident_traffic.py <lens> <frames> [W H] [flags]"""
+usage: python tools/resident_traffic.py <lens> <frames> [W H] [flags] [shape]"""
 import os
 import sys
 import time
@@ -22,6 +22,8 @@ W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 216
 wl = bench.OneGpuWorkload(torch, blinky_amd, S, 0, "cube", lens, None if lens != "panini" else "f_fov 180", W, H, 1)
 if len(sys.argv) > 5:
     wl.ctx.set_ablation(int(sys.argv[5]))
+if len(sys.argv) > 6:
+    wl.ctx.set_tile_shape(int(sys.argv[6]))           # 1 / 2 / 4: blocks of 128 x 8 / 16 / 32
 wl.launch(0, 1)
 if os.environ.get('RES_DEBUG'):
     blinky_amd.ffi.debug_set_option('print_model', 1)
