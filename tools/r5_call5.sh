@@ -1,7 +1,4 @@
-timeout -k 2 100 python tools/r5_diag.py --lenses panini --flags 0,33554432,67108864,75497472 2>&1 | grep DIAG
-for FL in 67117056; do
-RES_DEBUG=1 timeout -k 2 60 python tools/resident_traffic.py panini 2000 3840 2160 $FL > gpurun_out/r05_v2_dbg.txt 2>&1
-LAG=$(grep -o "'laggard': [0-9]*" gpurun_out/r05_v2_dbg.txt | grep -o "[0-9]*")
-BLINKY_DBG_WG=$LAG RES_DEBUG=1 timeout -k 2 60 python tools/resident_traffic.py panini 2000 3840 2160 $FL > gpurun_out/r05_v2_dbg.txt 2>&1
-grep -E "RESIDENT2 work" gpurun_out/r05_v2_dbg.txt | cut -c40-500
-done
+timeout -k 2 150 python -m pytest tests/test_apply_resident_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 2 100 python tools/r5_diag.py --lenses stereographic,hammer,panini --size 1920x1080 --flags 0,16 2>&1 | grep DIAG
+timeout -k 2 100 python tools/r5_diag.py --lenses panini,hammer --flags 0 2>&1 | grep DIAG
+for F in 0; do timeout -k 2 90 python tools/r5_stress.py $F 2>&1 | grep -v amdgpu.ids | tail -2 | cut -c1-200; done
