@@ -381,26 +381,6 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
             if (WT) {
                 const uint32_t off = (uint32_t)row0 * (uint32_t)dst_pitch + (uint32_t)x;       // (f = 0, one frame per command)
                 const __amdgpu_buffer_rsrc_t rd = bk_frame_rsrc(dst);
-                if (kflags & 16384) {          // (developer, TIMING ONLY: non-temporal stores instead of write-through - the frame is not published)
-                    if (RG == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rd, (int)off, 0, 2);
-                    else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rd, (int)off, 0, 2); }
-                    else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 2); }
-                } else
-                // A write-through store is a fabric write per LANE: 16 bytes per lane cost what a plain store does, 8 bytes 2.7x and 4 bytes
-                // 6x that per byte (MI355X_MICROARCH.md, stores of each flavour).  A lane of a 128x16 / 128x8 block owns only 8 / 4 pixels,
-                // but its neighbours in the row own the next ones: two (four) lanes hand their words to the first of them (DPP row shifts:
-                // lane i reads lane i + 1 / + 2 of its row of 16 - a lane's row segment never crosses one) and that lane stores all 16 bytes.
-                // (fast_store says the frame is aligned to a lane's own 4 * RG pixels; the wider store needs 16: kflags bit 2048 + x % 16)
-                if (RG == 2 && (kflags & 32768)) {
-                    const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x101, 0xF, 0xF, false);      // row_shl:1
-                    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[RG - 1], 0x101, 0xF, 0xF, false);
-                    if (!(threadIdx.x & 1u)) { v4u v = {w[0], w[RG - 1], n0, n1}; __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 16); }
-                } else if (RG == 1 && (kflags & 32768)) {
-                    const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x101, 0xF, 0xF, false);      // row_shl:1
-                    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x102, 0xF, 0xF, false);      // row_shl:2
-                    const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x103, 0xF, 0xF, false);      // row_shl:3
-                    if (!(threadIdx.x & 3u)) { v4u v = {w[0], n0, n1, n2}; __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 16); }
-                } else
                 if (RG == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rd, (int)off, 0, 16);
                 else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rd, (int)off, 0, 16); }
                 else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 16); }
