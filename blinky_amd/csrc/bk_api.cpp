@@ -2,11 +2,20 @@
 #include "bk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <dlfcn.h>
 
 static thread_local std::string g_create_error;
+
+// A resident apply kernel occupies the hardware queue its stream is mapped to for as long as it runs, and HIP maps all the streams of a
+// process onto GPU_MAX_HW_QUEUES (default 4) of them, round robin: with a fifth stream in the process - several stripe contexts on one
+// device, each with its own stream, exchange stream and resident stream - some stream shares a queue with a resident kernel and
+// everything queued on it (a plate's DMA, the frame's copy back) waits until that kernel idles out (measured: 200 ms per call, the
+// session's idle time, instead of 0.2 ms).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the
+// process, so it is set here, at load time, unless the user has set it.
+__attribute__((constructor)) static void bk_more_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 // ---- roctx ranges (bk::Range) --------------------------------------------------------------------------------------
 namespace {
@@ -136,7 +145,7 @@ extern "C" int bk_set_stream(bk_ctx *ctx, void *hip_stream)
 extern "C" int bk_synchronize(bk_ctx *ctx)
 {
     if (!ctx) return BK_E_INVALID;
-    if (int r = ensure_device(ctx)) return r;
+    if (int r = ensure_device(ctx, ctx->resident_mode != 0)) return r;      // (resident mode: the context's stream carries DMAs only; the session stays)
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BK_OK;
 }
@@ -430,6 +439,11 @@ extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t 
     if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate: call bk_resize first");
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_upload_plate: bad frame/plate/pitch");
+    if (ctx->resident_mode) {                       // re-tiled on the host, moved by one DMA: no kernel, the resident session stays
+        if (int r = bk_upload_plate_async(ctx, frame, plate, src, src_pitch)) return r;
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return BK_OK;
+    }
     if (int r = ensure_device(ctx)) return r;
     bk::Range range("bk_upload_plate");
     const size_t ps = ctx->ps;
@@ -451,8 +465,9 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
     if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate_async: call bk_resize first");
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_upload_plate_async: bad frame/plate/pitch");
-    if (int r = ensure_device(ctx)) return r;
-    const size_t ps = ctx->ps, gp = ctx->gp, bytes = gp * ps;
+    if (int r = ensure_device(ctx, ctx->resident_mode != 0)) return r;
+    // (the slots hold a whole plate image: rows gp apart for the re-tiling kernel, or - resident mode - the plate's tiles themselves)
+    const size_t ps = ctx->ps, gp = ctx->gp, bytes = ctx->plate_bytes();
     if (ctx->plate_slot_bytes != bytes) {
         free_plate_slots(ctx);
         for (int i = 0; i < bk_ctx::kPlateSlots; ++i) {
@@ -467,9 +482,24 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
     ctx->plate_next = (slot + 1) % bk_ctx::kPlateSlots;
     BK_HIP(ctx, hipEventSynchronize(ctx->plate_ev[slot]));               // (a never-recorded event is complete)
     uint8_t *h = ctx->h_plate[slot];
-    for (size_t y = 0; y < ps; ++y) memcpy(h + y * gp, src + y * (size_t)src_pitch, ps);      // rows gp apart, as the staging twin expects
     uint8_t *dst = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
-    BK_HIP(ctx, hipMemcpyAsync(ctx->d_plate_slot[slot], h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->resident_mode) {
+        // render_plate's row memcpy (fisheye.c:2441-2449) writing the device layout directly: 16 texels of a row are one 16-byte piece
+        // of a 16x8 tile (bk_texel_offset) - then ONE linear DMA into the globe.  No kernel: the resident apply holds the CUs, the
+        // SDMA engines do not need one (profiles/r05_resident_apply.txt (2)).  Padding texels (ps..gp, ps..ph) are never read.
+        const size_t tpr = gp >> 4, full = ps >> 4, rest = ps & 15;
+        for (size_t y = 0; y < ps; ++y) {
+            const uint8_t *srow = src + y * (size_t)src_pitch;
+            uint8_t *trow = h + (y >> 3) * tpr * 128 + (y & 7) * 16;
+            for (size_t cx = 0; cx < full; ++cx) memcpy(trow + cx * 128, srow + cx * 16, 16);
+            if (rest) memcpy(trow + full * 128, srow + full * 16, rest);
+        }
+        BK_HIP(ctx, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        BK_HIP(ctx, hipEventRecord(ctx->plate_ev[slot], ctx->stream));
+        return BK_OK;
+    }
+    for (size_t y = 0; y < ps; ++y) memcpy(h + y * gp, src + y * (size_t)src_pitch, ps);      // rows gp apart, as the staging twin expects
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_plate_slot[slot], h, gp * ps, hipMemcpyHostToDevice, ctx->stream));
     if (int r = bk::launch_plate_retile(ctx, dst, 1, ctx->d_plate_slot[slot])) return r;
     BK_HIP(ctx, hipEventRecord(ctx->plate_ev[slot], ctx->stream));
     return BK_OK;
@@ -551,6 +581,27 @@ extern "C" int bk_apply_device(bk_ctx *ctx, int frame0, int nframes, void *dst_d
 }
 
 // ---- resident single-frame apply (bk_apply_resident.inc) ------------------------------------------------------------
+extern "C" int bk_set_resident_share(bk_ctx *ctx, int part, int parts, int reserve_cus_per_xcd /* = workgroup slots per CU */)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (parts < 1 || parts > 8 || part < 0 || part >= parts || reserve_cus_per_xcd < 0 || reserve_cus_per_xcd > 7)
+        return ctx->fail(BK_E_INVALID, "bk_set_resident_share: part %d of %d, %d workgroup slots reserved per CU", part, parts, reserve_cus_per_xcd);
+    if (ctx->device >= 0 && (part != ctx->res_part || parts != ctx->res_parts || reserve_cus_per_xcd != ctx->res_reserve)) {
+        BK_HIP(ctx, hipSetDevice(ctx->device));
+        bk::resident_quiesce(ctx);                  // (the running kernel sits on the old share)
+    }
+    ctx->res_part = part; ctx->res_parts = parts; ctx->res_reserve = reserve_cus_per_xcd;
+    return BK_OK;
+}
+
+extern "C" int bk_set_resident_apply(bk_ctx *ctx, int on)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (!on && ctx->resident_mode && ctx->device >= 0) { BK_HIP(ctx, hipSetDevice(ctx->device)); bk::resident_quiesce(ctx); }
+    ctx->resident_mode = on ? 1 : 0;
+    return BK_OK;
+}
+
 extern "C" int bk_apply_resident_begin(bk_ctx *ctx, int rubix_on, const uint8_t pal[BK_MAX_PLATES][256], double idle_ms)
 {
     if (!ctx) return BK_E_INVALID;
@@ -646,6 +697,28 @@ extern "C" int bk_apply_begin(bk_ctx *ctx, int frame, int rubix_on, const uint8_
     if (!ctx) return BK_E_INVALID;
     if (!ctx->lensmap_valid) return ctx->fail(BK_E_STATE, "bk_apply: no lensmap (bk_build / bk_set_lensmap first)");
     if (frame < 0 || frame >= ctx->nframes) return ctx->fail(BK_E_INVALID, "bk_apply: bad frame %d", frame);
+    if (ctx->resident_mode && ctx->apply_variant != 0) {
+        // the frame as a command to the resident kernel (begun here if it is not running, or was begun with another palette)
+        if (int r = ensure_device(ctx, true)) return r;
+        bk::Range range("bk_apply_begin (resident)");
+        if (rubix_on && !pal) return ctx->fail(BK_E_INVALID, "rubix_on needs the palette LUTs");
+        bk::Resident *R = ctx->resident;
+        const bool same = R && ctx->res_rubix == (rubix_on != 0) && (!rubix_on || memcmp(ctx->res_pal, pal, sizeof ctx->res_pal) == 0);
+        if (!ctx->spans_valid || !R || !same) {
+            if (int r = ensure_device(ctx)) return r;                 // (ends a session begun with other settings; the mask kernel below needs the CUs)
+            if (int r = ensure_spans(ctx)) return r;
+            if (int r = upload_pal(ctx, rubix_on, pal)) return r;
+            BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (int r = bk::resident_begin(ctx, rubix_on, 0.0)) return r;
+            ctx->res_rubix = rubix_on != 0;
+            if (rubix_on) memcpy(ctx->res_pal, pal, sizeof ctx->res_pal);
+        }
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));               // the plates of this frame have arrived (bk_upload_plate_async)
+        uint8_t *first = ctx->d_frame;                                // a tight staging frame of the owned rows: its pixel (0, row0) is d_frame
+        if (int r = bk::resident_submit(ctx, frame, first, ctx->W, &ctx->apply_ticket)) return r;
+        ctx->apply_in_flight = true;
+        return BK_OK;
+    }
     if (int r = ensure_device(ctx)) return r;
     bk::Range range("bk_apply_begin");
     if (int r = ensure_spans(ctx)) return r;
@@ -662,9 +735,16 @@ extern "C" int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, in
 {
     if (!ctx || !dst) return BK_E_INVALID;
     if (!ctx->apply_in_flight) return ctx->fail(BK_E_STATE, "bk_apply_end without bk_apply_begin");
-    if (int r = ensure_device(ctx)) return r;
+    const bool resident = ctx->resident_mode && ctx->apply_ticket != 0;
+    if (int r = ensure_device(ctx, resident)) return r;
     ctx->apply_in_flight = false;
     const int rows = ctx->rows();
+    if (resident) {
+        const uint64_t t = ctx->apply_ticket;
+        ctx->apply_ticket = 0;
+        if (int r = bk::resident_wait(ctx, t, nullptr)) return r;     // the frame is in memory: the copies below are DMAs, they need no CU
+        if (!ctx->fully_mapped) BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (ctx->fully_mapped) {
         // nothing to preserve between the mapped pixels: one 2-D copy straight into the caller's buffer, no host merge
         BK_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)(y0 + ctx->row0) * dst_pitch + x0, (size_t)dst_pitch, ctx->d_frame, (size_t)ctx->W,

@@ -629,6 +629,20 @@ extern "C" int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], doubl
 
 // host destination: every device warps its stripe (all of them enqueued before any is waited for) and copies its rows
 // straight into the caller's frame; no inter-GPU exchange is needed for a host frame
+extern "C" int bk_multi_set_resident_apply(bk_multi *m, int on)
+{
+    if (!m) return BK_E_INVALID;
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        // contexts that share a device each get their own part of its CUs (a one-GPU box with the device named N times)
+        int part = 0, parts = 0;
+        for (size_t j = 0; j < m->ctx.size(); ++j)
+            if (m->ctx[j]->device == m->ctx[i]->device) { if (j < i) ++part; ++parts; }
+        if (int r = bk_set_resident_share(m->ctx[i], part, parts, m->ctx[i]->res_reserve)) return m->fail(r, bk_last_error(m->ctx[i]));
+        if (int r = bk_set_resident_apply(m->ctx[i], on)) return m->fail(r, bk_last_error(m->ctx[i]));
+    }
+    return BK_OK;
+}
+
 extern "C" int bk_multi_apply(bk_multi *m, int frame, uint8_t *dst, int dst_pitch, int x0, int y0, int rubix_on,
                               const uint8_t pal[BK_MAX_PLATES][256])
 {

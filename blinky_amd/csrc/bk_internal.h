@@ -117,6 +117,11 @@ struct bk_ctx {
     int tile_shape = 0;              // coop apply: 0 = block height by cost model, 1/2/4 = force 128x8 / 128x16 / 128x32
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
     bk::Resident *resident = nullptr;     // owned; freed with bk::resident_free (bk_apply_resident_begin .. _end)
+    int resident_mode = 0;                // bk_set_resident_apply: bk_apply / bk_apply_begin..end / bk_upload_plate* go through the resident kernel
+    int res_part = 0, res_parts = 1, res_reserve = 0;   // bk_set_resident_share: which CUs of every XCD the resident kernel may take
+    uint64_t apply_ticket = 0;            // resident mode: the frame bk_apply_begin submitted
+    uint8_t res_pal[BK_MAX_PLATES * 256] = {};   // resident mode: the palette the running session was begun with
+    bool res_rubix = false;
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
     double last_host_eval_ms = 0;    // of that: wall time of the host re-evaluation of the flagged entries

@@ -88,6 +88,9 @@ _SIGS = {
     "bk_get_size": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "bk_version": (C.c_char_p, []),
     "bk_set_apply_variant": (_i, [_vp, _i]),
+    "bk_set_resident_share": (_i, [_vp, _i, _i, _i]),
+    "bk_set_resident_apply": (_i, [_vp, _i]),
+    "bk_multi_set_resident_apply": (_i, [_vp, _i]),
     "bk_set_blockmap_tuning": (_i, [_vp, _i]),
     "bk_set_host_compile": (_i, [_i]),
     "bk_host_module_ready": (_i, [_vp, _i]),
@@ -560,6 +563,14 @@ class Context:
     def set_apply_variant(self, v):
         self._chk(lib.bk_set_apply_variant(self._h, v))
 
+    def set_resident_share(self, part=0, parts=1, reserve_slots_per_cu=0):
+        """how many of a CU's workgroup places the resident kernel may take (bk_set_resident_share)"""
+        self._chk(lib.bk_set_resident_share(self._h, part, parts, reserve_slots_per_cu))
+
+    def set_resident_apply(self, on=True):
+        """bk_apply / bk_upload_plate* through the resident kernel (bk_set_resident_apply)"""
+        self._chk(lib.bk_set_resident_apply(self._h, int(bool(on))))
+
 
 def comm_unique_id():
     """rank 0: the 128-byte id every rank passes to Comm (ncclGetUniqueId)"""
@@ -637,6 +648,9 @@ class Multi:
 
     def ctx(self, i):
         return Context(_borrowed=lib.bk_multi_ctx(self._h, i))
+
+    def set_resident_apply(self, on=True):
+        self._chk(lib.bk_multi_set_resident_apply(self._h, int(bool(on))))
 
     def uses_rccl(self):
         return bool(lib.bk_multi_uses_rccl(self._h))

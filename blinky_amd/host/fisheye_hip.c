@@ -395,6 +395,21 @@ void F_Init(void)                                   /* fisheye.c:642-676 */
         bk = bk_create(dev && !strcmp(dev, "none") ? BK_DEVICE_NONE : (dev ? atoi(dev) : (devs ? atoi(devs) : -1)));
         if (!bk) Con_Printf("fisheye: %s\n", bk_last_error(NULL));
     }
+    /* BLINKY_HIP_RESIDENT=1: F_RenderView's per-frame calls - bk_upload_plate_async for every displayed plate, bk_apply - go through
+     * the resident apply kernel (one kernel that stays on the GPU, a frame is a command; the plates travel by DMA, re-tiled on the
+     * host): no kernel launch per frame.  BLINKY_HIP_RESERVE_SLOTS=n keeps n workgroup places of every CU free for other users of the GPU. */
+    if (bk && getenv("BLINKY_HIP_RESIDENT") && atoi(getenv("BLINKY_HIP_RESIDENT")) != 0) {
+        const int reserve = getenv("BLINKY_HIP_RESERVE_SLOTS") ? atoi(getenv("BLINKY_HIP_RESERVE_SLOTS")) : 0;
+        int i, rc = BK_OK;
+        if (mg) {
+            for (i = 0; i < bk_multi_size(mg) && rc == BK_OK; ++i) rc = bk_set_resident_share(bk_multi_ctx(mg, i), 0, 1, reserve);
+            if (rc == BK_OK) rc = bk_multi_set_resident_apply(mg, 1);
+        } else {
+            rc = bk_set_resident_share(bk, 0, 1, reserve);
+            if (rc == BK_OK) rc = bk_set_resident_apply(bk, 1);
+        }
+        if (rc != BK_OK) Con_Printf("fisheye: %s\n", dev_error());
+    }
     /* the first use of a lens compiles it (hiprtc, 0.2-1.1 s): do that off the render thread and keep drawing with the
      * previous lensmap meanwhile - the reference's time-sliced builder never stalls a frame either (fisheye.c:2084-2217) */
     if (bk && !getenv("BLINKY_HIP_SYNC_COMPILE")) {

@@ -236,6 +236,22 @@ int bk_apply_resident_end(bk_ctx *ctx);
  * block height, workgroups per CU, kernel launches so far, submissions not yet known complete; of the last session that was ended:
  * min / median / max over its workgroups of the frames a workgroup ran on into the next one without draining; 0} */
 int bk_apply_resident_info(bk_ctx *ctx, int out[12]);
+/* (r5) The resident kernel beside other work, and under the drop-in calls.
+ * bk_set_resident_share: how much of every CU the resident kernel may occupy.  A CU holds up to eight of its workgroups (fewer for the
+ * forms that need more registers or LDS); `reserve_slots_per_cu` of those places stay free on every CU - kernels of this context, of
+ * other contexts and of other libraries are scheduled there while the kernel is resident, provided they fit what a place leaves
+ * (a quarter to an eighth of a CU's registers and LDS) - and the rest is split evenly between `parts` contexts of the same device, of
+ * which this one is number `part`: stripe contexts on a one-GPU box each keep their own resident kernel.  Default 0 / 1 / 0: the
+ * whole chip.  Takes effect at the next bk_apply_resident_begin / relaunch.  (Measured and not used: a CU-masked stream -
+ * hipExtStreamCreateWithCUMask streams are blocking streams, so every null-stream operation of the process, PyTorch's default
+ * stream included, then waits for the resident kernel to leave.)
+ * bk_set_resident_apply(ctx, 1): the per-frame calls of the drop-in go through the resident kernel - bk_apply / bk_apply_begin .. _end
+ * submit the frame as a command and copy it back with the DMA engines, bk_upload_plate / bk_upload_plate_async re-tile the plate on
+ * the HOST (render_plate's row memcpy, fisheye.c:2441-2449, writes tiles instead of rows) and move it with one DMA - no kernel launch
+ * per frame, and none of these calls ends the session (a session is begun by the first bk_apply after a build, with that call's
+ * rubix flag and palette, and begun again when they change).  Everything else (bk_build, bk_resize, bk_apply_device ...) still ends it. */
+int bk_set_resident_share(bk_ctx *ctx, int part, int parts, int reserve_slots_per_cu);
+int bk_set_resident_apply(bk_ctx *ctx, int on);
 
 /* ---- multi-GPU: row stripes + RCCL over xGMI ---------------------------------------------------------------
  * No counterpart in the reference (fisheye.c is single-threaded CPU code).  Every output pixel is independent, so
@@ -310,6 +326,9 @@ int bk_multi_wait(bk_multi *m, int slot);    /* bk_comm_wait on every rank */
 /* all stripes built concurrently (one host thread per device); display_out = OR over the stripes */
 int bk_multi_build(bk_multi *m, int display_out[BK_MAX_PLATES], double *scale_out);
 /* host frame: every device warps its stripe and copies it straight into dst (N PCIe links side by side) */
+/* bk_set_resident_apply on every stripe context; contexts that share a device (a device named twice) split the places of its CUs
+ * between them (bk_set_resident_share) so that each keeps its own resident kernel */
+int bk_multi_set_resident_apply(bk_multi *m, int on);
 int bk_multi_apply(bk_multi *m, int frame, uint8_t *dst, int dst_pitch, int x0, int y0, int rubix_on,
                    const uint8_t pal[BK_MAX_PLATES][256]);
 /* device frames: warp into per-device stripe buffers, then gather / rotating exchange as bk_comm_* */

@@ -380,3 +380,116 @@ def test_resident_4k_rubix_and_stripe_equal_oracle(bk):
         want[rows[0]:rows[1]] = (want_rubix if rubix else want_plain)[rows[0]:rows[1]]
         np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"rows {rows} rubix {rubix} {info}")
         ctx.close()
+
+
+# ---- the drop-in calls through the resident kernel (bk_set_resident_apply) ------------------------------------------------------
+
+@pytest.mark.parametrize("cfg", [("cube", "panini", None, 640, 480), ("cube", "hammer", None, 960, 540), ("cube", "stereographic", "f_fov 180", 322, 203)],
+                         ids=lambda c: f"{c[1]}-{c[3]}x{c[4]}")
+def test_fresh_plates_every_frame_without_ending_the_session(bk, cfg):
+    """what F_RenderView does (fisheye.c:764-803): every frame six freshly rendered plates (bk_upload_plate_async: re-tiled on the host,
+    one DMA each - no kernel) and one bk_apply into a host frame with pitch and origin; 50 frames on ONE launch of the resident kernel,
+    every frame the oracle's, the background of unmapped pixels untouched; then rubix is switched on (a new session), then off again"""
+    lm = O.lensmap(*cfg)
+    W, H = lm.W, lm.H
+    pal = O.palmap(O.synthetic_basepal())
+    ctx = make_ctx(bk, lm)
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    ctx.set_resident_apply(True)
+    pitch, x0, y0 = W + 8, 3, 2
+    for i in range(50):
+        globe = O.lcg_globe(lm.ps, 6, 100 + i)
+        for p in range(6):
+            (ctx.upload_plate_async if i % 2 else ctx.upload_plate)(0, p, globe[p])
+        bg = background(H, pitch, 4)
+        got = ctx.apply(bg.copy(), pitch=pitch, x0=x0, y0=y0)
+        want = O.apply(lm.offsets, lm.tints, W, H, globe, bg.copy(), pitch, x0, y0, False, pal)
+        np.testing.assert_array_equal(got, want, err_msg=f"frame {i}")
+        info = ctx.resident_info()
+        assert info["running"] and info["launches"] == 1, (i, info)
+    globe = O.lcg_globe(lm.ps, 6, 7)
+    for p in range(6):
+        ctx.upload_plate_async(0, p, globe[p])
+    for rubix, launches in ((True, 2), (True, 2), (False, 3)):
+        bg = background(H, pitch, 4)
+        got = ctx.apply(bg.copy(), pitch=pitch, x0=x0, y0=y0, rubix_on=rubix, pal=pal)
+        np.testing.assert_array_equal(got, O.apply(lm.offsets, lm.tints, W, H, globe, bg.copy(), pitch, x0, y0, rubix, pal))
+        assert ctx.resident_info()["launches"] == launches
+    ctx.close()
+
+
+def test_a_reserved_place_per_cu_lets_other_kernels_run_beside_the_resident_kernel(bk):
+    """bk_set_resident_share(0, 1, 1): one workgroup place of every CU stays free - ANOTHER context's kernels (a build, synthetic plates, a
+    batch apply on the null stream) run to completion while a chip-filling session (3840x2160 cube/panini) is up; without the reserve
+    they queue until the resident kernel leaves (idle_ms is 20 s here).  The session is still its first launch afterwards and its
+    frames are the reference's."""
+    import torch
+    import scripts as S
+    key = ("cube", "panini", None, 3840, 2160)
+    a = bk.Context()
+    S.configure(a, *key[:3], (3840, 2160))
+    a.build()
+    for p in range(6):
+        a.fill_plate_lcg(0, p, seed_frame=0)
+    a.set_resident_share(0, 1, 1)
+    out = torch.zeros((2160, 3840), dtype=torch.uint8, device="cuda")
+    # the other context, built and warmed up BEFORE the session: hipFree is a device-wide synchronise in HIP, and a build or a first
+    # apply frees scratch buffers - such calls do wait for a resident kernel whatever it leaves free (include/blinky_hip.h says so)
+    b = bk.Context()
+    S.configure(b, "cube", "hammer", None, (640, 480))
+    b.build()
+    b.fill_plate_lcg(0, 0, seed_frame=1)
+    b.apply(np.zeros((480, 640), np.uint8))
+    lmb = O.lensmap("cube", "hammer", None, 640, 480)
+    t = torch.arange(1 << 20, device="cuda", dtype=torch.int32)
+    a.synchronize()
+    torch.cuda.synchronize()
+    a.resident_begin(idle_ms=20000)
+    a.resident_wait(a.resident_submit(out.data_ptr(), 3840))
+    full = a.resident_info()
+    t0 = time.time()
+    for p in range(6):
+        b.fill_plate_lcg(0, p, seed_frame=3)                         # kernels of another context, on the null stream
+    got_b = b.apply(np.zeros((480, 640), np.uint8))                  # its warp + the copy back
+    s_torch = int((t * 2 + 1).sum().item())                          # another library's kernels (PyTorch, null stream)
+    dt = time.time() - t0
+    np.testing.assert_array_equal(got_b, O.apply(lmb.offsets, lmb.tints, 640, 480, O.lcg_globe(lmb.ps, 6, 3), np.zeros((480, 640), np.uint8)))
+    assert s_torch == (1 << 20) * ((1 << 20) - 1) + (1 << 20)
+    assert dt < 5.0, f"the other context's kernels took {dt:.1f} s: they waited for the resident kernel ({full})"
+    out.zero_()
+    a.resident_wait(a.resident_submit(out.data_ptr(), 3840))
+    info = a.resident_info()
+    assert info["running"] and info["launches"] == 1, info
+    a.resident_end()
+    assert O.fnv(out.cpu().numpy()) == GOLD[key]["fnv_frame"]
+    b.close()
+    a.close()
+
+
+def test_three_stripe_contexts_each_with_a_resident_kernel_on_one_gpu(bk):
+    """bk_multi on a device named three times, bk_multi_set_resident_apply: the three stripe contexts split every XCD's CUs between them
+    and each keeps its own resident kernel; fresh plates and a host frame per call, 12 frames, every one the oracle's"""
+    import scripts as S
+    lm = O.lensmap("cube", "hammer", None, 960, 540)
+    W, H = lm.W, lm.H
+    m = bk.Multi([0, 0, 0])
+    m.load_globe(S.script("globes", "cube"), "cube")
+    m.load_lens(S.script("lenses", "hammer"), "hammer")
+    m.set_zoom(*S.zoom_args(m.ctx(0).lens_info().onload.decode()))
+    m.resize(W, H)
+    m.build()
+    m.set_resident_apply(True)
+    settled = None
+    for i in range(16):
+        globe = O.lcg_globe(lm.ps, 6, 40 + i)
+        for p in range(6):
+            m.upload_plate(0, p, globe[p])
+        got = m.apply(np.zeros((H, W), np.uint8))
+        np.testing.assert_array_equal(got, O.apply(lm.offsets, lm.tints, W, H, globe, np.zeros((H, W), np.uint8)), err_msg=f"frame {i}")
+        if i == 3:
+            # (while the sessions START they do interrupt one another: beginning one allocates and frees - hipFree is a device-wide
+            #  synchronise - so an earlier one may have idled out and come back; from here on nothing is allocated any more)
+            settled = [m.ctx(k).resident_info()["launches"] for k in range(3)]
+    infos = [m.ctx(k).resident_info() for k in range(3)]
+    assert all(x["running"] for x in infos) and [x["launches"] for x in infos] == settled, (settled, infos)
+    m.close()

@@ -155,6 +155,23 @@ def test_the_engine_session_with_the_warp_spread_over_three_stripe_contexts():
     assert {n: hip_files[n] for n in ref_files} == ref_files
 
 
+@needs_engines
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"BLINKY_HIP_RESIDENT": "1"}, {"BLINKY_HIP_RESIDENT": "1", "BLINKY_HIP_RESERVE_SLOTS": "1"},
+                                 {"BLINKY_HIP_RESIDENT": "1", "BLINKY_HIP_DEVICES": "0,0,0"}],
+                         ids=["resident", "resident-reserve-1-slot", "resident-three-stripes"])
+def test_the_engine_session_through_the_resident_apply(env):
+    """BLINKY_HIP_RESIDENT=1: F_RenderView's per-frame calls (bk_upload_plate_async for every displayed plate, bk_apply) go through the
+    resident kernel - plates re-tiled on the host and moved by DMA, a frame is a command, the frame comes back by DMA - and every
+    presented frame, the console text and the written files still equal the unmodified engine's (fisheye.c:698-811, 2406-2450)"""
+    ref_out, ref_frames, ref_files = run_engine(TQ_REF, FRAME_SESSION, "640x480")
+    hip_out, hip_frames, hip_files = run_engine(TQ_HIP, FRAME_SESSION, "640x480", env_extra=env)
+    different = [(a, b) for a, b in zip(ref_frames, hip_frames) if a != b]
+    assert len(hip_frames) == len(ref_frames) and not different, different[:5]
+    assert console_text(hip_out) == console_text(ref_out)
+    assert {n: hip_files[n] for n in ref_files} == ref_files
+
+
 # ---- random sessions -----------------------------------------------------------------------------------------------------------
 
 def random_session(seed):
@@ -215,7 +232,7 @@ def _seeds(default):
 def test_random_sessions_in_the_real_engine_equal_the_reference(seed):
     """BLINKY_ENGINE_CAMPAIGN=lo:hi runs a longer developer campaign"""
     size, script = random_session(seed)
-    devices = {"BLINKY_HIP_DEVICES": "0,0"} if seed % 3 == 2 else None
+    devices = {"BLINKY_HIP_DEVICES": "0,0"} if seed % 3 == 2 else {"BLINKY_HIP_RESIDENT": "1"} if seed % 3 == 1 else None
     ref_out, ref_frames, ref_files = run_engine(TQ_REF, script, size)
     hip_out, hip_frames, hip_files = run_engine(TQ_HIP, script, size, env_extra=devices)
     assert console_text(hip_out) == console_text(ref_out), (seed, size)

@@ -1,4 +1,3 @@
-timeout -k 2 150 python -m pytest tests/test_apply_resident_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout -k 2 100 python tools/r5_diag.py --lenses stereographic,hammer,panini --size 1920x1080 --flags 0,16 2>&1 | grep DIAG
-timeout -k 2 100 python tools/r5_diag.py --lenses panini,hammer --flags 0 2>&1 | grep DIAG
-for F in 0; do timeout -k 2 90 python tools/r5_stress.py $F 2>&1 | grep -v amdgpu.ids | tail -2 | cut -c1-200; done
+timeout -k 2 300 python -m pytest tests/test_apply_resident_gpu.py -x -q -m gpu 2>&1 | tail -4 | cut -c1-300
+timeout -k 2 120 python tools/r5_dbg3.py 2>&1 | grep -v amdgpu.ids | tail -3
+timeout -k 2 900 python -m pytest tests/test_engine_dropin.py tests/test_host_layer.py tests/test_comm_gpu.py -x -q -m gpu 2>&1 | tail -4 | cut -c1-300
