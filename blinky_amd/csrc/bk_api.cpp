@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <vector>
 
 #include <dlfcn.h>
 
@@ -313,6 +315,7 @@ extern "C" int bk_debug_set_option(const char *name, int value)
     else if (!strcmp(name, "libm_rel_log2")) bk::g_debug.libm_rel_log2 = value;
     else if (!strcmp(name, "print_model")) bk::g_debug.print_model = value;
     else if (!strcmp(name, "host_module")) bk::g_debug.host_module = value;
+    else if (!strcmp(name, "no_direct_submit")) bk::g_debug.no_direct_submit = value;
     else return BK_E_INVALID;
     return BK_OK;
 }
@@ -645,6 +648,28 @@ extern "C" int bk_apply_resident_wait(bk_ctx *ctx, uint64_t ticket, double *gpu_
     if (int r = ensure_device(ctx, true)) return r;
     return bk::resident_wait(ctx, ticket, gpu_us);
 }
+
+#if BK_DEBUG_API
+extern "C" int bk_debug_resident_latency(bk_ctx *ctx, int frames, void *dst_dev, int dst_pitch, int globes, double *host_us, double *device_us)
+{
+    if (!ctx || !dst_dev || frames < 1 || globes < 1) return BK_E_INVALID;
+    std::vector<double> wall((size_t)frames), dev((size_t)frames);
+    for (int i = 0; i < frames; ++i) {
+        struct timespec t0, t1;
+        uint64_t ticket = 0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        if (int r = bk_apply_resident_submit(ctx, (7 * i) % globes, dst_dev, dst_pitch, 0, 0, &ticket)) return r;
+        if (int r = bk_apply_resident_wait(ctx, ticket, &dev[(size_t)i])) return r;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        wall[(size_t)i] = (double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3;
+    }
+    std::sort(wall.begin(), wall.end());
+    std::sort(dev.begin(), dev.end());
+    if (host_us) *host_us = wall[(size_t)frames / 2];
+    if (device_us) *device_us = dev[(size_t)frames / 2];
+    return BK_OK;
+}
+#endif
 
 extern "C" int bk_apply_resident_end(bk_ctx *ctx)
 {

@@ -21,7 +21,7 @@
 namespace bk {
 
 // process-wide developer / test switches (bk_debug_set_option, debug API builds only; always 0 otherwise)
-struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0, host_module = 0; };
+struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0, host_module = 0, no_direct_submit = 0; };
 extern DebugOptions g_debug;
 
 // roctx ranges around the library's phases (bk_build, block-map compile, apply launches, plate uploads, the resident session):

@@ -108,6 +108,7 @@ _SIGS = {
     "bk_debug_traffic_model": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "bk_debug_band_balance": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "bk_debug_stream_mix": (_i, [_vp, _sz, _i, _i, C.POINTER(_d)]),
+    "bk_debug_resident_latency": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d)]),
     "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "bk_debug_host_corners": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
@@ -400,6 +401,12 @@ class Context:
 
     def resident_end(self):
         self._chk(lib.bk_apply_resident_end(self._h))
+
+    def resident_latency(self, dst_ptr, pitch, frames=200, globes=1):
+        """(host us, device us): medians of `frames` submit + wait cycles timed by the C host itself (bk_debug_resident_latency)"""
+        h, d = _d(), _d()
+        self._chk(lib.bk_debug_resident_latency(self._h, frames, dst_ptr, pitch, globes, C.byref(h), C.byref(d)))
+        return h.value, d.value
 
     def resident_info(self):
         out = (_i * 12)()

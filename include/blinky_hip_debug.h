@@ -50,6 +50,10 @@ int         bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18]);
  * every `period` KiB of it back with non-temporal stores - what this memory system gives a kernel with that read : write
  * ratio and nothing else to do (best of 5 passes; allocates and frees 2 x bytes) */
 int         bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps);
+/* the resident apply one frame at a time, on the C host's clock (what fisheye_hip.c pays, without a binding in between): `frames`
+ * times bk_apply_resident_submit + bk_apply_resident_wait of globe (7 i) % globes into dst_dev; medians of the host wall clock and of
+ * the device's own figure (command seen -> frame complete), microseconds.  Needs a session (bk_apply_resident_begin). */
+int         bk_debug_resident_latency(bk_ctx *ctx, int frames, void *dst_dev, int dst_pitch, int globes, double *host_us, double *device_us);
 /* which XCD (HW_REG_XCC_ID) each workgroup of a 1-D launch of `nworkgroups` runs on: the apply kernel's screen bands
  * assume workgroup b -> XCD b % 8 (locality only; a test checks the assumption on the box it runs on) */
 int         bk_debug_xcd_of_workgroups(bk_ctx *ctx, int *out, int nworkgroups);

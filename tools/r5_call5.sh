@@ -1,3 +1,3 @@
-timeout -k 2 300 python -m pytest tests/test_apply_resident_gpu.py -x -q -m gpu 2>&1 | tail -4 | cut -c1-300
-timeout -k 2 120 python tools/r5_dbg3.py 2>&1 | grep -v amdgpu.ids | tail -3
-timeout -k 2 900 python -m pytest tests/test_engine_dropin.py tests/test_host_layer.py tests/test_comm_gpu.py -x -q -m gpu 2>&1 | tail -4 | cut -c1-300
+for ND in 0 1; do timeout -k 2 100 python tools/r5_lat.py panini $ND 2>&1 | grep LAT; done
+timeout -k 2 100 python tools/r5_lat.py hammer 0 2>&1 | grep LAT
+timeout -k 2 60 python -m pytest tests/test_abi.py -q 2>&1 | tail -2
