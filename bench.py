@@ -121,19 +121,26 @@ def compulsory_bytes(model, F):
     return F * (model["mapped_pixels"] + 128 * model["unique_globe_lines"]) + visits * model["blockmap_bytes_per_visit"]
 
 
-def resident_measure(torch, ctx, dst, W, rows, R, rubix=False, pal=None, frames=600, repeats=5, singles=100):
+def resident_measure(torch, ctx, dst, W, rows, R, rubix=False, pal=None, frames=600, repeats=5, singles=100, orig_first_row=0):
     """The engine's real call is ONE frame per F_RenderView (fisheye.c:803): the resident apply (bk_apply_resident_*) - one kernel
     that stays on the device with the block map in registers, a frame is a command - over the same cold ring.  -> dict:
     pipelined = `frames` submissions back to back (bk_apply_resident_submit_batch), host wall clock / frames, median of
     `repeats`; one_at_a_time = submit, wait, submit ...: host wall clock and the device's own figure per frame."""
+    # eight rotating output buffers: consecutive frames are in flight together (a stripe's resident kernel runs up to eight frames side
+    # by side), and frames that share a destination would make their write-through stores collide on the same lines
+    NB = 8
+    obuf = torch.zeros((NB, rows, W), dtype=torch.uint8, device="cuda")
+    obase = obuf.data_ptr() - (orig_first_row * W)
     torch.cuda.synchronize()
     ctx.resident_begin(rubix, pal, idle_ms=200)
     info = ctx.resident_info()
     ctx.resident_wait(ctx.resident_submit(dst, W, frame=0))
+    frames = max(NB, frames // NB * NB)
     pipe = []
     for rep in range(repeats):
         t0 = time.perf_counter()
-        last = ctx.resident_submit_batch(dst, W, 0, frame0=(rep * frames) % R, nframes=frames)
+        for b in range(frames // NB):
+            last = ctx.resident_submit_batch(obase, W, rows * W, frame0=(rep * frames + b * NB) % R, nframes=NB)
         ctx.resident_wait(last)
         pipe.append((time.perf_counter() - t0) / frames * 1e6)
     wall, dev = [], []
@@ -230,7 +237,7 @@ class OneGpuWorkload:
         return statistics.median(out)
 
     def resident_us(self, frames=600):
-        return resident_measure(self.torch, self.ctx, self.origin(self.out[0]), self.W, self.rows, self.R, self.rubix, self.pal, frames=frames)
+        return resident_measure(self.torch, self.ctx, self.origin(self.out[0]), self.W, self.rows, self.R, self.rubix, self.pal, frames=frames, orig_first_row=self.r0)
 
     def close(self):
         self.torch.cuda.synchronize()
@@ -285,7 +292,7 @@ def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W,
     return rec
 
 
-def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, steps, t1_ms=None):
+def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, steps, t1_ms=None, resident_us_1=None):
     """What row-striping would give on N GPUs, measured on ONE: for N = 2 / 4 / 8 every rank's stripe is built and its F-frame launch
     timed here; a step of the N-GPU job lasts as long as its slowest rank's launch (stripe-complete throughput: nothing is exchanged).
     The stripes are the ones `bench.py --gpus N` uses: cut by the block map's row costs (bk_comm_rebalance), multiples of 8 rows.
@@ -306,17 +313,31 @@ def predicted_stripes(torch, blinky_amd, S, device_index, globe, lens, zoom, W, 
     out = {"frames_per_launch": F, "one_gpu_us_per_launch": round(t1_ms * 1e3, 2)}
     for n in (2, 4, 8):
         bounds = ffi.stripe_bounds_from_costs(cost, 0, n)
-        per_rank = []
+        per_rank, res_rank, res_err = [], [], None
         for r in range(n):
             wl = OneGpuWorkload(torch, blinky_amd, S, device_index, globe, lens, zoom, W, H, F, rows=(bounds[r], bounds[r + 1]), ring_max=32)
             for i in range(3):
                 wl.launch(i)
             per_rank.append(wl.kernel_ms(launches=max(10, steps // 2), repeats=5)[0])
+            if resident_us_1:
+                # the per-frame display pipeline: the stripe through ITS resident kernel, frames submitted one by one (pipelined); a
+                # stripe has fewer blocks than the chip has places, so the kernel runs several frames side by side (frame stride)
+                try:
+                    res_rank.append(wl.resident_us(frames=300)["us"])
+                except Exception as e:      # noqa: BLE001
+                    res_err = f"{type(e).__name__}: {e}"
             wl.close()
         worst = max(per_rank)
         out[str(n)] = {"slowest_rank_us_per_launch": round(worst * 1e3, 2), "fastest_rank_us_per_launch": round(min(per_rank) * 1e3, 2),
                        "stripe_rows": [bounds[r + 1] - bounds[r] for r in range(n)],
                        "stripe_complete_mpx_s": round(W * H * F / (worst * 1e-3) / 1e6, 1), "speedup_vs_1": round(t1_ms / worst, 3)}
+        if resident_us_1:
+            out.setdefault("frames1_resident", {"what": "one frame per command through each stripe's resident kernel (bk_apply_resident_*), pipelined "
+                                                        "submissions; a step = one frame, as long as the slowest rank's",
+                                                "one_gpu_us_per_frame": round(resident_us_1, 3)})
+            out["frames1_resident"][str(n)] = ({"error": res_err} if res_err or len(res_rank) != n else
+                                               {"slowest_rank_us_per_frame": round(max(res_rank), 3), "fastest_rank_us_per_frame": round(min(res_rank), 3),
+                                                "stripe_complete_mpx_s": round(W * H / max(res_rank), 1), "speedup_vs_1": round(resident_us_1 / max(res_rank), 3)})
     return out
 
 
@@ -832,7 +853,7 @@ def main():
     single_resident = None
     if world == 1:
         try:
-            single_resident = resident_measure(torch, ctx, origin(stripes[0]), W, rows, R)
+            single_resident = resident_measure(torch, ctx, origin(stripes[0]), W, rows, R, orig_first_row=r0)
         except Exception as e:      # noqa: BLE001
             single_resident = {"error": f"{type(e).__name__}: {e}"}
 
@@ -1010,7 +1031,8 @@ def main():
                 out["predicted_stripe_complete"] = dict(
                     what="rank r's stripe for N = 2 / 4 / 8 built and timed on this one GPU with the launch `bench.py --gpus N` issues (64 frames "
                          "per step, stripes cut by the block map's row costs); a step lasts as long as the slowest rank; no exchange",
-                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, 64, args.steps, k_med if F == 64 else None),
+                    **predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, 64, args.steps, k_med if F == 64 else None,
+                                        resident_us_1=single_resident.get("us") if isinstance(single_resident, dict) else None),
                     frames16=predicted_stripes(torch, blinky_amd, S, local_rank, GLOBE, LENS, ZOOM, W, H, EXTRA_FRAMES, args.steps,
                                                k_med if F == EXTRA_FRAMES else None),
                     C4_trism_panini=predicted_stripes(torch, blinky_amd, S, local_rank, "trism", "panini", "f_fov 180", W, H, 64, args.steps))

@@ -81,6 +81,9 @@ def test_bench_line_and_check_single_gpu():
     assert all(ps[n]["speedup_vs_1"] > 0.5 for n in ("2", "4", "8")), ps
     assert ps["frames_per_launch"] == 64 and all(sum(ps[n]["stripe_rows"]) == 2160 for n in ("2", "4", "8")), ps
     assert all(ps["C4_trism_panini"][n]["speedup_vs_1"] > 0.5 and ps["frames16"][n]["speedup_vs_1"] > 0.5 for n in ("2", "4", "8")), ps
+    # ... and the per-frame pipeline: every stripe through its own resident kernel, one frame per command (frame stride)
+    f1 = ps["frames1_resident"]
+    assert all("error" not in f1[n] and f1[n]["speedup_vs_1"] > 0.5 for n in ("2", "4", "8")), f1
 
 
 def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():
