@@ -147,7 +147,7 @@ extern "C" int bk_set_stream(bk_ctx *ctx, void *hip_stream)
 extern "C" int bk_synchronize(bk_ctx *ctx)
 {
     if (!ctx) return BK_E_INVALID;
-    if (int r = ensure_device(ctx, ctx->resident_mode != 0)) return r;      // (resident mode: the context's stream carries DMAs only; the session stays)
+    if (int r = ensure_device(ctx, true)) return r;      // (while a resident session runs the context's stream carries DMAs only: every kernel launch ends the session first)
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BK_OK;
 }
@@ -442,7 +442,7 @@ extern "C" int bk_upload_plate(bk_ctx *ctx, int frame, int plate, const uint8_t 
     if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate: call bk_resize first");
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_upload_plate: bad frame/plate/pitch");
-    if (ctx->resident_mode) {                       // re-tiled on the host, moved by one DMA: no kernel, the resident session stays
+    if (ctx->resident_mode || bk::resident_running(ctx)) {        // re-tiled on the host, moved by one DMA: no kernel, the resident session stays
         if (int r = bk_upload_plate_async(ctx, frame, plate, src, src_pitch)) return r;
         BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return BK_OK;
@@ -468,7 +468,8 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
     if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate_async: call bk_resize first");
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_upload_plate_async: bad frame/plate/pitch");
-    if (int r = ensure_device(ctx, ctx->resident_mode != 0)) return r;
+    const bool dma_only = ctx->resident_mode != 0 || bk::resident_running(ctx);      // a pure DMA does not need the CUs the resident kernel holds
+    if (int r = ensure_device(ctx, dma_only)) return r;
     // (the slots hold a whole plate image: rows gp apart for the re-tiling kernel, or - resident mode - the plate's tiles themselves)
     const size_t ps = ctx->ps, gp = ctx->gp, bytes = ctx->plate_bytes();
     if (ctx->plate_slot_bytes != bytes) {
@@ -486,7 +487,7 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
     BK_HIP(ctx, hipEventSynchronize(ctx->plate_ev[slot]));               // (a never-recorded event is complete)
     uint8_t *h = ctx->h_plate[slot];
     uint8_t *dst = ctx->d_globe + (size_t)frame * ctx->globe_stride() + (size_t)plate * ctx->plate_bytes();
-    if (ctx->resident_mode) {
+    if (dma_only) {
         // render_plate's row memcpy (fisheye.c:2441-2449) writing the device layout directly: 16 texels of a row are one 16-byte piece
         // of a 16x8 tile (bk_texel_offset) - then ONE linear DMA into the globe.  No kernel: the resident apply holds the CUs, the
         // SDMA engines do not need one (profiles/r05_resident_apply.txt (2)).  Padding texels (ps..gp, ps..ph) are never read.

@@ -90,11 +90,20 @@ def test_resident_frames_match_oracle(bk, hip, cfg, rubix):
     t = ctx.resident_submit(outs[F].data_ptr(), pitch, frame=0, x0=x0, y0=y0)
     ctx.resident_wait(t)
     assert ctx.resident_info()["launches"] == 1, "the kernel was meant to stay on the device through all of this"
+    # ... and bk_upload_plate / _async while the session runs: re-tiled on the host and moved by DMA, the kernel stays (the calls
+    # used to end the session, and every frame after an upload paid a relaunch)
+    extra = torch.from_numpy(bg.copy()).cuda()
+    for p in range(6):
+        (ctx.upload_plate if p % 2 else ctx.upload_plate_async)(0, p, globes[2][p])
+    ctx.synchronize()
+    ctx.resident_wait(ctx.resident_submit(extra.data_ptr(), pitch, frame=0, x0=x0, y0=y0))
+    assert ctx.resident_info()["launches"] == 1 and ctx.resident_info()["running"]
     ctx.resident_end()
     assert not ctx.resident_info()["running"]
     for f in range(F + 1):
         want = O.apply(lm.offsets, lm.tints, W, H, globes[f if f < F else 1], bg.copy(), pitch, x0, y0, rubix, pal)
         np.testing.assert_array_equal(outs[f].cpu().numpy(), want, err_msg=f"frame {f}")
+    np.testing.assert_array_equal(extra.cpu().numpy(), O.apply(lm.offsets, lm.tints, W, H, globes[2], bg.copy(), pitch, x0, y0, rubix, pal), err_msg="after the uploads")
     ctx.close()
 
 
