@@ -1339,6 +1339,11 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     // hammer: 12.4 us strided against 13.4; at 1440p and below, where the grid fits, the one-block form wins by 5-20 %).
     int wgs_per_band = per;
     int per_cu = ctx->apply_wgs_per_cu;
+    // (r5) batch launches: one block per workgroup up to 64 workgroups per CU's worth of them (16 384 on the chip), i.e. also for 64-frame
+    // launches of a 4K map (2040 blocks x 8 frame groups), which used to fall to the strided walk at three blocks per workgroup: 4K panini
+    // x64 242 -> 227 us per launch, trism/panini 204 -> 190, hammer 449 -> 439 (profiles/r05_c4_whole_vs_halves.txt) - the hardware deals
+    // queued workgroups to CUs as they free up, a static walk cannot
+    if (fchunk > 1 && per_cu == 16) per_cu = 64;
     if (fchunk == 1 && ctx->apply_wgs_per_cu == 16) {
         const int by_lds = (int)((160u * 1024u) / (shmem ? shmem : 1));
         const int by_regs = 8;                              // (one-block form: <= 64 VGPRs)

@@ -4,6 +4,7 @@ import torch, bench, blinky_amd, scripts as S
 from blinky_amd import ffi
 W, H, F = 3840, 2160, 64
 globe, lens, zoom = sys.argv[1:4] if len(sys.argv) > 3 else ("trism", "panini", "f_fov 180")
+zoom = zoom or None
 full = blinky_amd.Context(0); S.configure(full, globe, lens, zoom, (W, H)); full.build(); cost = full.row_costs(); full.close()
 b2 = ffi.stripe_bounds_from_costs(cost, 0, 2)
 for rows in [(0, H), (b2[0], b2[1]), (b2[1], b2[2])]:
