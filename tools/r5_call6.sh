@@ -1,2 +1,2 @@
-timeout -k 5 300 python tools/r5_c4.py cube panini "f_fov 180" 2>&1 | grep C4PROBE | head -3
-timeout -k 5 300 python tools/r5_c4.py cube hammer "" 2>&1 | grep C4PROBE | head -3
+timeout -k 5 200 python tools/r5_rubix.py 2>&1 | grep RUBIX
+timeout -k 5 400 python -m pytest tests/test_apply_gpu.py tests/test_apply_resident_gpu.py tests/test_saveglobe.py -x -q -m gpu 2>&1 | tail -2
