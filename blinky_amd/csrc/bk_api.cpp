@@ -49,7 +49,7 @@ static int ensure_device(bk_ctx *ctx, bool keep_resident = false)
     return BK_OK;
 }
 
-extern "C" const char *bk_version(void) { return "blinky-hip 0.4 (gfx950)"; }
+extern "C" const char *bk_version(void) { return "blinky-hip 0.5 (gfx950)"; }
 
 extern "C" bk_ctx *bk_create(int device)
 {
