@@ -58,9 +58,17 @@ struct CoopHdr {              // 8 bytes per block
 
 struct CoopMap {
     CoopHdr *d_hdr = nullptr;
-    uint32_t *d_list = nullptr;     // [nblocks][256*4*RG] byte offsets (16-byte aligned) into a globe frame, ascending
+    uint32_t *d_list = nullptr;     // [nblocks][256*4*RG] byte offsets (16-byte aligned) into a globe frame, ascending; a TINTED map (below)
+                                    // keeps the chunk's tint class in the low three bits: 0 = as it is, c = through palette row c - 1
     uint16_t *d_idx = nullptr;      // [nblocks][4 waves][RG][64 lanes][4] LDS addresses, 0xFFFF = unmapped
-    uint8_t *d_tint = nullptr;      // same order (rubix)
+    // (r5) rubix: the tint is applied to the STAGED CHUNK, not to the gathered pixel.  A pixel's tint is a property of the texel it reads
+    // (set_lensmap_grid, fisheye.c:1922-1960: the plate's number where the texel is on the grid), so a tinted map lists a chunk once per
+    // tint class its pixels need - (chunk, class) is what is sorted and made unique - and the staging pass sends the 16 bytes of a
+    // classed chunk through that palette row on their way to LDS.  The gather, its registers and its stores are the plain apply's:
+    // no tint byte per pixel in registers (the tinted 128x32 kernel ran at 94 VGPRs = 5 workgroups per CU = two rounds of workgroups
+    // for a 4K frame), no tint plane read per block visit.  At the default grid 10 % of the chunks are listed twice (a 16-texel row
+    // that crosses a cell's edge).  Any tint plane works - bk_set_lensmap's too: classes are the tint VALUES.
+    bool tinted = false;            // compiled for rubix launches; a plain launch gets a plain map (ensure_coopmap recompiles on a switch)
     // Work-balanced walk of the persistent apply: the live (non-empty) blocks in walk order, and where each XCD's band of
     // them starts - bands of equal COST (128-byte lines staged + a constant per block), not of equal block count.  A lens
     // that leaves part of the screen unmapped (hammer's ellipse, quincuncial under f_contain) otherwise gives the XCDs that
@@ -103,7 +111,7 @@ template <int RG>
 __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ tints,
                                                            int W, int rows, int blocks_x, int nblocks,
                                                            CoopHdr *__restrict__ hdr, uint32_t *__restrict__ list,
-                                                           uint16_t *__restrict__ idx, uint8_t *__restrict__ tint_t,
+                                                           uint16_t *__restrict__ idx, int tinted,
                                                            uint32_t *__restrict__ stats, int row_stride, uint32_t *__restrict__ cost,
                                                            int block_cost)
 {
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     if (threadIdx.x == 0) s_flags = 0;
 
     uint32_t o[NP];
-    uint8_t tn[NP];
+    uint32_t kc[NP];                              // sort key: chunk number * 8 + tint class (0 on a plain map)
     bool all_l = true, any_l = false;
     uint32_t npx = 0;                             // mapped pixels of this lane
 #pragma unroll
@@ -136,8 +144,9 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         const int row = oy + ry, x = x0 + i;
         const bool in = row < rows && x < W;
         o[i] = in ? lmap[(size_t)row * W + x] : BK_NULL_OFFSET;
-        tn[i] = in ? tints[(size_t)row * W + x] : 255;
-        key[threadIdx.x * NP + i] = o[i] == BK_NULL_OFFSET ? 0xFFFFFFFFu : o[i] >> 4;
+        const uint32_t tn = in && tinted ? tints[(size_t)row * W + x] : 255u;
+        kc[i] = o[i] == BK_NULL_OFFSET ? 0xFFFFFFFFu : ((o[i] >> 4) << 3) | (tn < (uint32_t)BK_MAX_PLATES ? tn + 1u : 0u);
+        key[threadIdx.x * NP + i] = kc[i];
         all_l = all_l && o[i] != BK_NULL_OFFSET;
         any_l = any_l || o[i] != BK_NULL_OFFSET;
         npx += o[i] != BK_NULL_OFFSET ? 1u : 0u;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
         const uint32_t v = key[p], prev = p > 0 ? key[p - 1] : 0xFFFFFFFFu;
         const bool first = v != 0xFFFFFFFFu && (p == 0 || v != prev);
         cnt += first ? 1u : 0u;
-        lcnt += (first && (p == 0 || (v >> 3) != (prev >> 3))) ? 1u : 0u;       // a new 128-byte line
+        lcnt += (first && (p == 0 || (v >> 6) != (prev >> 6))) ? 1u : 0u;       // a new 128-byte line
     }
     uint32_t incl = cnt, lsum = lcnt;
     for (int m = 1; m < 64; m <<= 1) {
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
             const uint32_t v = key[p];
             if (v != 0xFFFFFFFFu && (p == 0 || v != key[p - 1])) {
                 uniq[k] = v;
-                if (!slow && !survey) list[(size_t)blk * N + k] = v << 4;
+                if (!slow && !survey) list[(size_t)blk * N + k] = ((v >> 3) << 4) | (v & 7u);
                 ++k;
             }
         }
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     //  registers (4K panini single frame 8.5 -> 10.7 us, x16 +3-5 %; profiles/r03_barrier_and_pipelining_experiments.txt (5)).)
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
-        uint32_t a[4], tw = 0;
+        uint32_t a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = r * 4 + k;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
             if (o[i] != BK_NULL_OFFSET) {
                 a[k] = 0;
                 if (!slow) {
-                    const uint32_t c = o[i] >> 4;
+                    const uint32_t c = kc[i];
                     uint32_t lo = 0, hi = nchunks;              // first slot with uniq[slot] >= c
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi) >> 1;
@@ -227,11 +236,9 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
                     a[k] = lo * 16u + (o[i] & 15u);
                 }
             }
-            tw |= (uint32_t)tn[i] << (8 * k);
         }
         const size_t slab = (((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4;
         *reinterpret_cast<uint2 *>(idx + slab) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
-        *reinterpret_cast<uint32_t *>(tint_t + slab) = tw;
     }
     }
     if (threadIdx.x == 0) {
@@ -274,10 +281,27 @@ __global__ __launch_bounds__(256) void coop_compile_kernel(const uint32_t *__res
     } while (0)
 
 template <int RG>
-struct CoopIdx {              // a lane's LDS addresses (two 16-bit per dword) and tints, per row group
+struct CoopIdx {              // a lane's LDS addresses (two 16-bit per dword), per row group
     uint2 iw[RG];
-    uint32_t t4[RG];
 };
+// (r5) a chunk of a TINTED block map on its way to LDS (CoopMap::tinted): list entry `e` carries the chunk's tint class in its low bits -
+// class c > 0: the 16 texels go through palette row c - 1 here, once per chunk, and the gather behind it is the plain one
+__device__ __forceinline__ uint4 bk_tint_chunk(uint4 q, uint32_t e, const uint8_t *pal_s)
+{
+    const uint32_t cls = e & 7u;
+    if (cls) {
+        const uint8_t *row = pal_s + (cls - 1u) * 256u;
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (uint32_t)row[w[i] & 0xFFu] | ((uint32_t)row[(w[i] >> 8) & 0xFFu] << 8) | ((uint32_t)row[(w[i] >> 16) & 0xFFu] << 16) |
+                   ((uint32_t)row[w[i] >> 24] << 24);
+        q = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return q;
+}
+#define BK_CHUNK_OFF(E_) (RUBIX ? (E_) & ~15u : (E_))            /* a list entry's byte offset into the globe frame */
+#define BK_CHUNK_VAL(Q_, E_) (RUBIX && !(kflags & 65536) ? bk_tint_chunk((Q_), (E_), pal_s) : (Q_))   /* (developer bit 65536: timing without the tint) */
 // What a thread fetches ahead for its workgroup's NEXT block: the header (a vector load, so that it
 // is tracked by vmcnt like everything else) and its first four chunk-list entries.  The per-pixel LDS addresses are
 // loaded by coop_block itself: they are not needed before the first gather, so that load rides behind the header and
@@ -320,9 +344,9 @@ __device__ __forceinline__ CoopPrefetch<RG> coop_fetch(const CoopHdr *__restrict
     return p;
 }
 
-// the block's per-pixel LDS addresses (and tints)
+// the block's per-pixel LDS addresses
 template <bool RUBIX, int RG>
-__device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict__ idx, const uint8_t *__restrict__ tint_t, int blk,
+__device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict__ idx, const uint8_t *__restrict__, int blk,
                                                      int wave, int lane)
 {
     CoopIdx<RG> ix;
@@ -332,7 +356,6 @@ __device__ __forceinline__ CoopIdx<RG> coop_load_idx(const uint16_t *__restrict_
     for (int r = 0; r < RG; ++r) {
         const size_t slab = (((size_t)blk * 4 + wave) * RG + r) * 256 + (size_t)lane * 4;
         ix.iw[r] = *reinterpret_cast<const uint2 *>(idx + slab);
-        ix.t4[r] = RUBIX ? *reinterpret_cast<const uint32_t *>(tint_t + slab) : 0xFFFFFFFFu;
     }
     return ix;
 }
@@ -360,7 +383,8 @@ template <bool RUBIX, int RG, bool WT = false>
 __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const CoopIdx<RG> &ix, bool fast_store, const uint8_t *pal_s,
                                                   uint8_t *__restrict__ dst, size_t frame_stride, int dst_pitch, int f, int row0, int x, int kflags)
 {
-    if (!RUBIX && fast_store) {
+    // (RUBIX: the chunks in `buf` are tinted already - bk_tint_chunk - and the gather is the plain one)
+    if (fast_store) {
         uint32_t w[RG];
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
@@ -393,7 +417,7 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
         }
     } else if (WT) {
         // the resident kernel in a tile that is only PARTLY mapped (the rim of hammer's ellipse, the block with stereographic's one NULL
-        // pixel) or with rubix: write-through stores narrower than 16 bytes are a fabric write each (a byte 12x, a word 6x the time
+        // pixel): write-through stores narrower than 16 bytes are a fabric write each (a byte 12x, a word 6x the time
         // per byte), so a lane stores as wide as its own pixels allow - all of them mapped and the frame aligned: the one wide store
         // of the fast path; else word by word, and bytes only in the words with a hole.  Without this the ONE workgroup with such a
         // tile ran at half the others' pace, and the slowest workgroup sets the frame rate.
@@ -406,11 +430,7 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
             w[r] = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint32_t v = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
-                if (RUBIX) {
-                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt < (uint32_t)BK_MAX_PLATES) v = pal_s[tt * 256 + v];
-                }
+                const uint32_t v = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
                 w[r] |= v << (8 * k);
                 m |= a[k] != 0xFFFFu ? 1u << (4 * r + k) : 0u;
                 asm volatile("" : "+v"(w[r]));               // (one texel at a time: sixteen conditional byte reads are not to be in flight - in registers - at once)
@@ -451,10 +471,6 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[k] = a[k] != 0xFFFFu ? buf[a[k]] : 0u;
-                if (RUBIX) {
-                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
-                }
             }
             w[r] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
             if (!fast_store) {
@@ -464,17 +480,8 @@ __device__ __forceinline__ void coop_gather_store(const uint8_t *buf, const Coop
                     if (a[k] != 0xFFFFu) out[k] = (uint8_t)v[k];
             }
         }
-        // (r4) the tinted frame leaves like the plain one: ONE store of the lane's 4 * RG pixels.  A store per four pixels - round 1 to 3 -
-        // wrote a quarter of every 16 bytes four times over: WRITE_SIZE 452 MB for 133 MB of frames, 13.4 us per frame against 3.8 plain
-        if (fast_store && !(kflags & 4)) {
-            typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            uint8_t *o = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x;
-            if (RG == 1) __builtin_nontemporal_store(w[0], reinterpret_cast<uint32_t *>(o));
-            else if (RG == 2) { v2u v = {w[0], w[RG - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(o)); }
-            else { v4u v = {w[0], w[1 % RG], w[2 % RG], w[3 % RG]}; __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(o)); }
-        }
     }
+    (void)pal_s;
 }
 
 // Frames of one staged block.  A thread's first four chunks (16 KiB per block) are in registers;
@@ -510,12 +517,12 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
 #define BK_COOP_LOADS(F)                                                                                   \
     do {                                                                                                   \
         const uint8_t *gl_ = globe + (size_t)((frame0 + (F)) % globe_frames) * globe_stride;              \
-        BK_COOP_LD(q0, gl_ + s0);                                                                          \
-        if (NQ > 1) BK_COOP_LD(q1, gl_ + s1);                                                              \
-        if (NQ > 2) BK_COOP_LD(q2, gl_ + s2);                                                              \
-        if (NQ > 3) BK_COOP_LD(q3, gl_ + s3);                                                              \
-        if (NQ > 4) BK_COOP_LD(q4, gl_ + s4);                                                              \
-        if (NQ > 5) BK_COOP_LD(q5, gl_ + s5);                                                              \
+        BK_COOP_LD(q0, gl_ + BK_CHUNK_OFF(s0));                                                            \
+        if (NQ > 1) BK_COOP_LD(q1, gl_ + BK_CHUNK_OFF(s1));                                                \
+        if (NQ > 2) BK_COOP_LD(q2, gl_ + BK_CHUNK_OFF(s2));                                                \
+        if (NQ > 3) BK_COOP_LD(q3, gl_ + BK_CHUNK_OFF(s3));                                                \
+        if (NQ > 4) BK_COOP_LD(q4, gl_ + BK_CHUNK_OFF(s4));                                                \
+        if (NQ > 5) BK_COOP_LD(q5, gl_ + BK_CHUNK_OFF(s5));                                                \
     } while (0)
     // DMA form (single-frame launches): the chunks go HBM -> LDS directly (global_load_lds_dwordx4: a wave-uniform LDS base
     // + lane * 16 - exactly "list entry i -> slot i"), no staging registers, no ds_write pass; the barrier's fence waits for them
@@ -539,12 +546,12 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
             }
         } else {
         if (!pipe && !(kflags & 2)) BK_COOP_LOADS(f);
-        if (k0) *reinterpret_cast<uint4 *>(mine) = q0;
-        if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(mine + 4096) = q1;
-        if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(mine + 8192) = q2;
-        if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(mine + 12288) = q3;
-        if (NQ > 4 && k4) *reinterpret_cast<uint4 *>(mine + 16384) = q4;
-        if (NQ > 5 && k5) *reinterpret_cast<uint4 *>(mine + 20480) = q5;
+        if (k0) *reinterpret_cast<uint4 *>(mine) = BK_CHUNK_VAL(q0, s0);
+        if (NQ > 1 && k1) *reinterpret_cast<uint4 *>(mine + 4096) = BK_CHUNK_VAL(q1, s1);
+        if (NQ > 2 && k2) *reinterpret_cast<uint4 *>(mine + 8192) = BK_CHUNK_VAL(q2, s2);
+        if (NQ > 3 && k3) *reinterpret_cast<uint4 *>(mine + 12288) = BK_CHUNK_VAL(q3, s3);
+        if (NQ > 4 && k4) *reinterpret_cast<uint4 *>(mine + 16384) = BK_CHUNK_VAL(q4, s4);
+        if (NQ > 5 && k5) *reinterpret_cast<uint4 *>(mine + 20480) = BK_CHUNK_VAL(q5, s5);
         }
         if (!DMA && (NQ == 4 || NQ == 6)) {
             for (uint32_t c0 = REG_CHUNKS; c0 < nchunks; c0 += 1024) {      // blocks above what the registers hold: rounds of four loads
@@ -552,15 +559,15 @@ __device__ __forceinline__ void coop_frames(const uint8_t *__restrict__ globe, s
                 const bool m0 = c < nchunks, m1 = c + 256u < nchunks, m2 = c + 512u < nchunks, m3 = c + 768u < nchunks;
                 const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
                                a3 = m3 ? blist[c + 768u] : 0u;
-                BK_COOP_LD(q0, gl + a0);
-                BK_COOP_LD(q1, gl + a1);
-                BK_COOP_LD(q2, gl + a2);
-                BK_COOP_LD(q3, gl + a3);
+                BK_COOP_LD(q0, gl + BK_CHUNK_OFF(a0));
+                BK_COOP_LD(q1, gl + BK_CHUNK_OFF(a1));
+                BK_COOP_LD(q2, gl + BK_CHUNK_OFF(a2));
+                BK_COOP_LD(q3, gl + BK_CHUNK_OFF(a3));
                 uint8_t *md = mine + (size_t)c0 * 16u;
-                if (m0) *reinterpret_cast<uint4 *>(md) = q0;
-                if (m1) *reinterpret_cast<uint4 *>(md + 4096) = q1;
-                if (m2) *reinterpret_cast<uint4 *>(md + 8192) = q2;
-                if (m3) *reinterpret_cast<uint4 *>(md + 12288) = q3;
+                if (m0) *reinterpret_cast<uint4 *>(md) = BK_CHUNK_VAL(q0, a0);
+                if (m1) *reinterpret_cast<uint4 *>(md + 4096) = BK_CHUNK_VAL(q1, a1);
+                if (m2) *reinterpret_cast<uint4 *>(md + 8192) = BK_CHUNK_VAL(q2, a2);
+                if (m3) *reinterpret_cast<uint4 *>(md + 12288) = BK_CHUNK_VAL(q3, a3);
             }
         }
         if (DMA) __syncthreads();             // (the LDS-DMA form needs the fence's vmcnt(0): its loads ARE the LDS writes)
@@ -586,6 +593,7 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                                                    uint32_t nchunks, const CoopIdx<RG> ix, bool fast_store, bool tile_empty,
                                                    const uint8_t *pal_s, int row0, int x)
 {
+    constexpr int kflags = 0;                                // (BK_CHUNK_VAL's developer bit: not here)
     const uint32_t cpb = lds_buf >> 4;                       // chunks per pass
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
@@ -599,13 +607,13 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
                 const bool m0 = c < end, m1 = c + 256u < end, m2 = c + 512u < end, m3 = c + 768u < end;
                 const uint32_t a0 = m0 ? blist[c] : 0u, a1 = m1 ? blist[c + 256u] : 0u, a2 = m2 ? blist[c + 512u] : 0u,
                                a3 = m3 ? blist[c + 768u] : 0u;
-                const uint4 q0 = *reinterpret_cast<const uint4 *>(gl + a0), q1 = *reinterpret_cast<const uint4 *>(gl + a1),
-                            q2 = *reinterpret_cast<const uint4 *>(gl + a2), q3 = *reinterpret_cast<const uint4 *>(gl + a3);
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(gl + BK_CHUNK_OFF(a0)), q1 = *reinterpret_cast<const uint4 *>(gl + BK_CHUNK_OFF(a1)),
+                            q2 = *reinterpret_cast<const uint4 *>(gl + BK_CHUNK_OFF(a2)), q3 = *reinterpret_cast<const uint4 *>(gl + BK_CHUNK_OFF(a3));
                 uint8_t *md = buf + (size_t)(c - base) * 16u;
-                if (m0) *reinterpret_cast<uint4 *>(md) = q0;
-                if (m1) *reinterpret_cast<uint4 *>(md + 4096) = q1;
-                if (m2) *reinterpret_cast<uint4 *>(md + 8192) = q2;
-                if (m3) *reinterpret_cast<uint4 *>(md + 12288) = q3;
+                if (m0) *reinterpret_cast<uint4 *>(md) = BK_CHUNK_VAL(q0, a0);
+                if (m1) *reinterpret_cast<uint4 *>(md + 4096) = BK_CHUNK_VAL(q1, a1);
+                if (m2) *reinterpret_cast<uint4 *>(md + 8192) = BK_CHUNK_VAL(q2, a2);
+                if (m3) *reinterpret_cast<uint4 *>(md + 12288) = BK_CHUNK_VAL(q3, a3);
             }
             __syncthreads();
             if (!tile_empty) {
@@ -629,12 +637,7 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[k] = (w[r] >> (8 * k)) & 0xFFu;
-                if (RUBIX) {
-                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
-                    if (tt < (uint32_t)BK_MAX_PLATES) v[k] = pal_s[tt * 256 + v[k]];
-                }
             }
-            w[r] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
             if (!fast_store) {
                 uint8_t *out = dst + (size_t)f * frame_stride + (size_t)row0 * dst_pitch + x + 4 * r;
 #pragma unroll
@@ -657,16 +660,19 @@ __device__ __forceinline__ void coop_frames_multipass(const uint8_t *__restrict_
 template <bool RUBIX, int RG>
 __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap, const uint8_t *__restrict__ globe, size_t globe_stride,
                                               int globe_frames, int frame0, int f_begin, int f_end, uint8_t *__restrict__ dst,
-                                              int dst_pitch, size_t frame_stride, int W, int rows, const CoopIdx<RG> ix,
+                                              int dst_pitch, size_t frame_stride, int W, int rows, const uint8_t *__restrict__ tints,
                                               const uint8_t *pal_s, int row0, int x)
 {
-    uint32_t so[RG][4];
+    // (a block without a chunk list: its pixels' tints straight from the lensmap's tint plane, [rows][W])
+    uint32_t so[RG][4], st[RG];
 #pragma unroll
     for (int r = 0; r < RG; ++r)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = row0, xx = x + 4 * r + k;
             so[r][k] = (row < rows && xx < W) ? lmap[(size_t)row * W + xx] : BK_NULL_OFFSET;
+            if (k == 0) st[r] = 0xFFFFFFFFu;
+            if (RUBIX && row < rows && xx < W) st[r] = (st[r] & ~(0xFFu << (8 * k))) | ((uint32_t)tints[(size_t)row * W + xx] << (8 * k));
         }
     for (int f = f_begin; f < f_end; ++f) {
         const uint8_t *gl = globe + (size_t)((frame0 + f) % globe_frames) * globe_stride;
@@ -678,7 +684,7 @@ __device__ __noinline__ void coop_slow_frames(const uint32_t *__restrict__ lmap,
                 if (so[r][k] == BK_NULL_OFFSET) continue;
                 uint32_t v = gl[so[r][k]];
                 if (RUBIX) {
-                    const uint32_t tt = (ix.t4[r] >> (8 * k)) & 0xFFu;
+                    const uint32_t tt = (st[r] >> (8 * k)) & 0xFFu;
                     if (tt < (uint32_t)BK_MAX_PLATES) v = pal_s[tt * 256 + v];
                 }
                 out[k] = (uint8_t)v;
@@ -710,7 +716,7 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     if (flags & CF_SLOW) {
         if (!tile_empty)
             coop_slow_frames<RUBIX, RG>(lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch,
-                                        frame_stride, W, rows, ix, pal_s, row0, x);
+                                        frame_stride, W, rows, tint_t, pal_s, row0, x);
     } else if ((int)(nchunks * 16u) > lds_buf) {
         // a chunk list larger than this launch's staging buffer goes through it in passes
         coop_frames_multipass<RUBIX, RG>(globe, globe_stride, globe_frames, frame0, f_begin, f_end, dst, dst_pitch, frame_stride,
@@ -752,9 +758,12 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                                                   \
     uint8_t *pal_s = smem + lds_buf;                                                                                               \
+    /* rubix: the palette's 384 dwords are REQUESTED here and put into LDS by BK_COOP_PAL_COMMIT, behind the block's header and    \
+       list loads - a copy + barrier up here was a trip to memory of its own in front of everything a single-frame launch does */  \
+    uint32_t pal_r0 = 0, pal_r1 = 0;                                                                                               \
     if (RUBIX) {                                                                                                                   \
-        for (int i = threadIdx.x; i < BK_MAX_PLATES * 256; i += 256) pal_s[i] = pal[i];                                           \
-        __syncthreads();                                                                                                           \
+        pal_r0 = reinterpret_cast<const uint32_t *>(pal)[threadIdx.x];                                                             \
+        if (threadIdx.x < BK_MAX_PLATES * 64 - 256) pal_r1 = reinterpret_cast<const uint32_t *>(pal)[256 + threadIdx.x];           \
     }                                                                                                                              \
     const int per = (nblocks + 7) / 8;                                                                                             \
     const int band = (int)(blockIdx.x & 7);                                                                                        \
@@ -766,13 +775,18 @@ __device__ __forceinline__ void coop_block(const CoopPrefetch<RG> &cur, int l, c
     constexpr int LPR = 32 / RG;                  /* same pixel -> lane mapping as coop_compile_kernel */                        \
     const int ry = wave * 2 * RG + lane / LPR, cx = lane % LPR
 
+#define BK_COOP_PAL_COMMIT                                                                                                         \
+    if (RUBIX) {                                                                                                                   \
+        reinterpret_cast<uint32_t *>(pal_s)[threadIdx.x] = pal_r0;                                                                 \
+        if (threadIdx.x < BK_MAX_PLATES * 64 - 256) reinterpret_cast<uint32_t *>(pal_s)[256 + threadIdx.x] = pal_r1;               \
+        __syncthreads();                                                                                                           \
+    }
+
 // persistent form: a workgroup walks a strided list of blocks and prefetches the next one.  By default the list is the
 // XCD's band of the LIVE blocks in walk order, the bands cut at equal cost (CoopMap::d_order / d_bands; ablation bit 64:
 // bands of equal block count over all blocks, empty ones included, as in rounds 1 and 2a).
 template <bool RUBIX, int RG, int MAXQ = 4>
-// (the tinted forms carry a word of tints per pixel row as well: at the plain forms' register budgets they spilled 124-220 bytes per lane
-//  into scratch - in the frame loop; one workgroup per CU fewer costs less than that)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX && RG == 4 ? 4 : 5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void apply_coop_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
     (void)wgmap;
@@ -789,6 +803,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX && RG
     bool has_next = l_next < l_hi;
     int b_next = has_next ? BK_BLOCK_OF(l_next) : 0;
     CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, b_cur);
+    BK_COOP_PAL_COMMIT;
     for (;;) {
         CoopPrefetch<RG> nxt = cur;
         if (has_next) nxt = coop_fetch<RUBIX, RG>(hdr, list, b_next);
@@ -813,7 +828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX && RG
 // (8 waves per SIMD = 8 workgroups per CU: the 128x32 form would take 67 VGPRs and 7; at 4K that is 1792 places for 2040
 // blocks, and the 248 left over wait a whole block's latency for theirs - single frame 9.4 -> 8.4 us at <= 64 VGPRs)
 template <bool RUBIX, int RG, bool DMA = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX ? (RG == 4 ? 5 : 7) : 8, 8))) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_coop_once_kernel(BK_COOP_KERNEL_ARGS)
 {
     BK_COOP_PROLOGUE;
     (void)wgs_per_band; (void)order; (void)bands;
@@ -827,6 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RUBIX ? (RG
         blk = bk_block_at(l, blocks_x, nblocks, kflags);
     }
     const CoopPrefetch<RG> cur = coop_fetch<RUBIX, RG>(hdr, list, blk);
+    BK_COOP_PAL_COMMIT;
     coop_block<RUBIX, RG, DMA>(cur, blk, list, idx, tint_t, lmap, globe, globe_stride, globe_frames, frame0, f_begin, f_end,
                                dst, dst_pitch, frame_stride, W, rows, blocks_x, smem, lds_buf, pal_s, aligned, ry, cx, wave, kflags);
 }
@@ -912,7 +928,6 @@ void coopmap_free(CoopMap *cm)
     (void)hipFree(cm->d_hdr);
     (void)hipFree(cm->d_list);
     (void)hipFree(cm->d_idx);
-    (void)hipFree(cm->d_tint);
     (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands); (void)hipFree(cm->d_wgmap);
     (void)hipFree(cm->d_stats);
     if (cm->h_stats) (void)hipHostFree(cm->h_stats);
@@ -950,7 +965,7 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
     BK_HIP(ctx, hipMemsetAsync(st, 0, 64 * BK_COOP_STATS * sizeof(uint32_t), ctx->stream));
     const dim3 grid((unsigned)(bx * sampled_rows)), block(256);
 #define BK_COMPILE(N) hipLaunchKernelGGL((coop_compile_kernel<N>), grid, block, 0, ctx->stream, ctx->d_offsets, ctx->d_tints, ctx->W, rows, \
-                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->d_tint, st, row_stride, cm->d_cost, ctx->apply_block_cost >= 0 ? ctx->apply_block_cost : BK_COOP_BLOCK_COST)
+                                         bx, bx * by, cm->d_hdr, cm->d_list, cm->d_idx, cm->tinted ? 1 : 0, st, row_stride, cm->d_cost, ctx->apply_block_cost >= 0 ? ctx->apply_block_cost : BK_COOP_BLOCK_COST)
     if (rg == 1) BK_COMPILE(1); else if (rg == 2) BK_COMPILE(2); else BK_COMPILE(4);
 #undef BK_COMPILE
     BK_HIP(ctx, hipGetLastError());
@@ -958,7 +973,7 @@ static int coop_compile_launch(bk_ctx *ctx, CoopMap *cm, int rg, int row_stride,
 }
 
 static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num_cus, double *cost_ns);
-static int ensure_coopmap(bk_ctx *ctx, int launch_frames = 0);
+static int ensure_coopmap(bk_ctx *ctx, int launch_frames = 0, int want_tinted = -1);
 
 // the statistics of the last full compile, once somebody needs them (the apply launch itself does not)
 static int coop_stats_wait(bk_ctx *ctx, CoopMap *cm)
@@ -1032,10 +1047,20 @@ static int coop_choose_buffer(const CoopMap *cm, int rg, double npixels, int num
 
 static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, uint8_t *dst, int dst_pitch, size_t frame_stride, int rubix_on);
 
-static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
+// want_tinted: 1 / 0 = the launch that follows is a rubix / a plain one (CoopMap::tinted), -1 = whichever map there is
+static int ensure_coopmap(bk_ctx *ctx, int launch_frames, int want_tinted)
 {
     if (!ctx->coopmap) ctx->coopmap = new CoopMap();
     CoopMap *cm = ctx->coopmap;
+    bool flavour_switch = false;
+    if (want_tinted >= 0 && (want_tinted != 0) != cm->tinted) {
+        // the other flavour of the map (f_rubix was switched): compiled and tuned afresh - a tinted map lists some chunks twice
+        if (cm->valid) { flavour_switch = true; resident_quiesce(ctx); }
+        cm->valid = false;
+        for (auto &t : cm->tuned) t = CoopMap::Tuned();
+        cm->flips = 0;
+        cm->tinted = want_tinted != 0;
+    }
     // The measured choice (below) holds for the KIND of launch it was measured with: single frames, batches of up to 16, long batches
     // (a 270-row stripe x 64 frames ran 40.8 us on the 128x8 blocks a 16-frame measurement had picked, 32.5 us on 128x16).  A caller
     // that changes kind gets a fresh measurement - ~1.5 ms once, against every launch after it (tuned_frames was written
@@ -1065,7 +1090,7 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     // two-stream job - so that case drains the device first, and every compile is complete before this function returns: the launch
     // that follows may be on one stream and the one after it on another.
     bk::Range range("blockmap compile + tuning");
-    if (retune) BK_HIP(ctx, hipDeviceSynchronize());
+    if (retune || flavour_switch) BK_HIP(ctx, hipDeviceSynchronize());
     struct Settle {                                       // (every way out of this function below)
         bk_ctx *c;
         ~Settle() { (void)hipStreamSynchronize(c->stream); }
@@ -1077,15 +1102,14 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
     const size_t max_blocks = bx * (size_t)((rows + 7) / 8);
     const size_t max_px = bx * 4 * 256 * (size_t)((rows + 31) / 32 * 4 + 4);
     if (max_px > cm->alloc_px || max_blocks > cm->alloc_blocks) {      // (the header count follows ceil(rows/8), the rest ceil(rows/32))
-        (void)hipFree(cm->d_hdr); (void)hipFree(cm->d_list); (void)hipFree(cm->d_idx); (void)hipFree(cm->d_tint);
+        (void)hipFree(cm->d_hdr); (void)hipFree(cm->d_list); (void)hipFree(cm->d_idx);
         (void)hipFree(cm->d_cost); (void)hipFree(cm->d_order); (void)hipFree(cm->d_cum); (void)hipFree(cm->d_bands); (void)hipFree(cm->d_wgmap);
-        cm->d_hdr = nullptr; cm->d_list = nullptr; cm->d_idx = nullptr; cm->d_tint = nullptr;
+        cm->d_hdr = nullptr; cm->d_list = nullptr; cm->d_idx = nullptr;
         cm->d_cost = nullptr; cm->d_order = nullptr; cm->d_cum = nullptr; cm->d_bands = nullptr; cm->d_wgmap = nullptr;
         cm->alloc_px = cm->alloc_blocks = 0;
         BK_HIP(ctx, hipMalloc((void **)&cm->d_hdr, max_blocks * sizeof(CoopHdr)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_list, max_px * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_idx, max_px * sizeof(uint16_t)));
-        BK_HIP(ctx, hipMalloc((void **)&cm->d_tint, max_px));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_cost, max_blocks * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_order, max_blocks * sizeof(uint32_t)));
         BK_HIP(ctx, hipMalloc((void **)&cm->d_cum, max_blocks * sizeof(uint32_t)));
@@ -1254,10 +1278,10 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames)
                     cm->single_form = vs[k].form;
                     cm->fchunk = vs[k].fchunk;
                     cm->lds_bytes = clamp_kb(vs[k].kb) * 1024;
-                    rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
+                    rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, cm->tinted ? 1 : 0);
                     if (rc == BK_OK && hipEventRecord(t0, ctx->stream) != hipSuccess) rc = ctx->fail(BK_E_HIP, "block map tuning: hipEventRecord failed");
                     for (int rep = 0; rep < train && rc == BK_OK; ++rep)
-                        rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, 0);
+                        rc = launch_compiled(ctx, cm, (seq++ * nf) % span, nf, scratch, ctx->W, (size_t)rows * ctx->W, cm->tinted ? 1 : 0);
                     float ms = 0;
                     if (rc == BK_OK && (hipEventRecord(t1, ctx->stream) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
                                         hipEventElapsedTime(&ms, t0, t1) != hipSuccess))
@@ -1309,7 +1333,7 @@ int launch_apply_coop(bk_ctx *ctx, int frame0, int nframes, uint8_t *dst, int ds
 {
     const int rows = ctx->rows();
     if (rows <= 0 || nframes <= 0) return BK_OK;
-    if (int r = ensure_coopmap(ctx, nframes)) return r;
+    if (int r = ensure_coopmap(ctx, nframes, rubix_on ? 1 : 0)) return r;
     return launch_compiled(ctx, ctx->coopmap, frame0, nframes, dst, dst_pitch, frame_stride, rubix_on);
 }
 
@@ -1318,6 +1342,7 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
 {
     const int rows = ctx->rows();
     const int blocks_x = cm->blocks_x, nblocks = blocks_x * cm->blocks_y;
+    if ((rubix_on != 0) != cm->tinted) return ctx->fail(BK_E_STATE, "apply: the block map is not of this launch's flavour (internal)");
     // frames per block visit: 8, but a batch of 8..15 frames is split in two groups so that the grid has more
     // workgroups than one scheduling round holds (8 frames: 3.86 -> 3.70 us/frame)
     int fmax = ctx->apply_fchunk > 0 ? ctx->apply_fchunk : cm->fchunk > 0 ? cm->fchunk : 8;
@@ -1373,7 +1398,7 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     // LDS-DMA staging (bit 256) measured neutral (panini 8.39 -> 8.26, hammer 12.42 -> 12.41): the launch is bound by what
     // crosses the fabric, not by the staging instructions - it stays a developer bit.  Bit 512 leaves both to the caller.
     if (fchunk == 1 && !(kflags & 512)) kflags |= 128;
-    const bool dma = fchunk == 1 && (kflags & 256) != 0;
+    const bool dma = fchunk == 1 && (kflags & 256) != 0 && !rubix_on;        // (LDS-DMA cannot tint a chunk on its way)
     // the strided walk with six chunks per thread in registers (82 instead of 64-67 VGPRs: 6 instead of 7 workgroups per CU) only for
     // block maps that have blocks above 16 KiB - the whole-globe lenses, whose staging buffers allow 6 per CU or fewer anyway -
     // and for batch launches, where the frame pipeline is what it keeps those blocks in (ablation bit 4096: never)
@@ -1386,21 +1411,23 @@ static int launch_compiled(bk_ctx *ctx, CoopMap *cm, int frame0, int nframes, ui
     //  whole-globe lenses it was meant for have larger blocks.  What separates mercator's 16.5 us from hammer's 11.5 is not per-block
     //  latency but the quantisation of rounds: 4050 live blocks on 1792 resident places are 2.26 rounds and take 3.)
 #define BK_APPLY_K(KERNEL, RBX, N) hipLaunchKernelGGL((KERNEL<RBX, N>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
-                                           cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
+                                           ctx->d_tints, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
-#define BK_APPLY_KD(RBX, N) hipLaunchKernelGGL((apply_coop_once_kernel<RBX, N, true>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
-                                           cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
+#define BK_APPLY_KD(N) hipLaunchKernelGGL((apply_coop_once_kernel<false, N, true>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
+                                           ctx->d_tints, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
 #define BK_APPLY_KW(N) hipLaunchKernelGGL((apply_coop_kernel<false, N, 6>), grid, dim3(256), shmem, ctx->stream, cm->d_hdr, cm->d_list, cm->d_idx, \
-                                           cm->d_tint, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
+                                           ctx->d_tints, ctx->d_offsets, ctx->d_globe, ctx->globe_stride(), ctx->nframes, frame0, dst,    \
                                            dst_pitch, frame_stride, ctx->W, rows, blocks_x, nblocks, nframes, fchunk, lds_buf,           \
                                            ctx->d_pal, kflags, cm->d_order, cm->d_bands, cm->d_wgmap)
-#define BK_APPLY(RBX, N) do { if (once && dma) BK_APPLY_KD(RBX, N); else if (once) BK_APPLY_K(apply_coop_once_kernel, RBX, N);        \
-                              else if (wideq && !RBX) BK_APPLY_KW(N); else BK_APPLY_K(apply_coop_kernel, RBX, N); } while (0)
-    if (rubix_on) { if (cm->rg == 1) BK_APPLY(true, 1); else if (cm->rg == 2) BK_APPLY(true, 2); else BK_APPLY(true, 4); }
-    else { if (cm->rg == 1) BK_APPLY(false, 1); else if (cm->rg == 2) BK_APPLY(false, 2); else BK_APPLY(false, 4); }
+#define BK_APPLY(N) do { if (once && dma) BK_APPLY_KD(N); else if (once) BK_APPLY_K(apply_coop_once_kernel, false, N);                 \
+                         else if (wideq) BK_APPLY_KW(N); else BK_APPLY_K(apply_coop_kernel, false, N); } while (0)
+#define BK_APPLY_R(N) do { if (once) BK_APPLY_K(apply_coop_once_kernel, true, N); else BK_APPLY_K(apply_coop_kernel, true, N); } while (0)
+    if (rubix_on) { if (cm->rg == 1) BK_APPLY_R(1); else if (cm->rg == 2) BK_APPLY_R(2); else BK_APPLY_R(4); }
+    else { if (cm->rg == 1) BK_APPLY(1); else if (cm->rg == 2) BK_APPLY(2); else BK_APPLY(4); }
+#undef BK_APPLY_R
 #undef BK_APPLY_K
 #undef BK_APPLY_KD
 #undef BK_APPLY_KW

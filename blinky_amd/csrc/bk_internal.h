@@ -121,6 +121,9 @@ struct bk_ctx {
     int res_part = 0, res_parts = 1, res_reserve = 0;   // bk_set_resident_share: which CUs of every XCD the resident kernel may take
     uint64_t apply_ticket = 0;            // resident mode: the frame bk_apply_begin submitted
     uint8_t res_pal[BK_MAX_PLATES * 256] = {};   // resident mode: the palette the running session was begun with
+    uint8_t pal_cache[BK_MAX_PLATES * 256] = {}; // what d_pal holds, uploaded on pal_stream (upload_pal)
+    hipStream_t pal_stream = nullptr;
+    bool pal_cached = false;
     bool res_rubix = false;
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;

@@ -369,6 +369,44 @@ def test_apply_on_every_shipped_lens(bk, lens):
     ctx.close()
 
 
+def test_rubix_is_tinted_in_the_staging_and_the_map_follows_the_launch(bk):
+    """(r5) A rubix launch compiles a TINTED block map - a chunk listed once per tint class its pixels need, the palette applied to the
+    staged chunk, the gather the plain one - and a plain launch a plain one: switching back and forth recompiles, the chunk count
+    says which map is in place, every frame equals the oracle's (single frames, a batch, an unaligned destination)."""
+    import torch
+    import scripts as S
+    W, H, F = 1280, 720, 9
+    ctx = bk.Context()
+    ctx.set_frames(F)
+    S.configure(ctx, "cube", "panini", None, (W, H))
+    ctx.build()
+    off, tin = ctx.read_lensmap()
+    assert 0.2 < float((tin != 255).mean()) < 0.8            # the default rubix grid: cells tinted, gaps not
+    ps = min(W, H)
+    globes = [O.lcg_globe(ps, 6, f) for f in range(F)]
+    for f in range(F):
+        upload_globe(ctx, globes[f], f)
+    pal = O.palmap(O.synthetic_basepal())
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_tile_shape(4)                                    # (128 x 32 blocks for both maps: their chunk counts are comparable)
+    chunks = {}
+    for rubix in (False, True, False, True):
+        for nf, pitch, x0, y0 in ((1, W, 0, 0), (F, W, 0, 0), (1, W + 3, 1, 2)):
+            out = torch.full((nf, H + 4, pitch), 3, dtype=torch.uint8, device="cuda")
+            ctx.apply_device(out.data_ptr(), pitch, (H + 4) * pitch, frame0=2, nframes=nf, x0=x0, y0=y0, rubix_on=rubix, pal=pal)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for f in range(nf):
+                want = np.full((H + 4, pitch), 3, np.uint8)
+                O.apply(off, tin, W, H, globes[(2 + f) % F], want, pitch, x0, y0, rubix, pal)
+                np.testing.assert_array_equal(got[f], want, err_msg=f"rubix {rubix} nframes {nf} pitch {pitch} frame {f}")
+        chunks.setdefault(rubix, []).append(ctx.traffic_model()["staged_chunks"])
+    # a 16-texel row that crosses a grid cell's edge is listed twice in the tinted map - and only there
+    assert chunks[False][0] == chunks[False][1] and chunks[True][0] == chunks[True][1], chunks
+    assert 1.02 * chunks[False][0] < chunks[True][0] < 1.4 * chunks[False][0], chunks
+    ctx.close()
+
+
 def test_two_contexts_on_two_streams_do_not_interfere(bk):
     """independent contexts (different lenses, sizes, block maps) driven alternately on their own HIP streams"""
     import torch
