@@ -263,7 +263,10 @@ def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W,
     job1 = wl.job_seconds_per_step(steps=steps, repeats=11, nstreams=1)
     trace("  resident")
     model = wl.ctx.traffic_model()
-    comp = compulsory_bytes(model, F) + (F * model["mapped_pixels"] if rubix else 0)          # (rubix: + one tint byte per mapped pixel and frame ... per visit, counted per frame as the contract does)
+    # (rubix, r5: the tint plane is not read by the apply any more - a tinted block map carries the tint classes in its chunk list,
+    #  `blockmap_bytes_per_visit` counts those entries - so the compulsory model is the plain one over the tinted map; the
+    #  ALGORITHMIC count stays the reference's 7 B/px: fisheye.c:2416-2419 reads a tint byte per pixel and frame)
+    comp = compulsory_bytes(model, F)
     bpp = ALGO_BYTES_PER_PX + (1 if rubix else 0)
     algo = bpp * W * H * F
     rec = {"name": name, "workload": f"{W}x{H} {globe}/{lens} {zoom or 'onload zoom'}{' rubix on' if rubix else ''}, {F} frames/step from a ring of {wl.R} distinct globes",

@@ -776,10 +776,13 @@ extern "C" int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, in
     if (resident) {
         const uint64_t t = ctx->apply_ticket;
         ctx->apply_ticket = 0;
-        if (int r = bk::resident_wait(ctx, t, nullptr)) return r;     // the frame is in memory: the copies below are DMAs, they need no CU
-        if (!ctx->fully_mapped) BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
+        if (int r = bk::resident_wait(ctx, t, nullptr)) return r;     // the frame is in memory: the copy below is a DMA, it needs no CU
+        // ALWAYS through the pinned frame, then host rows: a 2-D copy into the caller's pageable, pitched buffer is a shader copy in
+        // this runtime for small frames, and a shader needs a place on a CU - with every place taken by the resident kernel (a 6-per-CU
+        // form filling the chip: rubix at 640x480) it waited for the kernel's idle exit, 200 ms per frame, and the session restarted
+        BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (ctx->fully_mapped) {
+    if (ctx->fully_mapped && !resident) {
         // nothing to preserve between the mapped pixels: one 2-D copy straight into the caller's buffer, no host merge
         BK_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)(y0 + ctx->row0) * dst_pitch + x0, (size_t)dst_pitch, ctx->d_frame, (size_t)ctx->W,
                                      (size_t)ctx->W, (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));

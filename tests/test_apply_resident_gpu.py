@@ -322,6 +322,49 @@ def test_resident_4k_frame_hash_equals_reference_golden(bk, key, shape):
     ctx.close()
 
 
+def test_drop_in_calls_on_a_session_that_fills_the_chip(bk):
+    """bk_set_resident_apply at 3840x2160 cube/panini: 2040 blocks on 2048 workgroups - not a free place on the chip.  bk_upload_plate +
+    bk_apply into a pitched host frame must still run on ONE launch of the kernel, every call in milliseconds: the plates travel by DMA and
+    so does the frame (through the pinned frame; a 2-D copy into a pageable buffer is a shader copy for small frames and waited for the
+    kernel's idle exit - 200 ms a frame - in round 5's first version).  Frame hash = the unmodified reference's; also with rubix on."""
+    import scripts as S
+    key = ("cube", "panini", None, 3840, 2160)
+    rec = GOLD[key]
+    W, H = 3840, 2160
+    ctx = bk.Context()
+    S.configure(ctx, *key[:3], (W, H))
+    ctx.build()
+    off, tin = ctx.read_lensmap()
+    ctx.set_resident_apply(True)
+    globe = O.lcg_globe(min(W, H), 6, 0)                     # (the plate size of the reference: the frame's smaller side)
+    pal = O.palmap(O.synthetic_basepal())
+    pitch, x0, y0 = W + 16, 5, 3
+    for i in range(6):
+        for p in range(6):
+            ctx.upload_plate(0, p, globe[p])
+        frame = np.full((H + 4, pitch), 9, np.uint8)
+        t0 = time.time()
+        ctx.apply(frame, pitch=pitch, x0=x0, y0=y0)
+        dt = time.time() - t0
+        info = ctx.resident_info()
+        assert info["running"] and info["launches"] == 1 and info["workgroups"] == 2048, info
+        assert i == 0 or dt < 0.05, f"bk_apply took {dt * 1e3:.1f} ms beside a resident kernel that holds every place"
+        assert O.fnv(np.ascontiguousarray(frame[y0:y0 + H, x0:x0 + W])) == rec["fnv_frame"]
+        assert (frame[:y0] == 9).all() and (frame[:, :x0] == 9).all() and (frame[:, x0 + W:] == 9).all()
+    want = np.zeros((H, W), np.uint8)
+    O.apply(off, tin, W, H, globe, want, W, 0, 0, True, pal)
+    for i in range(3):
+        frame = np.zeros((H, W), np.uint8)
+        t0 = time.time()
+        ctx.apply(frame, rubix_on=True, pal=pal)
+        dt = time.time() - t0
+        info = ctx.resident_info()
+        assert info["running"] and info["launches"] == 2, info
+        assert i == 0 or dt < 0.05, f"rubix: bk_apply took {dt * 1e3:.1f} ms"
+        np.testing.assert_array_equal(frame, want)
+    ctx.close()
+
+
 def test_resident_c5_8k_frames_equal_reference_golden(bk):
     """BASELINE.json configs[4] (7680x4320 cube/hammer) through the resident kernel: frames 0, 1, 5 and 63 of the 64-frame golden
     batch (frame 0 recorded from the unmodified reference, the others from the oracle's gather over the reference's lensmap), submitted
