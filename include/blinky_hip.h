@@ -241,8 +241,9 @@ int bk_apply_resident_info(bk_ctx *ctx, int out[12]);
  * forms that need more registers or LDS); `reserve_slots_per_cu` of those places stay free on every CU - kernels of this context, of
  * other contexts and of other libraries are scheduled there while the kernel is resident, provided they fit what a place leaves
  * (a quarter to an eighth of a CU's registers and LDS) - and the rest is split evenly between `parts` contexts of the same device, of
- * which this one is number `part`: stripe contexts on a one-GPU box each keep their own resident kernel.  Default 0 / 1 / 0: the
- * whole chip.  Takes effect at the next bk_apply_resident_begin / relaunch.  (Measured and not used: a CU-masked stream -
+ * which this one is number `part`: stripe contexts on a one-GPU box each keep their own resident kernel.  A form that fits a CU no more
+ * often than the reserve asks to leave free (64 KiB of staging for a scrambled table: twice) keeps one place per context - the reserve
+ * yields, such a workgroup leaves most of the CU to others anyway.  Default 0 / 1 / 0: the whole chip.  Takes effect at the next bk_apply_resident_begin / relaunch.  (Measured and not used: a CU-masked stream -
  * hipExtStreamCreateWithCUMask streams are blocking streams, so every null-stream operation of the process, PyTorch's default
  * stream included, then waits for the resident kernel to leave.)
  * bk_set_resident_apply(ctx, 1): the per-frame calls of the drop-in go through the resident kernel - bk_apply / bk_apply_begin .. _end

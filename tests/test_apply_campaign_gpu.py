@@ -86,8 +86,9 @@ def test_random_apply_configuration(seed):
     y0 = int(rng.integers(0, 4))
     rubix = bool(rng.random() < 0.4)
     pal = O.palmap(((np.arange(768) * int(rng.integers(1, 250)) + 11) % 256).astype(np.uint8))
+    flip = bool(rng.random() < 0.35)                                  # (r5) f_rubix switched between launches: the block map changes flavour (tinted <-> plain)
     cfg = (f"seed {seed}: {W}x{H} {what} rows [{r0},{r1}) ring {R} frames {nf} from {frame0} variant {variant} shape {shape} lds {ldskb}K "
-           f"tuning {tuning} ablation {ablation} pitch {pitch} origin ({x0},{y0}) rubix {rubix}")
+           f"tuning {tuning} ablation {ablation} pitch {pitch} origin ({x0},{y0}) rubix {rubix} flip {flip}")
 
     ctx = bk.Context()
     ctx.set_frames(R)
@@ -107,7 +108,9 @@ def test_random_apply_configuration(seed):
             ctx.upload_plate(f, p, globes[f][p])
     ctx.set_lensmap(off.reshape(H, W)[r0:r1].ravel(), tints.reshape(H, W)[r0:r1].ravel())
     FH = H + y0 + 2
-    for rep in range(2):                                              # (the second launch runs on the block map the first one compiled / measured)
+    rubix0 = rubix
+    for rep in range(3 if flip else 2):                               # (the second launch runs on the block map the first one compiled / measured)
+        rubix = (not rubix0) if (flip and rep == 1) else rubix0
         out = torch.full((nf, FH, pitch), 77, dtype=torch.uint8, device="cuda")
         ctx.apply_device(out.data_ptr(), pitch, FH * pitch, frame0=frame0, nframes=nf, x0=x0, y0=y0, rubix_on=rubix, pal=pal)
         torch.cuda.synchronize()
