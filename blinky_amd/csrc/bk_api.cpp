@@ -468,8 +468,12 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
     if (!ctx->d_globe) return ctx->fail(BK_E_STATE, "bk_upload_plate_async: call bk_resize first");
     if (plate < 0 || plate >= BK_MAX_PLATES || frame < 0 || frame >= ctx->nframes || src_pitch < ctx->ps)
         return ctx->fail(BK_E_INVALID, "bk_upload_plate_async: bad frame/plate/pitch");
-    const bool dma_only = ctx->resident_mode != 0 || bk::resident_running(ctx);      // a pure DMA does not need the CUs the resident kernel holds
-    if (int r = ensure_device(ctx, dma_only)) return r;
+    // beside a resident kernel (the session is not ended): a pure DMA needs none of the CUs it holds - the plate is re-tiled on the host;
+    // with a place per CU reserved for this context's kernels (bk_set_resident_share) the usual path runs beside it: rows by DMA, re-tiled
+    // by a kernel - a 4K plate costs the host 0.11 ms that way and 0.35 ms re-tiled here
+    const bool beside = ctx->resident_mode != 0 || bk::resident_running(ctx);
+    const bool dma_only = beside && !bk::resident_leaves_room(ctx);
+    if (int r = ensure_device(ctx, beside)) return r;
     // (the slots hold a whole plate image: rows gp apart for the re-tiling kernel, or - resident mode - the plate's tiles themselves)
     const size_t ps = ctx->ps, gp = ctx->gp, bytes = ctx->plate_bytes();
     if (ctx->plate_slot_bytes != bytes) {
@@ -491,12 +495,17 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
         // render_plate's row memcpy (fisheye.c:2441-2449) writing the device layout directly: 16 texels of a row are one 16-byte piece
         // of a 16x8 tile (bk_texel_offset) - then ONE linear DMA into the globe.  No kernel: the resident apply holds the CUs, the
         // SDMA engines do not need one (profiles/r05_resident_apply.txt (2)).  Padding texels (ps..gp, ps..ph) are never read.
+        // (tile row by tile row: eight source rows read side by side, the destination written front to back, whole 128-byte tiles at a
+        //  time - 2.1 ms for the six plates of a 4K globe on one host thread, what a plain row memcpy of them takes; row by row: 2.9)
         const size_t tpr = gp >> 4, full = ps >> 4, rest = ps & 15;
-        for (size_t y = 0; y < ps; ++y) {
-            const uint8_t *srow = src + y * (size_t)src_pitch;
-            uint8_t *trow = h + (y >> 3) * tpr * 128 + (y & 7) * 16;
-            for (size_t cx = 0; cx < full; ++cx) memcpy(trow + cx * 128, srow + cx * 16, 16);
-            if (rest) memcpy(trow + full * 128, srow + full * 16, rest);
+        for (size_t ty = 0; ty * 8 < ps; ++ty) {
+            const size_t nr = ps - ty * 8 < 8 ? ps - ty * 8 : 8;
+            uint8_t *trow = h + ty * tpr * 128;
+            const uint8_t *s0 = src + ty * 8 * (size_t)src_pitch;
+            for (size_t cx = 0; cx < full; ++cx)
+                for (size_t r = 0; r < nr; ++r) memcpy(trow + cx * 128 + r * 16, s0 + r * (size_t)src_pitch + cx * 16, 16);
+            if (rest)
+                for (size_t r = 0; r < nr; ++r) memcpy(trow + full * 128 + r * 16, s0 + r * (size_t)src_pitch + full * 16, rest);
         }
         BK_HIP(ctx, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
         BK_HIP(ctx, hipEventRecord(ctx->plate_ev[slot], ctx->stream));
@@ -773,16 +782,20 @@ extern "C" int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, in
     if (int r = ensure_device(ctx, resident)) return r;
     ctx->apply_in_flight = false;
     const int rows = ctx->rows();
+    bool pinned = false;
     if (resident) {
         const uint64_t t = ctx->apply_ticket;
         ctx->apply_ticket = 0;
-        if (int r = bk::resident_wait(ctx, t, nullptr)) return r;     // the frame is in memory: the copy below is a DMA, it needs no CU
-        // ALWAYS through the pinned frame, then host rows: a 2-D copy into the caller's pageable, pitched buffer is a shader copy in
-        // this runtime for small frames, and a shader needs a place on a CU - with every place taken by the resident kernel (a 6-per-CU
-        // form filling the chip: rubix at 640x480) it waited for the kernel's idle exit, 200 ms per frame, and the session restarted
-        BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
+        if (int r = bk::resident_wait(ctx, t, nullptr)) return r;     // the frame is in memory
+        // Through the pinned frame (one DMA), then host rows - unless a place per CU is reserved for this context's kernels: a 2-D copy
+        // into the caller's pageable, pitched buffer is a shader copy in this runtime for small frames, and a shader needs a place on a
+        // CU - with every place taken by the resident kernel (a 6-per-CU form filling the chip: rubix at 640x480) it waited for the
+        // kernel's idle exit, 200 ms per frame, and the session restarted
+        pinned = !bk::resident_leaves_room(ctx);
+        if (pinned || !ctx->fully_mapped)
+            BK_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->d_frame, (size_t)ctx->W * rows, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (ctx->fully_mapped && !resident) {
+    if (ctx->fully_mapped && !pinned) {
         // nothing to preserve between the mapped pixels: one 2-D copy straight into the caller's buffer, no host merge
         BK_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)(y0 + ctx->row0) * dst_pitch + x0, (size_t)dst_pitch, ctx->d_frame, (size_t)ctx->W,
                                      (size_t)ctx->W, (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));

@@ -193,6 +193,7 @@ int resident_info(bk_ctx *ctx, int out[12]);
 // every other device entry point of a context calls this first: a resident kernel fills the chip, whatever else the context
 // launches would wait for it to leave
 inline void resident_quiesce(bk_ctx *ctx) { if (ctx->resident) (void)resident_stop(ctx); }
+bool resident_leaves_room(bk_ctx *ctx);
 bool resident_running(bk_ctx *ctx);      // a session's kernel is on the device right now
 
 // bk_lens.cpp

@@ -396,10 +396,13 @@ void F_Init(void)                                   /* fisheye.c:642-676 */
         if (!bk) Con_Printf("fisheye: %s\n", bk_last_error(NULL));
     }
     /* BLINKY_HIP_RESIDENT=1: F_RenderView's per-frame calls - bk_upload_plate_async for every displayed plate, bk_apply - go through
-     * the resident apply kernel (one kernel that stays on the GPU, a frame is a command; the plates travel by DMA, re-tiled on the
-     * host): no kernel launch per frame.  BLINKY_HIP_RESERVE_SLOTS=n keeps n workgroup places of every CU free for other users of the GPU. */
+     * the resident apply kernel (one kernel that stays on the GPU, a frame is a command): no apply launch per frame.
+     * BLINKY_HIP_RESERVE_SLOTS=n keeps n workgroup places of every CU free - for other users of the GPU and for this context's own small
+     * kernels (the plates' re-tiling, the frame's copy back), which then run beside the resident kernel as they do without it; the
+     * default is 1.  With 0 the resident kernel may take every place: plates are re-tiled on the host and travel by DMA, the frame
+     * comes back through a pinned copy (1 ms more host work per 4K frame, nothing per frame on the GPU but the warp). */
     if (bk && getenv("BLINKY_HIP_RESIDENT") && atoi(getenv("BLINKY_HIP_RESIDENT")) != 0) {
-        const int reserve = getenv("BLINKY_HIP_RESERVE_SLOTS") ? atoi(getenv("BLINKY_HIP_RESERVE_SLOTS")) : 0;
+        const int reserve = getenv("BLINKY_HIP_RESERVE_SLOTS") ? atoi(getenv("BLINKY_HIP_RESERVE_SLOTS")) : 1;
         int i, rc = BK_OK;
         if (mg) {
             for (i = 0; i < bk_multi_size(mg) && rc == BK_OK; ++i) rc = bk_set_resident_share(bk_multi_ctx(mg, i), 0, 1, reserve);

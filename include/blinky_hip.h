@@ -247,9 +247,13 @@ int bk_apply_resident_info(bk_ctx *ctx, int out[12]);
  * hipExtStreamCreateWithCUMask streams are blocking streams, so every null-stream operation of the process, PyTorch's default
  * stream included, then waits for the resident kernel to leave.)
  * bk_set_resident_apply(ctx, 1): the per-frame calls of the drop-in go through the resident kernel - bk_apply / bk_apply_begin .. _end
- * submit the frame as a command and copy it back with the DMA engines, bk_upload_plate / bk_upload_plate_async re-tile the plate on
- * the HOST (render_plate's row memcpy, fisheye.c:2441-2449, writes tiles instead of rows) and move it with one DMA - no kernel launch
- * per frame, and none of these calls ends the session (a session is begun by the first bk_apply after a build, with that call's
+ * submit the frame as a command, and none of bk_apply* / bk_upload_plate* ends the session.  How plates and frames travel depends on the
+ * share: with reserve_slots_per_cu >= 1 (recommended for a drop-in: fisheye_hip.c's default) this context's small kernels run beside
+ * the resident kernel, so plates are re-tiled on the device and a fully mapped frame is copied straight into the caller's buffer, as
+ * without a resident kernel; with 0 the kernel may hold every place of the chip, and bk_upload_plate / bk_upload_plate_async re-tile
+ * the plate on the HOST (render_plate's row memcpy, fisheye.c:2441-2449, writes tiles instead of rows) and move it with one DMA, the
+ * frame comes back through a pinned copy + host rows - about 1 ms more host time per 3840x2160 frame, no kernel launch at all per frame
+ * (a session is begun by the first bk_apply after a build, with that call's
  * rubix flag and palette, and begun again when they change).  Everything else (bk_build, bk_resize, bk_apply_device ...) still ends it. */
 int bk_set_resident_share(bk_ctx *ctx, int part, int parts, int reserve_slots_per_cu);
 int bk_set_resident_apply(bk_ctx *ctx, int on);

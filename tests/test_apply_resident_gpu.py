@@ -322,11 +322,14 @@ def test_resident_4k_frame_hash_equals_reference_golden(bk, key, shape):
     ctx.close()
 
 
-def test_drop_in_calls_on_a_session_that_fills_the_chip(bk):
+@pytest.mark.parametrize("reserve", [0, 1], ids=["whole-chip", "a-place-per-cu-reserved"])
+def test_drop_in_calls_on_a_session_that_fills_the_chip(bk, reserve):
     """bk_set_resident_apply at 3840x2160 cube/panini: 2040 blocks on 2048 workgroups - not a free place on the chip.  bk_upload_plate +
     bk_apply into a pitched host frame must still run on ONE launch of the kernel, every call in milliseconds: the plates travel by DMA and
     so does the frame (through the pinned frame; a 2-D copy into a pageable buffer is a shader copy for small frames and waited for the
-    kernel's idle exit - 200 ms a frame - in round 5's first version).  Frame hash = the unmodified reference's; also with rubix on."""
+    kernel's idle exit - 200 ms a frame - in round 5's first version).  With a place per CU reserved (bk_set_resident_share) the plates are
+    re-tiled by a kernel and the frame is copied straight out, BESIDE the resident kernel.  Frame hash = the unmodified reference's; also
+    with rubix on."""
     import scripts as S
     key = ("cube", "panini", None, 3840, 2160)
     rec = GOLD[key]
@@ -335,6 +338,7 @@ def test_drop_in_calls_on_a_session_that_fills_the_chip(bk):
     S.configure(ctx, *key[:3], (W, H))
     ctx.build()
     off, tin = ctx.read_lensmap()
+    ctx.set_resident_share(0, 1, reserve)
     ctx.set_resident_apply(True)
     globe = O.lcg_globe(min(W, H), 6, 0)                     # (the plate size of the reference: the frame's smaller side)
     pal = O.palmap(O.synthetic_basepal())
@@ -347,7 +351,7 @@ def test_drop_in_calls_on_a_session_that_fills_the_chip(bk):
         ctx.apply(frame, pitch=pitch, x0=x0, y0=y0)
         dt = time.time() - t0
         info = ctx.resident_info()
-        assert info["running"] and info["launches"] == 1 and info["workgroups"] == 2048, info
+        assert info["running"] and info["launches"] == 1 and (info["workgroups"] == 2048 if reserve == 0 else info["per_cu"] <= 7), info
         assert i == 0 or dt < 0.05, f"bk_apply took {dt * 1e3:.1f} ms beside a resident kernel that holds every place"
         assert O.fnv(np.ascontiguousarray(frame[y0:y0 + H, x0:x0 + W])) == rec["fnv_frame"]
         assert (frame[:y0] == 9).all() and (frame[:, :x0] == 9).all() and (frame[:, x0 + W:] == 9).all()
