@@ -40,7 +40,9 @@ def main():
     for lens in lenses:
         row = [lens]
         for name, binary, extra in (("reference", T.TQ_REF, None), ("drop-in", T.TQ_HIP, None),
-                                    ("drop-in, lens compiled before", T.TQ_HIP, None)):
+                                    ("drop-in, lens compiled before", T.TQ_HIP, None),
+                                    ("drop-in on the resident apply (BLINKY_HIP_RESIDENT=1, a place per CU reserved)", T.TQ_HIP, {"BLINKY_HIP_RESIDENT": "1"}),
+                                    ("resident, whole chip (BLINKY_HIP_RESERVE_SLOTS=0)", T.TQ_HIP, {"BLINKY_HIP_RESIDENT": "1", "BLINKY_HIP_RESERVE_SLOTS": "0"})):
             t = times_of(binary, session(lens, frames), size, extra)
             steady = t[-(frames // 2):]
             change = max(t[8:8 + frames // 2]) if len(t) > 8 + frames // 2 else float("nan")
