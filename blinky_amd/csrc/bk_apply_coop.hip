@@ -1055,11 +1055,21 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames, int want_tinted)
     bool flavour_switch = false;
     if (want_tinted >= 0 && (want_tinted != 0) != cm->tinted) {
         // the other flavour of the map (f_rubix was switched): compiled and tuned afresh - a tinted map lists some chunks twice
-        if (cm->valid) { flavour_switch = true; resident_quiesce(ctx); }
+        flavour_switch = cm->valid;
         cm->valid = false;
         for (auto &t : cm->tuned) t = CoopMap::Tuned();
         cm->flips = 0;
         cm->tinted = want_tinted != 0;
+        // (a resident session of the other flavour holds the old map: it leaves first - AFTER the state above is consistent: ending it may
+        //  finish pending frames, which comes back here through res_launch)
+        if (flavour_switch) {
+            resident_quiesce(ctx);
+            if (cm->tinted != (want_tinted != 0)) {          // (those frames were of the session's flavour and compiled it back)
+                cm->valid = false;
+                for (auto &t : cm->tuned) t = CoopMap::Tuned();
+                cm->tinted = want_tinted != 0;
+            }
+        }
     }
     // The measured choice (below) holds for the KIND of launch it was measured with: single frames, batches of up to 16, long batches
     // (a 270-row stripe x 64 frames ran 40.8 us on the 128x8 blocks a 16-frame measurement had picked, 32.5 us on 128x16).  A caller

@@ -369,6 +369,39 @@ def test_drop_in_calls_on_a_session_that_fills_the_chip(bk, reserve):
     ctx.close()
 
 
+def test_a_launch_of_the_other_flavour_in_the_middle_of_a_session(bk):
+    """a plain session with frames still pending, then bk_apply_device with rubix on (the block map changes flavour: tinted), then the
+    session goes on (the map changes back): the pending frames are finished first, every frame is the oracle's, nothing recurses"""
+    import torch
+    lm = O.lensmap("cube", "panini", None, 640, 480)
+    W, H = lm.W, lm.H
+    pal = O.palmap(O.synthetic_basepal())
+    ctx = make_ctx(bk, lm, nframes=3)
+    globes = [O.lcg_globe(lm.ps, 6, 40 + f) for f in range(3)]
+    for f in range(3):
+        for p in range(6):
+            ctx.upload_plate(f, p, globes[f][p])
+    ctx.set_lensmap(lm.offsets, lm.tints)
+    outs = torch.zeros((8, H, W), dtype=torch.uint8, device="cuda")
+    tinted = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    ctx.resident_begin(idle_ms=2000)
+    for i in range(4):
+        ctx.resident_submit(outs[i].data_ptr(), W, frame=i % 3)                 # (not waited for)
+    ctx.apply_device(tinted.data_ptr(), W, H * W, frame0=1, nframes=1, rubix_on=True, pal=pal)      # ends the session: pending frames first
+    torch.cuda.synchronize()
+    last = 0
+    for i in range(4, 8):
+        last = ctx.resident_submit(outs[i].data_ptr(), W, frame=i % 3)          # the session comes back, on a plain map again
+    ctx.resident_wait(last)
+    ctx.resident_end()
+    for i in range(8):
+        np.testing.assert_array_equal(outs[i].cpu().numpy(), O.apply(lm.offsets, lm.tints, W, H, globes[i % 3], np.zeros((H, W), np.uint8)), err_msg=f"frame {i}")
+    np.testing.assert_array_equal(tinted.cpu().numpy(), O.apply(lm.offsets, lm.tints, W, H, globes[1], np.zeros((H, W), np.uint8), W, 0, 0, True, pal))
+    ctx.close()
+
+
 def test_resident_c5_8k_frames_equal_reference_golden(bk):
     """BASELINE.json configs[4] (7680x4320 cube/hammer) through the resident kernel: frames 0, 1, 5 and 63 of the 64-frame golden
     batch (frame 0 recorded from the unmodified reference, the others from the oracle's gather over the reference's lensmap), submitted
