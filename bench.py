@@ -423,6 +423,74 @@ def measure_traffic(args, F, R, block_h, config=None):
         "WRITE_SIZE_KiB_per_launch": round(w[3], 2), "seconds": round(time.time() - t0, 1)}
 
 
+COMPACT_LIMIT = 3072          # bytes: the driver keeps an ~8 KB tail of stdout and parses its LAST line (r5's 21 KB line was cut: parsed = null)
+
+
+def compact_line(out):
+    """The ONE JSON line the driver parses: the contract's keys and nothing that grows with the number of configurations.  The full
+    record (configs_extra, predicted stripes, timed regions, the traffic model, every prose note) goes to bench_detail.json."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    rf, cfg = out["roofline"], out["config"]
+    sf = rf.get("single_frame") or {}
+    res = sf.get("resident") if isinstance(sf.get("resident"), dict) else {}
+    line = pick(out, ("metric", "value", "value_one_stream", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_one_stream",
+                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = pick(cfg, ("workload", "frames_per_step", "ring_globes", "parallelism", "streams"))
+    line["roofline"] = pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "frac_compulsory", "kernel_ms_per_launch",
+                                 "kernel_ms_min", "kernel_ms_max"))
+    line["roofline"]["single_frame_us"] = sf.get("us")
+    line["roofline"]["resident_us"] = res.get("us")
+    line["roofline"]["resident_submit_wait_host_us"] = res.get("one_at_a_time_host_us")
+    line["roofline"]["frac_note"] = ("frac = the contract's 6 B/px / kernel time / peak; the kernel reads a 2-byte address once per 8 frames instead of "
+                                     "a 4-byte index per pixel and frame, so frac > 1 is not utilisation: frac_traffic (PMC bytes) is")
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "build_ms"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        if isinstance(cb.get("allcores"), dict):
+            line["cpu_baseline"]["allcores"] = pick(cb["allcores"], ("value", "cores", "kind"))
+    line.update(pick(out, ("lensmap_build_ms", "value_at_16_frames", "stripe_complete_mpx_s")))
+    if out.get("n_gpus", 1) > 1:
+        line.update(pick(out, ("assembled_on_rank0_mpx_s", "scaling_reference_mpx_s", "speedup_vs_scaling_reference")))
+        line["exchange"] = pick(out.get("exchange") or {}, ("bound_mpx_s", "bound_all_on_rank0_mpx_s"))
+        line["stripes"] = out.get("stripes")
+        line["first_step_check_ok"] = (out.get("first_step_check") or {}).get("ok")
+    extras = out.get("configs_extra")
+    if extras:
+        # one short entry per extra configuration: [kernel us per launch, frac_traffic (PMC), resident us per frame]
+        line["extras"] = {str(c.get("name", "?")).split(" (")[0].rstrip(","): ([c.get("kernel_us_per_launch"), c.get("frac_traffic"),
+                                                                               ((c.get("single_frame") or {}).get("resident") or {}).get("us")]
+                                                                              if "error" not in c else "error") for c in extras}
+        line["extras_are"] = "[kernel us/launch, frac_traffic, resident us/frame]"
+    line["detail"] = out.get("detail_file")
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:                     # never let an optional key cost the headline
+        for k in ("extras", "extras_are", "stripes", "exchange"):
+            line.pop(k, None)
+        line["roofline"].pop("frac_note", None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(out, detail_path):
+    """full record -> bench_detail.json (and gpurun_out/ when that scratch directory exists); compact line -> the LAST line of stdout"""
+    paths = [detail_path or os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and not detail_path:
+        paths.append(os.path.join(ROOT, "gpurun_out", f"bench_detail_n{out.get('n_gpus', 1)}.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError as e:
+            print(f"[bench] could not write {p}: {e}", file=sys.stderr, flush=True)
+    out["detail_file"] = written
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` outside torchrun: one process per GPU, this node, RCCL"""
     s = socket.socket()
@@ -462,6 +530,7 @@ def main():
                          "workgroups) then overlaps the ramp of the next; 1 = every launch on one stream")
     ap.add_argument("--variant", type=int, default=-1, help="apply kernel variant (-1 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", default="", help="where the full record goes (default: bench_detail.json beside bench.py); stdout's last line is the compact one")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region, compare every reassembled frame this rank owns with a full-frame warp")
     ap.add_argument("--no-first-step-check", action="store_true",
@@ -950,7 +1019,9 @@ def main():
             "speedup_vs_scaling_reference": round(value / scaling_reference, 3) if scaling_reference else None,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} {GLOBE}/{LENS} {ZOOM}, {F} frames/step from a resident ring of {R} distinct globes "
-                                   f"({R * 6 * 2160 * 2176 / 1e9:.2f} GB, advanced every step), one lensmap",
+                                   f"({R * 6 * 2160 * 2176 / 1e9:.2f} GB, advanced every step), one lensmap; value / ms_per_step = the job with steps "
+                                   f"alternating between {nstreams} HIP stream(s), value_one_stream = the same on one stream, roofline.kernel_ms_per_launch "
+                                   "= the kernel alone under HIP events; 64 frames/step since r5 (r1-r4 ran 16: compare those with value_at_16_frames)",
                        "frames_per_step": F, "ring_globes": R,
                        "parallelism": f"row-stripes x{world}" + ("" if world == 1 else (" + bk_comm (librccl grouped ncclSend/ncclRecv behind the C ABI)" if comm else " + gloo host exchange (developer smoke)" if host_exchange else " + torch.distributed RCCL send/recv (bk_comm unavailable)") +
                                                                      (": frame f reassembled on rank f%N" if exchange_mode == "rotating" else ": every frame gathered onto rank 0")),
@@ -1043,7 +1114,7 @@ def main():
                 out["predicted_stripe_complete"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        emit(out, args.detail)
     if comm:
         comm.synchronize()
         comm.close()

@@ -21,14 +21,36 @@ def _free_port():
     return p
 
 
+COMPACT_KEYS = {"metric", "value", "value_one_stream", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _assert_compact_contract(c, n):
+    assert COMPACT_KEYS <= set(c), COMPACT_KEYS - set(c)
+    assert c["n_gpus"] == n and c["value"] > 0 and c["ms_per_step"] > 0 and c["higher_is_better"] is True
+    assert c["unit"] == "Mpixels/s" and c["dtype"] == "u8" and c["data"] == "synthetic" and c["vs_baseline"] is None
+    assert {"workload", "frames_per_step", "ring_globes", "parallelism", "streams"} <= set(c["config"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "kernel_ms_per_launch"} <= set(c["roofline"])
+    assert c["roofline"]["bound"] == "hbm" and c["roofline"]["peak"] == 8000.0
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-3
+
+
 def test_bench_line_and_check_single_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "3", "--check",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "[check] rank 0: OK" in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(line) == 1
-    out = json.loads(line[0])
+    assert len(line) == 1 and r.stdout.rstrip().splitlines()[-1] == line[0]
+    # the line the driver parses is the LAST line of stdout, compact (r5's 21 KB line was cut by the driver's 8 KB tail), and
+    # carries the whole contract; the full record sits in the file it names
+    compact = json.loads(line[0])
+    assert len(line[0]) < 4096, len(line[0])
+    _assert_compact_contract(compact, 1)
+    assert compact["steps"] == 3 and compact["warmup"] == 1
+    out = json.load(open(os.path.join(ROOT, compact["detail"])))
+    assert out["value"] == compact["value"] and out["roofline"]["frac"] == compact["roofline"]["frac"]
+    assert set(compact["extras"]) == {"C2", "C2x64", "C3", "C5", "headline, rubix on", "4K cube/hammer"}, compact["extras"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
@@ -94,7 +116,14 @@ def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "[check] rank 0: OK" in r.stderr and "[check] rank 1: OK" in r.stderr
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    compact = json.loads(r.stdout.rstrip().splitlines()[-1])
+    assert len(r.stdout.rstrip().splitlines()[-1]) < 4096
+    _assert_compact_contract(compact, 2)
+    # (the N > 1 compact line also carries the three figures SURVEY.md 8(e) asks for)
+    for k in ("stripe_complete_mpx_s", "assembled_on_rank0_mpx_s", "exchange", "stripes", "first_step_check_ok", "scaling_reference_mpx_s"):
+        assert k in compact, k
+    assert compact["first_step_check_ok"] is True and compact["exchange"]["bound_mpx_s"] > 0
+    out = json.load(open(os.path.join(ROOT, compact["detail"])))
     assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 5
     # the same JSON keys the RCCL path prints (the driver's SCALE run parses this line at N = 2 / 4 / 8), stripes cut by work, and the
     # first step checked on every rank before anything was timed
@@ -113,7 +142,9 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--repeats", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    compact = json.loads(r.stdout.rstrip().splitlines()[-1])
+    _assert_compact_contract(compact, 2)
+    out = json.load(open(os.path.join(ROOT, compact["detail"])))
     assert out["n_gpus"] == 2
     # the N > 1 line runs the SAME frames per step as the N = 1 line (no --frames given: the default), names the transport that was
     # timed, and carries the one-GPU job of that very workload, timed by rank 0 in the same run, as the curve's denominator
