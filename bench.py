@@ -532,7 +532,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", default="", help="where the full record goes (default: bench_detail.json beside bench.py); stdout's last line is the compact one")
     ap.add_argument("--check", action="store_true",
-                    help="after the timed region, compare every reassembled frame this rank owns with a full-frame warp")
+                    help="after the timed region, compare the FNV-1a-64 of every frame this rank holds with the reference's golden frames "
+                         "(tests/golden/lensmaps.json, recorded from the unmodified fisheye.c)")
     ap.add_argument("--no-first-step-check", action="store_true",
                     help="N > 1: skip the check of the first step's reassembled frames against a full-frame warp (on by default: the first "
                          "time the exchange runs on a node is the time to find out)")
@@ -930,31 +931,35 @@ def main():
             single_resident = {"error": f"{type(e).__name__}: {e}"}
 
     if args.check:
-        # every frame this rank ends up holding == the same frame warped whole by a full-height context
-        full_ctx = blinky_amd.Context(local_rank)
-        full_ctx.set_stream(stream.cuda_stream)
-        full_ctx.set_frames(F)
-        S.configure(full_ctx, GLOBE, LENS, ZOOM, (W, H))
-        full_ctx.build()
+        # Every frame this rank ends up holding after the LAST step of the timed region, against the reference: FNV-1a-64 per frame
+        # compared with tests/golden/lensmaps.json (frame 0 recorded from the unmodified fisheye.c, the rest from the oracle's
+        # render_lensmap over the reference's lensmap: tests/golden/make_golden.py).  Frame f of that step is LCG globe (g0 + f) % R,
+        # which the goldens cover while R <= 64.  Nothing of the CPU oracle is touched here: the hash is bk_debug_fnv1a64.
+        from concurrent.futures import ThreadPoolExecutor
+        gold = None
+        for rec in json.load(open(os.path.join(ROOT, "tests", "golden", "lensmaps.json")))["lensmaps"]:
+            if (rec["globe"], rec["lens"], rec["W"], rec["H"]) == (GLOBE, LENS, W, H) and rec["zoom"] in (None, ZOOM) and "fnv_frames" in rec:
+                gold, gold_rec = rec["fnv_frames"], rec
+        if gold is None or R > len(gold):
+            sys.exit(f"[check] no golden frames for {W}x{H} {GLOBE}/{LENS} over a ring of {R} globes (tests/golden/lensmaps.json)")
         last_i = args.warmup + max(1, nrep // 4 if one_stream_elapsed is not None else nrep) * args.steps - 1   # the last step of the last timed region
         g0 = first_globe(last_i)
-        for f in range(F):
-            for p in range(6):
-                full_ctx.fill_plate_lcg(f, p, (g0 + f) % R)
-        full = torch.zeros((F, H, W), dtype=torch.uint8, device=dev)
-        full_ctx.apply_device(full.data_ptr(), W, H * W, frame0=0, nframes=F)
-        torch.cuda.synchronize()
         if world > 1:
-            if exchange_mode == "rotating":
-                last = frames_out[last_i % NB]
-                bad = [f for f in multigpu.owned_frames(F, rank, world) if not torch.equal(last[f // world].to(dev), full[f])]
-            else:
-                bad = []
+            mine = multigpu.owned_frames(F, rank, world) if exchange_mode == "rotating" else []
+            held = {f: frames_out[last_i % NB][f // world] for f in mine}
         else:
-            ctx.apply_device(origin(stripe), W, rows * W, frame0=g0, nframes=F)
+            ctx.apply_device(origin(stripe), W, rows * W, frame0=g0, nframes=F)      # the timed launch once more, into a buffer read back here
             torch.cuda.synchronize()
-            bad = [f for f in range(F) if not torch.equal(stripe[f], full[f])]
-        print(f"[check] rank {rank}: {'OK' if not bad else 'MISMATCH in frames ' + str(bad)}", file=sys.stderr, flush=True)
+            held = {f: stripe[f] for f in range(F)}
+            off, tin = ctx.read_lensmap()                  # ... and the table the timed launches gathered through IS the reference's
+            if (blinky_amd.ffi.fnv1a64(off), blinky_amd.ffi.fnv1a64(tin), repr(scale)) != (gold_rec["fnv_offsets"], gold_rec["fnv_tints"], gold_rec["scale"]):
+                sys.exit("[check] the lensmap this run built differs from the reference's golden (offsets / tints / scale)")
+            del off, tin
+        with ThreadPoolExecutor(8) as pool:
+            got = dict(zip(held, pool.map(lambda t: blinky_amd.ffi.fnv1a64(t.cpu().numpy()), held.values())))
+        bad = [f for f in held if got[f] != gold[(g0 + f) % R]]
+        print(f"[check] rank {rank}: {'OK' if not bad else 'MISMATCH in frames ' + str(bad)} ({len(held)} frames against tests/golden/lensmaps.json)",
+              file=sys.stderr, flush=True)
         if bad:
             sys.exit(3)
 

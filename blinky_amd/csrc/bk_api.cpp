@@ -632,7 +632,11 @@ extern "C" int bk_apply_resident_begin(bk_ctx *ctx, int rubix_on, const uint8_t 
     if (int r = ensure_device(ctx)) return r;
     bk::Range range("bk_apply_resident_begin");
     if (int r = upload_pal(ctx, rubix_on, pal)) return r;
-    return bk::resident_begin(ctx, rubix_on, idle_ms);
+    if (int r = bk::resident_begin(ctx, rubix_on, idle_ms)) return r;
+    // what this session tints with: bk_apply_begin compares its own call's rubix flag and palette against these, whoever began the session
+    ctx->res_rubix = rubix_on != 0;
+    if (rubix_on) memcpy(ctx->res_pal, pal, sizeof ctx->res_pal);
+    return BK_OK;
 }
 
 extern "C" int bk_apply_resident_submit(bk_ctx *ctx, int frame, void *dst_dev, int dst_pitch, int x0, int y0, uint64_t *ticket)
@@ -760,8 +764,11 @@ extern "C" int bk_apply_begin(bk_ctx *ctx, int frame, int rubix_on, const uint8_
         uint8_t *first = ctx->d_frame;                                // a tight staging frame of the owned rows: its pixel (0, row0) is d_frame
         if (int r = bk::resident_submit(ctx, frame, first, ctx->W, &ctx->apply_ticket)) return r;
         ctx->apply_in_flight = true;
+        ctx->apply_was_resident = true;                               // bk_apply_end follows THIS call's path, whatever bk_set_resident_apply says by then
         return BK_OK;
     }
+    ctx->apply_was_resident = false;
+    ctx->apply_ticket = 0;
     if (int r = ensure_device(ctx)) return r;
     bk::Range range("bk_apply_begin");
     if (int r = ensure_spans(ctx)) return r;
@@ -778,7 +785,7 @@ extern "C" int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, in
 {
     if (!ctx || !dst) return BK_E_INVALID;
     if (!ctx->apply_in_flight) return ctx->fail(BK_E_STATE, "bk_apply_end without bk_apply_begin");
-    const bool resident = ctx->resident_mode && ctx->apply_ticket != 0;
+    const bool resident = ctx->apply_was_resident && ctx->apply_ticket != 0;
     if (int r = ensure_device(ctx, resident)) return r;
     ctx->apply_in_flight = false;
     const int rows = ctx->rows();

@@ -125,6 +125,7 @@ struct bk_ctx {
     hipStream_t pal_stream = nullptr;
     bool pal_cached = false;
     bool res_rubix = false;
+    bool apply_was_resident = false;      // latched by bk_apply_begin: the frame in flight went to the resident kernel
     bk::LensProgram *prog = nullptr;      // owned; freed with bk::lensprogram_free
     double last_build_ms = 0;
     double last_host_eval_ms = 0;    // of that: wall time of the host re-evaluation of the flagged entries

@@ -111,4 +111,16 @@ extern "C" int bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int wr
     *gbps = ((double)bytes + written) / ((double)best * 1e-3) / 1e9;
     return BK_OK;
 }
+
+// FNV-1a-64 of a host buffer: the hash tests/golden/lensmaps.json records frames with, so that `bench.py --check` can hold the
+// frames of its timed launch against the committed goldens without touching the CPU oracle
+extern "C" int bk_debug_fnv1a64(const void *host, size_t bytes, uint64_t *out)
+{
+    if ((!host && bytes) || !out) return BK_E_INVALID;
+    const unsigned char *p = (const unsigned char *)host;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    *out = h;
+    return BK_OK;
+}
 #endif

@@ -108,6 +108,7 @@ _SIGS = {
     "bk_debug_traffic_model": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "bk_debug_band_balance": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "bk_debug_stream_mix": (_i, [_vp, _sz, _i, _i, C.POINTER(_d)]),
+    "bk_debug_fnv1a64": (_i, [_vp, _sz, C.POINTER(C.c_uint64)]),
     "bk_debug_resident_latency": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d)]),
     "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
@@ -746,3 +747,14 @@ def create_palmap(basepal):
     out = np.empty((MAX_PLATES, 256), np.uint8)
     lib.bk_create_palmap(_ptr(basepal), _ptr(out))
     return out
+
+
+def fnv1a64(a):
+    """FNV-1a-64 of a host array, as the hex string tests/golden/lensmaps.json records (bk_debug_fnv1a64; ctypes drops the GIL,
+    so a thread pool hashes a batch of frames in parallel)"""
+    a = np.ascontiguousarray(a)
+    out = C.c_uint64()
+    rc = lib.bk_debug_fnv1a64(_ptr(a), a.nbytes, C.byref(out))
+    if rc != OK:
+        raise BlinkyError(f"[{rc}] bk_debug_fnv1a64")
+    return "%016x" % out.value

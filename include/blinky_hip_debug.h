@@ -50,6 +50,8 @@ int         bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18]);
  * every `period` KiB of it back with non-temporal stores - what this memory system gives a kernel with that read : write
  * ratio and nothing else to do (best of 5 passes; allocates and frees 2 x bytes) */
 int         bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps);
+/* FNV-1a-64 of a HOST buffer - the hash tests/golden/lensmaps.json pins frames with (bench.py --check) */
+int         bk_debug_fnv1a64(const void *host, size_t bytes, uint64_t *out);
 /* the resident apply one frame at a time, on the C host's clock (what fisheye_hip.c pays, without a binding in between): `frames`
  * times bk_apply_resident_submit + bk_apply_resident_wait of globe (7 i) % globes into dst_dev; medians of the host wall clock and of
  * the device's own figure (command seen -> frame complete), microseconds.  Needs a session (bk_apply_resident_begin). */

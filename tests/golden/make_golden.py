@@ -79,7 +79,11 @@ CONFIGS = [
 # configs whose record also carries `fnv_frames`: one hash per frame of a batch over the LCG globes 0..n-1
 # (SURVEY.md 8(d)).  Frame 0 comes from the unmodified reference; the others from the oracle's render_lensmap
 # restatement applied to the REFERENCE's lensmap (building the 8K map 64 times over would take ten minutes).
-BATCH = {("cube", "hammer", None, 7680, 4320): 64, ("cube", "panini", None, 3840, 2160): 16}
+# r6: the bench headline's own launch (4K cube/panini x 64) and C4 (4K trism/panini x 64) carry all 64 frames.
+BATCH = {("cube", "hammer", None, 7680, 4320): 64, ("cube", "panini", None, 3840, 2160): 64, ("trism", "panini", None, 3840, 2160): 64}
+# configs whose record also carries `fnv_frame_rubix`: frame 0 warped by the unmodified reference with f_rubix on (grid 10/4/1,
+# the reference's own create_palmap over the synthetic base palette: fisheye.c:2416-2419)
+RUBIX = {("cube", "panini", None, 3840, 2160), ("trism", "panini", None, 3840, 2160), ("cube", "panini", None, 640, 480)}
 
 
 def main():
@@ -91,8 +95,9 @@ def main():
             have[(r["globe"], r["lens"], r["zoom"], r["W"], r["H"])] = r
     out = []
     for globe, lens, zoom, W, H in CONFIGS:
-        if (globe, lens, zoom, W, H) in have:
-            out.append(have[(globe, lens, zoom, W, H)])
+        key = (globe, lens, zoom, W, H)
+        if key in have and len(have[key].get("fnv_frames", [])) >= BATCH.get(key, 0) and (key not in RUBIX or "fnv_frame_rubix" in have[key]):
+            out.append(have[key])
             continue
         lm, frame = O.ref_run(globe, lens, zoom, W, H)
         rec = dict(globe=globe, lens=lens, zoom=zoom, W=W, H=H, built=bool(lm.built), scale=repr(lm.scale),
@@ -107,6 +112,14 @@ def main():
                 hashes.append(O.fnv(fr))
             assert hashes[0] == rec["fnv_frame"]            # the restatement's frame 0 IS the reference's
             rec["fnv_frames"] = hashes
+        if key in RUBIX:
+            lm2, frame2 = O.ref_run(globe, lens, zoom, W, H, rubix_on=True)
+            assert O.fnv(lm2.offsets) == rec["fnv_offsets"] and O.fnv(lm2.tints) == rec["fnv_tints"]
+            rec["fnv_frame_rubix"] = O.fnv(frame2)
+        if key in have:                                     # an upgraded record must agree with what was pinned before
+            old = have[key]
+            assert all(rec[k] == old[k] for k in ("scale", "display", "nonnull", "fnv_offsets", "fnv_tints", "fnv_frame")), key
+            assert rec.get("fnv_frames", [])[: len(old.get("fnv_frames", []))] == old.get("fnv_frames", []), key
         print(rec)
         out.append(rec)
     pal = O.ref_palettes()

@@ -309,8 +309,9 @@ def test_apply_4k_frame_hash_equals_reference_golden(bk, key, variant):
 
 @pytest.mark.parametrize("key", [k for k, r in GOLD.items() if "fnv_frames" in r], ids=lambda k: f"{k[0]}-{k[1]}-{k[3]}x{k[4]}")
 def test_batch_launch_equals_reference_golden_frames(bk, key):
-    """BASELINE.json configs[4] at full size (7680x4320 cube/hammer, 64 frames, 64 distinct resident globes) and the
-    bench workload (3840x2160 cube/panini, 16 frames): the GPU builds the lensmap from the Lua scripts, ONE
+    """BASELINE.json configs[4] at full size (7680x4320 cube/hammer, 64 frames, 64 distinct resident globes), the bench
+    headline's own launch (3840x2160 cube/panini, 64 frames from a ring of 64: the grid `bench.py` times) and C4's map
+    (3840x2160 trism/panini, 64 frames): the GPU builds the lensmap from the Lua scripts, ONE
     bk_apply_device launch warps the whole batch, and every frame's hash equals the golden (frame 0 recorded from
     the unmodified reference, the others from the oracle's gather over the reference's lensmap)."""
     import torch
@@ -336,6 +337,43 @@ def test_batch_launch_equals_reference_golden_frames(bk, key):
     torch.cuda.synchronize()
     for f in range(F):
         assert O.fnv(out[f].cpu().numpy()) == rec["fnv_frames"][f], f"frame {f}"
+    ctx.close()
+
+
+@pytest.mark.parametrize("key", [k for k, r in GOLD.items() if "fnv_frame_rubix" in r], ids=lambda k: f"{k[0]}-{k[1]}-{k[3]}x{k[4]}")
+def test_rubix_frame_equals_reference_golden(bk, key):
+    """f_rubix on (fisheye.c:2416-2419): frame 0 warped by the unmodified reference with its own create_palmap over the synthetic
+    base palette; here the GPU builds the map (grid 10/4/1) from the scripts, the product's bk_create_palmap makes the LUTs, and
+    both the batch launch (16 frames, frame 0 compared; the bench's rubix line) and the single-frame launch must hash the same."""
+    import torch
+    import scripts as S
+    rec = GOLD[key]
+    globe, lens, zoom, W, H = key
+    pal = bk.ffi.create_palmap(O.synthetic_basepal())
+    assert O.fnv(pal) == json.load(open(os.path.join(HERE, "golden", "lensmaps.json")))["fnv_palettes"]
+    F = 16
+    ctx = bk.Context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_frames(F)
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    ctx.build()
+    off, tin = ctx.read_lensmap()
+    assert O.fnv(off) == rec["fnv_offsets"] and O.fnv(tin) == rec["fnv_tints"]
+    for f in range(F):
+        for p in range(len(rec["display"])):
+            ctx.fill_plate_lcg(f, p, seed_frame=f)
+    out = torch.zeros((F, H, W), dtype=torch.uint8, device="cuda")
+    ctx.apply_device(out.data_ptr(), W, H * W, frame0=0, nframes=F, rubix_on=True, pal=pal)
+    torch.cuda.synchronize()
+    assert O.fnv(out[0].cpu().numpy()) == rec["fnv_frame_rubix"], "batch launch, frame 0"
+    one = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    ctx.apply_device(one.data_ptr(), W, H * W, frame0=0, nframes=1, rubix_on=True, pal=pal)
+    torch.cuda.synchronize()
+    assert O.fnv(one.cpu().numpy()) == rec["fnv_frame_rubix"], "single-frame launch"
+    # ... and rubix off again on the same context: the untinted golden
+    ctx.apply_device(one.data_ptr(), W, H * W, frame0=0, nframes=1)
+    torch.cuda.synchronize()
+    assert O.fnv(one.cpu().numpy()) == rec["fnv_frame"]
     ctx.close()
 
 

@@ -28,6 +28,23 @@ def test_oracle_matches_reference_golden(rec):
     assert O.fnv(frame) == rec["fnv_frame"]
 
 
+@pytest.mark.parametrize("rec", [r for r in GOLD["lensmaps"] if "fnv_frame_rubix" in r or ("fnv_frames" in r and r["W"] <= 3840)],
+                         ids=lambda r: f"{r['globe']}-{r['lens']}-{r['W']}x{r['H']}")
+def test_oracle_matches_reference_golden_batch_and_rubix_frames(rec):
+    """the other frames of a golden batch (LCG globes 1.., oracle gather over the lensmap) and the f_rubix frame the unmodified
+    reference warped with its own palettes (fisheye.c:2416-2419): a sample of the batch, every rubix record"""
+    W, H = rec["W"], rec["H"]
+    lm = O.lensmap(rec["globe"], rec["lens"], rec["zoom"], W, H)
+    assert O.fnv(lm.offsets) == rec["fnv_offsets"]
+    for f in ([1, 17, len(rec["fnv_frames"]) - 1] if "fnv_frames" in rec else []):
+        frame = O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, lm.numplates, f), np.zeros((H, W), np.uint8))
+        assert O.fnv(frame) == rec["fnv_frames"][f], f
+    if "fnv_frame_rubix" in rec:
+        frame = O.apply(lm.offsets, lm.tints, W, H, O.lcg_globe(lm.ps, lm.numplates, 0), np.zeros((H, W), np.uint8), W, 0, 0, True,
+                        O.palmap(O.synthetic_basepal()))
+        assert O.fnv(frame) == rec["fnv_frame_rubix"]
+
+
 def test_palmap_golden():
     assert O.fnv(O.palmap(O.synthetic_basepal())) == GOLD["fnv_palettes"]
 
