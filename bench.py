@@ -952,8 +952,10 @@ def main():
             torch.cuda.synchronize()
             held = {f: stripe[f] for f in range(F)}
             off, tin = ctx.read_lensmap()                  # ... and the table the timed launches gathered through IS the reference's
-            if (blinky_amd.ffi.fnv1a64(off), blinky_amd.ffi.fnv1a64(tin), repr(scale)) != (gold_rec["fnv_offsets"], gold_rec["fnv_tints"], gold_rec["scale"]):
-                sys.exit("[check] the lensmap this run built differs from the reference's golden (offsets / tints / scale)")
+            mine_is = (blinky_amd.ffi.fnv1a64(off), blinky_amd.ffi.fnv1a64(tin), repr(scale))
+            if mine_is != (gold_rec["fnv_offsets"], gold_rec["fnv_tints"], gold_rec["scale"]):
+                sys.exit(f"[check] the lensmap this run built differs from the reference's golden: offsets / tints / scale {mine_is} against "
+                         f"{(gold_rec['fnv_offsets'], gold_rec['fnv_tints'], gold_rec['scale'])}")
             del off, tin
         with ThreadPoolExecutor(8) as pool:
             got = dict(zip(held, pool.map(lambda t: blinky_amd.ffi.fnv1a64(t.cpu().numpy()), held.values())))

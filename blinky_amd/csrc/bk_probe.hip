@@ -118,7 +118,7 @@ extern "C" int bk_debug_fnv1a64(const void *host, size_t bytes, uint64_t *out)
 {
     if ((!host && bytes) || !out) return BK_E_INVALID;
     const unsigned char *p = (const unsigned char *)host;
-    uint64_t h = 1469598103934665603ull;
+    uint64_t h = 0xcbf29ce484222325ull;                 // the standard offset basis
     for (size_t i = 0; i < bytes; ++i) h = (h ^ p[i]) * 1099511628211ull;
     *out = h;
     return BK_OK;

@@ -38,3 +38,17 @@ def test_compact_line_of_a_recorded_full_record_fits_the_drivers_tail():
     for i, e in enumerate(full["configs_extra"]):
         full["configs_extra"][i] = dict(e, name=f"{e['name']} #{i}")
     assert len(bench.compact_line(full)) < 4096
+
+
+def test_the_hash_bench_check_uses_is_the_goldens_hash():
+    """bench.py --check hashes frames with the product's bk_debug_fnv1a64 (the oracle is off limits there): it must be the FNV-1a-64
+    tests/golden/lensmaps.json was recorded with"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import blinky_amd
+    import oracle_ffi as O
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 17, 4096):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        assert blinky_amd.ffi.fnv1a64(a) == O.fnv(a)
+    assert blinky_amd.ffi.fnv1a64(np.zeros(0, np.uint8)) == "cbf29ce484222325"
