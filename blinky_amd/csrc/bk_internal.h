@@ -132,6 +132,8 @@ struct bk_ctx {
     double last_kernel_wall_ms = 0;  // inverse build: wall time of the kernel launch(es) + counter / flag-list read-back (sorted)
     int last_kernel_retries = 0;     // kernel re-runs because the flag list had to grow
     bool last_fixup_compiled = false;   // the flagged entries were re-derived by the compiled host module (not the interpreter)
+    int last_build_path = 0;         // of the last bk_build: 0 = GPU kernels, 1 = host worker pool, 2 = one sequential host scan (bk_last_build_path)
+    std::string last_build_why;
     int sequential_build = 1;        // bk_set_sequential_build: 0 never, 1 (default) when the callbacks carry state from pixel to pixel, 2 always
     bool async_compile = false;      // bk_set_async_compile: bk_build returns BK_PENDING instead of waiting for hiprtc
 

@@ -992,13 +992,17 @@ extern "C" int bk_set_async_compile(bk_ctx *ctx, int on)
     return BK_OK;
 }
 
-static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out)
+/* `refused` (nullable): a script whose callbacks use a construct the emitter does not turn into GPU code (recursion, tables made at
+ * run time, functions as values, strings ...) is not an error for a caller that passes it - the text of the refusal comes back in
+ * it, *out stays empty, and bk_build evaluates the callbacks with the host interpreter instead (build_on_host). */
+static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out, std::string *refused = nullptr)
 {
     bk::EmitRequest rq;
     rq.interp = &P->interp;
     rq.lens_inverse = P->lens_inverse;
     rq.lens_forward = P->lens_forward;
     rq.globe_plate = P->globe_plate;
+    if (refused) refused->clear();
     try {
         *out = bk::emit_build_source(rq);
         // test hook: a wider assumed libm discrepancy (tests pair it with bk_set_host_math(ctx, n): the host interpreter on a
@@ -1006,6 +1010,11 @@ static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out)
         if (const int n = bk::g_debug.libm_rel_log2)
             if (n >= 8 && n <= 52) *out = "#define BK_LIBM_REL 0x1p-" + std::to_string(n) + "\n" + *out;
     } catch (const LuaError &e) {
+        if (refused && strstr(e.what(), "GPU callback")) {          // (bk_emit.cpp's `unsupported`, and its two "assigned inside a GPU callback but holds a ..." refusals)
+            out->clear();
+            *refused = e.what();
+            return BK_OK;
+        }
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }
     P->last_source = *out;
@@ -1437,7 +1446,8 @@ static int build_sequential(bk_ctx *ctx, LensProgram *P, const std::string &sour
     int disp[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
     int errbits = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    HostModuleP hm = P->interp.math == &math_platform() && bk::g_debug.host_module != 2 ? host_module_for(source, true) : nullptr;
+    // (no generated source - the emitter declined the script, build_on_host - means no compiled host module either: the interpreter scans)
+    HostModuleP hm = !source.empty() && P->interp.math == &math_platform() && bk::g_debug.host_module != 2 ? host_module_for(source, true) : nullptr;
     ctx->last_fixup_compiled = hm != nullptr;
     try {
         if (hm) errbits = hm->inverse_scan(&bp, off.data(), tint.data(), disp);
@@ -1451,7 +1461,10 @@ static int build_sequential(bk_ctx *ctx, LensProgram *P, const std::string &sour
                     const size_t o = (size_t)lyl * ctx->W + lx;
                     int shown = -1;
                     h_inverse_entry(ev, bp, (uint32_t)o, &off[o], &tint[o], &shown, &errbits);
-                    if (errbits) { off[o] = BK_NULL_OFFSET; tint[o] = 255; }
+                    if (errbits) {
+                        off[o] = BK_NULL_OFFSET; tint[o] = 255;
+                        if (errbits == BK_ERR_RESULT) ctx->last_bad_key = (uint32_t)(((uint32_t)ctx->row0 + (uint32_t)lyl) * (uint32_t)ctx->W + ((uint32_t)ctx->W - 1u - (uint32_t)lx)) + 1u;
+                    }
                     else if (shown >= 0) disp[shown] = 1;
                 }
         }
@@ -1472,6 +1485,243 @@ static int build_sequential(bk_ctx *ctx, LensProgram *P, const std::string &sour
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
     if (errbits) return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
     return BK_OK;
+}
+
+// ---- the HOST build: scripts whose callbacks the emitter declines ---------------------------------------------------------------
+// The reference lua_calls whatever the script defines (fisheye.c:1551, 1597, 1640).  The emitter turns most of Lua into GPU code,
+// not all of it: recursion, tables made at run time, functions as values, strings.  Such a script is not refused: its callbacks are
+// evaluated by the product's own interpreter (the evaluator calc_zoom, the globe loader and the flagged-pixel fix-up use) - on the
+// worker pool, every worker on its own copy of the script state, when the callbacks provably carry nothing from one call to the
+// next (bk_lens_carries_state = 0), else as ONE scan in the reference's order.  Slower by orders of magnitude than the kernels
+// (seconds at 4K), and the reference's result.  Nothing here is a CPU fallback of the GPU work: the table it builds is uploaded and
+// applied by the same kernels; what runs on the host is the user's Lua, which only an interpreter can run.
+
+/* set_lensmap_from_plate (fisheye.c:1963-1982) on host tables, stripe-filtered like the kernels' commit; the tint of an on-grid
+ * writer leaves an earlier off-grid writer's tint in place (set_lensmap_grid only ever sets it: 1957-1958) */
+namespace {
+struct HostTable { const BkBuildParams *bp; uint32_t *off; uint8_t *tint; int *disp; };
+inline void h_fwd_set(const HostTable &T, int lx, int ly, int px, int py, int plate, bool offgrid)
+{
+    const BkBuildParams &P = *T.bp;
+    if (lx < 0 || lx >= P.W || ly < 0 || ly >= P.H) return;
+    T.disp[plate] = 1;                                         /* display is global, not per stripe (bk_fwd_set) */
+    if (ly < P.row0 || ly >= P.row0 + P.rows) return;
+    const size_t o = (size_t)(ly - P.row0) * P.W + lx;
+    T.off[o] = bk_texel_offset((unsigned)P.gp, (unsigned)P.ph, (unsigned)plate, (unsigned)px, (unsigned)py);
+    if (offgrid) T.tint[o] = (uint8_t)plate;
+}
+inline int h_wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+/* draw_quad (fisheye.c:2246-2338) with the x86-64 build's wrap-around on INT_MIN corners; the loops visit the visible part of a
+ * 2^31-long range only - the host twin of bk_draw_quad (bk_build_kernels.h), which says why that is bit-identical */
+void h_draw_quad(const HostTable &T, const int *tl, const int *tr, const int *bl, const int *br, int plate, int px, int py, bool offgrid)
+{
+    const BkBuildParams &P = *T.bp;
+    const int *p[4] = {tl, tr, br, bl};
+    int x = tl[0], y = tl[1];
+    int miny = y, maxy = y, minx = x, maxx = x;
+    for (int i = 1; i < 4; i++) {
+        const int tx = p[i][0], ty = p[i][1];
+        if (tx < minx) minx = tx; else if (tx > maxx) maxx = tx;
+        if (ty < miny) miny = ty; else if (ty > maxy) maxy = ty;
+    }
+    const int maxdiff = 20;
+    {
+        const int dx = h_wrap_sub(minx, maxx), dy = h_wrap_sub(miny, maxy);
+        const int adx = dx < 0 ? h_wrap_sub(0, dx) : dx, ady = dy < 0 ? h_wrap_sub(0, dy) : dy;
+        if (adx > maxdiff || ady > maxdiff) return;                                       /* :2272 */
+    }
+    const int vx0 = minx < 0 ? 0 : minx, vx1 = maxx >= P.W ? P.W - 1 : maxx;
+    const int vy0 = miny < 0 ? 0 : miny, vy1 = maxy >= P.H ? P.H - 1 : maxy;
+    if (miny == maxy && minx == maxx) { h_fwd_set(T, x, y, px, py, plate, offgrid); return; }
+    if (miny == maxy) { for (int tx = vx0; tx <= vx1; ++tx) h_fwd_set(T, tx, miny, px, py, plate, offgrid); return; }
+    if (minx == maxx) { for (int ty = vy0; ty <= vy1; ++ty) h_fwd_set(T, x, ty, px, py, plate, offgrid); return; }
+    const bool tall = h_wrap_sub(maxy, miny) < 0;
+    const int y_first = tall ? vy0 : miny, nrows = h_wrap_sub(tall ? vy1 : maxy, y_first);
+    for (int ky = 0; ky <= nrows; ++ky) {
+        y = (int)((unsigned)y_first + (unsigned)ky);
+        int tx[2] = {minx, maxx};
+        int txi = 0, j = 3;
+        for (int i = 0; i < 4; ++i) {
+            const int ix = p[i][0], iy = p[i][1], jx = p[j][0], jy = p[j][1];
+            if ((iy < y && y <= jy) || (jy < y && y <= iy)) {                             /* :2310 */
+                const double dy = (double)h_wrap_sub(jy, iy), dx = (double)h_wrap_sub(jx, ix);
+                tx[txi] = h_trunc_to_int((double)ix + (double)h_wrap_sub(y, iy) / dy * dx); /* :2313 */
+                if (++txi == 2) break;
+            }
+            j = i;
+        }
+        if (tx[0] > tx[1]) { const int t = tx[0]; tx[0] = tx[1]; tx[1] = t; }
+        if (h_wrap_sub(tx[1], tx[0]) > maxdiff) return;                                   /* :2327 aborts the quad */
+        const int x_first = tx[0] < 0 ? 0 : tx[0], x_last = tx[1] >= P.W ? P.W - 1 : tx[1];
+        for (x = x_first; x <= x_last; ++x) h_fwd_set(T, x, y, px, py, plate, offgrid);
+    }
+}
+}  // namespace
+
+/* what a host build leaves in the context: the table on the device, display flags, timings, and how it was built */
+static int finish_host_build(bk_ctx *ctx, const std::vector<uint32_t> &off, const std::vector<uint8_t> &tint, const int disp[BK_MAX_PLATES],
+                             int display_out[BK_MAX_PLATES], std::chrono::steady_clock::time_point t0)
+{
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    ctx->last_host_eval_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->last_build_ms = ctx->last_host_eval_ms;
+    ctx->last_flagged = ctx->last_changed = 0;
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, off.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tint.data(), px, hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
+    return BK_OK;
+}
+static int empty_host_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], const char *what)
+{
+    // a Lua run-time error, which the reference's unprotected lua_call does not survive: nothing is drawn (see bk_build)
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
+    return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", what);
+}
+
+/* resume_lensmap_inverse (fisheye.c:2084-2124) on the worker pool: every pixel by the interpreter, every worker on its own copy of
+ * the script state; a malformed result ends the reference's scan there, so what lies behind it in scan order is taken away again
+ * (the kernels' rule: launch_truncate_scan) */
+static int build_inverse_pool(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, int display_out[BK_MAX_PLATES])
+{
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    std::vector<uint32_t> off(px, BK_NULL_OFFSET);
+    std::vector<uint8_t> tint(px, 255);
+    std::vector<int8_t> shown(px, (int8_t)-1);
+    std::vector<uint8_t> err(px, 0);
+    int disp[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
+    const auto t0 = std::chrono::steady_clock::now();
+    try {
+        for_each_flagged(P, px, [&](HostEval &E, size_t o) {
+            int s = -1, e = 0;
+            h_inverse_entry(E, bp, (uint32_t)o, &off[o], &tint[o], &s, &e);
+            shown[o] = (int8_t)s; err[o] = (uint8_t)e;
+        });
+    } catch (const LuaError &e) {
+        return empty_host_build(ctx, display_out, e.what());
+    }
+    uint32_t bad_key = 0;
+    for (size_t o = 0; o < px; ++o) {
+        if (!err[o]) continue;
+        if (err[o] & ~BK_ERR_RESULT) return empty_host_build(ctx, display_out, err_text(err[o]));
+        const uint32_t lyl = (uint32_t)(o / (size_t)ctx->W), lx = (uint32_t)(o - (size_t)lyl * ctx->W);
+        bad_key = std::max(bad_key, (uint32_t)(((uint32_t)ctx->row0 + lyl) * (uint32_t)ctx->W + ((uint32_t)ctx->W - 1u - lx)) + 1u);
+    }
+    if (bad_key) {
+        // the scan reaches pixel (ly, lx) before the failing one iff its key is larger: everything else - the failing pixel too - is NULL
+        for (size_t o = 0; o < px; ++o) {
+            const uint32_t lyl = (uint32_t)(o / (size_t)ctx->W), lx = (uint32_t)(o - (size_t)lyl * ctx->W);
+            const uint32_t key = (uint32_t)(((uint32_t)ctx->row0 + lyl) * (uint32_t)ctx->W + ((uint32_t)ctx->W - 1u - lx)) + 1u;
+            if (key <= bad_key) { off[o] = BK_NULL_OFFSET; tint[o] = 255; shown[o] = -1; }
+        }
+    }
+    for (size_t o = 0; o < px; ++o) if (shown[o] >= 0) disp[shown[o]] = 1;
+    ctx->last_bad_key = bad_key;
+    if (int r = finish_host_build(ctx, off, tint, disp, display_out, t0)) return r;
+    if (bad_key) return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(BK_ERR_RESULT));
+    return BK_OK;
+}
+
+/* resume_lensmap_forward (fisheye.c:2126-2217) on the host.  sequential: ONE evaluator and the reference's own call order - per
+ * plate the bottom row of corners, then per texel row (from the last up) its upper corners left to right and its texels' "own
+ * plate" tests (globe_plate) left to right - so that state a script carries from call to call travels as in the reference.
+ * Otherwise a plate's corners (and its own-plate tests, with a globe_plate script) are evaluated on the worker pool and the
+ * quads are drawn afterwards in the reference's order (later writers overwrite).  A nil corner skips the quads that touch it
+ * (the reference reads a stale entry there; no shipped lens returns nil: DESIGN.md 5); a malformed
+ * result leaves an EMPTY lensmap, as the kernels' forward build does (blinky_hip.h). */
+static int build_forward_host(bk_ctx *ctx, LensProgram *P, const BkBuildParams &bp, bool sequential, int display_out[BK_MAX_PLATES])
+{
+    const size_t px_total = (size_t)ctx->W * ctx->rows();
+    std::vector<uint32_t> off(px_total, BK_NULL_OFFSET);
+    std::vector<uint8_t> tint(px_total, 255);
+    int disp[BK_MAX_PLATES] = {0, 0, 0, 0, 0, 0};
+    const HostTable T{&bp, off.data(), tint.data(), disp};
+    const int ps = bp.ps, n1 = ps + 1;
+    const size_t ncorner = (size_t)n1 * n1;
+    std::vector<int> cx(ncorner), cy(ncorner), cerr(ncorner);
+    std::vector<uint8_t> cok(ncorner), own((size_t)ps * ps, 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    int errbits = 0;
+    auto draw_row = [&](int plate, int py) {
+        for (int px = 0; px < ps; ++px) {
+            if (!own[(size_t)py * ps + px]) continue;                                               /* :2196 */
+            const size_t c_tl = (size_t)py * n1 + px, c_bl = c_tl + n1;
+            if (!(cok[c_tl] && cok[c_tl + 1] && cok[c_bl] && cok[c_bl + 1])) continue;
+            const int tl[2] = {cx[c_tl], cy[c_tl]}, tr[2] = {cx[c_tl + 1], cy[c_tl + 1]}, bl[2] = {cx[c_bl], cy[c_bl]}, br[2] = {cx[c_bl + 1], cy[c_bl + 1]};
+            h_draw_quad(T, tl, tr, bl, br, plate, px, py, h_offgrid(bp, px, py));
+        }
+    };
+    try {
+        const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
+        Values roots;
+        std::unique_ptr<Interp> mine = P->interp.clone(roots_in, &roots);
+        HostEval ev{mine.get(), roots[0], roots[1], roots[2]};
+        for (int plate = 0; plate < bp.numplates && !errbits; ++plate) {
+            const uint32_t c0 = (uint32_t)((size_t)plate * ncorner), t0id = (uint32_t)((size_t)plate * ps * ps);
+            if (sequential) {
+                auto corner_row = [&](int j) {
+                    for (int i = 0; i < n1 && !errbits; ++i) {
+                        const size_t k = (size_t)j * n1 + i;
+                        h_corner_entry(ctx, ev, bp, c0 + (uint32_t)k, &cx[k], &cy[k], &cok[k], &errbits);
+                    }
+                };
+                corner_row(ps);                                                                  /* :2148 the lower points of the last row */
+                for (int py = ps - 1; py >= 0 && !errbits; --py) {
+                    corner_row(py);                                                              /* :2172 upper points */
+                    if (errbits) break;
+                    for (int px = 0; px < ps; ++px) own[(size_t)py * ps + px] = h_texel_owns(ctx, ev, bp, t0id + (uint32_t)((size_t)py * ps + px)) ? 1 : 0;
+                    draw_row(plate, py);
+                }
+            } else {
+                std::fill(cerr.begin(), cerr.end(), 0);
+                for_each_flagged(P, ncorner, [&](HostEval &E, size_t k) { h_corner_entry(ctx, E, bp, c0 + (uint32_t)k, &cx[k], &cy[k], &cok[k], &cerr[k]); });
+                for (size_t k = 0; k < ncorner; ++k) errbits |= cerr[k];
+                if (errbits) break;
+                if (bp.has_globe_plate) for_each_flagged(P, (size_t)ps * ps, [&](HostEval &E, size_t k) { own[k] = h_texel_owns(ctx, E, bp, t0id + (uint32_t)k) ? 1 : 0; });
+                else for (size_t k = 0; k < (size_t)ps * ps; ++k) own[k] = h_texel_owns(ctx, ev, bp, t0id + (uint32_t)k) ? 1 : 0;
+                for (int py = ps - 1; py >= 0; --py) draw_row(plate, py);
+            }
+        }
+    } catch (const LuaError &e) {
+        return empty_host_build(ctx, display_out, e.what());
+    }
+    if (errbits) return empty_host_build(ctx, display_out, err_text(errbits));
+    return finish_host_build(ctx, off, tint, disp, display_out, t0);
+}
+
+/* bk_build for a script the emitter declined (`why` = its refusal) */
+static int build_on_host(bk_ctx *ctx, LensProgram *P, const std::string &why, int display_out[BK_MAX_PLATES])
+{
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    bk::EmitRequest rq;
+    rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
+    std::string which;
+    bool carries = true;                                   // (a script the state analysis cannot follow either is taken to carry state)
+    try { carries = bk::callbacks_carry_state(rq, &which); } catch (const LuaError &) { carries = true; which = "(callbacks not analysable)"; }
+    const bool sequential = ctx->sequential_build >= 2 || (ctx->sequential_build == 1 && carries);
+    ctx->last_build_path = sequential ? 2 : 1;
+    ctx->last_build_why = why + (sequential ? (carries ? "; state carried in '" + which + "': one sequential scan on the host" : "; one sequential scan on the host (bk_set_sequential_build 2)")
+                                            : "; callbacks carry no state: evaluated on the host's worker pool");
+    if (P->info.map_type == BK_MAP_INVERSE) {
+        if (!P->lens_inverse.is_function()) return ctx->fail(BK_E_STATE, "lens has no lens_inverse (map = \"lens_inverse\" without the function)");
+        return sequential ? build_sequential(ctx, P, std::string(), bp, display_out) : build_inverse_pool(ctx, P, bp, display_out);
+    }
+    if (!P->lens_forward.is_function()) return ctx->fail(BK_E_STATE, "lens has no lens_forward");
+    return build_forward_host(ctx, P, bp, sequential, display_out);
+}
+
+/* how the last bk_build evaluated the lens callbacks: 0 = the GPU kernels, 1 = the host's worker pool, 2 = one sequential scan on the
+ * host; `why` (nullable) receives the reason for 1 / 2 - the construct the emitter declined, and the state finding */
+extern "C" int bk_last_build_path(const bk_ctx *ctx, char *why, size_t cap)
+{
+    if (!ctx) return BK_E_INVALID;
+    if (why && cap) snprintf(why, cap, "%s", ctx->last_build_why.c_str());
+    return ctx->last_build_path;
 }
 
 extern "C" int bk_set_sequential_build(bk_ctx *ctx, int mode)
@@ -1523,14 +1773,17 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     ctx->last_kernel_retries = 0;
     ctx->last_fixup_compiled = false;
     ctx->last_flagged = ctx->last_changed = 0;
+    ctx->last_build_path = 0;
+    ctx->last_build_why.clear();
 
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
     if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
     if (int r = bk_calc_zoom(ctx, scale_out)) return r;                                        /* :2376 */
     if (P->info.map_type == BK_MAP_NONE) return ctx->fail(BK_E_STATE, "no inverse or forward map being used");   /* :2395 */
 
-    std::string src;
-    if (int r = generate_source(ctx, P, &src)) return r;
+    std::string src, refused;
+    if (int r = generate_source(ctx, P, &src, &refused)) return r;
+    if (!refused.empty()) return build_on_host(ctx, P, refused, display_out);     // callbacks the emitter declines: the interpreter evaluates them
     if (int r = compile_module(ctx, P, src)) return r;
     if (!ctx->d_flag_list) {
         BK_HIP(ctx, hipMalloc((void **)&ctx->d_flag_list, (size_t)65536 * 4 * sizeof(uint32_t)));
@@ -1541,11 +1794,18 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     fill_params(ctx, &bp);
     // bk_set_sequential_build: a lens whose callbacks carry state from pixel to pixel (or every lens, mode 2) is built the way the
     // reference builds it - one evaluator, its scan order - on the host
-    if (P->info.map_type == BK_MAP_INVERSE && ctx->sequential_build) {
+    if ((P->info.map_type == BK_MAP_INVERSE || P->info.map_type == BK_MAP_FORWARD) && ctx->sequential_build) {
         bk::EmitRequest rq;
         rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
         std::string which;
-        if (ctx->sequential_build >= 2 || bk::callbacks_carry_state(rq, &which)) return build_sequential(ctx, P, src, bp, display_out);
+        if (ctx->sequential_build >= 2 || bk::callbacks_carry_state(rq, &which)) {
+            ctx->last_build_path = 2;
+            ctx->last_build_why = ctx->sequential_build >= 2 ? "bk_set_sequential_build 2" : "state carried in '" + which + "'";
+            if (P->info.map_type == BK_MAP_INVERSE) return build_sequential(ctx, P, src, bp, display_out);
+            // (r6) the forward scan is just as sequential in the reference (fisheye.c:2126-2217): its call order, one evaluator
+            if (!P->lens_forward.is_function()) return ctx->fail(BK_E_STATE, "lens has no lens_forward");
+            return build_forward_host(ctx, P, bp, true, display_out);
+        }
     }
     void *args[] = {&bp};
     hipEvent_t e0, e1;

@@ -64,6 +64,7 @@ _SIGS = {
     "bk_last_build_fixups": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "bk_last_build_bad_key": (C.c_uint, [_vp]),
     "bk_set_sequential_build": (_i, [_vp, _i]),
+    "bk_last_build_path": (_i, [_vp, C.c_char_p, _sz]),
     "bk_lens_carries_state": (_i, [_vp, C.c_char_p, _sz]),
     "bk_truncate_build": (_i, [_vp, C.c_uint, C.POINTER(_i)]),
     "bk_set_cache_dir": (_i, [C.c_char_p]),
@@ -298,6 +299,14 @@ class Context:
         self._chk(lib.bk_debug_build_breakdown(self._h, out))
         return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4],
                     retries=int(out[5]) % 1000, compiled_host_module=out[5] >= 1000)
+
+    def last_build_path(self):
+        """(path, why) of the last build(): 0 GPU kernels, 1 host worker pool, 2 one sequential host scan"""
+        buf = C.create_string_buffer(1024)
+        rc = lib.bk_last_build_path(self._h, buf, 1024)
+        if rc < 0:
+            self._chk(rc)
+        return rc, buf.value.decode(errors="replace")
 
     def set_sequential_build(self, mode):
         self._chk(lib.bk_set_sequential_build(self._h, int(mode)))

@@ -520,6 +520,13 @@ void F_RenderView(void)                             /* fisheye.c:698-811 */
             }
         }
         build_pending = rc == BK_PENDING;
+        if (!build_pending && !mg) {
+            /* a lens whose callbacks do not become GPU code (recursion, run-time tables ...) or carry state is evaluated by the library's
+             * interpreter on the host: say so once per build, with the construct that forced it */
+            char why[512];
+            const int path = bk_last_build_path(bk, why, sizeof why);
+            if (path > 0) Con_Printf("lens callbacks evaluated on the host (%s): %s\n", path == 2 ? "sequential scan" : "worker pool", why);
+        }
         if (!build_pending) {                    /* (while the new lens compiles the previous lensmap and its plates stay) */
             /* the reference clears the display flags only once calc_zoom has succeeded (fisheye.c:2376-2385): after a zoom it cannot
              * compute, or with no valid lens / globe, the plates of the previous lensmap go on being rendered (into a lensmap that shows

@@ -85,7 +85,10 @@ int         bk_synchronize(bk_ctx *ctx);
  * load / dofile / require relative to the working directory).  What the per-pixel CALLBACKS (lens_inverse, lens_forward,
  * globe_plate and everything they call) may use is narrower - they become GPU code at bk_build: numbers, booleans, nil, string
  * constants, local tables (arrays, records {x = ..}, matrices {{..}, {..}}), constant tables of the chunk, every control structure but goto, the math library, functions
- * defined inside a callback, functions and constant tables passed as arguments, methods of constant objects, varargs; bk_build names the construct it cannot take (BK_E_SCRIPT). */
+ * defined inside a callback, functions and constant tables passed as arguments, methods of constant objects, varargs.  A script whose
+ * callbacks go beyond that (recursion, tables made at run time, functions as values, strings) is NOT refused: bk_build evaluates
+ * them with the library's own interpreter on the host instead - seconds instead of milliseconds at 4K - and bk_last_build_path
+ * names the construct that forced it (fisheye.c:1551, 1597, 1640 lua_call whatever the script defines). */
 int bk_load_globe(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_load_lens(bk_ctx *ctx, const char *src, size_t len, const char *chunkname);
 int bk_clear_lens(bk_ctx *ctx);    /* lens.valid = false ("not a valid lens", fisheye.c:1080-1083) */
@@ -126,12 +129,20 @@ int bk_set_rubixgrid(bk_ctx *ctx, int numcells, double cell_size, double pad_siz
  * sequential scan (fisheye.c:2084-2124), so by DEFAULT (bk_set_sequential_build mode 1) an inverse-map lens whose callbacks read
  * a script global before assigning it outside such a keyed cache, or assign a chunk local at all (bk_lens_carries_state), is built
  * as ONE sequential scan on the host, in the reference's order, by the compiled host module (else the script interpreter):
- * seconds instead of milliseconds at 4K, the reference's result for any script.  mode 2 = every inverse-map lens; 0 = never
- * (the GPU build whatever the script does).
+ * seconds instead of milliseconds at 4K, the reference's result for any script.  (r6) A FORWARD-map lens that carries state is
+ * scanned on the host too, by the interpreter, in the reference's own call order (fisheye.c:2126-2217: per plate the last row's
+ * lower corners, then row by row from the last up the upper corners left to right and the texels' globe_plate calls).
+ * mode 2 = every lens; 0 = never (the GPU build whatever the script does, unless the emitter declines it: bk_last_build_path).
  * Memory: a FORWARD-map build (lenses with lens_forward only) keeps its scratch - screen coordinates of every texel corner and two
  * key planes, about 10 bytes per plate texel + 8 per pixel: 320 MB at 3840x2160 on a cube globe - in the context from one build to
  * the next (allocating it cost more than the build's kernels); it is released when the context builds an inverse map or is destroyed. */
 int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *scale_out);
+/* how the last bk_build evaluated the lens callbacks: 0 = the GPU kernels; 1 = the interpreter on the host's worker pool (the
+ * emitter declined a construct and the callbacks carry no state: every worker has its own copy of the script state); 2 = ONE
+ * sequential scan on the host in the reference's order (state carried from call to call, or bk_set_sequential_build 2) - inverse
+ * maps: fisheye.c:2084-2124; forward maps: 2126-2217, the corners' and texels' calls in the reference's own sequence.  `why`
+ * (nullable) receives the construct the emitter declined and the state finding. */
+int bk_last_build_path(const bk_ctx *ctx, char *why /* nullable */, size_t cap);
 int bk_set_sequential_build(bk_ctx *ctx, int mode);
 int bk_lens_carries_state(bk_ctx *ctx, char *global_name /* nullable */, size_t cap);
 /* after a bk_build that returned BK_E_SCRIPT for a malformed result: 1 + scan key (ly * W + (W - 1 - lx)) of the first failing
