@@ -588,35 +588,27 @@ def main():
     ctx.set_rows(r0, r1)
     # the stripe exchange behind the C ABI: bk_comm = librccl called from libblinkyhip (grouped ncclSend / ncclRecv on the
     # communicator's own stream); torch.distributed only ships the unique id.  The gloo developer smoke keeps host tensors.
-    comm = None
+    comm, comm_fallback = None, None
     if world > 1 and not host_exchange:
-        # (should libblinkyhip's own communicator not come up on this node, say so and exchange through the process
-        # group's RCCL instead of losing the measurement; every rank takes the same decision)
-        # (ncclCommInitRank blocks until every rank has joined: should one of them never arrive, a minute is enough to know)
-        import threading
-        box = {}
-
-        def create():
-            try:
-                torch.cuda.set_device(local_rank)
-                box["comm"] = multigpu.rccl_comm(ctx, world, rank, dev)
-            except Exception as e:      # noqa: BLE001
-                box["error"] = e
-        th = threading.Thread(target=create, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("BLINKY_BENCH_COMM_TIMEOUT", "60")))
-        if th.is_alive() or "error" in box or "comm" not in box:
-            why = "timed out after 60 s" if th.is_alive() else f"{type(box.get('error')).__name__}: {box.get('error')}"
-            print(f"[bench] rank {rank}: bk_comm could not be created ({why}); using torch.distributed for the exchange", file=sys.stderr, flush=True)
-            comm, ok = None, 0
-        else:
-            comm = box["comm"]
+        # Should libblinkyhip's own communicator not come up on this node, say so and exchange through the process group's RCCL instead
+        # of losing the measurement; every rank takes the same decision.  (bk_comm_create waits for the other ranks at most
+        # BLINKY_HIP_COMM_TIMEOUT seconds - default 60 - and then fails with a message that says which rank was waiting.)
+        try:
+            comm = multigpu.rccl_comm(ctx, world, rank, dev)
             ok = 1 if comm.stripe(rank) == (r0, r1) else 0
+            why = "" if ok else "stripe bounds differ"
+        except Exception as e:      # noqa: BLE001
+            comm, ok, why = None, 0, f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: bk_comm could not be created ({why}); using torch.distributed for the exchange", file=sys.stderr, flush=True)
         t = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
+        if int(t.item()) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            reasons = [None] * world
+            dist.all_gather_object(reasons, why)
+            comm_fallback = "; ".join(f"rank {r}: {w}" for r, w in enumerate(reasons) if w)[:300] or "a rank could not create bk_comm"
     if args.variant >= 0:
         ctx.set_apply_variant(args.variant)
 
@@ -774,7 +766,7 @@ def main():
             # libblinkyhip's communicator came up but its exchange did not run: try the process group's RCCL before
             # giving up on rotating roots (the JSON line says which transport was timed)
             print(f"[bench] rank {rank}: falling back from bk_comm to torch.distributed", file=sys.stderr, flush=True)
-            comm = None
+            comm, comm_fallback = None, "the communicator came up but its first exchange failed"
             if not exchange_works():
                 exchange_mode = "root"
         else:
@@ -1030,7 +1022,7 @@ def main():
                                    f"alternating between {nstreams} HIP stream(s), value_one_stream = the same on one stream, roofline.kernel_ms_per_launch "
                                    "= the kernel alone under HIP events; 64 frames/step since r5 (r1-r4 ran 16: compare those with value_at_16_frames)",
                        "frames_per_step": F, "ring_globes": R,
-                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else (" + bk_comm (librccl grouped ncclSend/ncclRecv behind the C ABI)" if comm else " + gloo host exchange (developer smoke)" if host_exchange else " + torch.distributed RCCL send/recv (bk_comm unavailable)") +
+                       "parallelism": f"row-stripes x{world}" + ("" if world == 1 else (" + bk_comm (librccl grouped ncclSend/ncclRecv behind the C ABI)" if comm else " + gloo host exchange (developer smoke)" if host_exchange else f" + torch.distributed RCCL send/recv (bk_comm unavailable: {comm_fallback})") +
                                                                      (": frame f reassembled on rank f%N" if exchange_mode == "rotating" else ": every frame gathered onto rank 0")),
                        "apply_variant": args.variant, "streams": nstreams,
                        "streams_note": "consecutive steps alternate between this many HIP streams, so the tail of one batch launch "

@@ -19,6 +19,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <array>
 #include <cstring>
 #include <memory>
@@ -228,8 +231,39 @@ extern "C" bk_comm *bk_comm_create(bk_ctx *ctx, int nranks, int rank, const uint
     if (!R.ok || !id) { g_comm_create_error = R.ok ? "bk_comm_create: no unique id" : R.error; bk_comm_destroy(c); return nullptr; }
     ncclUniqueId u;
     memcpy(u.internal, id, BK_COMM_ID_BYTES);
-    const ncclResult_t r = R.CommInitRank(&c->comm, nranks, u, rank);      // blocks until every rank has joined
-    if (r != ncclSuccess) { g_comm_create_error = std::string("ncclCommInitRank: ") + R.GetErrorString(r); c->comm = nullptr; bk_comm_destroy(c); return nullptr; }
+    // ncclCommInitRank blocks until EVERY rank has joined: should one of them never arrive (a rank that died, a node where RCCL's
+    // bootstrap cannot reach its peers) the caller would hang for good.  The call runs on a helper thread and is given
+    // BLINKY_HIP_COMM_TIMEOUT seconds (default 60); past that bk_comm_create fails with a message that says so - bench.py then
+    // exchanges through torch.distributed and names that transport in config.parallelism - and the helper is left behind (it
+    // owns nothing of the caller's: the communicator it may still produce is destroyed by it).
+    struct Init { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto st = std::make_shared<Init>();
+    const int device = ctx->device;
+    std::thread([st, nranks, u, rank, device, &R]() {
+        (void)hipSetDevice(device);
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = R.CommInitRank(&comm, nranks, u, rank);
+        std::unique_lock<std::mutex> lock(st->m);
+        if (st->abandoned) { lock.unlock(); if (r == ncclSuccess && comm) (void)R.CommDestroy(comm); return; }
+        st->r = r; st->comm = comm; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    double timeout_s = 60.0;
+    if (const char *e = getenv("BLINKY_HIP_COMM_TIMEOUT")) { const double v = atof(e); if (v > 0) timeout_s = v; }
+    {
+        std::unique_lock<std::mutex> lock(st->m);
+        if (!st->cv.wait_for(lock, std::chrono::duration<double>(timeout_s), [&] { return st->done; })) {
+            st->abandoned = true;
+            char msg[200];
+            snprintf(msg, sizeof msg, "ncclCommInitRank did not return within %g s (BLINKY_HIP_COMM_TIMEOUT): rank %d of %d - did every rank join?", timeout_s, rank, nranks);
+            g_comm_create_error = msg;
+            lock.unlock();
+            bk_comm_destroy(c);
+            return nullptr;
+        }
+    }
+    if (st->r != ncclSuccess) { g_comm_create_error = std::string("ncclCommInitRank: ") + R.GetErrorString(st->r); c->comm = nullptr; bk_comm_destroy(c); return nullptr; }
+    c->comm = st->comm;
     return c;
 }
 

@@ -284,7 +284,8 @@ int bk_set_resident_apply(bk_ctx *ctx, int on);
 #define BK_COMM_SLOTS 4     /* exchanges in flight that a caller can tell apart (double / quadruple buffering) */
 typedef struct bk_comm bk_comm;
 int         bk_comm_unique_id(uint8_t id[BK_COMM_ID_BYTES]);                      /* ncclGetUniqueId */
-/* joins the communicator (ncclCommInitRank on the context's device; blocks until all nranks joined) and restricts the
+/* joins the communicator (ncclCommInitRank on the context's device; waits until all nranks joined, at most BLINKY_HIP_COMM_TIMEOUT
+ * seconds - default 60 - after which it fails and bk_last_error(NULL) says that a rank never arrived) and restricts the
  * context to this rank's stripe (bk_set_rows); needs bk_resize first.  nranks == 1 needs no id. */
 bk_comm    *bk_comm_create(bk_ctx *ctx, int nranks, int rank, const uint8_t id[BK_COMM_ID_BYTES]);
 void        bk_comm_destroy(bk_comm *c);

@@ -134,6 +134,32 @@ def test_bench_two_ranks_sharing_the_gpu_reassemble_every_frame():
     assert out["stripes"]["rebalanced"] and sum(out["stripes"]["rows_per_rank"]) == 2160 and all(r % 8 == 0 for r in out["stripes"]["rows_per_rank"][:-1])
 
 
+def test_bench_eight_ranks_sharing_the_gpu():
+    """First contact for N = 8 (no 8-GPU node is available before the driver tries one): `bench.py --gpus 8` with all eight ranks on
+    the one GPU over gloo - the control flow the RCCL run takes (stripes cut by work, rotating roots, first-step check on every rank,
+    the one-GPU scaling reference timed by rank 0) - and the N = 8 compact line the driver parses."""
+    env = dict(os.environ, BLINKY_BENCH_BACKEND="gloo", BLINKY_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--frames", "5", "--ring", "10", "--repeats", "2", "--check"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for k in range(8):
+        assert f"[check] rank {k}: OK" in r.stderr, k
+    last = r.stdout.rstrip().splitlines()[-1]
+    compact = json.loads(last)
+    assert len(last) < 4096
+    _assert_compact_contract(compact, 8)
+    for k in ("stripe_complete_mpx_s", "assembled_on_rank0_mpx_s", "exchange", "stripes", "first_step_check_ok", "scaling_reference_mpx_s",
+              "speedup_vs_scaling_reference"):
+        assert k in compact, k
+    assert compact["first_step_check_ok"] is True and compact["scaling_reference_mpx_s"] > 0 and compact["exchange"]["bound_mpx_s"] > 0
+    assert len(compact["stripes"]["rows_per_rank"]) == 8 and sum(compact["stripes"]["rows_per_rank"]) == 2160
+    assert compact["scaling"] == "strong" and "row-stripes x8" in compact["config"]["parallelism"]
+    out = json.load(open(os.path.join(ROOT, compact["detail"])))
+    assert out["first_step_check"] == {"ranks": ["ok"] * 8, "ok": True}
+
+
 def test_bench_gpus_flag_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (the round-1 bench silently
     measured one GPU); here both ranks share the one GPU over gloo."""
