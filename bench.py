@@ -552,9 +552,14 @@ def main():
         sys.exit(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a "
                  f"{world}-GPU number as a {args.gpus}-GPU one")
 
+    import gc
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
+    # A timing harness in CPython switches the cyclic collector off (as timeit does): with torch loaded a full collection takes
+    # 35-40 ms and a young one 1 ms, inside whatever launch train happens to be running - that was the "millisecond launch" of the
+    # rubix line in rounds 4 and 5 (profiles/r06_rubix_outlier.txt).  Reference counting still frees everything that is not a cycle.
+    gc.disable()
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

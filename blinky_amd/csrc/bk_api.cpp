@@ -131,6 +131,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipFree(ctx->d_flag_list);
     for (void *q : ctx->fwd_scratch) hipFree(q);
     bk::coopmap_free(ctx->coopmap);
+    bk::coopmap_free(ctx->coopmap_alt);
     bk::lensprogram_free(ctx->prog);
     delete ctx;
 }

@@ -938,11 +938,12 @@ void coopmap_free(CoopMap *cm)
 void coopmap_invalidate(bk_ctx *ctx)
 {
     resident_quiesce(ctx);          // (a resident apply kernel holds this block map in its registers)
-    if (ctx->coopmap) {
-        ctx->coopmap->valid = false;
-        for (auto &t : ctx->coopmap->tuned) t = CoopMap::Tuned();
-        ctx->coopmap->flips = 0;
-    }
+    for (CoopMap *cm : {ctx->coopmap, ctx->coopmap_alt})            // (both flavours: the parked one describes the same lensmap)
+        if (cm) {
+            cm->valid = false;
+            for (auto &t : cm->tuned) t = CoopMap::Tuned();
+            cm->flips = 0;
+        }
 }
 
 static void fold_stats(const uint32_t *rep, uint32_t *out, uint32_t scale)
@@ -1054,22 +1055,23 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames, int want_tinted)
     CoopMap *cm = ctx->coopmap;
     bool flavour_switch = false;
     if (want_tinted >= 0 && (want_tinted != 0) != cm->tinted) {
-        // the other flavour of the map (f_rubix was switched): compiled and tuned afresh - a tinted map lists some chunks twice
-        flavour_switch = cm->valid;
-        cm->valid = false;
-        for (auto &t : cm->tuned) t = CoopMap::Tuned();
-        cm->flips = 0;
-        cm->tinted = want_tinted != 0;
-        // (a resident session of the other flavour holds the old map: it leaves first - AFTER the state above is consistent: ending it may
-        //  finish pending frames, which comes back here through res_launch)
-        if (flavour_switch) {
-            resident_quiesce(ctx);
-            if (cm->tinted != (want_tinted != 0)) {          // (those frames were of the session's flavour and compiled it back)
-                cm->valid = false;
-                for (auto &t : cm->tuned) t = CoopMap::Tuned();
-                cm->tinted = want_tinted != 0;
-            }
+        // The other flavour of the map (f_rubix was switched; a tinted map lists some chunks twice).  (r6) BOTH flavours are kept: the
+        // map this launch does not want is parked in ctx->coopmap_alt and comes back, compiled and tuned as it was, when f_rubix is
+        // switched again - a toggle used to cost a compile + tuning (~1.5 ms, a dropped frame for an engine that toggles per frame),
+        // now only the first launch of each flavour after a build does.  coopmap_invalidate invalidates both.
+        // (a resident session of the current flavour holds the current map: it leaves first, while nothing has changed yet - ending it
+        //  may finish pending frames, which come back here through res_launch asking for the flavour the map still has)
+        if (cm->valid) resident_quiesce(ctx);
+        std::swap(ctx->coopmap, ctx->coopmap_alt);
+        if (!ctx->coopmap) ctx->coopmap = new CoopMap();
+        cm = ctx->coopmap;
+        if (cm->tinted != (want_tinted != 0)) {                  // (a fresh slot)
+            cm->valid = false;
+            for (auto &t : cm->tuned) t = CoopMap::Tuned();
+            cm->flips = 0;
+            cm->tinted = want_tinted != 0;
         }
+        flavour_switch = !cm->valid;                              // compiled below: drain first (the buffers may be those of an older map of this flavour)
     }
     // The measured choice (below) holds for the KIND of launch it was measured with: single frames, batches of up to 16, long batches
     // (a 270-row stripe x 64 frames ran 40.8 us on the 128x8 blocks a 16-frame measurement had picked, 32.5 us on 128x16).  A caller

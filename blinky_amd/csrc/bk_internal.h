@@ -116,6 +116,7 @@ struct bk_ctx {
     bool blockmap_tuning = true;     // bk_set_blockmap_tuning: block height of the staged apply chosen by timing the candidates
     int tile_shape = 0;              // coop apply: 0 = block height by cost model, 1/2/4 = force 128x8 / 128x16 / 128x32
     bk::CoopMap *coopmap = nullptr;       // owned; freed with bk::coopmap_free
+    bk::CoopMap *coopmap_alt = nullptr;   // owned: the block map of the OTHER flavour (plain / tinted), parked while f_rubix is the other way
     bk::Resident *resident = nullptr;     // owned; freed with bk::resident_free (bk_apply_resident_begin .. _end)
     int resident_mode = 0;                // bk_set_resident_apply: bk_apply / bk_apply_begin..end / bk_upload_plate* go through the resident kernel
     int res_part = 0, res_parts = 1, res_reserve = 0;   // bk_set_resident_share: which CUs of every XCD the resident kernel may take

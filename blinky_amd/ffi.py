@@ -382,10 +382,21 @@ class Context:
 
     def apply_device(self, dst_ptr, pitch, frame_stride, frame0=0, nframes=1, x0=0, y0=0,
                      rubix_on=False, pal=None):
-        if pal is not None:
-            pal = np.ascontiguousarray(pal, dtype=np.uint8)
+        # (the palette's pointer is kept between calls: `a.ctypes.data_as` builds a handful of container objects per call, and enough
+        #  of those wake CPython's cyclic collector in the middle of a caller's launch train - 1 ms for a young generation, 35-40 ms
+        #  for a full one with torch loaded: the "millisecond launch" of the rubix bench line, tools/r6_rubix_outlier.py)
+        if pal is None:
+            pp = None
+        else:
+            cached = getattr(self, "_pal_ptr", None)
+            if cached is not None and cached[0] is pal:
+                pp = cached[2]
+            else:
+                arr = np.ascontiguousarray(pal, dtype=np.uint8)
+                pp = _ptr(arr)
+                self._pal_ptr = (pal, arr, pp)
         self._chk(lib.bk_apply_device(self._h, frame0, nframes, dst_ptr, pitch, frame_stride, x0, y0,
-                                      int(rubix_on), _ptr(pal)))
+                                      int(rubix_on), pp))
 
     # ---- the resident single-frame apply (bk_apply_resident_*): one kernel stays on the device, frames are commands
     def resident_begin(self, rubix_on=False, pal=None, idle_ms=0.0):

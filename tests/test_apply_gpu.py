@@ -377,6 +377,53 @@ def test_rubix_frame_equals_reference_golden(bk, key):
     ctx.close()
 
 
+def test_toggling_rubix_every_frame_costs_no_recompile(bk):
+    """f_rubix toggled on EVERY frame for 50 frames at 4K (fisheye.c:2416-2419 picks the tint per call): both flavours of the block map
+    are kept (r6), so after the first frame of each flavour no call compiles or tunes anything - no call's host time or device time
+    above twice the median (a dropped frame for the engine), and both flavours' frames are the reference's goldens throughout.
+    (The cyclic collector of this Python process is off while timing: with torch loaded a collection is 1-40 ms of the CALLER's time.)"""
+    import gc
+    import time
+    import torch
+    import scripts as S
+    key = ("cube", "panini", None, 3840, 2160)
+    rec = GOLD[key]
+    globe, lens, zoom, W, H = key
+    pal = bk.ffi.create_palmap(O.synthetic_basepal())
+    ctx = bk.Context()
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    S.configure(ctx, globe, lens, zoom, (W, H))
+    ctx.build()
+    for p in range(6):
+        ctx.fill_plate_lcg(0, p, seed_frame=0)
+    out = torch.zeros((2, H, W), dtype=torch.uint8, device="cuda")
+    N = 60
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+    host = []
+    gc.collect()
+    gc.disable()
+    try:
+        ev[0].record(stream)
+        for i in range(N):
+            t0 = time.perf_counter()
+            ctx.apply_device(out[i & 1].data_ptr(), W, H * W, frame0=0, nframes=1, rubix_on=bool(i & 1), pal=pal)
+            host.append((time.perf_counter() - t0) * 1e6)
+            ev[i + 1].record(stream)
+            torch.cuda.synchronize()              # a frame per call, as the engine's F_RenderView
+    finally:
+        gc.enable()
+    dev = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(N)]
+    assert O.fnv(out[0].cpu().numpy()) == rec["fnv_frame"] and O.fnv(out[1].cpu().numpy()) == rec["fnv_frame_rubix"]
+    steady_h, steady_d = host[10:], dev[10:]      # (the first launch of each flavour compiles and tunes its map; a few more until clocks and caches have settled)
+    mh, md = sorted(steady_h)[len(steady_h) // 2], sorted(steady_d)[len(steady_d) // 2]
+    print(f"\nrubix toggled per frame at 4K: host call median {mh:.1f} us (max {max(steady_h):.1f}), device median {md:.1f} us (max {max(steady_d):.1f}); "
+          f"first four calls host {[round(h) for h in host[:4]]} us")
+    assert max(steady_h) <= max(2 * mh, 60.0), (mh, max(steady_h), steady_h.index(max(steady_h)))
+    assert max(steady_d) <= 2 * md, (md, max(steady_d), steady_d.index(max(steady_d)))
+    ctx.close()
+
+
 @pytest.mark.parametrize("lens", __import__("scripts").LENSES)
 def test_apply_on_every_shipped_lens(bk, lens):
     """build on the GPU, then warp two frames (rubix off / on) and compare with the oracle's render_lensmap over the
