@@ -498,16 +498,23 @@ extern "C" int bk_upload_plate_async(bk_ctx *ctx, int frame, int plate, const ui
         // SDMA engines do not need one (profiles/r05_resident_apply.txt (2)).  Padding texels (ps..gp, ps..ph) are never read.
         // (tile row by tile row: eight source rows read side by side, the destination written front to back, whole 128-byte tiles at a
         //  time - 2.1 ms for the six plates of a 4K globe on one host thread, what a plain row memcpy of them takes; row by row: 2.9)
-        const size_t tpr = gp >> 4, full = ps >> 4, rest = ps & 15;
-        for (size_t ty = 0; ty * 8 < ps; ++ty) {
-            const size_t nr = ps - ty * 8 < 8 ? ps - ty * 8 : 8;
-            uint8_t *trow = h + ty * tpr * 128;
-            const uint8_t *s0 = src + ty * 8 * (size_t)src_pitch;
-            for (size_t cx = 0; cx < full; ++cx)
-                for (size_t r = 0; r < nr; ++r) memcpy(trow + cx * 128 + r * 16, s0 + r * (size_t)src_pitch + cx * 16, 16);
-            if (rest)
-                for (size_t r = 0; r < nr; ++r) memcpy(trow + full * 128 + r * 16, s0 + r * (size_t)src_pitch + full * 16, rest);
-        }
+        // (r6) ... and on several: one host thread re-tiled at 13 GB/s, 28 MB of plates per 4K frame = 2.1 ms of the drop-in's 1.8 ms-per-frame
+        // budget in this mode; the tile rows are independent - eight pool threads take them in runs of 16
+        const size_t tpr = gp >> 4, full = ps >> 4, rest = ps & 15, tile_rows = (ps + 7) / 8;
+        const size_t run = 16, parts = (tile_rows + run - 1) / run;
+        bk::host_parallel(ps >= 512 ? std::min<size_t>(parts, 8) : 1, [&](size_t part) {
+            const size_t nparts = ps >= 512 ? std::min<size_t>(parts, 8) : 1;
+            for (size_t ty = part * run; ty < tile_rows; ty += nparts * run)
+                for (size_t t = ty; t < std::min(tile_rows, ty + run); ++t) {
+                    const size_t nr = ps - t * 8 < 8 ? ps - t * 8 : 8;
+                    uint8_t *trow = h + t * tpr * 128;
+                    const uint8_t *s0 = src + t * 8 * (size_t)src_pitch;
+                    for (size_t cx = 0; cx < full; ++cx)
+                        for (size_t r = 0; r < nr; ++r) memcpy(trow + cx * 128 + r * 16, s0 + r * (size_t)src_pitch + cx * 16, 16);
+                    if (rest)
+                        for (size_t r = 0; r < nr; ++r) memcpy(trow + full * 128 + r * 16, s0 + r * (size_t)src_pitch + full * 16, rest);
+                }
+        });
         BK_HIP(ctx, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
         BK_HIP(ctx, hipEventRecord(ctx->plate_ev[slot], ctx->stream));
         return BK_OK;
@@ -812,9 +819,15 @@ extern "C" int bk_apply_end(bk_ctx *ctx, uint8_t *dst, int dst_pitch, int x0, in
     }
     // merge only the mapped spans into the caller's buffer (VBUFFER(x+scr_vrect.x, y+scr_vrect.y), fisheye.c:2414-2421)
     BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (const bk::Span &s : ctx->spans)
-        memcpy(dst + (size_t)(y0 + ctx->row0 + s.row) * dst_pitch + x0 + s.x0,
-               ctx->h_frame + (size_t)s.row * ctx->W + s.x0, (size_t)(s.x1 - s.x0));
+    // (r6: a 4K frame is 8.3 MB of row copies - on a few pool threads when it is that large)
+    const size_t nspans = ctx->spans.size(), nparts = (size_t)ctx->W * rows >= ((size_t)1 << 21) ? std::min<size_t>(8, (nspans + 63) / 64) : 1;
+    bk::host_parallel(nparts, [&](size_t part) {
+        const size_t lo = nspans * part / nparts, hi = nspans * (part + 1) / nparts;
+        for (size_t i = lo; i < hi; ++i) {
+            const bk::Span &s = ctx->spans[i];
+            memcpy(dst + (size_t)(y0 + ctx->row0 + s.row) * dst_pitch + x0 + s.x0, ctx->h_frame + (size_t)s.row * ctx->W + s.x0, (size_t)(s.x1 - s.x0));
+        }
+    });
     return BK_OK;
 }
 

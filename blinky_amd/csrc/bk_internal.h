@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -198,6 +199,9 @@ int resident_info(bk_ctx *ctx, int out[12]);
 // launches would wait for it to leave
 inline void resident_quiesce(bk_ctx *ctx) { if (ctx->resident) (void)resident_stop(ctx); }
 bool resident_leaves_room(bk_ctx *ctx);
+/* job(i) for i in [0, parts) on the library's pool of host threads (bk_lens.cpp: the pool that re-derives flagged pixels), the caller
+ * waiting; parts <= 1 or a pool of one thread: on the calling thread */
+void host_parallel(size_t parts, const std::function<void(size_t)> &job);
 bool resident_running(bk_ctx *ctx);      // a session's kernel is on the device right now
 
 // bk_lens.cpp

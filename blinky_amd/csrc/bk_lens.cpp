@@ -1398,6 +1398,22 @@ void hostmod_runs(size_t n, Call call)
 
 }  // namespace
 
+void bk::host_parallel(size_t parts, const std::function<void(size_t)> &job)
+{
+    if (parts <= 1) { if (parts) job(0); return; }
+    FixupPool &pool = FixupPool::get();
+    const size_t nthreads = std::min(parts, pool.size());
+    if (nthreads <= 1) { for (size_t i = 0; i < parts; ++i) job(i); return; }
+    std::atomic<size_t> next{0};
+    pool.run(nthreads, [&](size_t) {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= parts) break;
+            job(i);
+        }
+    });
+}
+
 /* the compiled host module to re-derive flagged entries with, or nullptr: the interpreter does it (host math switched away
  * from the platform libm, no compiler on this machine, still compiling, switched off) */
 static HostModuleP fixup_module(LensProgram *P, const std::string &source)
