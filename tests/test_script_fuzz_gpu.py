@@ -85,7 +85,30 @@ def test_wide_random_scripts_build_the_oracle_table(seed):
     _builds_the_oracle_table(WideGen(17000 + seed).script(forward), seed, forward)
 
 
-def _builds_the_oracle_table(src, seed, forward):
+DECLINED_WRAP = """
+local function bk_down(v, n) if n == 0 then return v end return bk_down(v, n - 1) end
+local bk_inner = %s
+function %s(a, b, c) return bk_inner(bk_down(a, 2), b, c) end
+"""
+
+
+@pytest.mark.parametrize("mode", ["sequential", "declined"])
+@pytest.mark.parametrize("seed", _seeds(12, "BLINKY_FUZZ_HOST_SEEDS"))
+def test_random_scripts_through_the_host_paths_build_the_oracle_table(seed, mode):
+    """(r6) the same random scripts through the HOST evaluation of the callbacks: `sequential` = bk_set_sequential_build(2), one scan in the
+    reference's order (inverse: compiled host module or interpreter; forward: the interpreter in resume_lensmap_forward's call order);
+    `declined` = the callback routed through a recursive helper, which the GPU emitter declines - the interpreter on the worker pool, or
+    the one scan when the script carries state.  Same oracle, same verdicts (built / malformed / run-time error), same tables."""
+    forward = seed % 3 == 2
+    gen = (WideGen if seed % 2 else Gen)(21000 + seed)
+    src = gen.script(forward)
+    if mode == "declined":
+        cb = "lens_forward" if forward else "lens_inverse"
+        src = src + DECLINED_WRAP % (cb, cb)
+    _builds_the_oracle_table(src, seed, forward, host_path=mode)
+
+
+def _builds_the_oracle_table(src, seed, forward, host_path=None):
     """The whole build on random scripts: the GPU lensmap (inverse map for inverse scripts, the forward scatter for
     forward scripts - whose garbage projections push draw_quad through NaNs, huge coordinates and degenerate quads)
     against the oracle's fisheye.c restatement with its callbacks evaluated by the host interpreter on the same
@@ -112,12 +135,19 @@ def _builds_the_oracle_table(src, seed, forward):
     ctx.load_lens(src, f"fuzz{seed}.lua")
     ctx.set_zoom(*S.zoom_args(info.onload.decode()))
     ctx.resize(W, H)
+    if host_path == "sequential":
+        ctx.set_sequential_build(2)
     try:
         display, scale = ctx.build()
         built = True
     except blinky_amd.ffi.BlinkyError:
         built = False
     assert built == lm.built, src
+    if host_path and (built or ctx.last_build_path()[0]):
+        # (a build that failed before the callbacks were looked at - calc_zoom - has no path; otherwise it must be one of the host's)
+        path, why = ctx.last_build_path()
+        assert path in ((2,) if host_path == "sequential" else (1, 2)), (path, why, src)
+        assert host_path == "sequential" or "recursion" in why, why
     if built:
         off, tin = ctx.read_lensmap()
         assert scale == lm.scale or (scale != scale and lm.scale != lm.scale), src      # (a NaN scale builds an empty map, as in the reference)
