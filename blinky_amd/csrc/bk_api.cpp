@@ -249,6 +249,10 @@ extern "C" int bk_set_rows(bk_ctx *ctx, int row0, int row1)
     if (!ctx) return BK_E_INVALID;
     if (row0 < 0 || row1 > ctx->H || row0 > row1)
         return ctx->fail(BK_E_INVALID, "bk_set_rows: [%d,%d) outside 0..%d", row0, row1, ctx->H);
+    if (ctx->device < 0) {                      // a host-only context (BK_DEVICE_NONE) has no maps to allocate: the stripe is bookkeeping (as in bk_resize)
+        ctx->row0 = row0; ctx->row1 = row1;
+        return BK_OK;
+    }
     if (int r = ensure_device(ctx)) return r;
     if (row0 == ctx->row0 && row1 == ctx->row1) return BK_OK;
     ctx->row0 = row0; ctx->row1 = row1;

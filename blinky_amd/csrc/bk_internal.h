@@ -134,6 +134,7 @@ struct bk_ctx {
     double last_kernel_wall_ms = 0;  // inverse build: wall time of the kernel launch(es) + counter / flag-list read-back (sorted)
     int last_kernel_retries = 0;     // kernel re-runs because the flag list had to grow
     bool last_fixup_compiled = false;   // the flagged entries were re-derived by the compiled host module (not the interpreter)
+    uint32_t *host_sink_off = nullptr; uint8_t *host_sink_tint = nullptr;   // bk_debug_host_build: a host-built table goes here instead of the device
     int last_build_path = 0;         // of the last bk_build: 0 = GPU kernels, 1 = host worker pool, 2 = one sequential host scan (bk_last_build_path)
     std::string last_build_why;
     int sequential_build = 1;        // bk_set_sequential_build: 0 never, 1 (default) when the callbacks carry state from pixel to pixel, 2 always

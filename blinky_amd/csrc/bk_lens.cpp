@@ -1449,6 +1449,27 @@ static int read_flagged(bk_ctx *ctx, unsigned int count, std::vector<uint32_t> *
     return BK_OK;
 }
 
+/* Where a host-built table goes: into the context's device lensmap - or, for bk_debug_host_build on a context without a device, into the
+ * caller's arrays (ctx->host_sink_*).  `off` == nullptr: the empty table. */
+static int deliver_host_table(bk_ctx *ctx, const uint32_t *off, const uint8_t *tint)
+{
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    if (ctx->host_sink_off) {
+        if (off) { memcpy(ctx->host_sink_off, off, px * 4); memcpy(ctx->host_sink_tint, tint, px); }
+        else { memset(ctx->host_sink_off, 0xFF, px * 4); memset(ctx->host_sink_tint, 255, px); }
+        return BK_OK;
+    }
+    if (off) {
+        BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, off, px * 4, hipMemcpyHostToDevice, ctx->stream));
+        BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tint, px, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
+        BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+    }
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BK_OK;
+}
+
 // The inverse build as ONE sequential scan on the host (bk_set_sequential_build): what the reference does (fisheye.c:2084-2124) -
 // one evaluator whose script globals travel from pixel to pixel, rows from the bottom up, pixels left to right, stopping at the
 // first malformed result - by the compiled host module on the platform libm (waited for), else by the script interpreter.  For
@@ -1495,9 +1516,7 @@ static int build_sequential(bk_ctx *ctx, LensProgram *P, const std::string &sour
         std::fill(tint.begin(), tint.end(), (uint8_t)255);
         for (int &d : disp) d = 0;
     }
-    BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, off.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
-    BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tint.data(), px, hipMemcpyHostToDevice, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int r = deliver_host_table(ctx, off.data(), tint.data())) return r;
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
     if (errbits) return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
     return BK_OK;
@@ -1578,23 +1597,17 @@ void h_draw_quad(const HostTable &T, const int *tl, const int *tr, const int *bl
 static int finish_host_build(bk_ctx *ctx, const std::vector<uint32_t> &off, const std::vector<uint8_t> &tint, const int disp[BK_MAX_PLATES],
                              int display_out[BK_MAX_PLATES], std::chrono::steady_clock::time_point t0)
 {
-    const size_t px = (size_t)ctx->W * ctx->rows();
     ctx->last_host_eval_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->last_build_ms = ctx->last_host_eval_ms;
     ctx->last_flagged = ctx->last_changed = 0;
-    BK_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, off.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
-    BK_HIP(ctx, hipMemcpyAsync(ctx->d_tints, tint.data(), px, hipMemcpyHostToDevice, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int r = deliver_host_table(ctx, off.data(), tint.data())) return r;
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
     return BK_OK;
 }
 static int empty_host_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], const char *what)
 {
     // a Lua run-time error, which the reference's unprotected lua_call does not survive: nothing is drawn (see bk_build)
-    const size_t px = (size_t)ctx->W * ctx->rows();
-    BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
-    BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int r = deliver_host_table(ctx, nullptr, nullptr)) return r;
     for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
     return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", what);
 }
@@ -1739,6 +1752,48 @@ extern "C" int bk_last_build_path(const bk_ctx *ctx, char *why, size_t cap)
     if (why && cap) snprintf(why, cap, "%s", ctx->last_build_why.c_str());
     return ctx->last_build_path;
 }
+
+#if BK_DEBUG_API
+/* test hook: the HOST build paths on any context, a device-less one included (the CPU suite and the sanitizer run reach them this way).
+ * mode 1 = the worker pool, 2 = one sequential scan, 0 = whichever bk_build would take for a script the emitter declines.  The table
+ * comes back in the reference's layout (plate * ps * ps + py * ps + px, 0xFFFFFFFF = NULL); display_out as bk_build's; the return value
+ * is bk_build's (BK_E_SCRIPT with the truncated / empty table in place).  Inverse maps never use the compiled host module here. */
+extern "C" int bk_debug_host_build(bk_ctx *ctx, int mode, uint32_t *offsets, uint8_t *tints, int display_out[BK_MAX_PLATES], double *scale_out)
+{
+    if (!ctx || !offsets || !tints || mode < 0 || mode > 2) return BK_E_INVALID;
+    LensProgram *P = ctx->prog;
+    if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");
+    if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
+    if (ctx->W <= 0 || ctx->rows() <= 0) return ctx->fail(BK_E_STATE, "bk_debug_host_build: call bk_resize first");
+    const size_t px = (size_t)ctx->W * ctx->rows();
+    memset(offsets, 0xFF, px * 4);
+    memset(tints, 255, px);
+    for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
+    ctx->last_bad_key = 0;
+    if (int r = bk_calc_zoom(ctx, scale_out)) return r;
+    if (P->info.map_type == BK_MAP_NONE) return ctx->fail(BK_E_STATE, "no inverse or forward map being used");
+    BkBuildParams bp;
+    fill_params(ctx, &bp);
+    ctx->host_sink_off = offsets; ctx->host_sink_tint = tints;
+    int rc;
+    if (mode == 0) rc = build_on_host(ctx, P, "bk_debug_host_build", display_out);
+    else if (P->info.map_type == BK_MAP_INVERSE) {
+        if (!P->lens_inverse.is_function()) rc = ctx->fail(BK_E_STATE, "lens has no lens_inverse");
+        else rc = mode == 2 ? build_sequential(ctx, P, std::string(), bp, display_out) : build_inverse_pool(ctx, P, bp, display_out);
+    } else {
+        if (!P->lens_forward.is_function()) rc = ctx->fail(BK_E_STATE, "lens has no lens_forward");
+        else rc = build_forward_host(ctx, P, bp, mode == 2, display_out);
+    }
+    ctx->host_sink_off = nullptr; ctx->host_sink_tint = nullptr;
+    for (size_t i = 0; i < px; ++i) {
+        if (offsets[i] == BK_NULL_OFFSET) continue;
+        unsigned plate, x, y;
+        bk_texel_coords((unsigned)ctx->gp, (unsigned)ctx->ph, offsets[i], &plate, &x, &y);
+        offsets[i] = plate * (unsigned)(ctx->ps * ctx->ps) + y * (unsigned)ctx->ps + x;
+    }
+    return rc;
+}
+#endif
 
 extern "C" int bk_set_sequential_build(bk_ctx *ctx, int mode)
 {

@@ -110,6 +110,7 @@ _SIGS = {
     "bk_debug_band_balance": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "bk_debug_stream_mix": (_i, [_vp, _sz, _i, _i, C.POINTER(_d)]),
     "bk_debug_fnv1a64": (_i, [_vp, _sz, C.POINTER(C.c_uint64)]),
+    "bk_debug_host_build": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i), C.POINTER(_d)]),
     "bk_debug_resident_latency": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d)]),
     "bk_debug_build_params": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "bk_debug_host_entries": (_i, [_vp, _vp, _sz, _vp, _vp]),
@@ -299,6 +300,22 @@ class Context:
         self._chk(lib.bk_debug_build_breakdown(self._h, out))
         return dict(build_ms=out[0], host_eval_ms=out[1], flagged=int(out[2]), pool_threads=int(out[3]), kernel_wall_ms=out[4],
                     retries=int(out[5]) % 1000, compiled_host_module=out[5] >= 1000)
+
+    def host_build(self, mode=0):
+        """the host build paths (bk_debug_host_build; works without a device): (offsets in the reference layout, tints, display, scale, error
+        text or None) - a malformed result / run-time error comes back as text with the truncated / empty table in place"""
+        W, H, ps, r0, r1 = self.size()
+        off = np.empty((r1 - r0) * W, np.uint32)
+        tin = np.empty((r1 - r0) * W, np.uint8)
+        disp = (_i * MAX_PLATES)()
+        scale = _d()
+        rc = lib.bk_debug_host_build(self._h, int(mode), _ptr(off), _ptr(tin), disp, C.byref(scale))
+        err = None
+        if rc != OK:
+            err = lib.bk_last_error(self._h).decode(errors="replace")
+            if rc != -3:                                     # (BK_E_SCRIPT: the table is in place)
+                raise BlinkyError(f"[{rc}] {err}")
+        return off, tin, list(disp), scale.value, err
 
     def last_build_path(self):
         """(path, why) of the last build(): 0 GPU kernels, 1 host worker pool, 2 one sequential host scan"""

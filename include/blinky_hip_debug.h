@@ -50,6 +50,10 @@ int         bk_debug_band_balance(bk_ctx *ctx, uint32_t out[18]);
  * every `period` KiB of it back with non-temporal stores - what this memory system gives a kernel with that read : write
  * ratio and nothing else to do (best of 5 passes; allocates and frees 2 x bytes) */
 int         bk_debug_stream_mix(bk_ctx *ctx, size_t bytes, int period, int writes, double *gbps);
+/* the HOST build paths (scripts the GPU emitter declines, state-carrying scripts; blinky_hip.h at bk_last_build_path) on any context, a
+ * device-less one included: mode 1 = worker pool, 2 = one sequential scan in the reference's order, 0 = what bk_build would choose.
+ * offsets [rows * W] come back in the reference's layout (plate * ps * ps + py * ps + px, 0xFFFFFFFF = NULL); returns what bk_build returns */
+int         bk_debug_host_build(bk_ctx *ctx, int mode, uint32_t *offsets, uint8_t *tints, int display_out[BK_MAX_PLATES], double *scale_out);
 /* FNV-1a-64 of a HOST buffer - the hash tests/golden/lensmaps.json pins frames with (bench.py --check) */
 int         bk_debug_fnv1a64(const void *host, size_t bytes, uint64_t *out);
 /* the resident apply one frame at a time, on the C host's clock (what fisheye_hip.c pays, without a binding in between): `frames`
