@@ -95,6 +95,7 @@ struct CoopMap {
     // BK_COOP_MAX_FLIPS times per lensmap (after that the map stays as it is)
     struct Tuned { int rg = 0, kb = 0, form = 0, fchunk = 0, frames = 0; } tuned[3];
     int flips = 0;
+    int grown_rg = 0;               // != 0: this map's block height is one a resident session grew it to (res_launch): later sessions do not grow it again
     uint32_t stats[BK_COOP_STATS] = {0};
     uint32_t *h_stats = nullptr;    // pinned [64][BK_COOP_STATS]: the full compile's statistics land here asynchronously ...
     hipEvent_t stats_ready = nullptr;   // ... and are folded into `stats` when somebody asks (coopmap_stats / traffic model)
@@ -943,6 +944,7 @@ void coopmap_invalidate(bk_ctx *ctx)
             cm->valid = false;
             for (auto &t : cm->tuned) t = CoopMap::Tuned();
             cm->flips = 0;
+            cm->grown_rg = 0;
         }
 }
 

@@ -582,3 +582,33 @@ def test_three_stripe_contexts_each_with_a_resident_kernel_on_one_gpu(bk):
     infos = [m.ctx(k).resident_info() for k in range(3)]
     assert all(x["running"] for x in infos) and [x["launches"] for x in infos] == settled, (settled, infos)
     m.close()
+
+
+def test_a_second_session_takes_the_form_the_first_took(bk):
+    """(r6) a map whose blocks the first session had to grow (4K gumby: 128x8 -> 128x16, three blocks per workgroup in registers and three
+    fetched per frame) used to be grown AGAIN by the next session of the same lensmap - 128x32, eight blocks per workgroup on 256
+    workgroups, 35 us per frame instead of 15.  The form is a property of the lensmap, not of how many sessions it has seen."""
+    import torch
+    import scripts as S
+    W, H = 3840, 2160
+    ctx = bk.Context()
+    ctx.set_frames(2)
+    S.configure(ctx, "cube", "gumby", None, (W, H))
+    ctx.build()
+    for f in range(2):
+        for p in range(6):
+            ctx.fill_plate_lcg(f, p, seed_frame=f)
+    ref = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    ctx.apply_device(ref.data_ptr(), W, H * W, frame0=1, nframes=1)
+    torch.cuda.synchronize()
+    forms = []
+    for session in range(3):
+        out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+        ctx.resident_begin(idle_ms=500)
+        info = ctx.resident_info()
+        ctx.resident_wait(ctx.resident_submit(out.data_ptr(), W, frame=1))
+        ctx.resident_end()
+        forms.append((info["workgroups"], info["blocks_in_registers"], info["block_h"]))
+        assert torch.equal(out, ref), f"session {session}"
+    assert forms[0] == forms[1] == forms[2], forms
+    ctx.close()
