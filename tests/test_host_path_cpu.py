@@ -1,7 +1,7 @@
 """The host build paths without a GPU (bk_debug_host_build on a device-less context): what bk_build runs for scripts the GPU emitter
 declines and for scripts that carry state (tests/test_host_path_gpu.py has the same through bk_build on the device).  Here the tables
-are held against the goldens recorded from the unmodified reference and against the oracle's scan driven by Python callbacks - and
-tools/sanitize_host.sh runs this file under ASan / UBSan."""
+are held against the goldens recorded from the unmodified reference and against the oracle's scan driven by Python callbacks (the
+host-side sanitizer run of the CPU suite covers this file too)."""
 import json
 import os
 
