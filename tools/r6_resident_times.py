@@ -8,7 +8,7 @@ import torch, bench, blinky_amd, scripts as S
 CASES = [("panini", 3840, 2160), ("rectilinear", 3840, 2160), ("stereographic", 3840, 2160), ("hammer", 3840, 2160), ("quincuncial", 3840, 2160), ("mercator", 3840, 2160),
          ("gumby", 3840, 2160), ("stereographic", 1920, 1080), ("hammer", 1920, 1080), ("hammer", 7680, 4320)]
 if len(sys.argv) > 1:
-    CASES = [c for c in CASES if c[0] in sys.argv[1:]]
+    CASES = [c for c in CASES if c[0] in sys.argv[1:]] or CASES
 for lens, W, H in CASES:
     wl = bench.OneGpuWorkload(torch, blinky_amd, S, 0, "cube", lens, None, W, H, 1, ring_max=64 if W < 7000 else 16)
     r = [wl.resident_us(frames=600 if W < 7000 else 160) for _ in range(3)]
