@@ -428,6 +428,8 @@ def test_resident_c5_8k_frames_equal_reference_golden(bk):
     ctx.resident_wait(last)
     # ... and once more one at a time into the same buffers (a drained pipeline starts differently from a streaming one)
     out2 = torch.zeros_like(out)
+    torch.cuda.synchronize()                     # (the fill is a kernel on torch's stream, running BESIDE the resident kernel: a frame submitted before it
+    #                                               has finished is overwritten by its zeros - seen once the resident frame got faster than the fill, r6)
     for i in range(len(picks)):
         ctx.resident_wait(ctx.resident_submit(out2[i].data_ptr(), W, frame=i))
     ctx.resident_end()
@@ -604,6 +606,7 @@ def test_a_second_session_takes_the_form_the_first_took(bk):
     forms = []
     for session in range(3):
         out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         ctx.resident_begin(idle_ms=500)
         info = ctx.resident_info()
         ctx.resident_wait(ctx.resident_submit(out.data_ptr(), W, frame=1))
