@@ -17,7 +17,33 @@ static thread_local std::string g_create_error;
 // everything queued on it (a plate's DMA, the frame's copy back) waits until that kernel idles out (measured: 200 ms per call, the
 // session's idle time, instead of 0.2 ms).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the
 // process, so it is set here, at load time, unless the user has set it.
-__attribute__((constructor)) static void bk_more_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// (r6) It is a process-wide setting, so: BLINKY_HIP_KEEP_HW_QUEUES=1 leaves it alone; a value the user has set is never
+// overwritten; and when it could not take effect - the HIP runtime was in the process before this library was loaded, with the variable
+// unset - the first resident session says so once on stderr instead of leaving a 200 ms stall per call undiagnosed (bk::hw_queue_note).
+static bool g_hwq_late = false;                 // libamdhip64 was already loaded when the variable was set here: it may have been read already
+__attribute__((constructor)) static void bk_more_hardware_queues()
+{
+    const char *keep = getenv("BLINKY_HIP_KEEP_HW_QUEUES");
+    if (keep && *keep && *keep != '0') return;
+    if (getenv("GPU_MAX_HW_QUEUES")) return;
+    if (void *h = dlopen("libamdhip64.so", RTLD_NOW | RTLD_NOLOAD)) { g_hwq_late = true; (void)dlclose(h); }
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
+void bk::hw_queue_note()
+{
+    static bool said = false;
+    if (said) return;
+    const char *v = getenv("GPU_MAX_HW_QUEUES");
+    const int n = v ? atoi(v) : 4;
+    const char *keep = getenv("BLINKY_HIP_KEEP_HW_QUEUES");
+    if ((g_hwq_late || n < 8) && !(keep && *keep && *keep != '0' && n >= 8)) {
+        said = true;
+        fprintf(stderr, "libblinkyhip: the resident apply keeps a kernel on the device; streams that share one of the runtime's %s hardware queues with it wait "
+                        "until it idles out.  %s (set GPU_MAX_HW_QUEUES=16 in the environment before the process starts).\n",
+                v && !g_hwq_late ? v : "(default 4)",
+                g_hwq_late ? "The HIP runtime was loaded before this library could raise GPU_MAX_HW_QUEUES" : "GPU_MAX_HW_QUEUES is below 8");
+    }
+}
 
 // ---- roctx ranges (bk::Range) --------------------------------------------------------------------------------------
 namespace {

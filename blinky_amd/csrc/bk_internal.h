@@ -200,6 +200,7 @@ int resident_info(bk_ctx *ctx, int out[12]);
 // launches would wait for it to leave
 inline void resident_quiesce(bk_ctx *ctx) { if (ctx->resident) (void)resident_stop(ctx); }
 bool resident_leaves_room(bk_ctx *ctx);
+void hw_queue_note();      // one line on stderr, once, when GPU_MAX_HW_QUEUES could not be raised for the resident apply (bk_api.cpp)
 /* job(i) for i in [0, parts) on the library's pool of host threads (bk_lens.cpp: the pool that re-derives flagged pixels), the caller
  * waiting; parts <= 1 or a pool of one thread: on the calling thread */
 void host_parallel(size_t parts, const std::function<void(size_t)> &job);

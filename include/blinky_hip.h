@@ -265,7 +265,11 @@ int bk_apply_resident_info(bk_ctx *ctx, int out[12]);
  * the plate on the HOST (render_plate's row memcpy, fisheye.c:2441-2449, writes tiles instead of rows) and move it with one DMA, the
  * frame comes back through a pinned copy + host rows - about 1 ms more host time per 3840x2160 frame, no kernel launch at all per frame
  * (a session is begun by the first bk_apply after a build, with that call's
- * rubix flag and palette, and begun again when they change).  Everything else (bk_build, bk_resize, bk_apply_device ...) still ends it. */
+ * rubix flag and palette, and begun again when they change).  Everything else (bk_build, bk_resize, bk_apply_device ...) still ends it.
+ * A process-wide requirement of the resident kernel: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues
+ * (default 4), and a stream that shares a queue with the resident kernel waits until it idles out.  Loading this library sets the
+ * variable to 16 if it is unset (the runtime reads it at its first call); BLINKY_HIP_KEEP_HW_QUEUES=1 prevents that, a value already set
+ * is kept, and when the runtime was loaded first the first session prints one line on stderr saying so. */
 int bk_set_resident_share(bk_ctx *ctx, int part, int parts, int reserve_slots_per_cu);
 int bk_set_resident_apply(bk_ctx *ctx, int on);
 

@@ -37,7 +37,7 @@ def test_debug_entry_points_live_in_their_own_header():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 for env in re.findall(r'getenv\("([A-Z_]+)"\)', txt):
                     # (LUA_PATH / LUA_PATH_5_2: where Lua's `require` looks, as the reference's VM reads them - loadlib.c)
-                    assert env in ("BLINKY_HIP_CACHE", "XDG_CACHE_HOME", "HOME", "BLINKY_HIP_FIXUP_THREADS", "BLINKY_HIP_COMM", "BLINKY_HIP_COMM_TIMEOUT", "BLINKY_HIP_HOSTCXX", "PATH",
+                    assert env in ("BLINKY_HIP_CACHE", "XDG_CACHE_HOME", "HOME", "BLINKY_HIP_FIXUP_THREADS", "BLINKY_HIP_COMM", "BLINKY_HIP_COMM_TIMEOUT", "BLINKY_HIP_HOSTCXX", "BLINKY_HIP_KEEP_HW_QUEUES", "GPU_MAX_HW_QUEUES", "PATH",
                                    "LUA_PATH", "LUA_PATH_5_2"), (f, env)
 
 
