@@ -477,15 +477,21 @@ def test_resident_4k_rubix_and_stripe_equal_oracle(bk):
 
 @pytest.mark.parametrize("cfg", [("cube", "panini", None, 640, 480), ("cube", "hammer", None, 960, 540), ("cube", "stereographic", "f_fov 180", 322, 203)],
                          ids=lambda c: f"{c[1]}-{c[3]}x{c[4]}")
-def test_fresh_plates_every_frame_without_ending_the_session(bk, cfg):
+@pytest.mark.parametrize("reserve", [0, 1], ids=["plates-by-dma", "plates-by-kernel"])
+def test_fresh_plates_every_frame_without_ending_the_session(bk, cfg, reserve):
     """what F_RenderView does (fisheye.c:764-803): every frame six freshly rendered plates (bk_upload_plate_async: re-tiled on the host,
     one DMA each - no kernel) and one bk_apply into a host frame with pitch and origin; 50 frames on ONE launch of the resident kernel,
-    every frame the oracle's, the background of unmapped pixels untouched; then rubix is switched on (a new session), then off again"""
+    every frame the oracle's, the background of unmapped pixels untouched; then rubix is switched on (a new session), then off again.
+    reserve = 1: a place per CU is left free and the plates are re-tiled by a KERNEL on whatever XCD takes it, beside the
+    running resident kernel.  The globes here fit an XCD's L2 several times over and the SAME slot is rewritten every frame: that the
+    workers see the new texels rests on their chunk loads' `nt` policy (no line of a globe is kept from frame to frame) - stated in
+    DESIGN.md 3.2 as a dependency on the hardware; this is its permanent regression test, for both ways a slot gets rewritten."""
     lm = O.lensmap(*cfg)
     W, H = lm.W, lm.H
     pal = O.palmap(O.synthetic_basepal())
     ctx = make_ctx(bk, lm)
     ctx.set_lensmap(lm.offsets, lm.tints)
+    ctx.set_resident_share(0, 1, reserve)
     ctx.set_resident_apply(True)
     pitch, x0, y0 = W + 8, 3, 2
     for i in range(50):
