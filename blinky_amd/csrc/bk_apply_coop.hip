@@ -1274,7 +1274,9 @@ static int ensure_coopmap(bk_ctx *ctx, int launch_frames, int want_tinted)
             // (short launches - stripes, small frames - are timed on longer trains: at 10 us a launch the fixed costs and their
             //  jitter are as large as the differences looked for)
             const double work = (double)nf * rows * ctx->W;
-            const int train = work < 20e6 ? 12 : work < 40e6 ? 6 : 2;
+            // (r6: 5 / 3 instead of 2 for the large ones - a train of two 110 us launches picked 128x8 for 4K hammer x16 on one box and
+            //  128x16 on the next, 0.67 against 0.70 of the peak; the tuning runs once per lensmap and kind of launch)
+            const int train = work < 20e6 ? 12 : work < 40e6 ? 6 : work < 300e6 ? 5 : 3;
             const int span = ctx->nframes > nf ? ctx->nframes - nf + 1 : 1;
             int seq = 0;
             // (the cost model's pick is measured LAST: when it wins - the usual case - it is what is compiled at the end, and the map is not
