@@ -2,6 +2,8 @@
 #include "bk_lua.h"
 
 #include <mutex>
+#include <thread>
+#include <condition_variable>
 
 #include <cerrno>
 #include <cmath>
@@ -9,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 
 #include "bkm.h"
 
@@ -813,6 +816,7 @@ const char *Value::type_name() const
     case NUM: return "number";
     case STR: return "string";
     case TABLE: return "table";
+    case THREAD: return "thread";
     default: return "function";
     }
 }
@@ -1428,6 +1432,7 @@ struct Cloner {
             if (it == bis.end()) it = bis.emplace(v.bi(), std::make_shared<Builtin>(*v.bi())).first;
             o.p = it->second;
         } else if (v.t == Value::STR && v.p) o.p = std::make_shared<std::string>(v.str());
+        else if (v.t == Value::THREAD) o = Value();          // (a coroutine is a native stack of THIS interpreter: a copy of the state for another thread has none of it)
         return o;
     }
     std::shared_ptr<Table> table(const std::shared_ptr<Table> &t)
@@ -1499,6 +1504,7 @@ std::string Interp::tostring(const Value &v) const
         snprintf(buf, sizeof buf, "table: %p", (void *)v.tab());
         return buf;
     case Value::FUNC: snprintf(buf, sizeof buf, "function: %p", (void *)v.fn()); return buf;
+    case Value::THREAD: snprintf(buf, sizeof buf, "thread: %p", v.p.get()); return buf;
     default: return "function: builtin: " + v.bi()->name;
     }
 }
@@ -1921,6 +1927,19 @@ Interp::Interp(const MathLib &m) : math(&m)
         if (loaded.t != Value::TABLE) throw LuaError("'package.loaded' must be a table");
         Value have = loaded.tab()->get(Value::string(name));
         if (have.truthy()) { r.push_back(have); return; }
+        {                                                   // package.preload[name]: a loader the script registered itself (loadlib.c: searcher_preload)
+            const Value preload = pkg.tab()->get(Value::string("preload"));
+            const Value loader = preload.t == Value::TABLE ? preload.tab()->get(Value::string(name)) : Value();
+            if (loader.t != Value::NIL) {
+                Values out = I.call(loader, Values{Value::string(name)});
+                Value result = !out.empty() && out[0].t != Value::NIL ? out[0] : Value();
+                Value now = loaded.tab()->get(Value::string(name));
+                if (result.t == Value::NIL) result = now.t != Value::NIL ? now : Value::boolean(true);
+                loaded.tab()->set(Value::string(name), result);
+                r.push_back(result);
+                return;
+            }
+        }
         const Value pathv = pkg.tab()->get(Value::string("path"));
         if (pathv.t != Value::STR) throw LuaError("'package.path' must be a string");
         std::string file = name, tried;
@@ -2093,6 +2112,21 @@ Interp::Interp(const MathLib &m) : math(&m)
             if (fb->f) { fclose(fb->f); fb->f = nullptr; }
             r.push_back(Value::boolean(true));
         });
+        method("flush", [fb](Interp &, const Values &a, Values &r) {
+            if (!fb->f) throw LuaError("attempt to use a closed file");
+            fflush(fb->f);
+            r.push_back(a.empty() ? Value() : a[0]);
+        });
+        method("seek", [fb](Interp &, const Values &a, Values &r) {              // f_seek (liolib.c): whence "set" / "cur" / "end", offset
+            if (!fb->f) throw LuaError("attempt to use a closed file");
+            const std::string whence = a.size() > 1 && a[1].t == Value::STR ? a[1].str() : "cur";
+            const int w = whence == "set" ? SEEK_SET : whence == "cur" ? SEEK_CUR : whence == "end" ? SEEK_END : -1;
+            if (w < 0) throw LuaError("bad argument #1 to 'seek' (invalid option '" + whence + "')");
+            const double off = a.size() > 2 && a[2].t != Value::NIL ? argnum(a, 2, "seek") : 0.0;
+            if (fseek(fb->f, (long)off, w) != 0) { const int e = errno; r.push_back(Value()); r.push_back(Value::string(strerror(e))); r.push_back(Value::number((double)e)); return; }
+            r.push_back(Value::number((double)ftell(fb->f)));
+        });
+        method("setvbuf", [](Interp &, const Values &, Values &r) { r.push_back(Value::boolean(true)); });
         return obj;
     };
     register_builtin("io.open", [make_file](Interp &, const Values &a, Values &r) {
@@ -2118,6 +2152,314 @@ Interp::Interp(const MathLib &m) : math(&m)
             out += I.tostring(v);
         }
         if (I.print_sink) I.print_sink(out);
+    });
+    // (r6) the rest of what luaL_openlibs (fisheye.c:1224) gives a script while it LOADS, short of coroutines: os.date / difftime / remove /
+    // rename / tmpname / setlocale / exit, io.read / close / flush / input / output / stdin / stdout / stderr, table.pack, xpcall,
+    // collectgarbage, _VERSION, _G, package.preload, debug.traceback / getinfo, string.dump (refuses, as for a C function)
+    register_builtin("os.difftime", [](Interp &, const Values &a, Values &r) { r.push_back(Value::number(argnum(a, 0, "difftime") - (a.size() > 1 && a[1].t != Value::NIL ? argnum(a, 1, "difftime") : 0.0))); });
+    register_builtin("os.date", [](Interp &, const Values &a, Values &r) {
+        std::string fmt = !a.empty() && a[0].t == Value::STR ? a[0].str() : "%c";
+        const time_t t = a.size() > 1 && a[1].t != Value::NIL ? (time_t)argnum(a, 1, "date") : time(nullptr);
+        bool utc = false;
+        if (!fmt.empty() && fmt[0] == '!') { utc = true; fmt.erase(0, 1); }
+        struct tm tmv;
+        if (!(utc ? gmtime_r(&t, &tmv) : localtime_r(&t, &tmv))) { r.push_back(Value()); return; }
+        if (fmt.compare(0, 2, "*t") == 0) {
+            Value tv = Value::table(std::make_shared<Table>());
+            auto setn = [&](const char *k, double v) { tv.tab()->set(Value::string(k), Value::number(v)); };
+            setn("sec", tmv.tm_sec); setn("min", tmv.tm_min); setn("hour", tmv.tm_hour); setn("day", tmv.tm_mday); setn("month", tmv.tm_mon + 1);
+            setn("year", tmv.tm_year + 1900); setn("wday", tmv.tm_wday + 1); setn("yday", tmv.tm_yday + 1);
+            tv.tab()->set(Value::string("isdst"), Value::boolean(tmv.tm_isdst > 0));
+            r.push_back(tv);
+            return;
+        }
+        std::string out;
+        for (size_t i = 0; i < fmt.size(); ++i) {
+            if (fmt[i] != '%') { out += fmt[i]; continue; }
+            if (i + 1 >= fmt.size() || !strchr("aAbBcdHIjmMpSUwWxXyYZ%", fmt[i + 1])) throw LuaError("bad argument #1 to 'date' (invalid conversion specifier '%" + fmt.substr(i + 1, 1) + "')");
+            const char spec[3] = {'%', fmt[++i], 0};
+            char buf[200];
+            out.append(buf, strftime(buf, sizeof buf, spec, &tmv));
+        }
+        r.push_back(Value::string(out));
+    });
+    auto os_result = [](bool ok, const std::string &name, Values &r) {              // os_pushresult (loslib.c)
+        if (ok) { r.push_back(Value::boolean(true)); return; }
+        const int e = errno;
+        r.push_back(Value()); r.push_back(Value::string(name + ": " + strerror(e))); r.push_back(Value::number((double)e));
+    };
+    register_builtin("os.remove", [os_result](Interp &, const Values &a, Values &r) {
+        if (a.empty() || a[0].t != Value::STR) throw LuaError("bad argument #1 to 'remove' (string expected)");
+        os_result(remove(a[0].str().c_str()) == 0, a[0].str(), r);
+    });
+    register_builtin("os.rename", [os_result](Interp &, const Values &a, Values &r) {
+        if (a.size() < 2 || a[0].t != Value::STR || a[1].t != Value::STR) throw LuaError("bad argument to 'rename' (string expected)");
+        os_result(rename(a[0].str().c_str(), a[1].str().c_str()) == 0, a[0].str(), r);
+    });
+    register_builtin("os.tmpname", [](Interp &, const Values &, Values &r) {
+        char name[] = "/tmp/lua_XXXXXX";
+        const int fd = mkstemp(name);
+        if (fd < 0) throw LuaError("unable to generate a unique filename");
+        close(fd);
+        r.push_back(Value::string(name));
+    });
+    register_builtin("os.setlocale", [](Interp &, const Values &a, Values &r) {     // the library runs in the "C" locale and leaves the process's alone
+        const bool c = a.empty() || a[0].t == Value::NIL || (a[0].t == Value::STR && (a[0].str().empty() || a[0].str() == "C" || a[0].str() == "POSIX"));
+        r.push_back(c ? Value::string("C") : Value());
+    });
+    // (the reference's VM would end the engine's process; a library does not: the script gets an error it can see)
+    register_builtin("os.exit", [](Interp &, const Values &, Values &) { throw LuaError("os.exit: a lens / globe script cannot end the host process"); });
+    register_builtin("table.pack", [](Interp &, const Values &a, Values &r) {
+        Value t = Value::table(std::make_shared<Table>());
+        for (size_t i = 0; i < a.size(); ++i) t.tab()->set(Value::number((double)i + 1), a[i]);
+        t.tab()->set(Value::string("n"), Value::number((double)a.size()));
+        r.push_back(t);
+    });
+    register_builtin("collectgarbage", [](Interp &, const Values &a, Values &r) {   // reference counting: nothing to run; "count" answers 0 KB
+        const std::string opt = !a.empty() && a[0].t == Value::STR ? a[0].str() : "collect";
+        static const char *const known[] = {"collect", "stop", "restart", "count", "step", "setpause", "setstepmul", "isrunning", "generational", "incremental"};
+        bool ok = false;
+        for (const char *k : known) ok = ok || opt == k;
+        if (!ok) throw LuaError("bad argument #1 to 'collectgarbage' (invalid option '" + opt + "')");
+        if (opt == "isrunning" || opt == "step") r.push_back(Value::boolean(true));
+        else { r.push_back(Value::number(0)); if (opt == "count") r.push_back(Value::number(0)); }
+    });
+    // xpcall(f, msgh, ...): pcall with the message handed to msgh first (no traceback to unwind here: msgh sees the message)
+    register_builtin("xpcall", [](Interp &I, const Values &a, Values &r) {
+        if (a.size() < 2) throw LuaError("bad argument #2 to 'xpcall' (value expected)");
+        Values args;
+        args.append(a.begin() + 2, a.end());
+        const int depth = I.depth;
+        try {
+            Values out = I.call(a[0], args);
+            r.push_back(Value::boolean(true));
+            r.append(out.begin(), out.end());
+        } catch (const LuaError &e) {
+            I.depth = depth;
+            r.clear();
+            r.push_back(Value::boolean(false));
+            Values h = I.call(a[1], Values{Value::string(e.what())});
+            r.append(h.begin(), h.end());
+        }
+    });
+    register_builtin("debug.traceback", [](Interp &I, const Values &a, Values &r) {
+        if (!a.empty() && a[0].t != Value::STR && a[0].t != Value::NIL && a[0].t != Value::NUM) { r.push_back(a[0]); return; }   // (a non-string message is returned as it is)
+        r.push_back(Value::string((a.empty() || a[0].t == Value::NIL ? std::string() : I.tostring(a[0]) + "\n") + "stack traceback:\n\t[host interpreter: no frames recorded]"));
+    });
+    register_builtin("debug.getinfo", [](Interp &I, const Values &, Values &r) {
+        Value t = Value::table(std::make_shared<Table>());
+        t.tab()->set(Value::string("currentline"), Value::number((double)I.call_line));
+        t.tab()->set(Value::string("short_src"), Value::string(I.call_chunk ? *I.call_chunk : std::string("?")));
+        t.tab()->set(Value::string("source"), Value::string("@" + (I.call_chunk ? *I.call_chunk : std::string("?"))));
+        t.tab()->set(Value::string("what"), Value::string("Lua"));
+        r.push_back(t);
+    });
+    register_builtin("string.dump", [](Interp &, const Values &, Values &) { throw LuaError("unable to dump given function"); });
+    globals["_VERSION"] = Value::string("Lua 5.2");
+    {
+        // _G: the globals live in the interpreter's own map, not in a Lua table - _G is a proxy whose __index / __newindex reach them
+        // (_G.x, _G[name] = v, rawget / pairs on it see nothing: the one difference from lbaselib.c's table of globals)
+        Value g = Value::table(std::make_shared<Table>()), mt = Value::table(std::make_shared<Table>());
+        auto fn = [](const char *name, BuiltinFn f) { Value v; v.t = Value::BUILTIN; auto bp = std::make_shared<Builtin>(); bp->name = name; bp->fn = std::move(f); v.p = std::move(bp); return v; };
+        mt.tab()->set(Value::string("__index"), fn("_G.__index", [](Interp &I, const Values &a, Values &r) {
+            r.push_back(a.size() > 1 && a[1].t == Value::STR ? I.get_global(a[1].str()) : Value());
+        }));
+        mt.tab()->set(Value::string("__newindex"), fn("_G.__newindex", [](Interp &I, const Values &a, Values &) {
+            if (a.size() < 3 || a[1].t != Value::STR) throw LuaError("_G: global names are strings");
+            I.set_global(a[1].str(), a[2]);
+        }));
+        g.tab()->meta = mt.tab_ptr();
+        globals["_G"] = g;
+    }
+    if (get_global("package").t == Value::TABLE && get_global("package").tab()->get(Value::string("preload")).t == Value::NIL)
+        get_global("package").tab()->set(Value::string("preload"), Value::table(std::make_shared<Table>()));
+    // io.stdin / io.stdout / io.stderr and the default files of io.read / io.write (liolib.c): stdout is where print goes (the host's console)
+    {
+        auto std_file = [make_file, read_one](FILE *fp, bool to_console) {
+            Value f = make_file(nullptr);                    // (methods over a box that owns nothing: the standard streams are never closed)
+            auto named = [&f](const char *name, BuiltinFn fn) {
+                Value v; v.t = Value::BUILTIN;
+                auto bp = std::make_shared<Builtin>(); bp->name = std::string("file:") + name; bp->fn = std::move(fn); v.p = std::move(bp);
+                f.tab()->set(Value::string(name), v);
+            };
+            named("write", [fp, to_console](Interp &I, const Values &a, Values &r) {
+                std::string out;
+                for (size_t i = 1; i < a.size(); ++i) {
+                    if (a[i].t != Value::STR && a[i].t != Value::NUM) throw LuaError(std::string("bad argument to 'write' (string expected, got ") + a[i].type_name() + ")");
+                    out += I.tostring(a[i]);
+                }
+                if (to_console) { if (I.print_sink) I.print_sink(out); } else fwrite(out.data(), 1, out.size(), fp);
+                r.push_back(a.empty() ? Value() : a[0]);
+            });
+            named("read", [fp, read_one](Interp &, const Values &a, Values &r) {
+                struct Borrow { FileBox fb; ~Borrow() { fb.f = nullptr; } } b;          // (read_one works on a FileBox; this one must not close the stream)
+                b.fb.f = fp;
+                if (a.size() <= 1) { read_one(b.fb, Value::string("l"), r); return; }
+                for (size_t i = 1; i < a.size(); ++i) if (!read_one(b.fb, a[i], r)) break;
+            });
+            named("close", [](Interp &, const Values &, Values &r) { r.push_back(Value()); r.push_back(Value::string("cannot close standard file")); });
+            named("flush", [fp, to_console](Interp &, const Values &a, Values &r) { if (!to_console) fflush(fp); r.push_back(a.empty() ? Value() : a[0]); });
+            named("setvbuf", [](Interp &, const Values &, Values &r) { r.push_back(Value::boolean(true)); });
+            return f;
+        };
+        Value io = get_global("io");
+        const Value in = std_file(stdin, false), out = std_file(stdout, true), err = std_file(stderr, false);
+        io.tab()->set(Value::string("stdin"), in);
+        io.tab()->set(Value::string("stdout"), out);
+        io.tab()->set(Value::string("stderr"), err);
+        // the default input / output files: cells the io.* functions below share
+        auto def_in = std::make_shared<Value>(in), def_out = std::make_shared<Value>(out);
+        auto open_or_file = [make_file](const Values &a, const char *mode, const char *fn) -> Value {
+            if (a[0].t == Value::STR) {
+                FILE *fp = fopen(a[0].str().c_str(), mode);
+                if (!fp) throw LuaError(a[0].str() + ": " + strerror(errno));
+                return make_file(fp);
+            }
+            if (a[0].t == Value::TABLE && a[0].tab()->get(Value::string("read")).is_function()) return a[0];
+            throw LuaError(std::string("bad argument #1 to '") + fn + "' (file expected)");
+        };
+        register_builtin("io.input", [def_in, open_or_file](Interp &, const Values &a, Values &r) {
+            if (!a.empty() && a[0].t != Value::NIL) *def_in = open_or_file(a, "r", "input");
+            r.push_back(*def_in);
+        });
+        register_builtin("io.output", [def_out, open_or_file](Interp &, const Values &a, Values &r) {
+            if (!a.empty() && a[0].t != Value::NIL) *def_out = open_or_file(a, "w", "output");
+            r.push_back(*def_out);
+        });
+        register_builtin("io.read", [def_in](Interp &I, const Values &a, Values &r) {
+            Values args{*def_in};
+            args.append(a.begin(), a.end());
+            r = I.call(def_in->tab()->get(Value::string("read")), args);
+        });
+        register_builtin("io.write", [def_out](Interp &I, const Values &a, Values &r) {       // (the default output is the console until io.output says otherwise)
+            Values args{*def_out};
+            args.append(a.begin(), a.end());
+            r = I.call(def_out->tab()->get(Value::string("write")), args);
+        });
+        register_builtin("io.close", [def_out](Interp &I, const Values &a, Values &r) {
+            const Value f = !a.empty() && a[0].t == Value::TABLE ? a[0] : *def_out;
+            r = I.call(f.tab()->get(Value::string("close")), Values{f});
+        });
+        register_builtin("io.flush", [def_out](Interp &I, const Values &, Values &r) {
+            const Value fl = def_out->tab()->get(Value::string("flush"));
+            if (fl.is_function()) r = I.call(fl, Values{*def_out});
+        });
+    }
+    // ---- coroutines (lcorolib.c).  The interpreter walks the tree on the native stack, so a coroutine is a native stack of its own: a thread
+    // that runs ONLY while its resumer waits (strict hand-over under the coroutine's mutex: the interpreter's state is never touched by two
+    // threads at once).  create / resume / yield / status / running / wrap, yields across pcall and metamethods included (there is no C
+    // boundary here to refuse them).  A coroutine that is dropped while suspended is unwound (its yield throws) before its thread is joined.
+    struct CoKill {};
+    struct Coroutine {
+        Value fn;
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        enum { FRESH, RUNNING, SUSPENDED, NORMAL, DEAD } state = FRESH;
+        bool co_turn = false, kill = false, failed = false;
+        Values xfer;
+        std::string err;
+        int depth = 0;                                       // the interpreter's call depth inside this coroutine
+        void to_co() { std::unique_lock<std::mutex> lock(m); co_turn = true; cv.notify_all(); cv.wait(lock, [this] { return !co_turn; }); }
+        void to_resumer() { std::unique_lock<std::mutex> lock(m); co_turn = false; cv.notify_all(); cv.wait(lock, [this] { return co_turn; }); }
+        ~Coroutine()
+        {
+            if (!th.joinable()) return;
+            if (std::this_thread::get_id() == th.get_id()) { th.detach(); return; }      // (the last reference died inside its own body)
+            if (state != DEAD) { kill = true; to_co(); }
+            th.join();
+        }
+    };
+    auto co_of = [](const Values &a, const char *fn) -> std::shared_ptr<Coroutine> {
+        if (a.empty() || a[0].t != Value::THREAD) throw LuaError(std::string("bad argument #1 to '") + fn + "' (coroutine expected)");
+        return std::static_pointer_cast<Coroutine>(a[0].p);
+    };
+    auto co_resume = [](Interp &I, const std::shared_ptr<Coroutine> &co, const Value *first, const Value *last, Values &r) -> bool {
+        if (co->state == Coroutine::DEAD) { r.push_back(Value::string("cannot resume dead coroutine")); return false; }
+        if (co->state == Coroutine::RUNNING || co->state == Coroutine::NORMAL) { r.push_back(Value::string("cannot resume non-suspended coroutine")); return false; }
+        Coroutine *prev = static_cast<Coroutine *>(I.current_co);
+        if (prev) prev->state = Coroutine::NORMAL;
+        const int depth = I.depth;
+        const bool fresh = co->state == Coroutine::FRESH;
+        co->xfer.assign(first, last);
+        co->state = Coroutine::RUNNING;
+        I.current_co = co.get();
+        I.depth = co->depth;
+        if (fresh) {
+            Coroutine *c = co.get();
+            Interp *ip = &I;
+            co->th = std::thread([c, ip]() {
+                { std::unique_lock<std::mutex> lock(c->m); c->cv.wait(lock, [c] { return c->co_turn; }); }
+                if (!c->kill) {
+                    try { Values out = ip->call(c->fn, c->xfer); c->xfer = std::move(out); }
+                    catch (const LuaError &e) { c->failed = true; c->err = e.what(); }
+                    catch (const CoKill &) {}
+                }
+                c->state = Coroutine::DEAD;
+                std::unique_lock<std::mutex> lock(c->m);
+                c->co_turn = false;
+                c->cv.notify_all();
+            });
+        }
+        co->to_co();                                         // ... and wait until it yields, returns or fails
+        co->depth = I.depth;
+        I.depth = depth;
+        I.current_co = prev;
+        if (prev) prev->state = Coroutine::RUNNING;
+        if (co->failed) { co->failed = false; r.push_back(Value::string(co->err)); return false; }
+        r.append(co->xfer.begin(), co->xfer.end());
+        return true;
+    };
+    register_builtin("coroutine.create", [](Interp &, const Values &a, Values &r) {
+        if (a.empty() || !a[0].is_function()) throw LuaError("bad argument #1 to 'create' (function expected)");
+        auto co = std::make_shared<Coroutine>();
+        co->fn = a[0];
+        Value v;
+        v.t = Value::THREAD;
+        v.p = co;
+        r.push_back(v);
+    });
+    register_builtin("coroutine.resume", [co_of, co_resume](Interp &I, const Values &a, Values &r) {
+        auto co = co_of(a, "resume");
+        Values out;
+        const bool ok = co_resume(I, co, a.begin() + 1, a.end(), out);
+        r.push_back(Value::boolean(ok));
+        r.append(out.begin(), out.end());
+    });
+    register_builtin("coroutine.yield", [](Interp &I, const Values &a, Values &r) {
+        Coroutine *co = static_cast<Coroutine *>(I.current_co);
+        if (!co) throw LuaError("attempt to yield from outside a coroutine");
+        co->xfer = a;
+        co->state = Coroutine::SUSPENDED;
+        co->to_resumer();                                    // ... until somebody resumes (or drops) this coroutine
+        if (co->kill) throw CoKill();
+        r = co->xfer;                                        // what resume was given
+    });
+    register_builtin("coroutine.status", [co_of](Interp &, const Values &a, Values &r) {
+        static const char *const names[] = {"suspended", "running", "suspended", "normal", "dead"};
+        r.push_back(Value::string(names[co_of(a, "status")->state]));
+    });
+    register_builtin("coroutine.running", [](Interp &I, const Values &, Values &r) {
+        // (the main thread has no object here: nil, true - Lua 5.2 returns the main coroutine and true)
+        r.push_back(Value());
+        r.push_back(Value::boolean(I.current_co == nullptr));
+        (void)I;
+    });
+    register_builtin("coroutine.wrap", [co_resume](Interp &, const Values &a, Values &r) {
+        if (a.empty() || !a[0].is_function()) throw LuaError("bad argument #1 to 'wrap' (function expected)");
+        auto co = std::make_shared<Coroutine>();
+        co->fn = a[0];
+        Value v;
+        v.t = Value::BUILTIN;
+        auto bp = std::make_shared<Builtin>();
+        bp->name = "coroutine.wrap";
+        bp->fn = [co, co_resume](Interp &I, const Values &args, Values &out) {
+            Values res;
+            if (!co_resume(I, co, args.begin(), args.end(), res)) throw LuaError(!res.empty() && res[0].t == Value::STR ? res[0].str() : std::string("error in a wrapped coroutine"));
+            out = std::move(res);
+        };
+        v.p = std::move(bp);
+        r.push_back(v);
     });
     // pcall(f, ...): true + results, or false + the error message (lua_pcall; messages carry no traceback here either)
     register_builtin("pcall", [](Interp &I, const Values &a, Values &r) {

@@ -115,10 +115,10 @@ struct Builtin;
 // A Lua value: 32 bytes - tag, number / boolean, and ONE reference for the heap kinds (string, table, closure, builtin).
 // Numbers and booleans - nearly everything a lens callback touches - copy without touching a reference count.
 struct Value {
-    enum T : uint8_t { NIL, BOOL, NUM, STR, TABLE, FUNC, BUILTIN } t = NIL;
+    enum T : uint8_t { NIL, BOOL, NUM, STR, TABLE, FUNC, BUILTIN, THREAD } t = NIL;
     bool b = false;
     double n = 0;
-    std::shared_ptr<void> p;                // STR: std::string, TABLE: Table, FUNC: Closure, BUILTIN: Builtin
+    std::shared_ptr<void> p;                // STR: std::string, TABLE: Table, FUNC: Closure, BUILTIN: Builtin, THREAD: Coroutine (bk_lua.cpp)
 
     static Value nil() { return Value(); }
     static Value boolean(bool v) { Value x; x.t = BOOL; x.b = v; return x; }
@@ -241,6 +241,7 @@ struct Interp {
     const std::string *call_chunk = nullptr; // where the builtin call being made stands (error() puts "chunk:line:" in front of its message)
     int call_line = 0;
     int depth = 0;
+    void *current_co = nullptr;             // the coroutine whose body is running on this interpreter (coroutine library, bk_lua.cpp); null = the main thread
     std::function<void(const std::string &)> print_sink;   // `print` / io.write output, newlines included (Con_Printf)
 
     Value get_global(const std::string &name) const;

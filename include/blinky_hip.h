@@ -80,9 +80,10 @@ int         bk_synchronize(bk_ctx *ctx);
  * `src` is the text of <basedir>/lua-scripts/{globes,lenses}/<name>.lua.
  * One interpreter state lives in the context, so script globals leak between
  * loads exactly as in the reference (only the names of fisheye.c:1880-1903 are cleared).
- * The language: what runs while a script LOADS (the chunk, what it calls) is Lua 5.2 without coroutines and without most of
- * io / os (closures, varargs, metatables, goto, the string library with patterns, table.*, math.*, pcall / error,
- * load / dofile / require relative to the working directory).  What the per-pixel CALLBACKS (lens_inverse, lens_forward,
+ * The language: what runs while a script LOADS (the chunk, what it calls) is Lua 5.2 (closures, varargs, metatables, goto, coroutines,
+ * the string library with patterns, table.*, math.*, bit32.*, os.*, io.*, pcall / xpcall / error, load / dofile / require with
+ * package.path / package.preload relative to the working directory; r6: coroutines, the rest of os / io, _G as a proxy of the globals;
+ * not provided: string.dump, os.exit - an error the script can see -, the debug library beyond traceback / getinfo).  What the per-pixel CALLBACKS (lens_inverse, lens_forward,
  * globe_plate and everything they call) may use is narrower - they become GPU code at bk_build: numbers, booleans, nil, string
  * constants, local tables (arrays, records {x = ..}, matrices {{..}, {..}}), constant tables of the chunk, every control structure but goto, the math library, functions
  * defined inside a callback, functions and constant tables passed as arguments, methods of constant objects, varargs.  A script whose

@@ -1338,3 +1338,95 @@ def test_example_lenses(bk, name, monkeypatch):
     off, tin, flagged, err = emu.build_inverse(ctx)
     assert err == 0 and (off != 0xFFFFFFFF).sum() > 6000
     ctx.kernel_source(compile=True)
+
+
+# ---- (r6) the rest of the load-time library: coroutines, os / io / base functions luaL_openlibs (fisheye.c:1224) opens --------------------
+
+COROUTINES = r'''
+local co
+co = coroutine.create(function(a, b)
+   print("start", a, b, coroutine.status(co))
+   local c = coroutine.yield(a + b)
+   local d, e = coroutine.yield(c * 2)
+   return "done", d .. e
+end)
+print(type(co), coroutine.status(co))
+print(coroutine.resume(co, 1, 2))
+print(coroutine.status(co), coroutine.resume(co, 10))
+print(coroutine.resume(co, "x", "y"))
+print(coroutine.status(co), coroutine.resume(co))
+local function range(n) return coroutine.wrap(function() for i = 1, n do coroutine.yield(i) end end) end
+local s = 0; for v in range(10) do s = s + v end; print("sum", s)
+local bad = coroutine.create(function() coroutine.yield(1); error("oops") end)
+print(coroutine.resume(bad)); print(coroutine.resume(bad)); print(coroutine.status(bad))
+local pc = coroutine.wrap(function() local ok, v = pcall(function() local x = coroutine.yield("inside pcall"); error("after " .. x) end); coroutine.yield(tostring(ok) .. " " .. v); return "end" end)
+print(pc()); print(pc("resume")); print(pc())
+local outer
+outer = coroutine.create(function()
+   local inner = coroutine.create(function() print("outer seen from inner:", coroutine.status(outer)); coroutine.yield() end)
+   coroutine.resume(inner); print("inner:", coroutine.status(inner))
+end)
+coroutine.resume(outer)
+print(pcall(coroutine.yield, 1))
+print(select(2, coroutine.running()), pcall(coroutine.resume, 5))
+do local dropped = coroutine.create(function() coroutine.yield(1); print("never") end); coroutine.resume(dropped) end
+fib = coroutine.wrap(function() local a, b = 0, 1; while true do coroutine.yield(a); a, b = b, a + b end end)
+local t = {}; for i = 1, 10 do t[i] = fib() end; print(table.concat(t, " "))
+-- a lens whose table of samples is produced by a generator while the script loads
+local samples = {}
+for v in coroutine.wrap(function() for i = 0, 4 do coroutine.yield(i * 0.25) end end) do samples[#samples + 1] = v end
+function lens_inverse(x, y) return x * samples[3], y, 1 end
+'''
+
+
+def test_coroutines_on_the_host(bk):
+    """create / resume / yield / status / running / wrap: a generator, values both ways, an error inside (the coroutine dies, resume says
+    false + message), a yield across pcall, nesting ("normal"), yield outside a coroutine, a suspended coroutine dropped and one still
+    suspended when the context closes (both unwound, nothing hangs) - lcorolib.c's behaviour; the callbacks themselves stay coroutine-free"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(COROUTINES, "co.lua")
+    assert ctx.console().splitlines() == [
+        "thread\tsuspended", "start\t1\t2\trunning", "true\t3", "suspended\ttrue\t20", "true\tdone\txy", "dead\tfalse\tcannot resume dead coroutine",
+        "sum\t55", "true\t1", "false\tco.lua:16: oops", "dead", "inside pcall", "false co.lua:18: after resume", "end",
+        "outer seen from inner:\tnormal", "inner:\tsuspended", "false\tattempt to yield from outside a coroutine",
+        "true\tfalse\tbad argument #1 to 'resume' (coroutine expected)", "0 1 1 2 3 5 8 13 21 34"]
+    assert ctx.eval_host(0, 2.0, 1.0) == (1.0, 1.0, 1.0)
+    ctx.resize(64, 48)
+    assert "lens_inverse" in ctx.kernel_source(compile=False)       # samples is a constant table of the chunk: the callback still becomes GPU code
+    ctx.close()
+
+
+STDLIB_REST = r'''
+print(_VERSION, type(_G), _G.print == print, _G["math"].pi == math.pi)
+_G.zzz = 41; print(zzz + 1)
+local t = table.pack(1, nil, 3); print(t.n, t[1], t[3])
+print(xpcall(function(a) error("boom " .. a) end, function(m) return "handled: " .. m end, 7))
+print(xpcall(function(a, b) return a + b end, print, 1, 2))
+print(os.difftime(10, 4), type(os.date()), os.date("!%Y-%m-%d %H:%M:%S", 0), os.date("!*t", 86400).day, os.setlocale(), os.setlocale("xx"))
+print(pcall(os.exit))
+local name = os.tmpname(); local f = io.open(name, "w"); f:write("line one\n", 42, "\nrest"); f:flush(); f:close()
+f = io.open(name); print(f:read("l"), f:read("n"), f:seek("set", 0), f:read(4)); io.close(f)
+io.input(name); print(io.read("L") == "line one\n"); io.input():close()
+print(os.rename(name, name .. ".b"), os.remove(name .. ".b"), (os.remove(name .. ".b")))
+io.write("via io.write ", 1, "\n"); io.stdout:write("via stdout\n"); print(io.stdout:close())
+print(collectgarbage("count"), pcall(collectgarbage, "bogus"))
+print(type(debug.traceback("msg")), debug.getinfo(1).what, pcall(string.dump, print))
+package.preload["mine"] = function(n) return {name = n} end; print(require("mine").name, require("mine") == package.loaded.mine)
+function lens_inverse(x, y) return x, y, 1 end
+'''
+
+
+def test_the_rest_of_the_load_time_library(bk):
+    """what a script may call while it loads beyond rounds 3-5's set: _G / _VERSION, table.pack, xpcall, collectgarbage, os.date / difftime /
+    remove / rename / tmpname / setlocale (os.exit is an error a script can see: a library does not end its host), io.read / close / flush /
+    input / output / stdout, file:seek / flush, package.preload, debug.traceback / getinfo"""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(STDLIB_REST, "lib.lua")
+    assert ctx.console().splitlines() == [
+        "Lua 5.2\ttable\ttrue\ttrue", "42", "3\t1\t3", "false\thandled: lib.lua:5: boom 7", "true\t3", "6\tstring\t1970-01-01 00:00:00\t2\tC\tnil",
+        "false\tos.exit: a lens / globe script cannot end the host process", "line one\t42\t0\tline", "true", "true\ttrue\tnil",
+        "via io.write 1", "via stdout", "nil\tcannot close standard file", "0\tfalse\tbad argument #1 to 'collectgarbage' (invalid option 'bogus')",
+        "string\tLua\tfalse\tunable to dump given function", "mine\ttrue"]
+    ctx.close()
