@@ -156,6 +156,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipFree(ctx->d_display);
     hipFree(ctx->d_flag_list);
     for (void *q : ctx->fwd_scratch) hipFree(q);
+    hipFree(ctx->fwd_tables);
     bk::coopmap_free(ctx->coopmap);
     bk::coopmap_free(ctx->coopmap_alt);
     bk::lensprogram_free(ctx->prog);

@@ -178,10 +178,14 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
  * corner (i,j), i,j in 0..ps, is (u,v) = ((i-0.5)/ps, (j-0.5)/ps) */
 BK_DEV void bk_corner_at(const BkBuildParams &P, BkState &S, int plate, int j, int i, int *sx_out, int *sy_out, unsigned char *ok_out)
 {
+    float ray[3];
+#ifdef BK_HOST_MODULE
     const double u = ((double)i - 0.5) / P.ps;
     const double v = ((double)j - 0.5) / P.ps;
-    float ray[3];
     bk_plate_uv_to_ray(P, plate, u, v, ray);
+#else
+    bk_plate_fuv_to_ray(P, plate, P.fwd_uv[i], -P.fwd_uv[j], ray);          /* the same two floats, from the build's table */
+#endif
     bkv a[3] = {bk_num((double)ray[0]), bk_num((double)ray[1]), bk_num((double)ray[2])};
     bkv r[BK_MAXRET];
     const int n = LF_lens_forward(S, a, 3, r);
@@ -191,8 +195,8 @@ BK_DEV void bk_corner_at(const BkBuildParams &P, BkState &S, int plate, int j, i
         const double fx = r[0].n / P.scale + (double)(P.W / 2), fy = -r[1].n / P.scale + (double)(P.H / 2);
         sx = bk_trunc_to_int(fx);                                            /* :2239 */
         sy = bk_trunc_to_int(fy);                                            /* :2240 */
-        bk_need_same_trunc(S, fx, bk_eop(S, fx, r[0].e / P.scale));
-        bk_need_same_trunc(S, fy, bk_eop(S, fy, r[1].e / P.scale));
+        bk_need_same_trunc(S, fx, bk_eop(S, fx, r[0].e * P.inv_scale_up));
+        bk_need_same_trunc(S, fy, bk_eop(S, fy, r[1].e * P.inv_scale_up));
         ok = 1;
     } else if (!(n == 1 && r[0].t == BK_TNIL)) {
         S.err |= BK_ERR_RESULT;
@@ -215,7 +219,11 @@ BK_DEV void bk_corner_entry(const BkBuildParams &P, BkState &S, long long id, in
 BK_DEV bool bk_texel_owns_at(const BkBuildParams &P, BkState &S, int plate, int py, int px)
 {
     float ray[3];
+#ifdef BK_HOST_MODULE
     bk_plate_uv_to_ray(P, plate, (double)px / P.ps, (double)py / P.ps, ray);   /* :2193-2195 */
+#else
+    bk_plate_fuv_to_ray(P, plate, P.fwd_uv[P.ps + 1 + px], -P.fwd_uv[P.ps + 1 + py], ray);
+#endif
     return plate == bk_ray_to_plate_index(S, ray);                              /* :2196 */
 }
 BK_DEV bool bk_texel_owns(const BkBuildParams &P, BkState &S, long long id)     /* id = (plate * ps + py) * ps + px */
@@ -262,7 +270,18 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
 struct BkFwdWin {
     int x0, y0, w, h;                 /* window on the screen: origin, extent (<= BK_FWD_WIN each; rows are BK_FWD_WIN apart in LDS) */
     unsigned int *px, *tint;          /* [BK_FWD_WIN * BK_FWD_WIN] keys, 0 = none; px == nullptr: no window */
+    const double *quot;               /* BkBuildParams::fwd_quot, in LDS */
 };
+/* (double)a / (double)d of draw_quad's edge interpolation (fisheye.c:2313).  An edge of a quad that passed the 20-pixel size check has
+ * |d| <= 20 and a between 0 and d: the quotient is |a| / |d| - IEEE division is sign-symmetric - and comes from the build's table
+ * (a = 0 over a negative d reads +0 where the division gives -0: times dx, plus an integer, truncated, the same int).  Anything
+ * else - the wrapped differences of INT_MIN corners - is divided out as before. */
+BK_DEV double bk_edge_quot(int a, int d, const double *quot)
+{
+    const unsigned int ua = a < 0 ? 0u - (unsigned int)a : (unsigned int)a, ud = d < 0 ? 0u - (unsigned int)d : (unsigned int)d;
+    if (ua <= 20u && ud - 1u < 20u && ((a ^ d) >= 0 || a == 0)) return quot[ua * 21u + ud];
+    return (double)a / (double)d;
+}
 BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
 {
     if (lx < 0 || lx >= P.W || ly < 0 || ly >= P.H) return;                  /* :1966 */
@@ -286,17 +305,16 @@ BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key,
  * per-row abort - unless the x extent wraps as well (both bounds INT_MIN / 0 in x AND y: then the abort of an off-screen row is
  * not seen; the top-left pixel's neighbourhood under a lens that returns NaN for both coordinates). */
 BK_DEV int bk_wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
-BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, const int *bl, const int *br,
+BK_DEV int bk_imin(int a, int b) { return a < b ? a : b; }
+BK_DEV int bk_imax(int a, int b) { return a > b ? a : b; }
+BK_DEV void bk_draw_quad(const BkBuildParams &P, int x0, int y0, int x1, int y1, int x2, int y2, int x3, int y3,   /* tl, tr, br, bl: p[0..3] of :2251 */
                          unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
 {
-    const int *p[4] = {tl, tr, br, bl};
-    int x = tl[0], y = tl[1];
-    int miny = y, maxy = y, minx = x, maxx = x;
-    for (int i = 1; i < 4; i++) {
-        int tx = p[i][0], ty = p[i][1];
-        if (tx < minx) minx = tx; else if (tx > maxx) maxx = tx;
-        if (ty < miny) miny = ty; else if (ty > maxy) maxy = ty;
-    }
+    /* (the corners are values, and the edge loop below is written out: indexing an array of four corner pointers kept them in memory,
+     * and every edge of every row waited for two loads) */
+    int x = x0, y = y0;
+    const int minx = bk_imin(bk_imin(x0, x1), bk_imin(x2, x3)), maxx = bk_imax(bk_imax(x0, x1), bk_imax(x2, x3));       /* :2257-2268 */
+    const int miny = bk_imin(bk_imin(y0, y1), bk_imin(y2, y3)), maxy = bk_imax(bk_imax(y0, y1), bk_imax(y2, y3));
     const int maxdiff = 20;
     {
         int dx = bk_wrap_sub(minx, maxx), dy = bk_wrap_sub(miny, maxy);
@@ -313,22 +331,23 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, const int *tl, const int *tr, c
     const int y_first = tall ? vy0 : miny, nrows = bk_wrap_sub(tall ? vy1 : maxy, y_first);      /* <= 20, or <= H - 1; < 0: none */
     for (int ky = 0; ky <= nrows; ++ky) {
         y = (int)((unsigned)y_first + (unsigned)ky);
-        int tx[2] = {minx, maxx};
-        int txi = 0, j = 3;
-        for (int i = 0; i < 4; ++i) {
-            int ix = p[i][0], iy = p[i][1];
-            int jx = p[j][0], jy = p[j][1];
-            if ((iy < y && y <= jy) || (jy < y && y <= iy)) {                /* :2310 */
-                double dy = (double)bk_wrap_sub(jy, iy);
-                double dx = (double)bk_wrap_sub(jx, ix);
-                tx[txi] = bk_trunc_to_int((double)ix + (double)bk_wrap_sub(y, iy) / dy * dx);   /* :2313 */
-                if (++txi == 2) break;
-            }
-            j = i;
+        int t0 = minx, t1 = maxx, txi = 0;
+        /* edges in the reference's order - (p[0], p[3]), (p[1], p[0]), (p[2], p[1]), (p[3], p[2]) - until two of them cross the row */
+#define BK_QUAD_EDGE(ix, iy, jx, jy)                                                                                              \
+        if (txi < 2 && ((iy < y && y <= jy) || (jy < y && y <= iy))) {                                            /* :2310 */      \
+            const double dx_ = (double)bk_wrap_sub(jx, ix);                                                                        \
+            const int t_ = bk_trunc_to_int((double)ix + bk_edge_quot(bk_wrap_sub(y, iy), bk_wrap_sub(jy, iy), win.quot) * dx_);    /* :2313 */ \
+            if (txi == 0) t0 = t_; else t1 = t_;                                                                                   \
+            ++txi;                                                                                                                 \
         }
-        if (tx[0] > tx[1]) { int t = tx[0]; tx[0] = tx[1]; tx[1] = t; }
-        if (bk_wrap_sub(tx[1], tx[0]) > maxdiff) return;                     /* :2327 aborts the quad */
-        const int x_first = tx[0] < 0 ? 0 : tx[0], x_last = tx[1] >= P.W ? P.W - 1 : tx[1];
+        BK_QUAD_EDGE(x0, y0, x3, y3)
+        BK_QUAD_EDGE(x1, y1, x0, y0)
+        BK_QUAD_EDGE(x2, y2, x1, y1)
+        BK_QUAD_EDGE(x3, y3, x2, y2)
+#undef BK_QUAD_EDGE
+        if (t0 > t1) { const int t = t0; t0 = t1; t1 = t; }
+        if (bk_wrap_sub(t1, t0) > maxdiff) return;                           /* :2327 aborts the quad */
+        const int x_first = t0 < 0 ? 0 : t0, x_last = t1 >= P.W ? P.W - 1 : t1;
         for (x = x_first; x <= x_last; ++x) bk_fwd_set(P, x, y, key, offgrid, wrote, win);
     }
 }
@@ -341,7 +360,10 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
     __shared__ int s_disp[6];
     __shared__ int s_box[4];                         /* the tile's bounding box on the screen: min x, min y, max x, max y */
     __shared__ unsigned int s_px[BK_FWD_WIN * BK_FWD_WIN], s_tint[BK_FWD_WIN * BK_FWD_WIN];
+    __shared__ double s_quot[21 * 21];
     const int tid = (int)threadIdx.x;
+    s_quot[tid] = P.fwd_quot[tid];
+    if (tid + 256 < 21 * 21) s_quot[tid + 256] = P.fwd_quot[tid + 256];
     if (tid < 6) s_disp[tid] = 0;
     if (tid < 2) s_box[tid] = 0x7FFFFFFF;
     else if (tid < 4) s_box[tid] = -1;
@@ -349,10 +371,16 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
     const int px = (int)blockIdx.x * BK_FWD_TILE + (tid & (BK_FWD_TILE - 1)), py = (int)blockIdx.y * BK_FWD_TILE + tid / BK_FWD_TILE, plate = (int)blockIdx.z;
     int err = 0;
     bool have = false;                               /* this texel owns its ray and all four of its corners project */
-    const int *tl = nullptr, *bl = nullptr;
+    int q[8] = {0, 0, 0, 0, 0, 0, 0, 0};             /* its corners on the screen: tl, tr, bl, br (x, y each) */
     int mx = 0x7FFFFFFF, my = 0x7FFFFFFF, Mx = -1, My = -1;       /* this lane's vote for the box (none: the neutral elements) */
     if (px < P.ps && py < P.ps) {
         const unsigned int id = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)py) * (unsigned int)P.ps + (unsigned int)px;
+        /* the corners are asked for first - all of them, whether or not the texel turns out to own its ray: one round trip to memory,
+         * spent under the arithmetic of the ownership test */
+        const int n1 = P.ps + 1;
+        const size_t c_tl = ((size_t)plate * n1 + py) * n1 + px, c_bl = c_tl + n1;
+        const unsigned int ok4 = (unsigned int)P.corner_ok[c_tl] & (unsigned int)P.corner_ok[c_tl + 1] & (unsigned int)P.corner_ok[c_bl] & (unsigned int)P.corner_ok[c_bl + 1];
+        for (int c = 0; c < 4; ++c) { q[c] = P.corner_xy[2 * c_tl + c]; q[4 + c] = P.corner_xy[2 * c_bl + c]; }
         BkState S;
         bk_state_init(S, &P);
         bool own = bk_texel_owns_at(P, S, plate, py, px);
@@ -366,38 +394,41 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
             if (lo < P.ovr_count && (P.ovr_list[lo] >> 1) == id) own = P.ovr_list[lo] & 1u;
         } else if (S.flag) bk_push_flagged(P, id, own ? 1u : 0u, 0u, 0u);
 #endif
-        if (own) {
-            const int n1 = P.ps + 1;
-            const size_t c_tl = ((size_t)plate * n1 + py) * n1 + px, c_bl = c_tl + n1;
-            if (P.corner_ok[c_tl] && P.corner_ok[c_tl + 1] && P.corner_ok[c_bl] && P.corner_ok[c_bl + 1]) {
-                have = true;
-                tl = &P.corner_xy[2 * c_tl];
-                bl = &P.corner_xy[2 * c_bl];
-                /* the window covers the tile's quads from its top-left-most pixel on (corners that are nowhere near a screen - a NaN
-                 * projection is INT_MIN - do not vote) */
-                int a0 = tl[0], a1 = tl[1], b0 = tl[0], b1 = tl[1];
-                const int cx[3] = {tl[2], bl[0], bl[2]}, cy[3] = {tl[3], bl[1], bl[3]};
-                for (int c = 0; c < 3; ++c) {
-                    a0 = cx[c] < a0 ? cx[c] : a0; b0 = cx[c] > b0 ? cx[c] : b0;
-                    a1 = cy[c] < a1 ? cy[c] : a1; b1 = cy[c] > b1 ? cy[c] : b1;
-                }
-                if (a0 > -(1 << 24) && a1 > -(1 << 24) && b0 < (1 << 24) && b1 < (1 << 24)) { mx = a0 < 0 ? 0 : a0; my = a1 < 0 ? 0 : a1; Mx = b0; My = b1; }
-            }
+        if (own && ok4) {
+            have = true;
+            /* the window covers the tile's quads from its top-left-most pixel on (corners that are nowhere near a screen - a NaN
+             * projection is INT_MIN - do not vote) */
+            const int a0 = bk_imin(bk_imin(q[0], q[2]), bk_imin(q[4], q[6])), b0 = bk_imax(bk_imax(q[0], q[2]), bk_imax(q[4], q[6]));
+            const int a1 = bk_imin(bk_imin(q[1], q[3]), bk_imin(q[5], q[7])), b1 = bk_imax(bk_imax(q[1], q[3]), bk_imax(q[5], q[7]));
+            if (a0 > -(1 << 24) && a1 > -(1 << 24) && b0 < (1 << 24) && b1 < (1 << 24)) { mx = a0 < 0 ? 0 : a0; my = a1 < 0 ? 0 : a1; Mx = b0; My = b1; }
         }
         err = S.err;
     }
     /* the votes are settled inside the wave first: 256 lanes of a tile on four LDS words cost more than everything they decide saves
      * (measured: four contended LDS atomics per thread made the pass 0.4 ms longer); eight waves' worth do not */
-    for (int o = 32; o > 0; o >>= 1) {
-        const int q0 = __shfl_xor(mx, o), q1 = __shfl_xor(my, o), q2 = __shfl_xor(Mx, o), q3 = __shfl_xor(My, o);
-        mx = q0 < mx ? q0 : mx; my = q1 < my ? q1 : my; Mx = q2 > Mx ? q2 : Mx; My = q3 > My ? q3 : My;
+    /* ... as two pairs of 16-bit lanes (v_pk_min_i16 / v_pk_max_i16): the box only decides which writes meet in LDS, so clamping it to
+     * 32767 pixels costs nothing but the window of a screen wider than that */
+    {
+        typedef short bk_s2 __attribute__((ext_vector_type(2)));
+        const bool voted = mx != 0x7FFFFFFF;
+        bk_s2 lo = {(short)(mx > 32767 ? 32767 : mx), (short)(my > 32767 ? 32767 : my)};
+        bk_s2 hi = {(short)(Mx > 32767 ? 32767 : Mx < -1 ? -1 : Mx), (short)(My > 32767 ? 32767 : My < -1 ? -1 : My)};
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ql = __shfl_xor(__builtin_bit_cast(int, lo), o), qh = __shfl_xor(__builtin_bit_cast(int, hi), o);
+            lo = __builtin_elementwise_min(lo, __builtin_bit_cast(bk_s2, ql));
+            hi = __builtin_elementwise_max(hi, __builtin_bit_cast(bk_s2, qh));
+        }
+        const unsigned long long any = __ballot(voted);
+        if ((tid & 63) == 0 && any) {
+            atomicMin(&s_box[0], (int)lo.x); atomicMin(&s_box[1], (int)lo.y); atomicMax(&s_box[2], (int)hi.x); atomicMax(&s_box[3], (int)hi.y);
+        }
     }
-    if ((tid & 63) == 0 && mx != 0x7FFFFFFF) { atomicMin(&s_box[0], mx); atomicMin(&s_box[1], my); atomicMax(&s_box[2], Mx); atomicMax(&s_box[3], My); }
     __syncthreads();
     BkFwdWin win;
     win.x0 = s_box[0]; win.y0 = s_box[1];
     win.px = win.x0 != 0x7FFFFFFF ? s_px : nullptr;
     win.tint = s_tint;
+    win.quot = s_quot;
     win.w = win.px ? s_box[2] - win.x0 + 1 : 0;
     win.h = win.px ? s_box[3] - win.y0 + 1 : 0;
     win.w = win.w < 0 ? 0 : win.w > BK_FWD_WIN ? BK_FWD_WIN : win.w;
@@ -411,7 +442,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
     if (have) {
         const unsigned int key = ((unsigned int)plate * (unsigned int)P.ps + (unsigned int)(P.ps - 1 - py)) * (unsigned int)P.ps + (unsigned int)px + 1u;
         int wrote = 0;
-        bk_draw_quad(P, tl, tl + 2, bl, bl + 2, key, bk_offgrid(P, px, py), &wrote, win);
+        bk_draw_quad(P, q[0], q[1], q[2], q[3], q[6], q[7], q[4], q[5], key, bk_offgrid(P, px, py), &wrote, win);
         if (wrote) s_disp[plate] = 1;
     }
     __syncthreads();

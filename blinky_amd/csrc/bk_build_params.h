@@ -45,6 +45,14 @@ typedef struct {
     /* inverse build: 1 + scan key of the FIRST pixel (in the reference's scan order: rows bottom-up, pixels left to right,
      * fisheye.c:2093-2103) whose callback returned a malformed result - key = ly * W + (W - 1 - lx), max-reduced; 0 = none */
     unsigned int *first_bad;
+    /* forward build: what the kernels would otherwise divide out per texel corner / per texel / per quad edge, evaluated once on the
+     * host with the same IEEE operations (device memory; the host module of the flagged entries computes instead and never reads them):
+     * fwd_quot[a * 21 + d] = (double)a / (double)d for 0 <= a <= 20, 1 <= d <= 20 - draw_quad's edge interpolation (fisheye.c:2313);
+     * fwd_uv[i] = (float)(((double)i - 0.5) / ps - 0.5), i in 0..ps - a texel corner's offset along right (negated: along up) in
+     * plate_uv_to_ray (fisheye.c:1205-1211, 2229); fwd_uv[ps + 1 + i] = (float)((double)i / ps - 0.5) - a texel's own ray (:2193). */
+    const double *fwd_quot;
+    const float *fwd_uv;
+    double inv_scale_up;     /* >= 1 / scale: turns an error bound in lens units into screen pixels without a division */
 } BkBuildParams;
 
 /* Device globe layout.  A plate is gp = round_up(ps,64) texels wide and ph = round_up(ps,8) high and is

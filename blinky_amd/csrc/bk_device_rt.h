@@ -347,17 +347,22 @@ BK_DEV void bk_latlon_to_ray(BkState &S, double lat, double elat, double lon, do
     ray[1] = bk_narrow(S, slat, bk_elibm(S, slat, elat));
     ray[2] = bk_narrow(S, p2, bk_eop(S, p2, bk_abs(clon) * ec + bk_abs(clat) * ek + ec * ek));
 }
-BK_DEV void bk_plate_uv_to_ray(const BkBuildParams &P, int plate, double u, double v, float *ray)    /* fisheye.c:1198 */
+/* plate_uv_to_ray from the two floats VectorMA scales right and up by: fu = (float)(u - 0.5), fv = (float)(-(v - 0.5)) */
+BK_DEV void bk_plate_fuv_to_ray(const BkBuildParams &P, int plate, float fu, float fv, float *ray)
 {
     const BkPlateDev &p = P.plates[plate];
+    ray[0] = ray[1] = ray[2] = 0;
+    bk_vector_ma(ray, p.dist, p.forward, ray);
+    bk_vector_ma(ray, fu, p.right, ray);
+    bk_vector_ma(ray, fv, p.up, ray);
+    bk_vector_normalize(ray);
+}
+BK_DEV void bk_plate_uv_to_ray(const BkBuildParams &P, int plate, double u, double v, float *ray)    /* fisheye.c:1198 */
+{
     u -= 0.5;
     v -= 0.5;
     v = -v;
-    ray[0] = ray[1] = ray[2] = 0;
-    bk_vector_ma(ray, p.dist, p.forward, ray);
-    bk_vector_ma(ray, (float)u, p.right, ray);
-    bk_vector_ma(ray, (float)v, p.up, ray);
-    bk_vector_normalize(ray);
+    bk_plate_fuv_to_ray(P, plate, (float)u, (float)v, ray);
 }
 /* (int)double the way x86-64 cvttsd2si does: NaN / out of range -> INT_MIN */
 BK_DEV int bk_trunc_to_int(double v)

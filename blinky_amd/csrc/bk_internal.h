@@ -95,6 +95,8 @@ struct bk_ctx {
     // its kernels): texel-corner screen coordinates, corner flags, the two key planes; released when an inverse map is built
     void *fwd_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t fwd_scratch_bytes[4] = {0, 0, 0, 0};
+    void *fwd_tables = nullptr;          // BkBuildParams::fwd_quot + fwd_uv for platesize fwd_tables_ps (bk_lens.cpp)
+    int fwd_tables_ps = -1;
     int last_flagged = 0, last_changed = 0;   // of the last bk_build: entries re-evaluated on the host / entries that changed
     uint8_t *h_frame = nullptr;      // pinned, [row1-row0][W]
     uint64_t *h_mask = nullptr;      // pinned

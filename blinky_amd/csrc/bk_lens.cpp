@@ -1093,6 +1093,7 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
     bp->numplates = ctx->numplates;
     bp->has_globe_plate = ctx->prog->globe_plate.is_function();
     bp->scale = ctx->scale;
+    bp->inv_scale_up = 1.0 / __builtin_fabs(ctx->scale) * (1.0 + 0x1p-50);
     // set_lensmap_grid constants, fisheye.c:1938-1948 (same double operations)
     const double block_size = ctx->rubix.pad + ctx->rubix.cell;
     const double num_units = ctx->rubix.numcells * block_size + ctx->rubix.pad;
@@ -1973,6 +1974,26 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             bp.corner_ok = (unsigned char *)ctx->fwd_scratch[1];
             bp.fwd_key_px = (unsigned int *)ctx->fwd_scratch[2];
             bp.fwd_key_tint = (unsigned int *)ctx->fwd_scratch[3];
+            // the quotient / uv tables of bk_build_params.h: plain IEEE divisions, done here once per platesize instead of per texel
+            constexpr size_t NQ = 21 * 21;
+            if (ctx->fwd_tables_ps != ctx->ps) {
+                (void)hipFree(ctx->fwd_tables);
+                ctx->fwd_tables = nullptr; ctx->fwd_tables_ps = -1;
+                std::vector<double> q(NQ, 0.0);
+                for (int a = 0; a <= 20; ++a)
+                    for (int d = 1; d <= 20; ++d) q[(size_t)a * 21 + d] = (double)a / (double)d;
+                std::vector<float> uv(2 * n1);
+                for (size_t i = 0; i < n1; ++i) {
+                    uv[i] = (float)(((double)i - 0.5) / ctx->ps - 0.5);
+                    uv[n1 + i] = (float)((double)i / ctx->ps - 0.5);
+                }
+                BK_HIP_C(hipMalloc(&ctx->fwd_tables, NQ * sizeof(double) + uv.size() * sizeof(float)));
+                BK_HIP_C(hipMemcpy(ctx->fwd_tables, q.data(), NQ * sizeof(double), hipMemcpyHostToDevice));
+                BK_HIP_C(hipMemcpy((char *)ctx->fwd_tables + NQ * sizeof(double), uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice));
+                ctx->fwd_tables_ps = ctx->ps;
+            }
+            bp.fwd_quot = (const double *)ctx->fwd_tables;
+            bp.fwd_uv = (const float *)((const char *)ctx->fwd_tables + NQ * sizeof(double));
             BK_HIP_C(hipEventRecord(e0, ctx->stream));
             // texel corners -> screen; the flagged ones re-derived on the host
             for (;;) {

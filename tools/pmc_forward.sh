@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04_pmc_fwd; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r06_pmc_fwd}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 declare -A G
 G[valu]="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
