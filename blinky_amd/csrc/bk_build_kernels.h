@@ -297,6 +297,30 @@ BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key,
     atomicMax(&P.fwd_key_px[o], key);
     if (offgrid) atomicMax(&P.fwd_key_tint[o], key);
 }
+/* the pixels [xa, xb] of screen row ly, as bk_fwd_set would take them one by one - the row's tests made once */
+BK_DEV void bk_fwd_row(const BkBuildParams &P, int xa, int xb, int ly, unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
+{
+    if (ly < 0 || ly >= P.H) return;                                         /* :1966 */
+    xa = xa < 0 ? 0 : xa;
+    xb = xb >= P.W ? P.W - 1 : xb;
+    if (xa > xb) return;
+    *wrote = 1;
+    if (ly < P.row0 || ly >= P.row0 + P.rows) return;                        /* stripe-filtered commit */
+    const int wy = ly - win.y0;
+    const bool row_in = win.px && wy >= 0 && wy < win.h;
+    for (int lx = xa; lx <= xb; ++lx) {
+        const int wx = lx - win.x0;
+        if (row_in && wx >= 0 && wx < win.w) {
+            const int k = wy * BK_FWD_WIN + wx;
+            atomicMax(&win.px[k], key);
+            if (offgrid) atomicMax(&win.tint[k], key);
+        } else {
+            const size_t o = (size_t)(ly - P.row0) * P.W + lx;
+            atomicMax(&P.fwd_key_px[o], key);
+            if (offgrid) atomicMax(&P.fwd_key_tint[o], key);
+        }
+    }
+}
 /* draw_quad (fisheye.c:2246-2338); int overflow on INT_MIN coordinates wraps as on x86-64.
  * A NaN projection becomes INT_MIN in uv_to_screen (cvttsd2si), and abs(INT_MIN - 0) is INT_MIN again: a quad with one bound at
  * INT_MIN and the other at exactly 0 PASSES the reference's 20-pixel size check and its loops then run over 2^31 rows or columns,
@@ -320,6 +344,30 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, int x0, int y0, int x1, int y1,
         int dx = bk_wrap_sub(minx, maxx), dy = bk_wrap_sub(miny, maxy);
         int adx = dx < 0 ? bk_wrap_sub(0, dx) : dx, ady = dy < 0 ? bk_wrap_sub(0, dy) : dy;      /* abs(): INT_MIN stays INT_MIN */
         if (adx > maxdiff || ady > maxdiff) return;                          /* :2272 */
+    }
+    /* A quad on one or two rows - every quad of a minifying lens: a 4K screen from six 2160-texel plates is 3.4 texels per pixel -
+     * needs none of the arithmetic below.  Row miny: no edge has an end above it, the reference finds no crossing and fills
+     * [minx, maxx] (:2304-2331 with tx[] as initialised).  Row maxy = miny + 1: an edge crosses it iff its ends lie on different rows,
+     * and the interpolation (:2313) is (double)ix + 1.0 * dx or (double)ix + (+-0.0) * dx - exactly the x of the end that lies ON the
+     * row; the first two such edges in the reference's order give the span.  The one-pixel, one-row and one-column cases (:2276-2301)
+     * are the same two spans.  (Spans compared as wrapped differences: INT_MIN corners never pass.) */
+    if ((unsigned int)bk_wrap_sub(maxx, minx) <= (unsigned int)maxdiff && (unsigned int)bk_wrap_sub(maxy, miny) <= 1u) {
+        int t0 = minx, t1 = maxx, txi = 0;
+#define BK_QUAD_EDGE2(ix, iy, jx, jy)                                       \
+        if (txi < 2 && iy != jy) {                                          \
+            const int t_ = iy == maxy ? ix : jx;                            \
+            if (txi == 0) t0 = t_; else t1 = t_;                            \
+            ++txi;                                                          \
+        }
+        BK_QUAD_EDGE2(x0, y0, x3, y3)
+        BK_QUAD_EDGE2(x1, y1, x0, y0)
+        BK_QUAD_EDGE2(x2, y2, x1, y1)
+        BK_QUAD_EDGE2(x3, y3, x2, y2)
+#undef BK_QUAD_EDGE2
+        if (t0 > t1) { const int t = t0; t0 = t1; t1 = t; }
+        const int nr = maxy - miny;
+        for (int r = 0; r <= nr; ++r) bk_fwd_row(P, r ? t0 : minx, r ? t1 : maxx, r ? maxy : miny, key, offgrid, wrote, win);
+        return;
     }
     /* the part of [min, max] that is on the screen (all of a normal, <= 21-long range that matters; one end of a 2^31-long one) */
     const int vx0 = minx < 0 ? 0 : minx, vx1 = maxx >= P.W ? P.W - 1 : maxx;
