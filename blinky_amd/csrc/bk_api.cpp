@@ -157,6 +157,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     hipFree(ctx->d_flag_list);
     for (void *q : ctx->fwd_scratch) hipFree(q);
     hipFree(ctx->fwd_tables);
+    if (ctx->h_build_flags) hipHostFree(ctx->h_build_flags);
     bk::coopmap_free(ctx->coopmap);
     bk::coopmap_free(ctx->coopmap_alt);
     bk::lensprogram_free(ctx->prog);

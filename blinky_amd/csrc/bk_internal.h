@@ -95,6 +95,10 @@ struct bk_ctx {
     // its kernels): texel-corner screen coordinates, corner flags, the two key planes; released when an inverse map is built
     void *fwd_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t fwd_scratch_bytes[4] = {0, 0, 0, 0};
+    // fill_params' rubix grid bitmap for (platesize, rubix numcells / cell / pad): a division and an fmod per texel column, once - not per build
+    unsigned int grid_cache[256] = {0};
+    double grid_cache_key[4] = {-1, 0, 0, 0};
+    int *h_build_flags = nullptr;        // pinned: the counters of a forward build's two passes, read back without a stop in between
     void *fwd_tables = nullptr;          // BkBuildParams::fwd_quot + fwd_uv for platesize fwd_tables_ps (bk_lens.cpp)
     int fwd_tables_ps = -1;
     int last_flagged = 0, last_changed = 0;   // of the last bk_build: entries re-evaluated on the host / entries that changed

@@ -63,6 +63,7 @@ struct LensProgram {
     hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr;
     std::shared_future<::CodeResult> pending;     // bk_set_async_compile: hiprtc running on another thread ...
     std::string pending_source;                      // ... for this generated source
+    bool fwd_needs_host = false;  // the last forward build flagged entries for the host: the next one stops after each pass again
     std::string last_source;      // for bk_debug_kernel_source
     std::string console;          // print() output of the scripts
 
@@ -1101,8 +1102,15 @@ static void fill_params(bk_ctx *ctx, BkBuildParams *bp)
     bp->rubix_pad = ctx->rubix.pad;
     bp->rubix_unit_px = (double)ctx->ps / num_units;
     if (ctx->ps <= 32 * (int)(sizeof bp->grid_bits / sizeof bp->grid_bits[0])) {
-        for (int p = 0; p < ctx->ps; ++p)                /* fisheye.c:1950-1957; division and fmod are exact operations */
-            if (__builtin_fmod((double)p / bp->rubix_unit_px, bp->rubix_block) < bp->rubix_pad) bp->grid_bits[p >> 5] |= 1u << (p & 31);
+        const double key[4] = {(double)ctx->ps, (double)ctx->rubix.numcells, ctx->rubix.cell, ctx->rubix.pad};
+        if (memcmp(key, ctx->grid_cache_key, sizeof key) != 0) {
+            memset(ctx->grid_cache, 0, sizeof ctx->grid_cache);
+            for (int p = 0; p < ctx->ps; ++p)            /* fisheye.c:1950-1957; division and fmod are exact operations */
+                if (__builtin_fmod((double)p / bp->rubix_unit_px, bp->rubix_block) < bp->rubix_pad) ctx->grid_cache[p >> 5] |= 1u << (p & 31);
+            memcpy(ctx->grid_cache_key, key, sizeof key);
+        }
+        static_assert(sizeof ctx->grid_cache == sizeof bp->grid_bits, "one bitmap");
+        memcpy(bp->grid_bits, ctx->grid_cache, sizeof bp->grid_bits);
         bp->grid_n = ctx->ps;
     }
     for (int i = 0; i < ctx->numplates; ++i) {
@@ -1994,6 +2002,46 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             }
             bp.fwd_quot = (const double *)ctx->fwd_tables;
             bp.fwd_uv = (const float *)((const char *)ctx->fwd_tables + NQ * sizeof(double));
+            const auto launch_quads = [&]() -> hipError_t {
+                hipError_t e = hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, ctx->stream);
+                if (e == hipSuccess) e = hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, ctx->stream);
+                if (e == hipSuccess) e = hipModuleLaunchKernel(P->k_quads, (unsigned)((ctx->ps + 15) / 16), (unsigned)((ctx->ps + 15) / 16), (unsigned)ctx->numplates, 256, 1, 1, 0,
+                                                               ctx->stream, args, nullptr);       // (BK_FWD_TILE = 16: bk_build_kernels.h)
+                return e;
+            };
+            const auto launch_resolve = [&]() -> hipError_t {
+                return hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+            };
+            // The three passes in one go, their counters read back into pinned memory on the way: nearly every build flags nothing - no
+            // corner and no texel for the host to look at again - and then the table is final when the stream drains, two stops (a
+            // read-back and a decision each, 25-30 us apiece at 4K) earlier.  A build that did flag something is done over the careful
+            // way below, and so is the next build of the same lens.
+            bool speculated = false;
+            if (!P->fwd_needs_host) {
+                constexpr size_t NF = BK_MAX_PLATES + 3;
+                if (!ctx->h_build_flags) BK_HIP_C(hipHostMalloc((void **)&ctx->h_build_flags, 2 * NF * sizeof(int), hipHostMallocDefault));
+                int *const after_corners = ctx->h_build_flags, *const after_quads = ctx->h_build_flags + NF;
+                BK_HIP_C(hipEventRecord(e0, ctx->stream));
+                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                BK_HIP_C(hipMemcpyAsync(after_corners, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                BK_HIP_C(reset_counters());
+                BK_HIP_C(launch_quads());
+                BK_HIP_C(hipMemcpyAsync(after_quads, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                BK_HIP_C(launch_resolve());
+                BK_HIP_C(hipEventRecord(e1, ctx->stream));
+                BK_HIP_C(hipStreamSynchronize(ctx->stream));
+                if (after_corners[BK_MAX_PLATES + 1] == 0 && after_quads[BK_MAX_PLATES + 1] == 0) {
+                    memcpy(flags, after_quads, sizeof flags);
+                    flags[BK_MAX_PLATES] |= after_corners[BK_MAX_PLATES];
+                    ctx->last_flagged = 0;
+                    ctx->last_changed = 0;
+                    speculated = true;
+                } else {
+                    P->fwd_needs_host = true;
+                    BK_HIP_C(reset_counters());
+                }
+            }
+            if (!speculated) {
             BK_HIP_C(hipEventRecord(e0, ctx->stream));
             // texel corners -> screen; the flagged ones re-derived on the host
             for (;;) {
@@ -2045,10 +2093,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 bool again = false;
                 for (;;) {
                     BK_HIP_C(reset_counters());
-                    BK_HIP_C(hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, ctx->stream));
-                    BK_HIP_C(hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, ctx->stream));
-                    BK_HIP_C(hipModuleLaunchKernel(P->k_quads, (unsigned)((ctx->ps + 15) / 16), (unsigned)((ctx->ps + 15) / 16), (unsigned)ctx->numplates, 256, 1, 1, 0,
-                                                   ctx->stream, args, nullptr));       // (BK_FWD_TILE = 16: bk_build_kernels.h)
+                    BK_HIP_C(launch_quads());
                     BK_HIP_C(read_counters());
                     if (pass == 1) break;
                     bool retry = false;
@@ -2081,8 +2126,10 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 if (!again) break;
             }
             flags[BK_MAX_PLATES] |= corner_err;
-            BK_HIP_C(hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+            BK_HIP_C(launch_resolve());
             BK_HIP_C(hipEventRecord(e1, ctx->stream));
+            P->fwd_needs_host = ctx->last_flagged != 0;
+            }
         }
     } catch (const LuaError &e) {
         cleanup();
