@@ -158,6 +158,8 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     for (void *q : ctx->fwd_scratch) hipFree(q);
     hipFree(ctx->fwd_tables);
     if (ctx->h_build_flags) hipHostFree(ctx->h_build_flags);
+    if (ctx->build_aux) hipStreamDestroy(ctx->build_aux);
+    for (hipEvent_t e : ctx->build_ev) if (e) hipEventDestroy(e);
     bk::coopmap_free(ctx->coopmap);
     bk::coopmap_free(ctx->coopmap_alt);
     bk::lensprogram_free(ctx->prog);

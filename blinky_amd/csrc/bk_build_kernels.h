@@ -29,11 +29,17 @@ BK_DEV int bk_ray_to_plate_index(BkState &S, const float *ray)
     if (plate < 0 || plate >= P.numplates) return -1;       /* the reference would index out of bounds */
     return plate;
 #else
+    /* (the reference widens each float dot to double and compares those, :2042: widening is exact and keeps the order, NaN included -
+     * the floats compare the same.  Written out for the six plates a globe can have: the plate vectors arrive in one scalar load
+     * instead of one per turn of a loop.) */
     int plate_index = 0;
-    double max_dp = -2;
-    for (int i = 0; i < P.numplates; ++i) {
-        double dp = (double)bk_dot3(ray, P.plates[i].forward);   /* float dot, widened   :2042 */
-        if (dp > max_dp) { max_dp = dp; plate_index = i; }   /* strict >: first maximum wins */
+    float max_dp = -2.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (i < P.numplates) {
+            const float dp = bk_dot3(ray, P.plates[i].forward);
+            if (dp > max_dp) { max_dp = dp; plate_index = i; }   /* strict >: first maximum wins */
+        }
     }
     return plate_index;
 #endif

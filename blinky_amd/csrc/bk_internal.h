@@ -98,6 +98,8 @@ struct bk_ctx {
     // fill_params' rubix grid bitmap for (platesize, rubix numcells / cell / pad): a division and an fmod per texel column, once - not per build
     unsigned int grid_cache[256] = {0};
     double grid_cache_key[4] = {-1, 0, 0, 0};
+    hipStream_t build_aux = nullptr;     // a forward build clears its key planes here, beside the corner pass
+    hipEvent_t build_ev[2] = {nullptr, nullptr};
     int *h_build_flags = nullptr;        // pinned: the counters of a forward build's two passes, read back without a stop in between
     void *fwd_tables = nullptr;          // BkBuildParams::fwd_quot + fwd_uv for platesize fwd_tables_ps (bk_lens.cpp)
     int fwd_tables_ps = -1;

@@ -2002,9 +2002,12 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             }
             bp.fwd_quot = (const double *)ctx->fwd_tables;
             bp.fwd_uv = (const float *)((const char *)ctx->fwd_tables + NQ * sizeof(double));
-            const auto launch_quads = [&]() -> hipError_t {
-                hipError_t e = hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, ctx->stream);
-                if (e == hipSuccess) e = hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, ctx->stream);
+            const auto clear_keys = [&](hipStream_t st) -> hipError_t {
+                hipError_t e = hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, st);
+                return e == hipSuccess ? hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, st) : e;
+            };
+            const auto launch_quads = [&](bool keys_cleared = false) -> hipError_t {
+                hipError_t e = keys_cleared ? hipSuccess : clear_keys(ctx->stream);
                 if (e == hipSuccess) e = hipModuleLaunchKernel(P->k_quads, (unsigned)((ctx->ps + 15) / 16), (unsigned)((ctx->ps + 15) / 16), (unsigned)ctx->numplates, 256, 1, 1, 0,
                                                                ctx->stream, args, nullptr);       // (BK_FWD_TILE = 16: bk_build_kernels.h)
                 return e;
@@ -2021,11 +2024,21 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 constexpr size_t NF = BK_MAX_PLATES + 3;
                 if (!ctx->h_build_flags) BK_HIP_C(hipHostMalloc((void **)&ctx->h_build_flags, 2 * NF * sizeof(int), hipHostMallocDefault));
                 int *const after_corners = ctx->h_build_flags, *const after_quads = ctx->h_build_flags + NF;
+                if (!ctx->build_aux) {
+                    BK_HIP_C(hipStreamCreateWithFlags(&ctx->build_aux, hipStreamNonBlocking));
+                    for (hipEvent_t &e : ctx->build_ev) BK_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                }
                 BK_HIP_C(hipEventRecord(e0, ctx->stream));
+                // the key planes (66 MB at 4K) are cleared on the side stream while the corner pass - arithmetic only - has the chip
+                BK_HIP_C(hipEventRecord(ctx->build_ev[0], ctx->stream));
+                BK_HIP_C(hipStreamWaitEvent(ctx->build_aux, ctx->build_ev[0], 0));
+                BK_HIP_C(clear_keys(ctx->build_aux));
+                BK_HIP_C(hipEventRecord(ctx->build_ev[1], ctx->build_aux));
                 BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
                 BK_HIP_C(hipMemcpyAsync(after_corners, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 BK_HIP_C(reset_counters());
-                BK_HIP_C(launch_quads());
+                BK_HIP_C(hipStreamWaitEvent(ctx->stream, ctx->build_ev[1], 0));
+                BK_HIP_C(launch_quads(true));
                 BK_HIP_C(hipMemcpyAsync(after_quads, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 BK_HIP_C(launch_resolve());
                 BK_HIP_C(hipEventRecord(e1, ctx->stream));
