@@ -160,6 +160,7 @@ extern "C" void bk_destroy(bk_ctx *ctx)
     if (ctx->h_build_flags) hipHostFree(ctx->h_build_flags);
     if (ctx->build_aux) hipStreamDestroy(ctx->build_aux);
     for (hipEvent_t e : ctx->build_ev) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->build_time_ev) if (e) hipEventDestroy(e);
     bk::coopmap_free(ctx->coopmap);
     bk::coopmap_free(ctx->coopmap_alt);
     bk::lensprogram_free(ctx->prog);

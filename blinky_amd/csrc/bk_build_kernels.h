@@ -335,6 +335,24 @@ BK_DEV void bk_fwd_row(const BkBuildParams &P, int xa, int xb, int ly, unsigned 
  * per-row abort - unless the x extent wraps as well (both bounds INT_MIN / 0 in x AND y: then the abort of an off-screen row is
  * not seen; the top-left pixel's neighbourhood under a lens that returns NaN for both coordinates). */
 BK_DEV int bk_wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+/* two signed 16-bit lanes in an int: v_pk_min_i16 / v_pk_max_i16 on the device */
+BK_DEV int bk_pack_i16(int x, int y) { return (int)(((unsigned int)x & 0xFFFFu) | ((unsigned int)y << 16)); }
+#if defined(__clang__)
+typedef short bk_s2 __attribute__((ext_vector_type(2)));
+BK_DEV int bk_pk_min_i16(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(bk_s2, a), __builtin_bit_cast(bk_s2, b))); }
+BK_DEV int bk_pk_max_i16(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(bk_s2, a), __builtin_bit_cast(bk_s2, b))); }
+#else
+BK_DEV int bk_pk_min_i16(int a, int b)
+{
+    const int ax = (short)(a & 0xFFFF), bx = (short)(b & 0xFFFF), ay = a >> 16, by = b >> 16;
+    return bk_pack_i16(ax < bx ? ax : bx, ay < by ? ay : by);
+}
+BK_DEV int bk_pk_max_i16(int a, int b)
+{
+    const int ax = (short)(a & 0xFFFF), bx = (short)(b & 0xFFFF), ay = a >> 16, by = b >> 16;
+    return bk_pack_i16(ax > bx ? ax : bx, ay > by ? ay : by);
+}
+#endif
 BK_DEV int bk_imin(int a, int b) { return a < b ? a : b; }
 BK_DEV int bk_imax(int a, int b) { return a > b ? a : b; }
 BK_DEV void bk_draw_quad(const BkBuildParams &P, int x0, int y0, int x1, int y1, int x2, int y2, int x3, int y3,   /* tl, tr, br, bl: p[0..3] of :2251 */
@@ -463,18 +481,18 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
     /* ... as two pairs of 16-bit lanes (v_pk_min_i16 / v_pk_max_i16): the box only decides which writes meet in LDS, so clamping it to
      * 32767 pixels costs nothing but the window of a screen wider than that */
     {
-        typedef short bk_s2 __attribute__((ext_vector_type(2)));
         const bool voted = mx != 0x7FFFFFFF;
-        bk_s2 lo = {(short)(mx > 32767 ? 32767 : mx), (short)(my > 32767 ? 32767 : my)};
-        bk_s2 hi = {(short)(Mx > 32767 ? 32767 : Mx < -1 ? -1 : Mx), (short)(My > 32767 ? 32767 : My < -1 ? -1 : My)};
+        int lo = bk_pack_i16(mx > 32767 ? 32767 : mx, my > 32767 ? 32767 : my);
+        int hi = bk_pack_i16(Mx > 32767 ? 32767 : Mx < -1 ? -1 : Mx, My > 32767 ? 32767 : My < -1 ? -1 : My);
         for (int o = 32; o > 0; o >>= 1) {
-            const int ql = __shfl_xor(__builtin_bit_cast(int, lo), o), qh = __shfl_xor(__builtin_bit_cast(int, hi), o);
-            lo = __builtin_elementwise_min(lo, __builtin_bit_cast(bk_s2, ql));
-            hi = __builtin_elementwise_max(hi, __builtin_bit_cast(bk_s2, qh));
+            const int ql = __shfl_xor(lo, o), qh = __shfl_xor(hi, o);
+            lo = bk_pk_min_i16(lo, ql);
+            hi = bk_pk_max_i16(hi, qh);
         }
         const unsigned long long any = __ballot(voted);
         if ((tid & 63) == 0 && any) {
-            atomicMin(&s_box[0], (int)lo.x); atomicMin(&s_box[1], (int)lo.y); atomicMax(&s_box[2], (int)hi.x); atomicMax(&s_box[3], (int)hi.y);
+            atomicMin(&s_box[0], (int)(short)(lo & 0xFFFF)); atomicMin(&s_box[1], lo >> 16);
+            atomicMax(&s_box[2], (int)(short)(hi & 0xFFFF)); atomicMax(&s_box[3], hi >> 16);
         }
     }
     __syncthreads();

@@ -42,9 +42,6 @@ typedef struct {
      * texels the first pass flagged (globe_plate scripts): (texel id << 1 | answer), ascending */
     const unsigned int *ovr_list;
     unsigned int ovr_count;
-    /* inverse build: 1 + scan key of the FIRST pixel (in the reference's scan order: rows bottom-up, pixels left to right,
-     * fisheye.c:2093-2103) whose callback returned a malformed result - key = ly * W + (W - 1 - lx), max-reduced; 0 = none */
-    unsigned int *first_bad;
     /* forward build: what the kernels would otherwise divide out per texel corner / per texel / per quad edge, evaluated once on the
      * host with the same IEEE operations (device memory; the host module of the flagged entries computes instead and never reads them):
      * fwd_quot[a * 21 + d] = (double)a / (double)d for 0 <= a <= 20, 1 <= d <= 20 - draw_quad's edge interpolation (fisheye.c:2313);
@@ -53,6 +50,9 @@ typedef struct {
     const double *fwd_quot;
     const float *fwd_uv;
     double inv_scale_up;     /* >= 1 / scale: turns an error bound in lens units into screen pixels without a division */
+    /* inverse build: 1 + scan key of the FIRST pixel (in the reference's scan order: rows bottom-up, pixels left to right,
+     * fisheye.c:2093-2103) whose callback returned a malformed result - key = ly * W + (W - 1 - lx), max-reduced; 0 = none */
+    unsigned int *first_bad;
 } BkBuildParams;
 
 /* Device globe layout.  A plate is gp = round_up(ps,64) texels wide and ph = round_up(ps,8) high and is

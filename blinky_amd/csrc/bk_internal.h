@@ -100,6 +100,7 @@ struct bk_ctx {
     double grid_cache_key[4] = {-1, 0, 0, 0};
     hipStream_t build_aux = nullptr;     // a forward build clears its key planes here, beside the corner pass
     hipEvent_t build_ev[2] = {nullptr, nullptr};
+    hipEvent_t build_time_ev[2] = {nullptr, nullptr};   // bk_build's timing pair, kept (creating and destroying them is four runtime calls a build)
     int *h_build_flags = nullptr;        // pinned: the counters of a forward build's two passes, read back without a stop in between
     void *fwd_tables = nullptr;          // BkBuildParams::fwd_quot + fwd_uv for platesize fwd_tables_ps (bk_lens.cpp)
     int fwd_tables_ps = -1;

@@ -63,6 +63,9 @@ struct LensProgram {
     hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr;
     std::shared_future<::CodeResult> pending;     // bk_set_async_compile: hiprtc running on another thread ...
     std::string pending_source;                      // ... for this generated source
+    // generate_source's last answer and the interpreter activity it was given at: emitting the translation unit walks the callbacks
+    // (16 us for winkel2, 43 for panini, 280 for quincuncial on the build host) and was done again on every bk_build
+    struct { bool valid = false; unsigned long long activity = 0; int libm_rel = 0; bool stateless = false; std::string src, refused; } emitted;
     bool fwd_needs_host = false;  // the last forward build flagged entries for the host: the next one stops after each pass again
     std::string last_source;      // for bk_debug_kernel_source
     std::string console;          // print() output of the scripts
@@ -1004,6 +1007,20 @@ static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out, std::s
     rq.lens_forward = P->lens_forward;
     rq.globe_plate = P->globe_plate;
     if (refused) refused->clear();
+    if (P->emitted.valid && P->emitted.activity == P->interp.activity && P->emitted.libm_rel == bk::g_debug.libm_rel_log2 &&
+        (refused || P->emitted.refused.empty())) {
+        *out = P->emitted.src;
+        if (refused) *refused = P->emitted.refused;
+        return BK_OK;
+    }
+    P->emitted.valid = false;
+    const auto remember = [&](const std::string &src, const std::string &why) {
+        P->emitted.src = src; P->emitted.refused = why;
+        P->emitted.activity = P->interp.activity; P->emitted.libm_rel = bk::g_debug.libm_rel_log2;
+        // callbacks that change nothing a script can see: bk_build may run them (calc_zoom, the flagged entries) and keep this answer
+        try { std::string which; P->emitted.stateless = !bk::callbacks_carry_state(rq, &which); } catch (const LuaError &) { P->emitted.stateless = false; }
+        P->emitted.valid = true;
+    };
     try {
         *out = bk::emit_build_source(rq);
         // test hook: a wider assumed libm discrepancy (tests pair it with bk_set_host_math(ctx, n): the host interpreter on a
@@ -1014,11 +1031,13 @@ static int generate_source(bk_ctx *ctx, LensProgram *P, std::string *out, std::s
         if (refused && strstr(e.what(), "GPU callback")) {          // (bk_emit.cpp's `unsupported`, and its two "assigned inside a GPU callback but holds a ..." refusals)
             out->clear();
             *refused = e.what();
+            remember(*out, *refused);
             return BK_OK;
         }
         return ctx->fail(BK_E_SCRIPT, "%s", e.what());
     }
     P->last_source = *out;
+    remember(*out, std::string());
     return BK_OK;
 }
 
@@ -1840,8 +1859,13 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     const size_t px = (size_t)ctx->W * ctx->rows();
     // F_RenderView clears the maps before (re)building, fisheye.c:731-732; whatever fails below,
     // the lensmap stays valid-and-empty so that bk_apply draws nothing, as the reference does.
-    BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
-    BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+    // (the device passes write every entry of the owned rows, so the clearing - 41 MB at 4K - is left to the ways out that have not
+    //  filled the table: `empty_unless_built`; the host paths are handed a cleared table up front, as before)
+    struct EmptyUnlessBuilt {
+        bk_ctx *ctx; size_t px; bool armed = true;
+        void now() { if (armed) { (void)hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream); (void)hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream); armed = false; } }
+        ~EmptyUnlessBuilt() { now(); }
+    } empty_unless_built{ctx, px};
     BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 3) * sizeof(int), ctx->stream));
     ctx->lensmap_valid = true;
     ctx->last_bad_key = 0;
@@ -1858,12 +1882,20 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
 
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
     if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
+    // Callbacks that were found to change nothing a script can see (LensProgram::emitted) leave the interpreter's activity count where
+    // the translation unit was generated, however often this build runs them - calc_zoom, the flagged entries; a build runs nothing
+    // else: the next bk_build of the same lens finds its translation unit still valid.
+    struct KeepActivity {
+        LensProgram *P; unsigned long long at; bool armed;
+        ~KeepActivity() { if (P->emitted.valid && P->emitted.stateless && P->emitted.activity >= at) P->interp.activity = P->emitted.activity; }
+    } keep_activity{P, P->interp.activity, P->emitted.valid && P->emitted.stateless && P->emitted.activity == P->interp.activity};
     if (int r = bk_calc_zoom(ctx, scale_out)) return r;                                        /* :2376 */
     if (P->info.map_type == BK_MAP_NONE) return ctx->fail(BK_E_STATE, "no inverse or forward map being used");   /* :2395 */
 
     std::string src, refused;
+    if (keep_activity.armed) P->interp.activity = keep_activity.at;      // (calc_zoom ran the callbacks: they are stateless)
     if (int r = generate_source(ctx, P, &src, &refused)) return r;
-    if (!refused.empty()) return build_on_host(ctx, P, refused, display_out);     // callbacks the emitter declines: the interpreter evaluates them
+    if (!refused.empty()) { empty_unless_built.now(); return build_on_host(ctx, P, refused, display_out); }     // callbacks the emitter declines: the interpreter evaluates them
     if (int r = compile_module(ctx, P, src)) return r;
     if (!ctx->d_flag_list) {
         BK_HIP(ctx, hipMalloc((void **)&ctx->d_flag_list, (size_t)65536 * 4 * sizeof(uint32_t)));
@@ -1881,6 +1913,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         if (ctx->sequential_build >= 2 || bk::callbacks_carry_state(rq, &which)) {
             ctx->last_build_path = 2;
             ctx->last_build_why = ctx->sequential_build >= 2 ? "bk_set_sequential_build 2" : "state carried in '" + which + "'";
+            empty_unless_built.now();
             if (P->info.map_type == BK_MAP_INVERSE) return build_sequential(ctx, P, src, bp, display_out);
             // (r6) the forward scan is just as sequential in the reference (fisheye.c:2126-2217): its call order, one evaluator
             if (!P->lens_forward.is_function()) return ctx->fail(BK_E_STATE, "lens has no lens_forward");
@@ -1889,14 +1922,12 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     }
     void *args[] = {&bp};
     hipEvent_t e0, e1;
-    BK_HIP(ctx, hipEventCreate(&e0));
-    BK_HIP(ctx, hipEventCreate(&e1));
+    for (hipEvent_t &e : ctx->build_time_ev) if (!e) BK_HIP(ctx, hipEventCreate(&e));
+    e0 = ctx->build_time_ev[0]; e1 = ctx->build_time_ev[1];
     void *scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int rc = BK_OK;
     auto cleanup = [&]() {
         for (void *p : scratch) if (p) (void)hipFree(p);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     };
 #define BK_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = ctx->fail(BK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
 #define BK_RC_C(expr) do { rc = (expr); if (rc != BK_OK) { cleanup(); return rc; } } while (0)
@@ -2029,12 +2060,13 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                     for (hipEvent_t &e : ctx->build_ev) BK_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 }
                 BK_HIP_C(hipEventRecord(e0, ctx->stream));
-                // the key planes (66 MB at 4K) are cleared on the side stream while the corner pass - arithmetic only - has the chip
                 BK_HIP_C(hipEventRecord(ctx->build_ev[0], ctx->stream));
+                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
+                // the key planes (66 MB at 4K) are cleared on the side stream while the corner pass - arithmetic only - has the chip
+                // (after whatever the stream held before this build, which may still read them: build_ev[0])
                 BK_HIP_C(hipStreamWaitEvent(ctx->build_aux, ctx->build_ev[0], 0));
                 BK_HIP_C(clear_keys(ctx->build_aux));
                 BK_HIP_C(hipEventRecord(ctx->build_ev[1], ctx->build_aux));
-                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
                 BK_HIP_C(hipMemcpyAsync(after_corners, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 BK_HIP_C(reset_counters());
                 BK_HIP_C(hipStreamWaitEvent(ctx->stream, ctx->build_ev[1], 0));
@@ -2170,17 +2202,18 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         int disp[BK_MAX_PLATES];
         if (int r = bk::launch_truncate_scan(ctx, ctx->last_bad_key, disp)) return r;
         for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = i < ctx->numplates ? disp[i] : 0; if (display_out) display_out[i] = ctx->display[i]; }
+        empty_unless_built.armed = false;
         return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
     }
     if (errbits) {
         // Any other per-pixel error is a Lua runtime error, which the reference does not survive (lua_call is unprotected:
         // fisheye.c:1551); here the build leaves an EMPTY map (nothing is drawn) and reports it.
-        BK_HIP(ctx, hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream));
-        BK_HIP(ctx, hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream));
+        empty_unless_built.now();
         BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < BK_MAX_PLATES; ++i) { ctx->display[i] = 0; if (display_out) display_out[i] = 0; }
         return ctx->fail(BK_E_SCRIPT, "lensmap build: %s", err_text(errbits));
     }
+    empty_unless_built.armed = false;
     return BK_OK;
 }
 

@@ -1396,6 +1396,7 @@ Value Interp::get_global(const std::string &name) const
 }
 void Interp::set_global(const std::string &name, const Value &v)
 {
+    ++activity;
     globals[name] = v;                        // (nil stays as a nil-valued node: gslots point at the nodes)
 }
 void Interp::register_builtin(const std::string &name, BuiltinFn fn)
@@ -1511,6 +1512,7 @@ std::string Interp::tostring(const Value &v) const
 
 Values Interp::call(const Value &fv, const Values &args)
 {
+    ++activity;
     if (depth == 0) call_chunk = nullptr;       // (a call from the host: no script call site yet, and the last one's chunk may be gone)
     if (fv.t == Value::BUILTIN) {
         Values rets;
@@ -1561,6 +1563,7 @@ Values Interp::call(const Value &fv, const Values &args)
 
 void Interp::run(const std::string &src, const std::string &chunkname)
 {
+    ++activity;
     std::shared_ptr<Chunk> ch = parse(src, chunkname);
     Value f;
     f.t = Value::FUNC;

@@ -237,6 +237,7 @@ struct Interp {
         return *p;
     }
     long steps = 0, max_steps = 200000000;  // runaway-script guard
+    unsigned long long activity = 0;        // bumped whenever script code runs or the host changes a global: "nothing a script can see has changed since"
     std::string goto_label;                 // the label a `goto` under way is looking for
     const std::string *call_chunk = nullptr; // where the builtin call being made stands (error() puts "chunk:line:" in front of its message)
     int call_line = 0;
