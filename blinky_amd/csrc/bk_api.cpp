@@ -107,7 +107,7 @@ extern "C" bk_ctx *bk_create(int device)
     }
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc((void **)&ctx->d_pal, BK_MAX_PLATES * 256) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_display, (BK_MAX_PLATES + 3) * sizeof(int)) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_display, 2 * (BK_MAX_PLATES + 3) * sizeof(int)) != hipSuccess) {
         g_create_error = "bk_create: hipSetDevice/hipMalloc failed";
         delete ctx;
         return nullptr;

@@ -535,6 +535,8 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_resolve(BkBuildPara
 {
     const size_t n = (size_t)P.rows * P.W;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    /* the counters of the two passes before this one go to the host with the table: no copy command, no second stop (bk_lens.cpp) */
+    if (P.counters_out && i < 18) P.counters_out[i] = P.display[i];
     if (i >= n) return;
     unsigned int off = 0xFFFFFFFFu;
     unsigned char tint = 255;

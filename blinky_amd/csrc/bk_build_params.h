@@ -49,6 +49,7 @@ typedef struct {
      * plate_uv_to_ray (fisheye.c:1205-1211, 2229); fwd_uv[ps + 1 + i] = (float)((double)i / ps - 0.5) - a texel's own ray (:2193). */
     const double *fwd_quot;
     const float *fwd_uv;
+    int *counters_out;       /* forward build, resolve pass: where to leave a copy of the 2 x 9 counters at display[] (pinned host memory), or null */
     double inv_scale_up;     /* >= 1 / scale: turns an error bound in lens units into screen pixels without a division */
     /* inverse build: 1 + scan key of the FIRST pixel (in the reference's scan order: rows bottom-up, pixels left to right,
      * fisheye.c:2093-2103) whose callback returned a malformed result - key = ly * W + (W - 1 - lx), max-reduced; 0 = none */

@@ -1866,7 +1866,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
         void now() { if (armed) { (void)hipMemsetAsync(ctx->d_offsets, 0xFF, px * 4, ctx->stream); (void)hipMemsetAsync(ctx->d_tints, 255, px, ctx->stream); armed = false; } }
         ~EmptyUnlessBuilt() { now(); }
     } empty_unless_built{ctx, px};
-    BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 3) * sizeof(int), ctx->stream));
+    BK_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, 2 * (BK_MAX_PLATES + 3) * sizeof(int), ctx->stream));      // (two sets of counters: see the forward build)
     ctx->lensmap_valid = true;
     ctx->last_bad_key = 0;
     ctx->spans_valid = false;
@@ -2037,19 +2037,20 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 hipError_t e = hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, st);
                 return e == hipSuccess ? hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, st) : e;
             };
-            const auto launch_quads = [&](bool keys_cleared = false) -> hipError_t {
+            const auto launch_quads = [&](bool keys_cleared = false, void **with = nullptr) -> hipError_t {
                 hipError_t e = keys_cleared ? hipSuccess : clear_keys(ctx->stream);
                 if (e == hipSuccess) e = hipModuleLaunchKernel(P->k_quads, (unsigned)((ctx->ps + 15) / 16), (unsigned)((ctx->ps + 15) / 16), (unsigned)ctx->numplates, 256, 1, 1, 0,
-                                                               ctx->stream, args, nullptr);       // (BK_FWD_TILE = 16: bk_build_kernels.h)
+                                                               ctx->stream, with ? with : args, nullptr);       // (BK_FWD_TILE = 16: bk_build_kernels.h)
                 return e;
             };
-            const auto launch_resolve = [&]() -> hipError_t {
-                return hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+            const auto launch_resolve = [&](void **with = nullptr) -> hipError_t {
+                return hipModuleLaunchKernel(P->k_resolve, (unsigned)((px + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, with ? with : args, nullptr);
             };
-            // The three passes in one go, their counters read back into pinned memory on the way: nearly every build flags nothing - no
-            // corner and no texel for the host to look at again - and then the table is final when the stream drains, two stops (a
-            // read-back and a decision each, 25-30 us apiece at 4K) earlier.  A build that did flag something is done over the careful
-            // way below, and so is the next build of the same lens.
+            // The three passes in one go, each of the first two counting into its own set of counters, both sets left in pinned memory
+            // by the last pass: nearly every build flags nothing - no corner and no texel for the host
+            // to look at again - and then the table is final when the stream drains, two stops (a read-back and a decision each, 25-30 us
+            // apiece at 4K) earlier.  A build that did flag something is done over the careful way below, and so is the next build of
+            // the same lens.
             bool speculated = false;
             if (!P->fwd_needs_host) {
                 constexpr size_t NF = BK_MAX_PLATES + 3;
@@ -2067,12 +2068,19 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 BK_HIP_C(hipStreamWaitEvent(ctx->build_aux, ctx->build_ev[0], 0));
                 BK_HIP_C(clear_keys(ctx->build_aux));
                 BK_HIP_C(hipEventRecord(ctx->build_ev[1], ctx->build_aux));
-                BK_HIP_C(hipMemcpyAsync(after_corners, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                BK_HIP_C(reset_counters());
+                BkBuildParams bq = bp;                       // the quad pass counts into the second set (cleared with the first, above)
+                bq.display = ctx->d_display + NF;
+                bq.err = bq.display + BK_MAX_PLATES;
+                bq.flag_count = (unsigned int *)(bq.display + BK_MAX_PLATES + 1);
+                bq.first_bad = (unsigned int *)(bq.display + BK_MAX_PLATES + 2);
+                void *args_q[] = {&bq};
                 BK_HIP_C(hipStreamWaitEvent(ctx->stream, ctx->build_ev[1], 0));
-                BK_HIP_C(launch_quads(true));
-                BK_HIP_C(hipMemcpyAsync(after_quads, ctx->d_display, NF * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                BK_HIP_C(launch_resolve());
+                BK_HIP_C(launch_quads(true, args_q));
+                static_assert(2 * NF == 18, "bk_forward_resolve copies 18 counters");
+                BkBuildParams br = bp;
+                br.counters_out = ctx->h_build_flags;
+                void *args_r[] = {&br};
+                BK_HIP_C(launch_resolve(args_r));
                 BK_HIP_C(hipEventRecord(e1, ctx->stream));
                 BK_HIP_C(hipStreamSynchronize(ctx->stream));
                 if (after_corners[BK_MAX_PLATES + 1] == 0 && after_quads[BK_MAX_PLATES + 1] == 0) {

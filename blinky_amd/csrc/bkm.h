@@ -42,6 +42,19 @@ typedef unsigned int bkm_u32;
 
 #include "bkm_tables.h"
 
+/* One Horner step a * z + c with a coefficient c.  On the device the coefficient is handed to v_fma_f64 as an SGPR pair: left to itself
+ * the compiler picks v_fmac_f64, whose addend is its destination, and pays two v_mov_b32 per coefficient to get the literal there. */
+#if defined(__HIPCC_RTC__)
+static __device__ inline double bkm_horner(double a, double z, double c)
+{
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(z), "s"(c));
+    return r;
+}
+#else
+#define bkm_horner(a, z, c) __builtin_fma((a), (z), (c))
+#endif
+
 typedef struct { double hi, lo; } bkm_dd;
 
 #define BKM_INF (__builtin_inf())
@@ -258,14 +271,14 @@ BKM_FN bkm_scp bkm_sincos_poly(double th)
     bkm_scp q;
     double z = th * th, sp, cp;
     sp = bkm_sin_c[3];
-    sp = __builtin_fma(sp, z, bkm_sin_c[2]);
-    sp = __builtin_fma(sp, z, bkm_sin_c[1]);
-    sp = __builtin_fma(sp, z, bkm_sin_c[0]);
+    sp = bkm_horner(sp, z, bkm_sin_c[2]);
+    sp = bkm_horner(sp, z, bkm_sin_c[1]);
+    sp = bkm_horner(sp, z, bkm_sin_c[0]);
     q.sp = (th * z) * sp;
     cp = bkm_cos_c[3];
-    cp = __builtin_fma(cp, z, bkm_cos_c[2]);
-    cp = __builtin_fma(cp, z, bkm_cos_c[1]);
-    cp = __builtin_fma(cp, z, bkm_cos_c[0]);
+    cp = bkm_horner(cp, z, bkm_cos_c[2]);
+    cp = bkm_horner(cp, z, bkm_cos_c[1]);
+    cp = bkm_horner(cp, z, bkm_cos_c[0]);
     q.cp = __builtin_fma(z * z, cp, -0.5 * z);
     return q;
 }
@@ -355,12 +368,12 @@ BKM_FN bkm_dd bkm_atan_frac(double nh, double nl, double dh, double dl)
     tl = ((rem + Nl) - th * D.lo) * rD;
     z = th * th;
     a = bkm_atan_c[6];
-    a = __builtin_fma(a, z, bkm_atan_c[5]);
-    a = __builtin_fma(a, z, bkm_atan_c[4]);
-    a = __builtin_fma(a, z, bkm_atan_c[3]);
-    a = __builtin_fma(a, z, bkm_atan_c[2]);
-    a = __builtin_fma(a, z, bkm_atan_c[1]);
-    a = __builtin_fma(a, z, bkm_atan_c[0]);
+    a = bkm_horner(a, z, bkm_atan_c[5]);
+    a = bkm_horner(a, z, bkm_atan_c[4]);
+    a = bkm_horner(a, z, bkm_atan_c[3]);
+    a = bkm_horner(a, z, bkm_atan_c[2]);
+    a = bkm_horner(a, z, bkm_atan_c[1]);
+    a = bkm_horner(a, z, bkm_atan_c[0]);
     pl = (th * z) * a;
     s = bkm_fast_two_sum(bkm_atan_tab[i][0], th);              /* entry 0 is 0; the others are >= 0.124 > |t| */
     o.hi = s.hi;
