@@ -419,8 +419,10 @@ def test_toggling_rubix_every_frame_costs_no_recompile(bk):
     mh, md = sorted(steady_h)[len(steady_h) // 2], sorted(steady_d)[len(steady_d) // 2]
     print(f"\nrubix toggled per frame at 4K: host call median {mh:.1f} us (max {max(steady_h):.1f}), device median {md:.1f} us (max {max(steady_d):.1f}); "
           f"first four calls host {[round(h) for h in host[:4]]} us")
-    assert max(steady_h) <= max(2 * mh, 60.0), (mh, max(steady_h), steady_h.index(max(steady_h)))
-    assert max(steady_d) <= 2 * md, (md, max(steady_d), steady_d.index(max(steady_d)))
+    # a recompiled block map is 1.5 ms on either clock; a busy box is good for a 60 us call now and then (seen: one of 50 at 62 us
+    # against a 25 us median)
+    assert max(steady_h) <= max(4 * mh, 300.0), (mh, max(steady_h), steady_h.index(max(steady_h)))
+    assert max(steady_d) <= max(4 * md, 300.0), (md, max(steady_d), steady_d.index(max(steady_d)))
     ctx.close()
 
 
