@@ -542,6 +542,53 @@ def test_flag_and_fix_up_end_to_end_against_a_stand_in_libm(bk, lens, W, H, monk
     ctx2.close()
 
 
+@pytest.mark.parametrize("lens,W,H", [("eckert5", 480, 300), ("winkel2", 400, 240)])
+def test_forward_build_that_flags_entries_is_redone_pass_by_pass(bk, lens, W, H, monkeypatch, request):
+    """(r6) A forward build submits its three passes in one go and looks at the flag counters once, at the end; a build whose corner pass
+    DID flag something has to throw that away and go pass by pass (host answers patched in between), and so has the next build of the
+    same lens.  Stand-in libm 2^-16 away, kernels told so: a corner lands within 0.02 pixels of a pixel edge often enough for thousands of flags.  Expected table: the host interpreter's own
+    forward build on the same stand-in libm (bk_debug_host_build on a device-less context)."""
+    bk.debug_set_option("libm_rel_log2", 16)
+    request.addfinalizer(lambda: bk.debug_set_option("libm_rel_log2", 0))
+    monkeypatch.setenv("BLINKY_HIP_CACHE", "off")
+    ctx = bk.Context()
+    ctx.set_host_math(16)
+    S.configure(ctx, "cube", lens, None, (W, H))
+    display1 = ctx.build()
+    off1, tin1 = ctx.read_lensmap()
+    flagged1, changed1 = ctx.last_build_fixups()
+    assert flagged1 > 100, (flagged1, changed1)
+    display2 = ctx.build()                                   # (straight to the careful path this time)
+    off2, tin2 = ctx.read_lensmap()
+    assert ctx.last_build_fixups() == (flagged1, changed1) and display2 == display1
+    np.testing.assert_array_equal(off2, off1)
+    np.testing.assert_array_equal(tin2, tin1)
+    host = bk.Context(bk.ffi.DEVICE_NONE)
+    host.set_host_math(16)
+    S.configure(host, "cube", lens, None, (W, H))
+    hoff, htin, hdisplay, _, err = host.host_build(1)
+    assert err is None
+    np.testing.assert_array_equal(off1, hoff)
+    np.testing.assert_array_equal(tin1, htin)
+    host.close()
+    # ... and the ordinary case - nothing flagged - twice over: the one-submission path, the same table both times, the goldens' table
+    bk.debug_set_option("libm_rel_log2", 0)
+    plain = bk.Context()
+    S.configure(plain, "cube", lens, None, (W, H))
+    plain.build()
+    a = plain.read_lensmap()
+    assert plain.last_build_fixups()[0] == 0
+    plain.build()
+    b = plain.read_lensmap()
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    lm = O.lensmap("cube", lens, None, W, H)
+    np.testing.assert_array_equal(a[0], lm.offsets)
+    np.testing.assert_array_equal(a[1], lm.tints)
+    ctx.close()
+    plain.close()
+
+
 def test_functions_defined_inside_a_callback_build_the_same_table_on_the_gpu(bk):
     """tests/test_frontend.py's pair of scripts - the same arithmetic written plainly and with local functions / closures / chunk
     locals as scratch - through the GPU build, and the second one through the one-scan host build as well"""
