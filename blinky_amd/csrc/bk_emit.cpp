@@ -67,7 +67,34 @@ struct Emitter {
     struct SinCos { std::string s, c; long epoch; };
     std::map<std::string, SinCos> sincos;
     long epoch = 0;
-    void forget(const std::string &var) { sincos.erase(var); }
+    // (r6) The same memory for every other pure operation - arithmetic, comparisons, the one-argument math functions, atan2 - keyed by
+    // the call as it is written out ("bk_mul(S, l4, sn15)"): `1/tan(lat)` twice in two statements, or `sin(lon*sin(lat))` next to
+    // `cos(lon*sin(lat))` (polyconic.lua), are evaluated once.  Each is a function of its operands' values alone (the flags it may raise
+    // are raised the first time), so the rules are the sin / cos ones: same epoch, no operand assigned since.  Not while the
+    // derivative of a loop body is being written out (every temporary there carries its own derivative note).
+    struct Pure { std::string name; long epoch; };
+    std::map<std::string, Pure> pure;
+    std::string last_single, last_single_of;          // emit_call: the value of a one-result builtin call (when it is a plain name), and the result array it was the call of
+    static bool is_name(const std::string &v)
+    {
+        if (v.empty() || (v[0] >= '0' && v[0] <= '9')) return false;
+        for (char c : v) if (!(c == '_' || c == '.' || (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'))) return false;
+        return true;
+    }
+    static bool mentions(const std::string &key, const std::string &var)
+    {
+        auto word = [](char c) { return c == '_' || c == '.' || (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+        for (size_t at = key.find(var); at != std::string::npos; at = key.find(var, at + 1)) {
+            const bool left = at == 0 || !word(key[at - 1]), right = at + var.size() >= key.size() || !word(key[at + var.size()]);
+            if (left && right) return true;
+        }
+        return false;
+    }
+    void forget(const std::string &var)
+    {
+        sincos.erase(var);
+        for (auto it = pure.begin(); it != pure.end();) it = mentions(it->first, var) ? pure.erase(it) : std::next(it);
+    }
     // string constants: device code only ever compares them, so a string is its number in this table
     std::map<std::string, int> strings{{"nil", 1}, {"boolean", 2}, {"number", 3}, {"string", 4}};   // (type() results first)
     std::string str_literal(const std::string &v)
@@ -153,6 +180,15 @@ struct Emitter {
     }
     std::string tmp(const char *p = "t") { return std::string(p) + std::to_string(++uid); }
     static void line(Fn &f, const std::string &s) { f.out << std::string((size_t)f.indent * 4, ' ') << s << "\n"; }
+    std::string pure_value(Fn &f, const std::string &call)
+    {
+        auto hit = pure.find(call);
+        if (hit != pure.end() && hit->second.epoch == epoch) return hit->second.name;
+        const std::string t = tmp();
+        line(f, "bkv " + t + " = " + call + ";");
+        pure.insert_or_assign(call, Pure{t, epoch});
+        return t;
+    }
 
     // t[key] of a table known now, as the interpreter finds it: the table's own field, else along metatables whose __index is a table
     static Value static_field(const Value &t, const Value &key)
@@ -404,6 +440,7 @@ struct Emitter {
         case Expr::Call: {
             std::string arr, cnt;
             emit_call(f, e, &arr, &cnt);
+            if (!ad_active && last_single_of == arr && is_name(last_single)) return last_single;     // (of THIS call, not of one among its arguments)
             std::string t = tmp();
             line(f, "bkv " + t + " = " + cnt + " > 0 ? " + arr + "[0] : bk_nil();");
             if (ad_active && !ad_call.empty()) ad_note(f, t, ad_call);
@@ -470,6 +507,7 @@ struct Emitter {
             else if (op == ">") call = "bk_lt(S, " + b + ", " + a + ")";
             else if (op == ">=") call = "bk_le(S, " + b + ", " + a + ")";
             else unsupported(f.chunk, e.line, "operator '" + op + "'");
+            if (!ad_active) return pure_value(f, call);
             line(f, "bkv " + t + " = " + call + ";");
             if (ad_active && (d_of(a) != "0.0" || d_of(b) != "0.0")) {
                 const std::string da = d_of(a), db = d_of(b);
@@ -505,6 +543,11 @@ struct Emitter {
             if (i + 1 == list.size() && x.kind == Expr::Call && !(ad_active && single_valued_call(f, x))) {
                 a.multi = true;               // (inside a contracted loop a math call in the last place is taken as the ONE value it is:
                 emit_call(f, x, &a.marr, &a.mcnt);   //  its derivative hangs on the temp emit_expr gives it)
+                if (!ad_active && last_single_of == a.marr && is_name(last_single)) {   // exactly one value, and it has a name: an ordinary argument
+                    a.multi = false;
+                    a.fixed.push_back(last_single);
+                    a.marr.clear(); a.mcnt.clear();
+                }
             } else if (i + 1 == list.size() && x.kind == Expr::Vararg) {       // the extra arguments of this function, all of them
                 // (value lists hold BK_MAXRET values: more extra arguments than that is this translation's limit - the script error bit)
                 const std::string np = std::to_string(f.proto->nparams), vc = tmp("va");
@@ -629,6 +672,8 @@ struct Emitter {
         auto A = [&](size_t i) { return arg_at(a, i); };
         auto single = [&](const std::string &expr) {
             line(f, "bkv " + *arr + "[1] = {" + expr + "}; const int " + *cnt + " = 1;");
+            last_single = expr;
+            last_single_of = *arr;
         };
         // the math library: value + error bound (bk_device_rt.h); one bkm.h call per Lua call, as in the interpreter
         static const std::map<std::string, std::string> unary = {
@@ -651,6 +696,7 @@ struct Emitter {
         }
         auto u = unary.find(bn);
         if (u != unary.end()) {
+            if (!ad_active) { single(pure_value(f, u->second + "(S, " + A(0) + ")")); return; }
             single(u->second + "(S, " + A(0) + ")");
             if (ad_active && d_of(A(0)) != "0.0") {              // (contraction_pattern admits exactly these)
                 const std::string x = A(0) + ".n", r = *arr + "[0].n", d = d_of(A(0));
@@ -667,6 +713,7 @@ struct Emitter {
             return;
         }
         if (bn == "math.atan2") {
+            if (!ad_active) { single(pure_value(f, "bk_f_atan2(S, " + A(0) + ", " + A(1) + ")")); return; }
             single("bk_f_atan2(S, " + A(0) + ", " + A(1) + ")");
             if (ad_active && (d_of(A(0)) != "0.0" || d_of(A(1)) != "0.0")) {
                 const std::string y = A(0) + ".n", x = A(1) + ".n";

@@ -515,6 +515,54 @@ def test_keyed_caches_are_not_state(bk, body, carries):
         assert np.array_equal(v["val"][used, :3].view(np.uint64), out[used].view(np.uint64))
 
 
+SHARED_SUBEXPRESSIONS = """
+max_fov = 360
+max_vfov = 180
+lens_width = 4
+lens_height = 3
+onload = "f_contain"
+function lens_inverse(x, y)
+   local a = 1/tan(y + 2) * sin(x * sin(y))
+   local b = y + 1/tan(y + 2) * (1 - cos(x * sin(y)))      -- tan(y + 2), sin(y), x * sin(y) and its sine / cosine: all evaluated above
+   x = x + 1
+   local c = sin(x * sin(y)) + atan2(a, b) + atan2(a, b)   -- x was assigned: x * sin(y) is a new value, sin(y) is not
+   if y > 0 then y = y * 0.5 end
+   local d = sqrt(abs(y)) + sqrt(abs(y)) + tan(y + 2)      -- after the branch nothing from before it is trusted
+   return a + c, b, d
+end
+"""
+
+
+def test_repeated_pure_subexpressions_are_evaluated_once(bk):
+    """(r6) polyconic.lua writes `1/tan(lat)` and `lon*sin(lat)` twice each: the emitter remembers what it has computed from which
+    operands in a stretch of straight-line code (bk_emit.cpp, `pure`) - until an operand is assigned or a block begins or ends.  The
+    text shows what is shared; the values are the interpreter's, pixel for pixel."""
+    ctx = lens_ctx(bk, SHARED_SUBEXPRESSIONS)
+    ctx.set_zoom(bk.ffi.ZOOM_CONTAIN, 0)
+    ctx.resize(64, 48)
+    src = ctx.kernel_source()
+    body = src[src.index("LF1_lens_inverse"):]
+    assert body.count("bk_f_tan(") == 2                      # y + 2 before the branch, once more after it
+    assert body.count("bk_f_sincos(") == 3                   # sin(y); sin / cos of x * sin(y); sin of the new x * sin(y)
+    assert body.count("bk_f_atan2(") == 1 and body.count("bk_f_sqrt(") == 1 and body.count("bk_f_abs(") == 1
+    assert body.count("bk_div(") == 1                        # 1 / tan(y + 2), once
+    from hostemu import emu
+    v = emu.inverse_values(ctx)
+    seq = lens_ctx(bk, SHARED_SUBEXPRESSIONS)
+    seq.set_host_math(1)
+    used = np.flatnonzero(v["nret"] > 0)
+    assert len(used) == 64 * 48
+    for i in used[:: 7]:
+        r = seq.eval_host(0, float(v["x"][i]), float(v["y"][i]))
+        assert r is not None and len(r) == v["nret"][i] == 3
+        assert np.array_equal(np.array(r).view(np.uint64), v["val"][i, :3].view(np.uint64)), (i, r, v["val"][i, :3])
+    # polyconic itself: one tan, two sincos
+    poly = lens_ctx(bk, S.script("lenses", "polyconic"))
+    poly.resize(64, 48)
+    text = poly.kernel_source()
+    assert text.count("bk_f_tan(") == 1 and text.count("bk_f_sincos(") == 2
+
+
 # ---- functions defined inside callbacks, chunk locals as per-pixel state ---------------------------------------------------------
 
 PLAIN_LENS = '''
