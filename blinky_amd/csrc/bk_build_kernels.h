@@ -276,7 +276,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_corners(BkBuildPara
 struct BkFwdWin {
     int x0, y0, w, h;                 /* window on the screen: origin, extent (<= BK_FWD_WIN each; rows are BK_FWD_WIN apart in LDS) */
     unsigned int *px, *tint;          /* [BK_FWD_WIN * BK_FWD_WIN] keys, 0 = none; px == nullptr: no window */
-    const double *quot;               /* BkBuildParams::fwd_quot, in LDS */
+    const double *quot;               /* BkBuildParams::fwd_quot */
 };
 /* (double)a / (double)d of draw_quad's edge interpolation (fisheye.c:2313).  An edge of a quad that passed the 20-pixel size check has
  * |d| <= 20 and a between 0 and d: the quotient is |a| / |d| - IEEE division is sign-symmetric - and comes from the build's table
@@ -432,10 +432,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
     __shared__ int s_disp[6];
     __shared__ int s_box[4];                         /* the tile's bounding box on the screen: min x, min y, max x, max y */
     __shared__ unsigned int s_px[BK_FWD_WIN * BK_FWD_WIN], s_tint[BK_FWD_WIN * BK_FWD_WIN];
-    __shared__ double s_quot[21 * 21];
     const int tid = (int)threadIdx.x;
-    s_quot[tid] = P.fwd_quot[tid];
-    if (tid + 256 < 21 * 21) s_quot[tid + 256] = P.fwd_quot[tid + 256];
     if (tid < 6) s_disp[tid] = 0;
     if (tid < 2) s_box[tid] = 0x7FFFFFFF;
     else if (tid < 4) s_box[tid] = -1;
@@ -500,7 +497,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
     win.x0 = s_box[0]; win.y0 = s_box[1];
     win.px = win.x0 != 0x7FFFFFFF ? s_px : nullptr;
     win.tint = s_tint;
-    win.quot = s_quot;
+    win.quot = P.fwd_quot;                          /* (read where it lies: only quads on three rows or more - magnifying lenses - interpolate) */
     win.w = win.px ? s_box[2] - win.x0 + 1 : 0;
     win.h = win.px ? s_box[3] - win.y0 + 1 : 0;
     win.w = win.w < 0 ? 0 : win.w > BK_FWD_WIN ? BK_FWD_WIN : win.w;
