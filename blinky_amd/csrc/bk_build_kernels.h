@@ -447,7 +447,7 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
         /* the corners are asked for first - all of them, whether or not the texel turns out to own its ray: one round trip to memory,
          * spent under the arithmetic of the ownership test */
         const int n1 = P.ps + 1;
-        const size_t c_tl = ((size_t)plate * n1 + py) * n1 + px, c_bl = c_tl + n1;
+        const unsigned int c_tl = ((unsigned int)plate * (unsigned int)n1 + (unsigned int)py) * (unsigned int)n1 + (unsigned int)px, c_bl = c_tl + (unsigned int)n1;   /* (< 2^27 at 8K) */
         const unsigned int ok4 = (unsigned int)P.corner_ok[c_tl] & (unsigned int)P.corner_ok[c_tl + 1] & (unsigned int)P.corner_ok[c_bl] & (unsigned int)P.corner_ok[c_bl + 1];
         for (int c = 0; c < 4; ++c) { q[c] = P.corner_xy[2 * c_tl + c]; q[4 + c] = P.corner_xy[2 * c_bl + c]; }
         BkState S;
