@@ -843,11 +843,16 @@ static HostModuleP compile_host_module(const std::string &source, const std::str
 // unless `wait`.  Never throws; nullptr simply means "use the interpreter".
 static HostModuleP host_module_for(const std::string &source, bool wait)
 {
-    uint64_t key = fnv1a64(source.data(), source.size());                  // (source + everything it is compiled with)
-    for (const char *h : {"bk_hostmod_bkm.h", "bk_hostmod_driver.inc", "bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h"}) {
-        const char *t = embedded_text(h);
-        key = fnv1a64(t, strlen(t), key);
-    }
+    // (source + everything it is compiled with; the headers' part once - they are 100 KB, and this runs in every build that flagged a pixel)
+    static const uint64_t headers_key = [] {
+        uint64_t k = 1469598103934665603ull;
+        for (const char *h : {"bk_hostmod_bkm.h", "bk_hostmod_driver.inc", "bk_build_params.h", "bk_device_rt.h", "bk_build_kernels.h"}) {
+            const char *t = embedded_text(h);
+            k = fnv1a64(t, strlen(t), k);
+        }
+        return k;
+    }();
+    const uint64_t key = fnv1a64(source.data(), source.size(), headers_key);
     std::shared_future<HostModuleP> job;
     {
         std::lock_guard<std::mutex> lock(g_hostmod_mutex);
@@ -1375,6 +1380,7 @@ void for_each_flagged(LensProgram *P, size_t n, Fn fn)
     // (never on the context's own interpreter: a callback that assigns script globals - fahey's `lat`, `lon` - would leave them
     //  changed, the next build's generated source would carry different initial values for them, and the lens would go through
     //  hiprtc again for nothing: the 490 ms second build of fahey in round 2's tables)
+    if (!n) return;                                 // (nothing flagged - most builds: no copy of the interpreter, 30 us at 4K panini)
     const Values roots_in{P->lens_inverse, P->lens_forward, P->globe_plate};
     FixupPool *pool_p = n >= 256 ? &FixupPool::get() : nullptr;
     const size_t nthreads = pool_p ? std::max<size_t>(1, std::min(pool_p->size(), n / 96)) : 1;
@@ -1937,9 +1943,12 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     int host_err = 0;
     std::vector<uint32_t> flagged;
     auto reset_counters = [&]() -> hipError_t { return hipMemsetAsync(ctx->d_display, 0, (BK_MAX_PLATES + 3) * sizeof(int), ctx->stream); };
-    auto read_counters = [&]() -> hipError_t {
-        hipError_t e = hipMemcpyAsync(flags, ctx->d_display, sizeof flags, hipMemcpyDeviceToHost, ctx->stream);
-        return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+    if (!ctx->h_build_flags) BK_HIP_C(hipHostMalloc((void **)&ctx->h_build_flags, 2 * sizeof flags, hipHostMallocDefault));
+    auto read_counters = [&]() -> hipError_t {       // (into pinned memory: a pageable destination goes through the runtime's staging buffer)
+        hipError_t e = hipMemcpyAsync(ctx->h_build_flags, ctx->d_display, sizeof flags, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) memcpy(flags, ctx->h_build_flags, sizeof flags);
+        return e;
     };
 
     try {
@@ -2054,7 +2063,6 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             bool speculated = false;
             if (!P->fwd_needs_host) {
                 constexpr size_t NF = BK_MAX_PLATES + 3;
-                if (!ctx->h_build_flags) BK_HIP_C(hipHostMalloc((void **)&ctx->h_build_flags, 2 * NF * sizeof(int), hipHostMallocDefault));
                 int *const after_corners = ctx->h_build_flags, *const after_quads = ctx->h_build_flags + NF;
                 if (!ctx->build_aux) {
                     BK_HIP_C(hipStreamCreateWithFlags(&ctx->build_aux, hipStreamNonBlocking));
