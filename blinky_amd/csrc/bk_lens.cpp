@@ -982,6 +982,10 @@ int bk::build_module_ready(bk_ctx *ctx)
     std::string psrc;
     bk::EmitRequest rq;
     rq.interp = &P->interp; rq.lens_inverse = P->lens_inverse; rq.lens_forward = P->lens_forward; rq.globe_plate = P->globe_plate;
+    if (P->emitted.valid && P->emitted.activity == P->interp.activity && P->emitted.libm_rel == bk::g_debug.libm_rel_log2) {
+        if (!P->emitted.refused.empty()) return BK_OK;                                       // (a host-path lens: nothing to compile)
+        psrc = P->emitted.src;                                                                // (generate_source's answer still stands)
+    } else
     try { psrc = bk::emit_build_source(rq); } catch (const LuaError &) { return BK_OK; }      // (reported by the normal path)
     // A module that is ready gets LOADED here (hipModuleLoadData / hipModuleGetFunction): that has to happen on the context's own
     // device, whatever device the calling thread was left on - bk_multi_build asks on behalf of stripe 0 right after a
