@@ -2107,93 +2107,93 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 }
             }
             if (!speculated) {
-            BK_HIP_C(hipEventRecord(e0, ctx->stream));
-            // texel corners -> screen; the flagged ones re-derived on the host
-            for (;;) {
-                BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
-                BK_HIP_C(read_counters());
-                bool retry = false;
-                BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
-                if (!retry) break;
-                bp.flag_list = ctx->d_flag_list; bp.flag_cap = (unsigned)ctx->flag_cap;
-                BK_HIP_C(reset_counters());
-            }
-            int corner_err = flags[BK_MAX_PLATES];
-            {
-                std::vector<uint32_t> ixy, vxy, iok;
-                std::vector<uint8_t> vok;
-                const size_t nfl = flagged.size() / 4;
-                std::vector<int> rsx(nfl), rsy(nfl), rerr(nfl, 0);
-                std::vector<uint8_t> rok(nfl);
-                const auto th0 = std::chrono::steady_clock::now();
-                const HostModuleP hm = nfl ? fixup_module(P, src) : nullptr;
-                ctx->last_fixup_compiled = hm != nullptr;
-                if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) {
-                    hm->corners(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &rsx[i0], &rsy[i0], &rok[i0], &rerr[i0]);
-                });
-                else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
-                    h_corner_entry(ctx, E, bp, flagged[4 * i], &rsx[i], &rsy[i], &rok[i], &rerr[i]);
-                });
-                ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
-                for (size_t i = 0; i < nfl; ++i) {
-                    const size_t k = 4 * i;
-                    const int sx = rsx[i], sy = rsy[i];
-                    const uint8_t ok = rok[i];
-                    host_err |= rerr[i];
-                    if ((uint32_t)sx != flagged[k + 1] || (uint32_t)sy != flagged[k + 2] || ok != (uint8_t)flagged[k + 3]) {
-                        ixy.push_back(2 * flagged[k]); vxy.push_back((uint32_t)sx);
-                        ixy.push_back(2 * flagged[k] + 1); vxy.push_back((uint32_t)sy);
-                        iok.push_back(flagged[k]); vok.push_back(ok);
-                    }
-                }
-                ctx->last_flagged = (int)(flagged.size() / 4);
-                ctx->last_changed = (int)iok.size();
-                BK_RC_C(bk::launch_scatter32(ctx, (uint32_t *)bp.corner_xy, ixy.data(), vxy.data(), ixy.size()));
-                BK_RC_C(bk::launch_scatter8(ctx, bp.corner_ok, iok.data(), vok.data(), iok.size()));
-            }
-            // quads; with a globe_plate script a texel's "own plate" test can be flagged too: the host answers those and
-            // the scatter runs once more with its answers
-            std::vector<uint32_t> ovr;
-            for (int pass = 0; pass < 2; ++pass) {
-                bool again = false;
+                BK_HIP_C(hipEventRecord(e0, ctx->stream));
+                // texel corners -> screen; the flagged ones re-derived on the host
                 for (;;) {
-                    BK_HIP_C(reset_counters());
-                    BK_HIP_C(launch_quads());
+                    BK_HIP_C(hipModuleLaunchKernel(P->k_corners, (unsigned)((n1 + 255) / 256), (unsigned)n1, (unsigned)ctx->numplates, 256, 1, 1, 0, ctx->stream, args, nullptr));
                     BK_HIP_C(read_counters());
-                    if (pass == 1) break;
                     bool retry = false;
                     BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
                     if (!retry) break;
                     bp.flag_list = ctx->d_flag_list; bp.flag_cap = (unsigned)ctx->flag_cap;
+                    BK_HIP_C(reset_counters());
                 }
-                if (pass == 0 && !flagged.empty()) {
-                    std::vector<std::pair<uint32_t, uint32_t>> ans;
+                int corner_err = flags[BK_MAX_PLATES];
+                {
+                    std::vector<uint32_t> ixy, vxy, iok;
+                    std::vector<uint8_t> vok;
                     const size_t nfl = flagged.size() / 4;
-                    std::vector<uint8_t> rown(nfl);
-                    const HostModuleP hm = fixup_module(P, src);
-                    if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) { hm->texel_owns(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &rown[i0]); });
-                    else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) { rown[i] = h_texel_owns(ctx, E, bp, flagged[4 * i]) ? 1 : 0; });
-                    for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
-                        const bool own = rown[k / 4] != 0;
-                        if ((own ? 1u : 0u) != flagged[k + 1]) { again = true; ++ctx->last_changed; }
-                        ans.push_back({flagged[k], own ? 1u : 0u});
+                    std::vector<int> rsx(nfl), rsy(nfl), rerr(nfl, 0);
+                    std::vector<uint8_t> rok(nfl);
+                    const auto th0 = std::chrono::steady_clock::now();
+                    const HostModuleP hm = nfl ? fixup_module(P, src) : nullptr;
+                    ctx->last_fixup_compiled = hm != nullptr;
+                    if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) {
+                        hm->corners(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &rsx[i0], &rsy[i0], &rok[i0], &rerr[i0]);
+                    });
+                    else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) {
+                        h_corner_entry(ctx, E, bp, flagged[4 * i], &rsx[i], &rsy[i], &rok[i], &rerr[i]);
+                    });
+                    ctx->last_host_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+                    for (size_t i = 0; i < nfl; ++i) {
+                        const size_t k = 4 * i;
+                        const int sx = rsx[i], sy = rsy[i];
+                        const uint8_t ok = rok[i];
+                        host_err |= rerr[i];
+                        if ((uint32_t)sx != flagged[k + 1] || (uint32_t)sy != flagged[k + 2] || ok != (uint8_t)flagged[k + 3]) {
+                            ixy.push_back(2 * flagged[k]); vxy.push_back((uint32_t)sx);
+                            ixy.push_back(2 * flagged[k] + 1); vxy.push_back((uint32_t)sy);
+                            iok.push_back(flagged[k]); vok.push_back(ok);
+                        }
                     }
-                    ctx->last_flagged += (int)ans.size();
-                    if (again) {
-                        std::sort(ans.begin(), ans.end());
-                        for (auto &a : ans) { ovr.push_back((a.first << 1) | a.second); }
-                        BK_HIP_C(hipMalloc(&scratch[4], ovr.size() * 4));
-                        BK_HIP_C(hipMemcpyAsync(scratch[4], ovr.data(), ovr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-                        bp.ovr_list = (const unsigned int *)scratch[4];
-                        bp.ovr_count = (unsigned)ovr.size();
-                    }
+                    ctx->last_flagged = (int)(flagged.size() / 4);
+                    ctx->last_changed = (int)iok.size();
+                    BK_RC_C(bk::launch_scatter32(ctx, (uint32_t *)bp.corner_xy, ixy.data(), vxy.data(), ixy.size()));
+                    BK_RC_C(bk::launch_scatter8(ctx, bp.corner_ok, iok.data(), vok.data(), iok.size()));
                 }
-                if (!again) break;
-            }
-            flags[BK_MAX_PLATES] |= corner_err;
-            BK_HIP_C(launch_resolve());
-            BK_HIP_C(hipEventRecord(e1, ctx->stream));
-            P->fwd_needs_host = ctx->last_flagged != 0;
+                // quads; with a globe_plate script a texel's "own plate" test can be flagged too: the host answers those and
+                // the scatter runs once more with its answers
+                std::vector<uint32_t> ovr;
+                for (int pass = 0; pass < 2; ++pass) {
+                    bool again = false;
+                    for (;;) {
+                        BK_HIP_C(reset_counters());
+                        BK_HIP_C(launch_quads());
+                        BK_HIP_C(read_counters());
+                        if (pass == 1) break;
+                        bool retry = false;
+                        BK_RC_C(read_flagged(ctx, (unsigned)flags[BK_MAX_PLATES + 1], &flagged, &retry));
+                        if (!retry) break;
+                        bp.flag_list = ctx->d_flag_list; bp.flag_cap = (unsigned)ctx->flag_cap;
+                    }
+                    if (pass == 0 && !flagged.empty()) {
+                        std::vector<std::pair<uint32_t, uint32_t>> ans;
+                        const size_t nfl = flagged.size() / 4;
+                        std::vector<uint8_t> rown(nfl);
+                        const HostModuleP hm = fixup_module(P, src);
+                        if (hm) hostmod_runs(nfl, [&](size_t i0, size_t cnt) { hm->texel_owns(&bp, &flagged[4 * i0], 4, (unsigned long)cnt, &rown[i0]); });
+                        else for_each_flagged(P, nfl, [&](HostEval &E, size_t i) { rown[i] = h_texel_owns(ctx, E, bp, flagged[4 * i]) ? 1 : 0; });
+                        for (size_t k = 0; k + 3 < flagged.size(); k += 4) {
+                            const bool own = rown[k / 4] != 0;
+                            if ((own ? 1u : 0u) != flagged[k + 1]) { again = true; ++ctx->last_changed; }
+                            ans.push_back({flagged[k], own ? 1u : 0u});
+                        }
+                        ctx->last_flagged += (int)ans.size();
+                        if (again) {
+                            std::sort(ans.begin(), ans.end());
+                            for (auto &a : ans) { ovr.push_back((a.first << 1) | a.second); }
+                            BK_HIP_C(hipMalloc(&scratch[4], ovr.size() * 4));
+                            BK_HIP_C(hipMemcpyAsync(scratch[4], ovr.data(), ovr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                            bp.ovr_list = (const unsigned int *)scratch[4];
+                            bp.ovr_count = (unsigned)ovr.size();
+                        }
+                    }
+                    if (!again) break;
+                }
+                flags[BK_MAX_PLATES] |= corner_err;
+                BK_HIP_C(launch_resolve());
+                BK_HIP_C(hipEventRecord(e1, ctx->stream));
+                P->fwd_needs_host = ctx->last_flagged != 0;
             }
         }
     } catch (const LuaError &e) {
