@@ -356,6 +356,37 @@ def test_draw_quad_with_int_min_corners_scans_like_the_reference():
     ctx.close()
 
 
+def test_draw_quad_small_quads_equal_the_reference_pixel_for_pixel():
+    """(r6) The generated draw_quad settles a quad on one or two rows with integer rules (row miny: [minx, maxx]; row miny + 1: the x of the
+    ends that lie on it) and interpolates only from three rows on, with a table of quotients instead of the division.  4000 random quads
+    around and across the screen's edges - one pixel, lines, two rows, three and more, wider than the 20-pixel limit, bow ties - against
+    the oracle's draw_quad (fisheye.c:2246-2338), pixel for pixel."""
+    import ctypes as C
+    import blinky_amd
+    W, H = 40, 24
+    ctx = blinky_amd.Context(blinky_amd.ffi.DEVICE_NONE)
+    S.configure(ctx, "cube", "eckert5", None, (W, H))
+    O._o.ok_test_draw_quad.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(20260930)
+    kinds = {"one row": 0, "two rows": 0, "three or more": 0, "rejected": 0}
+    for k in range(4000):
+        cx, cy = int(rng.integers(-6, W + 6)), int(rng.integers(-6, H + 6))
+        spread_x = int(rng.choice([0, 1, 1, 2, 3, 6, 12, 22]))
+        spread_y = int(rng.choice([0, 1, 1, 1, 2, 3, 6, 12, 22]))
+        c = np.empty(8, np.int32)
+        c[0::2] = cx + rng.integers(0, spread_x + 1, 4)
+        c[1::2] = cy + rng.integers(0, spread_y + 1, 4)
+        ys, xs = c[1::2], c[0::2]
+        dy, dx = int(ys.max() - ys.min()), int(xs.max() - xs.min())
+        kinds["rejected" if dx > 20 or dy > 20 else "one row" if dy == 0 else "two rows" if dy == 1 else "three or more"] += 1
+        want = np.zeros((H, W), np.uint8)
+        O._o.ok_test_draw_quad(W, H, c.ctypes.data, want.ctypes.data)
+        got = emu.draw_quad(ctx, c)
+        np.testing.assert_array_equal(got, want, err_msg=f"quad {k}: {c.tolist()}")
+    assert min(kinds.values()) > 30, kinds
+    ctx.close()
+
+
 # ---- self-correcting iterations: the contraction-aware bound (bk_emit.cpp contraction_pattern, bk_device_rt.h bk_contract) ----------
 ITERATIONS = {
     # Kepler's equation by Newton's method: converges quadratically, forgets its starting error
