@@ -424,6 +424,54 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, int x0, int y0, int x1, int y1,
     }
 }
 
+#ifndef BK_HAS_GLOBE_PLATE
+/* Which 16 x 16 tiles of plate texels lie wholly inside their plate's own region, by a margin no rounding can bridge: one thread per
+ * tile, grid (ceil(nt * nt / 256), plates).  A texel selects the plate whose forward vector has the largest float dot product with its
+ * NORMALISED ray (fisheye.c:2023-2050; bk_ray_to_plate_index).  Before normalisation the ray is dist * forward + fu * right + fv * up,
+ * affine in (fu, fv), so D_p - D_j - the un-normalised dot with the own plate's forward minus that with another's - is affine over the
+ * tile and at least its minimum over the tile's four corner texels everywhere inside.  If that minimum is >= 1e-4 * Rmax * Fmax
+ * (Rmax >= any ray's length on the plate, Fmax = the longest forward vector) the normalised dots differ by >= 1e-4 * Fmax, two hundred
+ * times what the float operations of the reference's path can move them (a few 2^-24 * Fmax): every texel of the tile owns its ray,
+ * strictly, and D_p >= 0 keeps the winning dot above the -2 the reference's search starts from.  Anything else - the tiles along a
+ * plate's border, NaNs - is left to the exact test, texel by texel. */
+extern "C" __global__ __launch_bounds__(256) void bk_forward_tiles(BkBuildParams P, unsigned char *tile_own)
+{
+    const int nt = (P.ps + BK_FWD_TILE - 1) / BK_FWD_TILE;
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x), plate = (int)blockIdx.y;
+    if (t >= nt * nt) return;
+    const int ty = t / nt, tx = t - ty * nt;
+    const BkPlateDev &p = P.plates[plate];
+    double fmax = 0.0;
+    for (int i = 0; i < P.numplates; ++i) {
+        const float *f = P.plates[i].forward;
+        const double l = __builtin_sqrt((double)f[0] * f[0] + (double)f[1] * f[1] + (double)f[2] * f[2]);
+        fmax = l > fmax ? l : fmax;
+    }
+    const double lf = __builtin_sqrt((double)p.forward[0] * p.forward[0] + (double)p.forward[1] * p.forward[1] + (double)p.forward[2] * p.forward[2]);
+    const double lr = __builtin_sqrt((double)p.right[0] * p.right[0] + (double)p.right[1] * p.right[1] + (double)p.right[2] * p.right[2]);
+    const double lu = __builtin_sqrt((double)p.up[0] * p.up[0] + (double)p.up[1] * p.up[1] + (double)p.up[2] * p.up[2]);
+    const double rmax = __builtin_fabs((double)p.dist) * lf + 0.5 * (lr + lu);
+    const double margin = 1e-4 * rmax * fmax;
+    bool all = margin > 0.0 && margin < BKM_INF;
+    for (int c = 0; c < 4; ++c) {
+        int x = tx * BK_FWD_TILE + ((c & 1) ? BK_FWD_TILE - 1 : 0), y = ty * BK_FWD_TILE + ((c & 2) ? BK_FWD_TILE - 1 : 0);
+        x = x < P.ps ? x : P.ps - 1;
+        y = y < P.ps ? y : P.ps - 1;
+        const double fu = (double)P.fwd_uv[P.ps + 1 + x], fv = -(double)P.fwd_uv[P.ps + 1 + y];
+        double r[3];
+        for (int k = 0; k < 3; ++k) r[k] = (double)p.dist * p.forward[k] + fu * p.right[k] + fv * p.up[k];
+        const double own = r[0] * p.forward[0] + r[1] * p.forward[1] + r[2] * p.forward[2];
+        all = all && own >= 0.0;
+        for (int j = 0; j < P.numplates; ++j) {
+            if (j == plate) continue;
+            const float *f = P.plates[j].forward;
+            all = all && own - (r[0] * f[0] + r[1] * f[1] + r[2] * f[2]) >= margin;
+        }
+    }
+    tile_own[((size_t)plate * nt + ty) * nt + tx] = all ? 1 : 0;
+}
+#endif
+
 /* the quad loop of resume_lensmap_forward (fisheye.c:2189-2202): one thread per plate texel.
  * The reference writes plate-major, py descending, px ascending, later writers overwriting;
  * key = 1 + that sequence number, committed with atomicMax, reproduces the final state. */
@@ -452,7 +500,9 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams
         for (int c = 0; c < 4; ++c) { q[c] = P.corner_xy[2 * c_tl + c]; q[4 + c] = P.corner_xy[2 * c_bl + c]; }
         BkState S;
         bk_state_init(S, &P);
-        bool own = bk_texel_owns_at(P, S, plate, py, px);
+        /* (a tile bk_forward_tiles found inside its plate's region: uniform over the workgroup, the whole test is jumped over) */
+        const bool tile_owns = P.tile_own && P.tile_own[((size_t)plate * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x];
+        bool own = tile_owns || bk_texel_owns_at(P, S, plate, py, px);
 #ifdef BK_HAS_GLOBE_PLATE
         if (P.ovr_count) {                          /* second pass: the host's answers for the texels the first pass flagged */
             unsigned int lo = 0, hi = P.ovr_count;

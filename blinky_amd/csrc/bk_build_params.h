@@ -49,6 +49,9 @@ typedef struct {
      * plate_uv_to_ray (fisheye.c:1205-1211, 2229); fwd_uv[ps + 1 + i] = (float)((double)i / ps - 0.5) - a texel's own ray (:2193). */
     const double *fwd_quot;
     const float *fwd_uv;
+    /* forward build: tile_own[(plate * nt + ty) * nt + tx], nt = ceil(ps / 16) - 1 when EVERY texel of that 16 x 16 tile selects its own
+     * plate with room to spare (bk_forward_tiles), so that the quad pass need not ask texel by texel; null: ask */
+    const unsigned char *tile_own;
     int *counters_out;       /* forward build, resolve pass: where to leave a copy of the 2 x 9 counters at display[] (pinned host memory), or null */
     double inv_scale_up;     /* >= 1 / scale: turns an error bound in lens units into screen pixels without a division */
     /* inverse build: 1 + scan key of the FIRST pixel (in the reference's scan order: rows bottom-up, pixels left to right,

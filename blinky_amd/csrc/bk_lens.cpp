@@ -60,7 +60,7 @@ struct LensProgram {
     std::string module_source;
     hipModule_t module = nullptr;
     bool module_from_cache = false;      // the last compile_module() loaded its code object from BLINKY_HIP_CACHE
-    hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr;
+    hipFunction_t k_inverse = nullptr, k_corners = nullptr, k_quads = nullptr, k_resolve = nullptr, k_tiles = nullptr;
     std::shared_future<::CodeResult> pending;     // bk_set_async_compile: hiprtc running on another thread ...
     std::string pending_source;                      // ... for this generated source
     // generate_source's last answer and the interpreter activity it was given at: emitting the translation unit walks the callbacks
@@ -913,7 +913,7 @@ static int load_module(bk_ctx *ctx, LensProgram *P, const std::string &source, c
 {
     if (cr.rc != BK_OK) return ctx->fail(cr.rc, "%s", cr.log.c_str());
     if (P->module) { (void)hipModuleUnload(P->module); P->module = nullptr; }
-    P->k_inverse = P->k_corners = P->k_quads = P->k_resolve = nullptr;
+    P->k_inverse = P->k_corners = P->k_quads = P->k_resolve = P->k_tiles = nullptr;
     P->module_from_cache = cr.from_disk;
     if (ctx->device < 0) {              // host-only context: compiling is all we can do
         P->module_source = source;
@@ -924,6 +924,7 @@ static int load_module(bk_ctx *ctx, LensProgram *P, const std::string &source, c
     (void)hipModuleGetFunction(&P->k_corners, P->module, "bk_forward_corners");
     (void)hipModuleGetFunction(&P->k_quads, P->module, "bk_forward_quads");
     (void)hipModuleGetFunction(&P->k_resolve, P->module, "bk_forward_resolve");
+    if (hipModuleGetFunction(&P->k_tiles, P->module, "bk_forward_tiles") != hipSuccess) P->k_tiles = nullptr;   // (absent under a globe_plate script)
     (void)hipGetLastError();
     P->module_source = source;
     return BK_OK;
@@ -2028,6 +2029,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             bp.fwd_key_tint = (unsigned int *)ctx->fwd_scratch[3];
             // the quotient / uv tables of bk_build_params.h: plain IEEE divisions, done here once per platesize instead of per texel
             constexpr size_t NQ = 21 * 21;
+            const size_t ntile = ((size_t)ctx->ps + 15) / 16;              // (BK_FWD_TILE = 16; the tile flags of bk_forward_tiles live behind the tables)
             if (ctx->fwd_tables_ps != ctx->ps) {
                 (void)hipFree(ctx->fwd_tables);
                 ctx->fwd_tables = nullptr; ctx->fwd_tables_ps = -1;
@@ -2039,13 +2041,14 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                     uv[i] = (float)(((double)i - 0.5) / ctx->ps - 0.5);
                     uv[n1 + i] = (float)((double)i / ctx->ps - 0.5);
                 }
-                BK_HIP_C(hipMalloc(&ctx->fwd_tables, NQ * sizeof(double) + uv.size() * sizeof(float)));
+                BK_HIP_C(hipMalloc(&ctx->fwd_tables, NQ * sizeof(double) + uv.size() * sizeof(float) + (size_t)BK_MAX_PLATES * ntile * ntile));
                 BK_HIP_C(hipMemcpy(ctx->fwd_tables, q.data(), NQ * sizeof(double), hipMemcpyHostToDevice));
                 BK_HIP_C(hipMemcpy((char *)ctx->fwd_tables + NQ * sizeof(double), uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice));
                 ctx->fwd_tables_ps = ctx->ps;
             }
             bp.fwd_quot = (const double *)ctx->fwd_tables;
             bp.fwd_uv = (const float *)((const char *)ctx->fwd_tables + NQ * sizeof(double));
+            unsigned char *const tile_own = (unsigned char *)ctx->fwd_tables + NQ * sizeof(double) + 2 * n1 * sizeof(float);
             const auto clear_keys = [&](hipStream_t st) -> hipError_t {
                 hipError_t e = hipMemsetAsync(ctx->fwd_scratch[2], 0, px * 4, st);
                 return e == hipSuccess ? hipMemsetAsync(ctx->fwd_scratch[3], 0, px * 4, st) : e;
@@ -2079,9 +2082,17 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                 // (after whatever the stream held before this build, which may still read them: build_ev[0])
                 BK_HIP_C(hipStreamWaitEvent(ctx->build_aux, ctx->build_ev[0], 0));
                 BK_HIP_C(clear_keys(ctx->build_aux));
+                // ... and the tiles that lie wholly inside their plate's own region are found there too (the plates may have changed
+                // since the last build: 110 K threads, a few microseconds)
+                BkBuildParams bq = bp;
+                if (P->k_tiles) {
+                    unsigned char *flags_out = tile_own;
+                    void *args_t[] = {&bp, &flags_out};
+                    BK_HIP_C(hipModuleLaunchKernel(P->k_tiles, (unsigned)((ntile * ntile + 255) / 256), (unsigned)ctx->numplates, 1, 256, 1, 1, 0, ctx->build_aux, args_t, nullptr));
+                    bq.tile_own = tile_own;
+                }
                 BK_HIP_C(hipEventRecord(ctx->build_ev[1], ctx->build_aux));
-                BkBuildParams bq = bp;                       // the quad pass counts into the second set (cleared with the first, above)
-                bq.display = ctx->d_display + NF;
+                bq.display = ctx->d_display + NF;            // the quad pass counts into the second set (cleared with the first, above)
                 bq.err = bq.display + BK_MAX_PLATES;
                 bq.flag_count = (unsigned int *)(bq.display + BK_MAX_PLATES + 1);
                 bq.first_bad = (unsigned int *)(bq.display + BK_MAX_PLATES + 2);
