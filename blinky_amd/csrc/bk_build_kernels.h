@@ -475,7 +475,9 @@ extern "C" __global__ __launch_bounds__(256) void bk_forward_tiles(BkBuildParams
 /* the quad loop of resume_lensmap_forward (fisheye.c:2189-2202): one thread per plate texel.
  * The reference writes plate-major, py descending, px ascending, later writers overwriting;
  * key = 1 + that sequence number, committed with atomicMax, reproduces the final state. */
-extern "C" __global__ __launch_bounds__(256) void bk_forward_quads(BkBuildParams P)      /* grid (ceil(ps/16), ceil(ps/16), plates): a tile of 16 x 16 texels */
+/* (eight waves per SIMD - 64 VGPRs, the few beyond that spilled in the general scanline path: once the instruction count was down the
+ *  pass was waiting on its own chain of loads and barriers, and the eighth wave is worth 17 % - profiles/r06_build_counters.txt, step l) */
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bk_forward_quads(BkBuildParams P)      /* grid (ceil(ps/16), ceil(ps/16), plates): a tile of 16 x 16 texels */
 {
     __shared__ int s_disp[6];
     __shared__ int s_box[4];                         /* the tile's bounding box on the screen: min x, min y, max x, max y */
