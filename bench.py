@@ -22,7 +22,8 @@ The timed region of K steps is repeated (--repeats; by default as many regions a
 min / max are printed beside it.  `value_one_stream` is the same measurement with every launch on one stream - the figure
 `roofline.kernel_ms_per_launch` (the kernel alone, HIP events) must be consistent with.
 At N = 1 the line also carries `configs_extra` (BASELINE.json configs[1], 1920x1080 cube/stereographic, timed the same
-way) and `predicted_stripe_complete` (rank r's stripe for N = 2 / 4 / 8 timed on this GPU, max over ranks).
+way), `predicted_stripe_complete` (rank r's stripe for N = 2 / 4 / 8 timed on this GPU, max over ranks) and `build_ms` - the
+metric's other half: bk_build at the headline's size as a call, for its own lens, quincuncial and two forward-map lenses.
 Prints ONE JSON line (rank 0).  `value` = whole-job Mpixels/s = W*H*frames*steps / time.
 """
 import argparse
@@ -245,6 +246,35 @@ class OneGpuWorkload:
         self.out = None
 
 
+def build_times(torch, blinky_amd, S, device_index, W, H, lenses=(("panini", "f_fov 180"), ("quincuncial", None), ("winkel2", None), ("polyconic", None))):
+    """the metric's other half - lensmap BUILD ms at WxH on the cube globe - for the headline's lens, C3's quincuncial and two forward-map
+    lenses (winkel2, polyconic: fisheye.c:2126-2338): bk_build as a call on the host's clock (best and median of 9 after the compile) and
+    its device part under HIP events (bk_last_build_ms)."""
+    import statistics
+    rec = {}
+    for lens, zoom in lenses:
+        ctx = blinky_amd.Context(device_index)
+        try:
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            S.configure(ctx, "cube", lens, zoom, (W, H))
+            ctx.build()                                   # hiprtc / code cache, scratch, host module
+            ctx.build()
+            wall, dev = [], []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                ctx.build()
+                wall.append((time.perf_counter() - t0) * 1e3)
+                dev.append(ctx.last_build_ms())
+            flagged, changed = ctx.last_build_fixups()
+            rec[lens] = {"call_ms_best": round(min(wall), 3), "call_ms_median": round(statistics.median(wall), 3), "device_ms": round(min(dev), 3),
+                         "entries_rederived_on_host": flagged, "map": "forward" if ctx.lens_info().map_type == 2 else "inverse"}
+        except Exception as e:      # noqa: BLE001
+            rec[lens] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ctx.close()
+    return rec
+
+
 def extra_config(torch, blinky_amd, S, device_index, name, globe, lens, zoom, W, H, F, steps, args=None, rubix=False, ring_max=64):
     """one more BASELINE.json configuration, driver-timed beside the headline (N = 1 only); with `args`, its HBM traffic is measured
     the way the headline's is (measure_traffic: two rocprofv3 --pmc child runs of the same launch).  rubix: the tint LUT path
@@ -451,6 +481,8 @@ def compact_line(out):
         if isinstance(cb.get("allcores"), dict):
             line["cpu_baseline"]["allcores"] = pick(cb["allcores"], ("value", "cores", "kind"))
     line.update(pick(out, ("lensmap_build_ms", "value_at_16_frames", "stripe_complete_mpx_s")))
+    if isinstance(out.get("build_ms"), dict):         # lens -> bk_build as a call, best of 9 (ms); winkel2 / polyconic are forward maps
+        line["build_ms"] = {k: v.get("call_ms_best", "error") for k, v in out["build_ms"].items() if isinstance(v, dict)}
     if out.get("n_gpus", 1) > 1:
         line.update(pick(out, ("assembled_on_rank0_mpx_s", "scaling_reference_mpx_s", "speedup_vs_scaling_reference")))
         line["exchange"] = pick(out.get("exchange") or {}, ("bound_mpx_s", "bound_all_on_rank0_mpx_s"))
@@ -1098,6 +1130,10 @@ def main():
                       ("C5 (BASELINE.json configs[4], on one GPU)", "cube", "hammer", None, 7680, 4320, 64, max(6, args.steps // 5), False, 64),
                       ("headline, rubix on (fisheye.c:2416-2419)", GLOBE, LENS, ZOOM, W, H, FX, args.steps, True, 64),
                       ("4K cube/hammer (whole-globe lens)", "cube", "hammer", None, 3840, 2160, FX, args.steps, False, 64)]
+            trace("build times")
+            out["build_ms"] = dict(what=f"bk_build at {W}x{H} on the cube globe: [call on the host clock, best of 9] / median / device part; "
+                                        "the reference's create_lensmap beside it: cpu_baseline.build_ms",
+                                   **build_times(torch, blinky_amd, S, local_rank, W, H))
             out["configs_extra"] = []
             for (nm, g, l, z, w_, h_, f_, st_, rb_, rm_) in extras:
                 try:

@@ -51,6 +51,11 @@ def test_bench_line_and_check_single_gpu():
     out = json.load(open(os.path.join(ROOT, compact["detail"])))
     assert out["value"] == compact["value"] and out["roofline"]["frac"] == compact["roofline"]["frac"]
     assert set(compact["extras"]) == {"C2", "C2x64", "C3", "C5", "headline, rubix on", "4K cube/hammer"}, compact["extras"]
+    # the metric's other half: lensmap build ms at the headline's size - its own lens, C3's, and two forward-map lenses (r6: under / near 1 ms)
+    assert set(compact["build_ms"]) == {"panini", "quincuncial", "winkel2", "polyconic"}, compact["build_ms"]
+    assert all(isinstance(v, float) and 0.05 < v < 10.0 for v in compact["build_ms"].values()), compact["build_ms"]
+    assert out["build_ms"]["winkel2"]["map"] == "forward" and out["build_ms"]["panini"]["map"] == "inverse"
+    assert out["build_ms"]["winkel2"]["call_ms_best"] < 1.5 and out["build_ms"]["panini"]["call_ms_best"] < 0.5
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
