@@ -1283,23 +1283,39 @@ public:
         return pool;
     }
     size_t size() const { return threads_.size(); }
-    /* run job(worker_index) on `want` workers (<= size()) and wait for all of them */
+    /* run job(worker_index) on UP TO `want` workers (<= size() + 1; the caller is one of them) and wait for those that started: every job
+     * passed here draws its work from a counter its workers share and returns when that is used up - a worker index that never gets its
+     * turn is no loss */
     void run(size_t want, const std::function<void(size_t)> &job)
     {
+        if (!want) return;
         std::unique_lock<std::mutex> submit(submit_mutex_);  // one parallel section at a time
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            job_ = &job;
-            want_ = want;
-            next_ = 0;
-            done_ = 0;
-            ++generation_;
+        // The caller is the last worker: the section starts now, not when the first sleeper has woken up (waking forty sleepers through
+        // one mutex takes longer than a short section's whole work - the jobs here all draw their work from a shared counter, so whoever
+        // arrives late simply takes less).
+        const size_t pooled = want - 1;
+        if (pooled) {
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                job_ = &job;
+                want_ = pooled;
+                next_ = 0;
+                done_ = 0;
+                ++generation_;
+            }
+            if (pooled >= threads_.size() / 2) wake_.notify_all();
+            else for (size_t i = 0; i < pooled; ++i) wake_.notify_one();
         }
-        if (want >= threads_.size() / 2) wake_.notify_all();
-        else for (size_t i = 0; i < want; ++i) wake_.notify_one();
-        std::unique_lock<std::mutex> lock(m_);
-        finished_.wait(lock, [&] { return done_ == want_; });
-        job_ = nullptr;
+        job(pooled);
+        if (pooled) {
+            // (the caller's job returns when the shared counter is used up: workers that have not even woken yet are not waited for -
+            //  their turns are withdrawn - only those that are in the middle of their last piece)
+            std::unique_lock<std::mutex> lock(m_);
+            want_ = next_;
+            finished_.wait(lock, [&] { return done_ == want_; });
+            job_ = nullptr;
+            want_ = next_ = done_ = 0;
+        }
     }
     ~FixupPool()
     {
@@ -1421,9 +1437,12 @@ void for_each_flagged(LensProgram *P, size_t n, Fn fn)
 template <typename Call>
 void hostmod_runs(size_t n, Call call)
 {
-    const size_t run = 512;
+    const size_t run = n < 65536 ? 128 : 512;       // (short lists in short runs: the last one to finish decides)
     FixupPool &pool = FixupPool::get();
-    const size_t nthreads = n < 2 * run ? 1 : std::min<size_t>(std::min<size_t>(pool.size(), (n + run - 1) / run), n > 200000 ? 128 : 48);
+    // (two runs per worker at least; r6: the cap was 48 below 200 K entries - waking more sleepers than that cost more than they brought
+    //  while every one of them was waited for; measured at 4K: quincuncial's 20 132 entries 0.67-0.94 -> 0.49-0.55 ms, eckert4's 7 707 0.13 -> 0.12,
+    //  winkeltripel's 10 431 0.50 -> 0.40-0.58: what is left is the sleepers' wake-up, one after the other)
+    const size_t nthreads = n < 2 * run ? 1 : std::min<size_t>(std::min<size_t>(pool.size(), (n + 2 * run - 1) / (2 * run)), 128);
     if (nthreads <= 1) { if (n) call((size_t)0, n); return; }
     std::atomic<size_t> next{0};
     pool.run(nthreads, [&](size_t) {
