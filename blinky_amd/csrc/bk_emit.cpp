@@ -953,8 +953,10 @@ struct Emitter {
                 o << pad << "bkv " << f.ap << i << "[" << cells + 1 << "];   /* " << p->slot_names[i] << " */\n";
                 o << pad << "for (int q = 0; q <= " << cells << "; ++q) " << f.ap << i << "[q] = bk_nil();\n";
             } else if (f.array_slots.count(i)) {
+                // (no nil-filling: the array's size IS its constructor's length and `local t = {..}` assigns every element before anything can
+                //  read one - element 0 is never addressed.  The compiler had found most of those stores dead already: quincuncial's kernel
+                //  kept 12 of 40, and is no faster without them)
                 o << pad << "bkv " << f.ap << i << "[" << f.array_slots.at(i) + 1 << "];   /* " << p->slot_names[i] << " */\n";
-                o << pad << "for (int q = 0; q <= " << f.array_slots.at(i) << "; ++q) " << f.ap << i << "[q] = bk_nil();\n";
             } else if (i < p->nparams) {
                 o << pad << "bkv " << f.lp << i << " = na > " << i << " ? a[" << i << "] : bk_nil();   /* " << p->slot_names[i] << " */\n";
             } else {
