@@ -288,29 +288,14 @@ BK_DEV double bk_edge_quot(int a, int d, const double *quot)
     if (ua <= 20u && ud - 1u < 20u && ((a ^ d) >= 0 || a == 0)) return quot[ua * 21u + ud];
     return (double)a / (double)d;
 }
-BK_DEV void bk_fwd_set(const BkBuildParams &P, int lx, int ly, unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
-{
-    if (lx < 0 || lx >= P.W || ly < 0 || ly >= P.H) return;                  /* :1966 */
-    *wrote = 1;                                                               /* display (:1976) is global, not per stripe */
-    if (ly < P.row0 || ly >= P.row0 + P.rows) return;                        /* stripe-filtered commit */
-    if (win.px && lx >= win.x0 && ly >= win.y0 && lx - win.x0 < win.w && ly - win.y0 < win.h) {   /* (0 <= lx, ly here; 0 <= x0, y0) */
-        const int k = (ly - win.y0) * BK_FWD_WIN + (lx - win.x0);
-        atomicMax(&win.px[k], key);
-        if (offgrid) atomicMax(&win.tint[k], key);
-        return;
-    }
-    const size_t o = (size_t)(ly - P.row0) * P.W + lx;
-    atomicMax(&P.fwd_key_px[o], key);
-    if (offgrid) atomicMax(&P.fwd_key_tint[o], key);
-}
-/* the pixels [xa, xb] of screen row ly, as bk_fwd_set would take them one by one - the row's tests made once */
+/* set_lensmap_from_plate (fisheye.c:1963-1982) for the pixels [xa, xb] of screen row ly: the row's tests made once */
 BK_DEV void bk_fwd_row(const BkBuildParams &P, int xa, int xb, int ly, unsigned int key, bool offgrid, int *wrote, const BkFwdWin &win)
 {
     if (ly < 0 || ly >= P.H) return;                                         /* :1966 */
     xa = xa < 0 ? 0 : xa;
     xb = xb >= P.W ? P.W - 1 : xb;
     if (xa > xb) return;
-    *wrote = 1;
+    *wrote = 1;                                                               /* display (:1976) is global, not per stripe */
     if (ly < P.row0 || ly >= P.row0 + P.rows) return;                        /* stripe-filtered commit */
     const int wy = ly - win.y0;
     const bool row_in = win.px && wy >= 0 && wy < win.h;
@@ -396,9 +381,9 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, int x0, int y0, int x1, int y1,
     /* the part of [min, max] that is on the screen (all of a normal, <= 21-long range that matters; one end of a 2^31-long one) */
     const int vx0 = minx < 0 ? 0 : minx, vx1 = maxx >= P.W ? P.W - 1 : maxx;
     const int vy0 = miny < 0 ? 0 : miny, vy1 = maxy >= P.H ? P.H - 1 : maxy;
-    if (miny == maxy && minx == maxx) { bk_fwd_set(P, x, y, key, offgrid, wrote, win); return; }
-    if (miny == maxy) { for (int tx = vx0; tx <= vx1; ++tx) bk_fwd_set(P, tx, miny, key, offgrid, wrote, win); return; }
-    if (minx == maxx) { for (int ty = vy0; ty <= vy1; ++ty) bk_fwd_set(P, x, ty, key, offgrid, wrote, win); return; }
+    /* (a single pixel - :2276 - was a one-row quad above; what is left of :2283-2301 are lines of three pixels and more, and the 2^31-long ones) */
+    if (miny == maxy) { bk_fwd_row(P, vx0, vx1, miny, key, offgrid, wrote, win); return; }
+    if (minx == maxx) { for (int ty = vy0; ty <= vy1; ++ty) bk_fwd_row(P, x, x, ty, key, offgrid, wrote, win); return; }
     const bool tall = bk_wrap_sub(maxy, miny) < 0;                            /* 2^31 rows: visible ones only (see above) */
     const int y_first = tall ? vy0 : miny, nrows = bk_wrap_sub(tall ? vy1 : maxy, y_first);      /* <= 20, or <= H - 1; < 0: none */
     for (int ky = 0; ky <= nrows; ++ky) {
@@ -419,8 +404,7 @@ BK_DEV void bk_draw_quad(const BkBuildParams &P, int x0, int y0, int x1, int y1,
 #undef BK_QUAD_EDGE
         if (t0 > t1) { const int t = t0; t0 = t1; t1 = t; }
         if (bk_wrap_sub(t1, t0) > maxdiff) return;                           /* :2327 aborts the quad */
-        const int x_first = t0 < 0 ? 0 : t0, x_last = t1 >= P.W ? P.W - 1 : t1;
-        for (x = x_first; x <= x_last; ++x) bk_fwd_set(P, x, y, key, offgrid, wrote, win);
+        bk_fwd_row(P, t0, t1, y, key, offgrid, wrote, win);
     }
 }
 
@@ -567,7 +551,7 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         if (wrote) s_disp[plate] = 1;
     }
     __syncthreads();
-    if (col < win.w)                                 /* the window's pixels, once each (they passed bk_fwd_set's tests when they went in) */
+    if (col < win.w)                                 /* the window's pixels, once each (they passed bk_fwd_row's tests when they went in) */
         for (int wy = row0w; wy < win.h; wy += 4) {
             const unsigned int key = s_px[wy * BK_FWD_WIN + col];
             if (!key) continue;
