@@ -2257,6 +2257,68 @@ Interp::Interp(const MathLib &m) : math(&m)
         t.tab()->set(Value::string("what"), Value::string("Lua"));
         r.push_back(t);
     });
+    // the rest of ldblib.c, as far as a tree-walking interpreter without a register stack can honour it: metatables without the
+    // __metatable guard, a closure's upvalues by number (the cells themselves: setupvalue / upvaluejoin act on what the closure sees),
+    // hooks that are accepted and never fire, locals that are not there to be had (nil), the registry as one table per state
+    register_builtin("debug.getmetatable", [](Interp &, const Values &a, Values &r) {
+        r.push_back(!a.empty() && a[0].t == Value::TABLE && a[0].tab()->meta ? Value::table(a[0].tab()->meta) : Value());
+    });
+    register_builtin("debug.setmetatable", [](Interp &, const Values &a, Values &r) {
+        if (a.size() < 2 || (a[1].t != Value::NIL && a[1].t != Value::TABLE)) throw LuaError("bad argument #2 to 'setmetatable' (nil or table expected)");
+        if (a[0].t == Value::TABLE) a[0].tab()->meta = a[1].t == Value::TABLE ? a[1].tab_ptr() : nullptr;
+        else if (a[1].t != Value::NIL) throw LuaError("debug.setmetatable: only tables carry a metatable in this interpreter");
+        r.push_back(a[0]);
+    });
+    register_builtin("debug.getupvalue", [](Interp &, const Values &a, Values &r) {
+        if (a.size() < 2 || (a[0].t != Value::FUNC && a[0].t != Value::BUILTIN)) throw LuaError("bad argument #1 to 'getupvalue' (function expected)");
+        if (a[1].t != Value::NUM) throw LuaError("bad argument #2 to 'getupvalue' (number expected)");
+        if (a[0].t != Value::FUNC) return;                                  // (a C function here has none)
+        const Closure *c = a[0].fn();
+        const double k = a[1].n;
+        if (!(k >= 1 && k <= (double)c->upvals.size()) || k != (double)(size_t)k) return;
+        const size_t i = (size_t)k - 1;
+        r.push_back(Value::string(i < c->proto->upvals.size() ? c->proto->upvals[i].name : std::string("?")));
+        r.push_back(c->upvals[i] ? *c->upvals[i] : Value());
+    });
+    register_builtin("debug.setupvalue", [](Interp &I, const Values &a, Values &r) {
+        if (a.size() < 3 || a[0].t != Value::FUNC) throw LuaError("bad argument #1 to 'setupvalue' (Lua function expected)");
+        if (a[1].t != Value::NUM) throw LuaError("bad argument #2 to 'setupvalue' (number expected)");
+        Closure *c = a[0].fn();
+        const double k = a[1].n;
+        if (!(k >= 1 && k <= (double)c->upvals.size()) || k != (double)(size_t)k) return;
+        const size_t i = (size_t)k - 1;
+        if (!c->upvals[i]) c->upvals[i] = std::make_shared<Value>();
+        *c->upvals[i] = a[2];
+        ++I.activity;
+        r.push_back(Value::string(i < c->proto->upvals.size() ? c->proto->upvals[i].name : std::string("?")));
+    });
+    register_builtin("debug.upvalueid", [](Interp &, const Values &a, Values &r) {
+        if (a.size() < 2 || a[0].t != Value::FUNC || a[1].t != Value::NUM) throw LuaError("bad argument to 'upvalueid' (Lua function, number expected)");
+        const Closure *c = a[0].fn();
+        const double k = a[1].n;
+        if (!(k >= 1 && k <= (double)c->upvals.size())) throw LuaError("bad argument #2 to 'upvalueid' (invalid upvalue index)");
+        r.push_back(Value::number((double)(reinterpret_cast<uintptr_t>(c->upvals[(size_t)k - 1].get()) >> 3)));   // (a light userdata there: comparable, nothing more)
+    });
+    register_builtin("debug.upvaluejoin", [](Interp &I, const Values &a, Values &) {
+        if (a.size() < 4 || a[0].t != Value::FUNC || a[2].t != Value::FUNC || a[1].t != Value::NUM || a[3].t != Value::NUM)
+            throw LuaError("bad argument to 'upvaluejoin' (Lua function, number, Lua function, number expected)");
+        Closure *c1 = a[0].fn(), *c2 = a[2].fn();
+        const double k1 = a[1].n, k2 = a[3].n;
+        if (!(k1 >= 1 && k1 <= (double)c1->upvals.size()) || !(k2 >= 1 && k2 <= (double)c2->upvals.size())) throw LuaError("bad argument to 'upvaluejoin' (invalid upvalue index)");
+        c1->upvals[(size_t)k1 - 1] = c2->upvals[(size_t)k2 - 1];
+        ++I.activity;
+    });
+    register_builtin("debug.getlocal", [](Interp &, const Values &, Values &r) { r.push_back(Value()); });          // (no frame keeps its locals by name)
+    register_builtin("debug.setlocal", [](Interp &, const Values &, Values &r) { r.push_back(Value()); });
+    register_builtin("debug.gethook", [](Interp &, const Values &, Values &r) { r.push_back(Value()); });           // (none is ever set)
+    register_builtin("debug.sethook", [](Interp &, const Values &, Values &) {});                                   // (accepted, never called)
+    register_builtin("debug.getuservalue", [](Interp &, const Values &, Values &r) { r.push_back(Value()); });      // (no userdata in this interpreter)
+    register_builtin("debug.setuservalue", [](Interp &, const Values &a, Values &r) { r.push_back(a.empty() ? Value() : a[0]); });
+    register_builtin("debug.debug", [](Interp &, const Values &, Values &) {});                                     // (no console to read commands from)
+    register_builtin("debug.getregistry", [](Interp &I, const Values &, Values &r) {                               // (one table per interpreter state)
+        if (I.registry.t != Value::TABLE) I.registry = Value::table(std::make_shared<Table>());
+        r.push_back(I.registry);
+    });
     register_builtin("string.dump", [](Interp &, const Values &, Values &) { throw LuaError("unable to dump given function"); });
     globals["_VERSION"] = Value::string("Lua 5.2");
     {

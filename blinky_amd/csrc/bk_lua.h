@@ -242,6 +242,7 @@ struct Interp {
     const std::string *call_chunk = nullptr; // where the builtin call being made stands (error() puts "chunk:line:" in front of its message)
     int call_line = 0;
     int depth = 0;
+    Value registry;                         // debug.getregistry's table, made when first asked for (a copy of the interpreter starts with none)
     void *current_co = nullptr;             // the coroutine whose body is running on this interpreter (coroutine library, bk_lua.cpp); null = the main thread
     std::function<void(const std::string &)> print_sink;   // `print` / io.write output, newlines included (Con_Printf)
 

@@ -83,7 +83,9 @@ int         bk_synchronize(bk_ctx *ctx);
  * The language: what runs while a script LOADS (the chunk, what it calls) is Lua 5.2 (closures, varargs, metatables, goto, coroutines,
  * the string library with patterns, table.*, math.*, bit32.*, os.*, io.*, pcall / xpcall / error, load / dofile / require with
  * package.path / package.preload relative to the working directory; r6: coroutines, the rest of os / io, _G as a proxy of the globals;
- * not provided: string.dump, os.exit - an error the script can see -, the debug library beyond traceback / getinfo; a coroutine created
+ * not provided: string.dump, os.exit - an error the script can see -, and of the debug library what needs a register stack
+ * (getlocal / setlocal answer nil, hooks are accepted and never fire; traceback, getinfo, get/setmetatable, get/setupvalue,
+ * upvalueid / upvaluejoin and getregistry work); a coroutine created
  * while loading is nil inside the per-pixel callbacks: the build evaluates them on copies of the script state, and a coroutine is a
  * native stack of the original).  What the per-pixel CALLBACKS (lens_inverse, lens_forward,
  * globe_plate and everything they call) may use is narrower - they become GPU code at bk_build: numbers, booleans, nil, string

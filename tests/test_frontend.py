@@ -515,6 +515,44 @@ def test_keyed_caches_are_not_state(bk, body, carries):
         assert np.array_equal(v["val"][used, :3].view(np.uint64), out[used].view(np.uint64))
 
 
+DEBUG_LIBRARY = """
+max_fov = 360
+local count = 10
+local function bump() count = count + 1 return count end
+local function peek() return count end
+print(debug.getupvalue(bump, 1))
+print(debug.setupvalue(bump, 1, 41), bump(), peek())
+print(debug.upvalueid(bump, 1) == debug.upvalueid(peek, 1), debug.getupvalue(print, 1))
+local other = 100
+local function far() return other end
+debug.upvaluejoin(far, 1, bump, 1)
+print(far(), debug.getupvalue(far, 2))
+local t = setmetatable({}, {__metatable = "locked", __index = function() return 7 end})
+print(getmetatable(t), type(debug.getmetatable(t)), t.x)
+print(debug.setmetatable(t, nil) == t, getmetatable(t), t.x)
+print(pcall(debug.setmetatable, 5, {}))
+print(debug.getlocal(1, 1), debug.gethook(), debug.sethook(print, "l"), debug.getuservalue(t))
+local reg = debug.getregistry()
+reg.mine = 3
+print(type(reg), debug.getregistry().mine, debug.getregistry() == reg)
+function lens_inverse(x, y) return x, y, count end
+"""
+
+
+def test_the_debug_library_as_far_as_a_tree_walker_can_honour_it(bk):
+    """(r6) ldblib.c's functions: metatables past the __metatable guard, upvalues by number (the cells the closures share: setupvalue and
+    upvaluejoin change what they see - and what the per-pixel code is generated from), the registry; locals and hooks answer nil."""
+    ctx = host_ctx(bk)
+    ctx.load_globe(S.script("globes", "cube"), "cube")
+    ctx.load_lens(DEBUG_LIBRARY, "dbg.lua")
+    assert ctx.console().splitlines() == [
+        "count\t10", "count\t42\t42", "true", "42", "locked\ttable\t7", "true\tnil\tnil",
+        "false\tdebug.setmetatable: only tables carry a metatable in this interpreter", "nil\tnil\tnil\tnil", "table\t3\ttrue"]
+    assert ctx.eval_host(0, 0.25, 0.5) == (0.25, 0.5, 42.0) or list(ctx.eval_host(0, 0.25, 0.5)) == [0.25, 0.5, 42.0]
+    assert "0x1.5p+5" in ctx.kernel_source()                # the upvalue the callback returns, as debug.setupvalue / bump left it: 42
+    ctx.close()
+
+
 SHARED_SUBEXPRESSIONS = """
 max_fov = 360
 max_vfov = 180
