@@ -352,6 +352,7 @@ extern "C" int bk_debug_set_option(const char *name, int value)
     else if (!strcmp(name, "print_model")) bk::g_debug.print_model = value;
     else if (!strcmp(name, "host_module")) bk::g_debug.host_module = value;
     else if (!strcmp(name, "no_direct_submit")) bk::g_debug.no_direct_submit = value;
+    else if (!strcmp(name, "forward_careful")) bk::g_debug.forward_careful = value;          // forward builds pass by pass, every texel's ownership asked (tests)
     else return BK_E_INVALID;
     return BK_OK;
 }

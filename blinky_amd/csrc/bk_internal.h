@@ -22,7 +22,7 @@
 namespace bk {
 
 // process-wide developer / test switches (bk_debug_set_option, debug API builds only; always 0 otherwise)
-struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0, host_module = 0, no_direct_submit = 0; };
+struct DebugOptions { int no_memcache = 0, libm_rel_log2 = 0, print_model = 0, host_module = 0, no_direct_submit = 0, forward_careful = 0; };
 extern DebugOptions g_debug;
 
 // roctx ranges around the library's phases (bk_build, block-map compile, apply launches, plate uploads, the resident session):
@@ -102,6 +102,7 @@ struct bk_ctx {
     hipEvent_t build_ev[2] = {nullptr, nullptr};
     hipEvent_t build_time_ev[2] = {nullptr, nullptr};   // bk_build's timing pair, kept (creating and destroying them is four runtime calls a build)
     int *h_build_flags = nullptr;        // pinned: the counters of a forward build's two passes, read back without a stop in between
+    bool fwd_tiles_used = false;         // the last build's quad pass went by bk_forward_tiles' flags (bk_debug_forward_tiles)
     void *fwd_tables = nullptr;          // BkBuildParams::fwd_quot + fwd_uv for platesize fwd_tables_ps (bk_lens.cpp)
     int fwd_tables_ps = -1;
     int last_flagged = 0, last_changed = 0;   // of the last bk_build: entries re-evaluated on the host / entries that changed

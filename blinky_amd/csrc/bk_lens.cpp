@@ -1909,6 +1909,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     ctx->last_flagged = ctx->last_changed = 0;
     ctx->last_build_path = 0;
     ctx->last_build_why.clear();
+    ctx->fwd_tiles_used = false;
 
     if (!P || !P->lens_valid) return ctx->fail(BK_E_STATE, "not a valid lens");               /* create_lensmap :2372 */
     if (!ctx->globe_valid) return ctx->fail(BK_E_STATE, "not a valid globe");
@@ -2087,7 +2088,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
             // apiece at 4K) earlier.  A build that did flag something is done over the careful way below, and so is the next build of
             // the same lens.
             bool speculated = false;
-            if (!P->fwd_needs_host) {
+            if (!P->fwd_needs_host && !bk::g_debug.forward_careful) {
                 constexpr size_t NF = BK_MAX_PLATES + 3;
                 int *const after_corners = ctx->h_build_flags, *const after_quads = ctx->h_build_flags + NF;
                 if (!ctx->build_aux) {
@@ -2109,6 +2110,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                     void *args_t[] = {&bp, &flags_out};
                     BK_HIP_C(hipModuleLaunchKernel(P->k_tiles, (unsigned)((ntile * ntile + 255) / 256), (unsigned)ctx->numplates, 1, 256, 1, 1, 0, ctx->build_aux, args_t, nullptr));
                     bq.tile_own = tile_own;
+                    ctx->fwd_tiles_used = true;
                 }
                 BK_HIP_C(hipEventRecord(ctx->build_ev[1], ctx->build_aux));
                 bq.display = ctx->d_display + NF;            // the quad pass counts into the second set (cleared with the first, above)
@@ -2133,6 +2135,7 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
                     speculated = true;
                 } else {
                     P->fwd_needs_host = true;
+                    ctx->fwd_tiles_used = false;
                     BK_HIP_C(reset_counters());
                 }
             }
@@ -2266,6 +2269,26 @@ extern "C" int bk_build(bk_ctx *ctx, int display_out[BK_MAX_PLATES], double *sca
     empty_unless_built.armed = false;
     return BK_OK;
 }
+
+#if BK_DEBUG_API
+extern "C" int bk_debug_forward_tiles(bk_ctx *ctx, int *taken, int *total)
+{
+    if (!ctx || !taken || !total) return BK_E_INVALID;
+    const size_t nt = ((size_t)ctx->ps + 15) / 16, n = (size_t)ctx->numplates * nt * nt;
+    *total = (int)n;
+    *taken = -1;
+    if (!ctx->fwd_tiles_used || !ctx->fwd_tables || ctx->fwd_tables_ps != ctx->ps) return BK_OK;
+    std::vector<unsigned char> flags(n);
+    const size_t at = 21 * 21 * sizeof(double) + 2 * ((size_t)ctx->ps + 1) * sizeof(float);       // (behind the quotient and uv tables: bk_build)
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BK_HIP(ctx, hipMemcpy(flags.data(), (const char *)ctx->fwd_tables + at, n, hipMemcpyDeviceToHost));
+    int k = 0;
+    for (unsigned char f : flags) k += f ? 1 : 0;
+    *taken = k;
+    return BK_OK;
+}
+#endif
 
 #if BK_DEBUG_API
 /* test hook: the kernel-argument block bk_build would launch with (calc_zoom done, device pointers as they are -

@@ -96,6 +96,7 @@ _SIGS = {
     "bk_set_host_compile": (_i, [_i]),
     "bk_host_module_ready": (_i, [_vp, _i]),
     "bk_debug_module_from_cache": (_i, [_vp]),
+    "bk_debug_forward_tiles": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "bk_debug_set_option": (_i, [C.c_char_p, _i]),
     "bk_debug_build_breakdown": (_i, [_vp, C.POINTER(_d)]),
     "bk_multi_lensmap_valid": (_i, [_vp]),
@@ -587,6 +588,12 @@ class Context:
 
     def console(self):
         return lib.bk_script_console(self._h).decode()
+
+    def forward_tiles(self):
+        """(tiles of the last forward build whose texels' ownership was taken on bk_forward_tiles' word, or -1; tiles in all)"""
+        a, b = _i(), _i()
+        self._chk(lib.bk_debug_forward_tiles(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def module_from_cache(self):
         return bool(lib.bk_debug_module_from_cache(self._h))

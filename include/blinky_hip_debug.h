@@ -21,11 +21,17 @@ extern "C" {
  *   "print_model"        != 0: the block-shape cost model prints its inputs to stderr, one line per candidate
  *   "host_module"        1: flagged entries are re-derived by the compiled host module only (it is waited for; an error if
  *                        there is none), 2: by the script interpreter only; 0: whichever is there (the default)
+ *   "forward_careful"    != 0: a forward-map build goes pass by pass (a stop and a look at the flag lists after each) and asks every
+ *                        texel whether its ray selects its own plate - no tile is taken on bk_forward_tiles' word
  * returns BK_E_INVALID for an unknown name */
 int         bk_debug_set_option(const char *name, int value);
 /* bk_debug_module_from_cache: 1 if the current module was loaded from the disk cache (test hook; BLINKY_HIP_NO_MEMCACHE
  * in the environment bypasses the in-process cache so that the disk path can be observed). */
 int         bk_debug_module_from_cache(const bk_ctx *ctx);
+/* bk_debug_forward_tiles: after a forward-map build on the device, how many of its 16 x 16 texel tiles the quad pass took as wholly
+ * inside their plate's own region (bk_forward_tiles) and how many tiles there are; taken = -1 when the last build did not use the
+ * shortcut (an inverse map, a globe_plate script, "forward_careful", a build that went pass by pass). */
+int         bk_debug_forward_tiles(bk_ctx *ctx, int *taken, int *total);
 /* developer only: timing ablations of the staged apply (2 no globe loads, 4 no stores, 8 no load
  * pipelining; 16 row-major block walk, 32 persistent form always, 64 XCD bands of equal block count instead of equal
  * cost, 128 non-temporal globe loads, 256 LDS-DMA staging (global_load_lds) in single-frame launches of the one-block form,
