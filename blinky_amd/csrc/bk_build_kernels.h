@@ -180,6 +180,26 @@ extern "C" __global__ __launch_bounds__(256) void bk_build_inverse(BkBuildParams
 #endif
 
 #ifdef BK_HAS_FORWARD
+/* (int)(v / scale + half), uv_to_screen's last step (fisheye.c:2236-2240), and the question whether another libm's v (within e) would give
+ * another pixel.  On the device nearly every corner is answered without the division: fa = v * (1 / scale) + half is within
+ * 2^-49 * (|v| / scale + half) of the reference's rounded f, so when trunc is the same number T over [fa - ea, fa + ea] - ea that, doubled
+ * twice over, plus the libm bound - T is trunc(f) and every admissible f's trunc: no flag, no division (and T in int range is what the
+ * x86 conversion gives).  The few corners within 1e-11 of a pixel's edge take the reference's own operations, as before. */
+BK_DEV int bk_to_screen(const BkBuildParams &P, BkState &S, double v, double e, int half)
+{
+#ifndef BK_HOST_MODULE
+    {
+        const double fa = __builtin_fma(v, P.inv_scale_up, (double)half);
+        const double ea = __builtin_fma(__builtin_fma(bk_abs(v), P.inv_scale_up, (double)half), 0x1p-47, e * P.inv_scale_up);
+        const double lo = bkm_trunc(fa - ea);
+        if (lo == bkm_trunc(fa + ea) && lo > -2147483649.0 && lo < 2147483648.0) return (int)lo;
+    }
+#endif
+    const double f = v / P.scale + (double)half;
+    bk_need_same_trunc(S, f, bk_eop(S, f, e * P.inv_scale_up));
+    return bk_trunc_to_int(f);                                               /* :2239-2240 */
+}
+
 /* uv_to_screen (fisheye.c:2227-2243) for every texel-corner of every plate:
  * corner (i,j), i,j in 0..ps, is (u,v) = ((i-0.5)/ps, (j-0.5)/ps) */
 BK_DEV void bk_corner_at(const BkBuildParams &P, BkState &S, int plate, int j, int i, int *sx_out, int *sy_out, unsigned char *ok_out)
@@ -198,11 +218,8 @@ BK_DEV void bk_corner_at(const BkBuildParams &P, BkState &S, int plate, int j, i
     unsigned char ok = 0;
     int sx = 0, sy = 0;
     if (n == 2 && bk_isnum(r[0]) && bk_isnum(r[1])) {
-        const double fx = r[0].n / P.scale + (double)(P.W / 2), fy = -r[1].n / P.scale + (double)(P.H / 2);
-        sx = bk_trunc_to_int(fx);                                            /* :2239 */
-        sy = bk_trunc_to_int(fy);                                            /* :2240 */
-        bk_need_same_trunc(S, fx, bk_eop(S, fx, r[0].e * P.inv_scale_up));
-        bk_need_same_trunc(S, fy, bk_eop(S, fy, r[1].e * P.inv_scale_up));
+        sx = bk_to_screen(P, S, r[0].n, r[0].e, P.W / 2);                    /* r[0].n / scale + W / 2, :2236 */
+        sy = bk_to_screen(P, S, -r[1].n, r[1].e, P.H / 2);                   /* -r[1].n / scale + H / 2, :2237 */
         ok = 1;
     } else if (!(n == 1 && r[0].t == BK_TNIL)) {
         S.err |= BK_ERR_RESULT;
