@@ -589,6 +589,47 @@ def test_forward_build_that_flags_entries_is_redone_pass_by_pass(bk, lens, W, H,
     plain.close()
 
 
+def test_one_context_through_lenses_globes_sizes_and_stripes(bk):
+    """(r6) bk_build keeps things between builds now - the generated translation unit while no script state has moved, the rubix bitmap per
+    platesize and grid, the forward build's uv / quotient tables per platesize, whether a forward lens' last build flagged anything - and
+    decides per build which of them still hold.  One context driven through what an engine session does: f_lens, f_globe, a window
+    resize, f_rubixgrid, zoom commands, a stripe set and lifted again, forward and inverse maps in turn, the same build twice; every table
+    against the oracle's."""
+    ctx = bk.Context()
+    steps = [("cube", "panini", "f_fov 180", 640, 400, None, None), ("cube", "eckert5", None, 640, 400, None, None),
+             ("cube", "eckert5", None, 640, 400, None, None),                       # (nothing changed: kept source, kept tables)
+             ("cube", "eckert5", None, 500, 300, None, None),                       # a new platesize under the same lens
+             ("trism", "eckert5", None, 500, 300, None, None),                      # another globe: the tiles' flags are the plates'
+             ("trism", "winkel2", None, 500, 300, (100, 233), None),                # a stripe of a forward map
+             ("trism", "winkel2", None, 500, 300, None, (6, 3.0, 2.0)),             # the grid changes under a kept source
+             ("cube", "hammer", "f_cover", 500, 300, None, (6, 3.0, 2.0)), ("cube", "hammer", "f_contain", 500, 300, None, None),
+             ("cube", "winkel2", None, 640, 400, None, None), ("cube", "panini", "f_fov 120", 640, 400, (0, 17), None),
+             ("cube", "panini", "f_fov 120", 640, 400, None, None)]
+    loaded = (None, None)
+    for k, (globe, lens, zoom, W, H, rows, grid) in enumerate(steps):
+        if globe != loaded[0]:
+            ctx.load_globe(S.script("globes", globe), globe + ".lua")
+        if (globe, lens) != loaded:
+            ctx.load_lens(S.script("lenses", lens), lens + ".lua")                  # (the reference reloads the lens after f_globe too)
+        loaded = (globe, lens)
+        cmd = (zoom or ctx.lens_info().onload.decode()).split()
+        ctx.set_zoom(S.ZOOM_CMD[cmd[0]], int(float(cmd[1])) if len(cmd) > 1 else 0)
+        ctx.resize(W, H)
+        ctx.set_rows(*(rows or (0, H)))
+        g = grid or (10, 4.0, 1.0)
+        ctx.set_rubixgrid(*g)
+        display, scale = ctx.build()
+        off, tin = ctx.read_lensmap()
+        lm = O.lensmap(globe, lens, zoom, W, H, grid=g)
+        r0, r1 = rows or (0, H)
+        np.testing.assert_array_equal(off, lm.offsets.reshape(H, W)[r0:r1].ravel(), err_msg=f"step {k}: {steps[k]}")
+        np.testing.assert_array_equal(tin, lm.tints.reshape(H, W)[r0:r1].ravel(), err_msg=f"step {k}: {steps[k]}")
+        assert scale == lm.scale
+        if not rows:
+            assert display[: lm.numplates] == lm.display, (k, display, lm.display)
+    ctx.close()
+
+
 def _random_globe(rng):
     """a globe script with 2-6 plates in general position: random forward / up vectors (the loader makes right and up from them,
     not normalised - fisheye.c:1818-1850), fields of view from narrow to wider than a half-space's"""
